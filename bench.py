@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py — reads/s classified on the synthetic ONT pile-up (BASELINE.json configs[1]).
+
+A "step" is one pass of the hot path (plan -> sweeps -> scan/compact/classify) over one batch
+of overlaps already resident in HBM.  One process per GPU; reads are independent, so ranks get
+their own shard (weak scaling: every rank holds a configs[1]-sized batch) and there is no
+data-path collective — torch.distributed is used only for the barrier and the max over ranks.
+
+Prints ONE JSON line on rank 0 (see the contract in the task statement) carrying `roofline`
+for the dominant kernel (HIP-event time measured inside the engine, on the engine's stream)
+and `cpu_baseline` (the CPU oracle timed on this box's cores; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s measured-copy ceiling
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--reads", type=int, default=100_000)
+    ap.add_argument("--overlaps", type=int, default=5_000_000)
+    ap.add_argument("--profile", default="ont", choices=["ont", "sequel", "skewed"])
+    ap.add_argument("--coverage", type=int, default=None)
+    ap.add_argument("--not-coverage", type=float, default=0.4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lds-sort", action="store_true", help="A/B: LDS-sort kernel for the small class")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+    import yacrd_amd
+    from yacrd_amd import host
+    yacrd_amd.load_library()  # binds to torch's HIP runtime before torch initialises it
+
+    import torch
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        try:
+            dist.init_process_group("nccl", device_id=dev)
+        except Exception:
+            dist.init_process_group("gloo")
+
+    prof = {"ont": host.SYNTH_ONT, "sequel": host.SYNTH_SEQUEL, "skewed": host.SYNTH_SKEWED}[args.profile]
+    cov = args.coverage if args.coverage is not None else (3 if args.profile == "sequel" else 4)
+    cfg_no = {"ont": 2, "sequel": 3, "skewed": 4}[args.profile]
+    seed = 20241108 + cfg_no + 1000 * rank
+    offsets, intervals, lengths = host.synth_csr(prof, args.reads, args.overlaps, seed)
+    R, I = args.reads, int(offsets[-1])
+
+    d_off = torch.from_numpy(offsets.view(np.int64)).to(dev)
+    d_iv = torch.from_numpy(intervals.view(np.int32)).to(dev)
+    d_len = torch.from_numpy(lengths.view(np.int32)).to(dev)
+    torch.cuda.synchronize()
+
+    flags = yacrd_amd.F_FORCE_LDS_SORT if args.lds_sort else 0
+    eng = yacrd_amd.Engine(device_id=local_rank, flags=flags)
+
+    def step():
+        return eng.run_device(d_off.data_ptr(), d_iv.data_ptr(), d_len.data_ptr(), R, I, cov,
+                              args.not_coverage)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    keys = ("plan_ms", "sweep_small_ms", "sweep_medium_ms", "sweep_general_ms", "compact_ms", "total_ms")
+    acc = dict.fromkeys(keys, 0.0)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+        t = eng.timing()  # HIP events recorded on the engine's stream inside run_device
+        for k in keys:
+            acc[k] += t[k]
+    barrier()
+    elapsed = time.perf_counter() - t0
+
+    G = int(out.n_regions)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        K = args.steps
+        avg = {k: acc[k] / K for k in keys}
+        # algorithmic bytes per pass, SURVEY.md §8(d): 16 B per overlap + 29 B per read + 8 B per region
+        b_alg = 8 * I + 8 * (R + 1) + 4 * R + 8 * (R + 1) + 8 * G + R
+        dom = "sweep_small" if avg["sweep_small_ms"] >= max(avg["sweep_medium_ms"], avg["sweep_general_ms"]) else (
+            "sweep_medium" if avg["sweep_medium_ms"] >= avg["sweep_general_ms"] else "sweep_general")
+        dom_ms = avg[dom + "_ms"]
+        achieved = b_alg / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("%s_%d_%d" % (args.profile, R, args.overlaps))
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "reads_per_sec_classified",
+            "value": world * R * K / elapsed,
+            "unit": "reads/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: synthetic %s pile-up, %d reads / %d PAF overlaps per GPU, -c %d -n %g, inputs resident in HBM"
+                                   % (args.profile.upper(), R, args.overlaps, cov, args.not_coverage),
+                       "reads_per_gpu": R, "overlaps_per_gpu": args.overlaps, "intervals_per_gpu": I,
+                       "regions_per_gpu": G, "parallelism": "read-partition x%d, no collective" % world},
+            "overlaps_per_sec": world * args.overlaps * K / elapsed,
+            "kernel_ms": avg,
+            "path_gbps": b_alg / (avg["total_ms"] * 1e-3) / 1e9 if avg["total_ms"] > 0 else None,
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes": b_alg, "kernel_ms": dom_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            import oracle
+            ncores = os.cpu_count() or 1
+            l64 = lengths.astype(np.uint64)
+            oracle.run(offsets[:1001], intervals[: int(offsets[1000])], l64[:1000], cov, args.not_coverage, 1)
+            t1 = time.perf_counter()
+            want = oracle.run(offsets, intervals, l64, cov, args.not_coverage, n_threads=ncores)
+            cpu_all = time.perf_counter() - t1
+            # reference default is -t 1 (src/main.rs:75-77): time a bounded single-thread sample too
+            rs = min(R, 20000)
+            t1 = time.perf_counter()
+            oracle.run(offsets[: rs + 1], intervals[: int(offsets[rs])], l64[:rs], cov, args.not_coverage, 1)
+            cpu_1 = time.perf_counter() - t1
+            got = eng.fetch()
+            parity = bool(np.array_equal(got.bad_offsets, want[0]) and np.array_equal(got.bad_regions, want[1])
+                          and np.array_equal(got.read_type, want[2]))
+            line["cpu_baseline"] = {"value": R / cpu_all, "unit": "reads/s", "cores": ncores, "kind": "port",
+                                    "sample": "the whole batch (%d reads, %d intervals) once on %d threads; "
+                                              "single-thread (reference default -t 1) on the first %d reads: %.0f reads/s"
+                                              % (R, I, ncores, rs, rs / cpu_1),
+                                    "value_1thread": rs / cpu_1}
+            line["parity"] = "bit-exact vs oracle on all %d reads" % R if parity else "MISMATCH vs oracle"
+        print(json.dumps(line), flush=True)
+    eng.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,135 @@
+/*
+ * yacrd_engine.h — C ABI of the MI355X bad-region engine (libyacrd_hip.so).
+ *
+ * This is the drop-in boundary for natir/yacrd's `trait BadPart` (reference src/stack.rs:35-41):
+ * a Rust `struct FromGpu: BadPart` calls yacrd_engine_run() from
+ * `compute_all_bad_part` (src/stack.rs:143-162, called once from src/main.rs:78) and answers
+ * `get_bad_part` (src/stack.rs:164-169) / `get_reads` (:171-173) from the returned CSR.
+ *
+ * Data contract (CSR over reads, the device-side replacement of
+ * `MapReads2Ovl = FxHashMap<String,(Vec<(u32,u32)>,usize)>`, src/reads2ovl/mod.rs:41):
+ *   offsets   u64[R+1]  prefix sums of intervals per read (offsets[0] = 0)
+ *   intervals u32[2*I]  (start,end) pairs in any order within a read (src/io.rs:23-34 cols
+ *                       3-4 / 8-9; both sides of each overlap line, src/reads2ovl/mod.rs:108-109)
+ *   lengths   u32[R]    first length seen per read (src/reads2ovl/fullmemory.rs:82-90)
+ * Results:
+ *   bad_offsets u64[R+1], bad_regions u32[2*G] (begin,end) pairs in the reference's order
+ *   (src/stack.rs:61-139), read_type u8[R] (src/editor/mod.rs:85-100).
+ *
+ * Conventions: every function returns 0 on success or a YACRD_E* code; the message for the
+ * last error on the calling thread is yacrd_last_error().  Calls on one engine must not
+ * overlap; different engines (one per GPU) may be driven from different threads/processes.
+ * Plain C types only — no torch, no HIP types in the signatures.
+ *
+ * Deviations from the reference, all loud: read lengths must fit u32 (the reference keeps
+ * usize and truncates with `as u32` when emitting, src/stack.rs:112); `coverage` is u32 (the
+ * CLI's u64, src/cli.rs:53-54, saturates — a read never has 2^32 intervals here either).
+ */
+#ifndef YACRD_ENGINE_H
+#define YACRD_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YACRD_ABI_VERSION 1
+
+/* src/editor/mod.rs:42-59 ReadType; numeric encoding is ours, names are the reference's. */
+enum { YACRD_NOT_BAD = 0, YACRD_CHIMERIC = 1, YACRD_NOT_COVERED = 2 };
+
+enum {
+    YACRD_OK = 0,
+    YACRD_EINVAL = 1,  /* bad argument / malformed CSR */
+    YACRD_ENODEV = 2,  /* no usable gfx950 device, or HIP runtime error */
+    YACRD_ENOMEM = 3,  /* host or device allocation failed */
+    YACRD_EINTERNAL = 4
+};
+
+typedef struct yacrd_engine yacrd_engine;
+
+typedef struct {
+    int32_t device_id;  /* HIP device ordinal; -1 = the calling thread's current device */
+    uint32_t flags;     /* YACRD_F_* */
+} yacrd_engine_cfg;
+
+#define YACRD_F_DEFAULT 0u
+/* route every read through the fully general (arbitrary-input) kernel; testing only */
+#define YACRD_F_FORCE_GENERAL 1u
+/* use the LDS-sort kernel for the small class instead of the register-sort kernel; A/B only */
+#define YACRD_F_FORCE_LDS_SORT 2u
+
+/* Host-side result, allocated by the engine, released with yacrd_result_free(). */
+typedef struct {
+    uint64_t n_reads;
+    uint64_t n_regions;    /* G */
+    uint64_t *bad_offsets; /* R+1 */
+    uint32_t *bad_regions; /* 2*G */
+    uint8_t *read_type;    /* R */
+} yacrd_result;
+
+/* Device-side result: pointers into engine-owned HBM, valid until the next run / destroy. */
+typedef struct {
+    uint64_t n_reads;
+    uint64_t n_regions;
+    const void *d_bad_offsets; /* u64[R+1] */
+    const void *d_bad_regions; /* u32[2*G] */
+    const void *d_read_type;   /* u8[R]   */
+} yacrd_device_result;
+
+/* Per-phase wall times of the last run, measured with HIP events on the engine's stream. */
+typedef struct {
+    float h2d_ms;
+    float plan_ms;          /* size-class binning */
+    float sweep_small_ms;   /* one read per wavefront (dominant kernel) */
+    float sweep_medium_ms;  /* one read per workgroup, LDS resident */
+    float sweep_general_ms; /* global-memory path: huge / degenerate reads */
+    float compact_ms;       /* scan + compact + classify */
+    float d2h_ms;
+    float total_ms;         /* first kernel start -> last kernel end */
+    uint64_t n_small, n_medium, n_general;     /* reads per class */
+    uint64_t iv_small, iv_medium, iv_general;  /* intervals per class */
+} yacrd_timing;
+
+int yacrd_abi_version(void);
+const char *yacrd_last_error(void);
+
+int yacrd_engine_create(const yacrd_engine_cfg *cfg, yacrd_engine **out);
+void yacrd_engine_destroy(yacrd_engine *e);
+
+/* Blocking: H2D, kernels, D2H.  Replaces FromOverlap::compute_all_bad_part
+ * (src/stack.rs:143-162) + the per-read type_of_read of the report loop
+ * (src/main.rs:80-84, src/editor/mod.rs:71). */
+int yacrd_engine_run(yacrd_engine *e, const uint64_t *offsets, const uint32_t *intervals,
+                     const uint32_t *lengths, uint64_t n_reads, uint32_t coverage,
+                     double not_coverage, yacrd_result *out);
+void yacrd_result_free(yacrd_result *r);
+
+/* Same computation on inputs already resident in HBM (device pointers, same layout).
+ * n_intervals must equal offsets[n_reads].  Blocking (synchronises the engine's stream). */
+int yacrd_engine_run_device(yacrd_engine *e, const void *d_offsets, const void *d_intervals,
+                            const void *d_lengths, uint64_t n_reads, uint64_t n_intervals,
+                            uint32_t coverage, double not_coverage, yacrd_device_result *out);
+
+/* Copy the last device result to host (allocates like yacrd_engine_run). */
+int yacrd_engine_fetch(yacrd_engine *e, yacrd_result *out);
+
+int yacrd_engine_last_timing(const yacrd_engine *e, yacrd_timing *t);
+
+/* Read-id partitioning for multi-GPU: cuts[n_parts+1], contiguous read
+ * ranges balanced by interval count; reads are independent so there is no exchange step. */
+int yacrd_partition_reads(const uint64_t *offsets, uint64_t n_reads, uint32_t n_parts,
+                          uint64_t *cuts);
+
+/* Standalone classification of an existing region CSR (the reference calls type_of_read
+ * again in every editor, e.g. src/editor/scrubbing.rs:181).  Host buffers in, host out. */
+int yacrd_engine_classify(yacrd_engine *e, const uint64_t *bad_offsets,
+                          const uint32_t *bad_regions, const uint32_t *lengths,
+                          uint64_t n_reads, double not_coverage, uint8_t *read_type);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,75 @@
+/*
+ * yacrd_host.h — C ABI of the host side (libyacrd_host.so, plain C++17, no GPU code):
+ * overlap ingest into the CSR the engine consumes, the .yacrd report writer, and the
+ * deterministic synthetic workload generator used by bench.py and the scale tests.
+ *
+ * Reference interfaces replaced (paths relative to the reference root):
+ *   yacrd_csr_from_file   <- Reads2Ovl::init / init_paf / init_m4  (src/reads2ovl/mod.rs:43-145)
+ *                            + FullMemory::add_overlap_and_length  (src/reads2ovl/fullmemory.rs:82-90)
+ *   yacrd_report_write    <- editor::report loop of main           (src/main.rs:80-84,
+ *                            src/editor/mod.rs:61-107)
+ */
+#ifndef YACRD_HOST_H
+#define YACRD_HOST_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char *yacrd_host_last_error(void);
+
+/* ---- CSR built from an overlap file --------------------------------------------------------- */
+typedef struct yacrd_csr yacrd_csr; /* opaque, owns its arrays */
+
+typedef struct {
+    uint64_t n_reads;
+    uint64_t n_intervals;
+    uint64_t n_records;        /* overlap lines ingested */
+    const uint64_t *offsets;   /* R+1 */
+    const uint32_t *intervals; /* 2*I */
+    const uint32_t *lengths;   /* R (first length seen) */
+    const uint64_t *name_off;  /* R+1 offsets into names */
+    const char *names;         /* concatenated read ids, first-appearance order */
+} yacrd_csr_view;
+
+/* format: 0 = by file name like util::get_file_type (src/util.rs:39-55), 1 = PAF, 2 = M4.
+ * n_threads: parser threads (0 = hardware concurrency). */
+int yacrd_csr_from_file(const char *path, int format, int n_threads, yacrd_csr **out);
+int yacrd_csr_from_memory(const char *text, size_t len, int format, int n_threads,
+                          yacrd_csr **out);
+int yacrd_csr_get(const yacrd_csr *c, yacrd_csr_view *v);
+/* index of a read id, or -1 (BadPart::get_bad_part answers unknown ids with an empty list,
+ * src/stack.rs:164-169) */
+int64_t yacrd_csr_find(const yacrd_csr *c, const char *name, size_t name_len);
+void yacrd_csr_free(yacrd_csr *c);
+
+/* ---- report ---------------------------------------------------------------------------------- */
+/* One line per read: "{type}\t{id}\t{len}\t{len_i,begin_i,end_i;...}\n" (src/editor/mod.rs:61-107),
+ * reads in CSR (first-appearance) order. */
+int yacrd_report_write(const char *path, const yacrd_csr_view *reads, const uint64_t *bad_offsets,
+                       const uint32_t *bad_regions, const uint8_t *read_type);
+
+/* ---- synthetic workloads ------------------------------------------------------ */
+enum { YACRD_SYNTH_ONT = 0, YACRD_SYNTH_SEQUEL = 1, YACRD_SYNTH_SKEWED = 2 };
+
+typedef struct {
+    uint32_t profile;       /* YACRD_SYNTH_* */
+    uint32_t flags;         /* bit0: no abutting/degenerate injection */
+    uint64_t n_reads;
+    uint64_t n_overlaps;    /* PAF lines; intervals = 2 * n_overlaps */
+    uint64_t seed;
+} yacrd_synth_cfg;
+
+/* Fills caller-allocated arrays: offsets[R+1], intervals[4*n_overlaps], lengths[R]. */
+int yacrd_synth_csr(const yacrd_synth_cfg *cfg, uint64_t *offsets, uint32_t *intervals,
+                    uint32_t *lengths);
+/* Same overlaps as PAF text (12 columns + tp:A:S), read ids r%09u. */
+int yacrd_synth_paf(const yacrd_synth_cfg *cfg, const char *path);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

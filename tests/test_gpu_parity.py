@@ -1,0 +1,193 @@
+"""HIP path vs CPU oracle, bit-exact, through the C ABI.  Needs an MI355X."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import yacrd_amd
+from cases import assert_same, make_csr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    with yacrd_amd.Engine() as e:
+        yield e
+
+
+@pytest.fixture(scope="module")
+def engine_general():
+    with yacrd_amd.Engine(flags=yacrd_amd.F_FORCE_GENERAL) as e:
+        yield e
+
+
+@pytest.fixture(scope="module")
+def engine_lds():
+    with yacrd_amd.Engine(flags=yacrd_amd.F_FORCE_LDS_SORT) as e:
+        yield e
+
+
+def check(e, csr, cov, nc, ctx):
+    offsets, intervals, lengths = csr
+    want = oracle.run(offsets, intervals, lengths.astype(np.uint64), cov, nc, n_threads=4)
+    got = e.run(offsets, intervals, lengths, cov, nc)
+    assert_same(got, want, ctx)
+    return got
+
+
+# ---- reference golden vectors through the GPU -------------------------------------------------
+def test_reference_known_answers(engine):
+    from test_oracle import STACK_KATS
+    for ovl, length, cov, expect in STACK_KATS:
+        off = np.array([0, len(ovl)], dtype=np.uint64)
+        got = engine.run(off, np.array(ovl, dtype=np.uint32), np.array([length]), cov, 0.8)
+        assert got.bad_regions.tolist() == [list(x) for x in expect]
+
+
+@pytest.mark.parametrize("cov,nc", [(0, 0.8), (1, 0.8), (2, 0.4), (3, 0.4), (4, 0.4)])
+def test_fixture_truth(engine, golden_dir, cov, nc):
+    with open(os.path.join(golden_dir, "reads.paf")) as f:
+        reads = oracle.parse_paf(f)
+    names, offsets, intervals, lengths = oracle.to_csr(reads)
+    got = check(engine, (offsets, intervals, lengths.astype(np.uint32)), cov, nc, "fixture")
+    if cov == 0:
+        with open(os.path.join(golden_dir, "truth.yacrd")) as f:
+            truth = set(line.rstrip("\n") for line in f)
+        lines = oracle.report_from_csr(names, lengths, got.bad_offsets, got.bad_regions,
+                                       got.read_type)
+        assert set(lines) == truth
+
+
+# ---- size classes x coverage ------------------------------------------------------------------
+REGULAR_MODES = ("regular", "abutting", "dups", "beyond", "sparse")
+
+
+@pytest.mark.parametrize("cov", [0, 1, 3, 4, 9])
+def test_small_class(engine, cov):
+    rng = np.random.default_rng(1)
+    sizes = np.concatenate([np.arange(0, 40), rng.integers(1, 513, size=1500),
+                            [511, 512, 256, 255, 257, 128, 64, 63, 65, 32, 33, 1, 2]])
+    check(engine, make_csr(100 + cov, sizes, REGULAR_MODES), cov, 0.4, "small c=%d" % cov)
+
+
+@pytest.mark.parametrize("cov", [0, 4])
+def test_small_class_lds_variant(engine_lds, cov):
+    rng = np.random.default_rng(2)
+    sizes = np.concatenate([np.arange(0, 20), rng.integers(1, 513, size=600)])
+    check(engine_lds, make_csr(150 + cov, sizes, REGULAR_MODES), cov, 0.4, "small-lds")
+
+
+@pytest.mark.parametrize("cov", [0, 3, 4])
+def test_medium_classes(engine, cov):
+    rng = np.random.default_rng(3)
+    sizes = np.concatenate([rng.integers(513, 4097, size=40), rng.integers(4097, 16385, size=12),
+                            [513, 4096, 4097, 16384, 2048, 8192]])
+    check(engine, make_csr(200 + cov, sizes, REGULAR_MODES, len_lo=20000, len_hi=400000), cov,
+          0.4, "medium c=%d" % cov)
+
+
+@pytest.mark.parametrize("cov", [0, 4])
+def test_general_class_large_reads(engine, cov):
+    sizes = [16385, 20000, 40000, 70001, 5, 300]
+    check(engine, make_csr(300 + cov, sizes, ("regular", "abutting"), len_lo=200000,
+                           len_hi=1000000), cov, 0.4, "large c=%d" % cov)
+
+
+@pytest.mark.parametrize("cov", [0, 1, 2, 4])
+def test_degenerate_and_huge_positions(engine, cov):
+    rng = np.random.default_rng(4)
+    sizes = np.concatenate([np.arange(1, 30), rng.integers(1, 600, size=400),
+                            rng.integers(600, 5000, size=10)])
+    check(engine, make_csr(400 + cov, sizes, ("degenerate", "regular", "huge_pos", "degenerate")),
+          cov, 0.4, "degenerate c=%d" % cov)
+
+
+@pytest.mark.parametrize("cov", [0, 2, 4])
+def test_general_kernel_on_everything(engine_general, cov):
+    """The exact general kernel must agree with the oracle on regular reads too."""
+    rng = np.random.default_rng(5)
+    sizes = np.concatenate([np.arange(0, 30), rng.integers(1, 700, size=300),
+                            rng.integers(700, 6000, size=8)])
+    modes = REGULAR_MODES + ("degenerate", "huge_pos")
+    check(engine_general, make_csr(500 + cov, sizes, modes), cov, 0.4, "general-all c=%d" % cov)
+
+
+def test_paths_agree_with_each_other(engine, engine_general, engine_lds):
+    rng = np.random.default_rng(6)
+    sizes = rng.integers(0, 513, size=800)
+    csr = make_csr(600, sizes, REGULAR_MODES)
+    a = engine.run(*csr, 3, 0.4)
+    b = engine_general.run(*csr, 3, 0.4)
+    c = engine_lds.run(*csr, 3, 0.4)
+    assert_same(a, (b.bad_offsets, b.bad_regions, b.read_type), "wave vs general")
+    assert_same(c, (b.bad_offsets, b.bad_regions, b.read_type), "lds vs general")
+
+
+# ---- edge cases -------------------------------------------------------------------------------
+def test_empty_batch(engine):
+    got = engine.run(np.zeros(1, np.uint64), np.zeros((0, 2), np.uint32), np.zeros(0, np.uint32),
+                     0, 0.8)
+    assert got.bad_offsets.tolist() == [0] and got.bad_regions.shape == (0, 2)
+
+
+def test_reads_without_intervals_and_zero_length(engine):
+    offsets = np.array([0, 0, 0, 2, 2], dtype=np.uint64)
+    intervals = np.array([[0, 10], [5, 20]], dtype=np.uint32)
+    lengths = np.array([1000, 0, 20, 7], dtype=np.uint32)
+    check(engine, (offsets, intervals, lengths), 0, 0.8, "empty reads")
+
+
+def test_coverage_saturation(engine):
+    csr = make_csr(700, [50, 200, 3], ("regular",))
+    check(engine, csr, 0xFFFFFFFF, 0.4, "c=u32 max")
+    check(engine, csr, 1000, 0.0, "c=1000 n=0")
+
+
+def test_classification_thresholds(engine):
+    """-n edge: strict >, NaN for len 0, NotCovered before Chimeric (editor/mod.rs:85-100)."""
+    offsets = np.array([0, 1, 2, 4], dtype=np.uint64)
+    intervals = np.array([[0, 600], [0, 599], [0, 300], [700, 1000]], dtype=np.uint32)
+    lengths = np.array([1000, 1000, 1000], dtype=np.uint32)
+    for nc in (0.4, 0.401, 0.399999, 0.0, 1.0):
+        check(engine, (offsets, intervals, lengths), 0, nc, "thresholds n=%r" % nc)
+
+
+def test_standalone_classify_kernel(engine):
+    csr = make_csr(800, np.random.default_rng(8).integers(1, 300, size=500), REGULAR_MODES)
+    got = check(engine, csr, 2, 0.4, "classify")
+    for nc in (0.1, 0.4, 0.8):
+        rt = engine.classify(got.bad_offsets, got.bad_regions, csr[2], nc)
+        want = np.array([oracle.type_of_read(int(csr[2][r]),
+                                             got.bad_regions[int(got.bad_offsets[r]):
+                                                             int(got.bad_offsets[r + 1])].tolist(),
+                                             nc) for r in range(len(csr[2]))], dtype=np.uint8)
+        assert np.array_equal(rt, want)
+
+
+def test_repeated_runs_are_deterministic(engine):
+    csr = make_csr(900, np.random.default_rng(9).integers(0, 513, size=3000), REGULAR_MODES)
+    a = engine.run(*csr, 4, 0.4)
+    for _ in range(3):
+        b = engine.run(*csr, 4, 0.4)
+        assert_same(b, (a.bad_offsets, a.bad_regions, a.read_type), "rerun")
+
+
+def test_device_resident_entry_point(engine):
+    torch = pytest.importorskip("torch")
+    csr = make_csr(1000, np.random.default_rng(10).integers(0, 400, size=2000), REGULAR_MODES)
+    offsets, intervals, lengths = csr
+    d_off = torch.from_numpy(offsets.astype(np.int64)).cuda()
+    d_iv = torch.from_numpy(intervals.astype(np.int64).astype(np.int32) if False else
+                            intervals.view(np.int32)).cuda()
+    d_len = torch.from_numpy(lengths.view(np.int32)).cuda()
+    torch.cuda.synchronize()
+    out = engine.run_device(d_off.data_ptr(), d_iv.data_ptr(), d_len.data_ptr(), len(lengths),
+                            int(offsets[-1]), 4, 0.4)
+    got = engine.fetch()
+    want = oracle.run(offsets, intervals, lengths.astype(np.uint64), 4, 0.4)
+    assert int(out.n_regions) == int(want[0][-1])
+    assert_same(got, want, "run_device")
+    t = engine.timing()
+    assert t["n_small"] == len(lengths) and t["total_ms"] > 0

@@ -1,0 +1,12 @@
+"""yacrd_amd — MI355X-native bad-region engine behind yacrd's BadPart boundary.
+
+The product is the C-ABI library `yacrd_amd/lib/libyacrd_hip.so` (HIP kernels for gfx950 +
+host launcher, include/yacrd_engine.h) and the C++ host (`yacrd_amd/bin/yacrd`).  This Python
+package is a thin ctypes binding used by tests and bench.py; it has no CPU fallback: without
+the built library, or without a gfx950 device, it raises.
+"""
+from .engine import (  # noqa: F401
+    Engine, EngineError, Result, lib_path, load_library, build, partition_reads,
+    NOT_BAD, CHIMERIC, NOT_COVERED, TYPE_NAMES, F_FORCE_GENERAL, F_FORCE_LDS_SORT,
+    EXPORTED_SYMBOLS,
+)

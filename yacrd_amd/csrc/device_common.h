@@ -1,0 +1,186 @@
+// device_common.h — shared device-side types and wave/workgroup primitives (gfx950, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+typedef int32_t i32;
+
+namespace yk {
+
+constexpr u32 kNoKey = 0xFFFFFFFFu;
+
+// Size classes by events per read (m = 2 * intervals).
+constexpr u32 kSmallEvents = 1024;    // one read per wavefront
+constexpr u32 kMedium1Events = 8192;  // one read per 256-thread workgroup, 32 KiB LDS
+constexpr u32 kMedium2Events = 32768; // one read per 1024-thread workgroup, 128 KiB LDS
+enum { CLS_SMALL = 0, CLS_MED1 = 1, CLS_MED2 = 2, CLS_GENERAL = 3, CLS_COUNT = 4 };
+
+// Device-side counters written by the plan kernel and the sweeps.
+struct Counters {
+    u32 n[CLS_COUNT];        // reads per class (general also receives reads rejected by a sweep)
+    u32 pad0[4];
+    u64 iv[CLS_COUNT];       // intervals per class (plan kernel only)
+    u32 rejected;            // reads a sweep handed to the general queue
+    u32 region_overflow;     // compaction ran out of bad_regions capacity
+    u32 pad1[2];
+};
+
+struct SweepArgs {
+    const u64 *off;      // [R+1]
+    const uint2 *iv;     // [I] (start,end)
+    const u32 *len;      // [R]
+    const u32 *list;     // read ids of this class
+    const u32 *list_n;   // device-side count
+    u32 cov;
+    uint2 *stage;        // per-read slot of n+2 regions at off[r] + 2r
+    u32 *counts;         // [R] regions per read
+    u32 *gen_list;       // general queue (append)
+    Counters *ctr;
+};
+
+__device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
+
+// ---- wave64 inclusive scans (shuffle based; used by the workgroup-wide paths) --------------
+__device__ __forceinline__ u32 wave_incl_add(u32 v)
+{
+    const u32 lane = lane_id();
+#pragma unroll
+    for (u32 d = 1; d < 64; d <<= 1) {
+        u32 t = __shfl_up(v, d, 64);
+        if (lane >= d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ u32 wave_incl_max(u32 v)
+{
+    const u32 lane = lane_id();
+#pragma unroll
+    for (u32 d = 1; d < 64; d <<= 1) {
+        u32 t = __shfl_up(v, d, 64);
+        if (lane >= d) v = max(v, t);
+    }
+    return v;
+}
+__device__ __forceinline__ u32 wave_min(u32 v)
+{
+#pragma unroll
+    for (u32 d = 32; d > 0; d >>= 1) v = min(v, (u32)__shfl_xor(v, d, 64));
+    return v;
+}
+__device__ __forceinline__ u32 wave_max(u32 v)
+{
+#pragma unroll
+    for (u32 d = 32; d > 0; d >>= 1) v = max(v, (u32)__shfl_xor(v, d, 64));
+    return v;
+}
+__device__ __forceinline__ u32 wave_or(u32 v)
+{
+#pragma unroll
+    for (u32 d = 32; d > 0; d >>= 1) v |= (u32)__shfl_xor(v, d, 64);
+    return v;
+}
+
+// ---- workgroup-wide (T threads, T % 64 == 0) exclusive scans through LDS scratch ------------
+// `sc` needs T/64 u32.  Both calls end with a barrier so `sc` can be reused immediately.
+template <int T>
+__device__ __forceinline__ u32 block_excl_add(u32 v, u32 *sc, u32 &total)
+{
+    u32 incl = wave_incl_add(v);
+    if (T == 64) {
+        total = __shfl(incl, 63, 64);
+        return incl - v;
+    }
+    const u32 wid = threadIdx.x >> 6;
+    if (lane_id() == 63) sc[wid] = incl;
+    __syncthreads();
+    u32 base = 0, tot = 0;
+#pragma unroll
+    for (u32 w = 0; w < T / 64; w++) {
+        u32 x = sc[w];
+        if (w < wid) base += x;
+        tot += x;
+    }
+    __syncthreads();
+    total = tot;
+    return base + incl - v;
+}
+template <int T>
+__device__ __forceinline__ u32 block_excl_max(u32 v, u32 *sc, u32 &total)
+{
+    u32 incl = wave_incl_max(v);
+    u32 prev = __shfl_up(incl, 1, 64);
+    if (lane_id() == 0) prev = 0;
+    if (T == 64) {
+        total = __shfl(incl, 63, 64);
+        return prev;
+    }
+    const u32 wid = threadIdx.x >> 6;
+    if (lane_id() == 63) sc[wid] = incl;
+    __syncthreads();
+    u32 base = 0, tot = 0;
+#pragma unroll
+    for (u32 w = 0; w < T / 64; w++) {
+        u32 x = sc[w];
+        if (w < wid) base = max(base, x);
+        tot = max(tot, x);
+    }
+    __syncthreads();
+    total = tot;
+    return max(base, prev);
+}
+template <int T>
+__device__ __forceinline__ u32 block_min(u32 v, u32 *sc)
+{
+    v = wave_min(v);
+    if (T == 64) return v;
+    if (lane_id() == 0) sc[threadIdx.x >> 6] = v;
+    __syncthreads();
+    u32 r = kNoKey;
+#pragma unroll
+    for (u32 w = 0; w < T / 64; w++) r = min(r, sc[w]);
+    __syncthreads();
+    return r;
+}
+template <int T>
+__device__ __forceinline__ u32 block_max(u32 v, u32 *sc)
+{
+    v = wave_max(v);
+    if (T == 64) return v;
+    if (lane_id() == 0) sc[threadIdx.x >> 6] = v;
+    __syncthreads();
+    u32 r = 0;
+#pragma unroll
+    for (u32 w = 0; w < T / 64; w++) r = max(r, sc[w]);
+    __syncthreads();
+    return r;
+}
+
+// ---- final assembly shared by every regular-read sweep --------------------------------------
+// After the event sweep a read is described by:
+//   g      closed regions already written to slot[0..g)
+//   mf_t   key of the last flagged end (0 = none);   ml_t  key of the last low start
+//   min_ge smallest flagged tail end >= len (kNoKey = none)
+// This reproduces reference src/stack.rs:93-113 (tail loop, prepend, append) and the part of
+// the equal-begin merge (:119-136) that touches the last region.  Returns the region count.
+__device__ __forceinline__ u32 finish_read(uint2 *slot, u32 g, u32 mf_t, u32 ml_t, u32 min_ge,
+                                           u32 len)
+{
+    const u32 lcf = (min_ge != kNoKey) ? min_ge : (mf_t >> 1);
+    if (ml_t > mf_t) { // the last low start comes after the last flagged end: open run
+        const u32 b = mf_t >> 1, e = ml_t >> 1;
+        if (mf_t == 0) { // nothing ever exceeded the coverage threshold
+            if (e != 0 && len != 0) slot[g++] = make_uint2(0, max(e, len));
+            else if (e != 0) slot[g++] = make_uint2(0, e);
+            else if (len != 0) slot[g++] = make_uint2(0, len);
+        } else {
+            slot[g++] = make_uint2(b, (lcf != len) ? max(e, len) : e);
+        }
+    } else if (lcf != len) {
+        slot[g++] = make_uint2(lcf, len);
+    }
+    return g;
+}
+
+} // namespace yk

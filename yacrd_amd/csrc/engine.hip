@@ -1,0 +1,550 @@
+// engine.hip — C ABI of include/yacrd_engine.h: buffer management, launch sequence, timing.
+//
+// Launch sequence per run (one HIP stream per engine, no host sync until the end):
+//   memset(counters, counts) -> plan -> sweep_small -> sweep_med1 -> sweep_med2
+//   -> [speculative] count_block_sums -> scan_block_sums -> compact_classify -> sync
+//   if the general queue is non-empty (huge or degenerate reads): gather sizes, lay out the
+//   scratch, sweep_general, redo the scan/compact.  If bad_regions was too small: grow, redo.
+#include "../../include/yacrd_engine.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "device_common.h"
+#include "plan_compact.h"
+#include "sweep_general.h"
+#include "sweep_lds.h"
+#include "sweep_wave.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return fail(_e == hipErrorOutOfMemory ? YACRD_ENOMEM : YACRD_ENODEV,               \
+                        std::string(#expr) + ": " + hipGetErrorString(_e));                   \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            e = hipMalloc(&p, bytes);
+            want = bytes;
+        }
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T *as() const
+    {
+        return reinterpret_cast<T *>(p);
+    }
+};
+
+enum { EV_START = 0, EV_PLAN, EV_SMALL, EV_MED1, EV_MED2, EV_COMPACT0, EV_GEN0, EV_GEN1, EV_END, EV_COUNT };
+
+} // namespace
+
+struct yacrd_engine {
+    int device = 0;
+    uint32_t flags = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[EV_COUNT] = {};
+    hipEvent_t ev_h2d0 = nullptr, ev_h2d1 = nullptr, ev_d2h0 = nullptr, ev_d2h1 = nullptr;
+    int num_cu = 256;
+
+    // inputs staged by yacrd_engine_run
+    DevBuf in_off, in_iv, in_len;
+    // work buffers
+    DevBuf lists, counters, stage, counts, block_sums, gen_sizes, gen_scratch_off, gen_scratch;
+    // results
+    DevBuf bad_offsets, bad_regions, read_type;
+    yk::Counters *h_ctr = nullptr; // pinned
+    uint64_t *h_total = nullptr;   // pinned
+
+    uint64_t last_reads = 0, last_regions = 0;
+    bool has_result = false;
+    yacrd_timing timing = {};
+};
+
+namespace {
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+        else prev = -1;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+float ev_ms(hipEvent_t a, hipEvent_t b)
+{
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0.f;
+    return ms;
+}
+
+int launch_compact(yacrd_engine *e, const u64 *d_off, const u32 *d_len, u32 n_reads, double not_cov)
+{
+    const u32 nb = (n_reads + yk::kScanBlock - 1) / yk::kScanBlock;
+    hipLaunchKernelGGL(yk::count_block_sums_kernel, dim3(nb), dim3(yk::kScanBlock), 0, e->stream,
+                       e->counts.as<u32>(), n_reads, e->block_sums.as<u64>());
+    hipLaunchKernelGGL(yk::scan_block_sums_kernel, dim3(1), dim3(yk::kScanBlock), 0, e->stream,
+                       e->block_sums.as<u64>(), nb);
+    hipLaunchKernelGGL(yk::compact_classify_kernel, dim3(nb), dim3(yk::kScanBlock), 0, e->stream,
+                       d_off, d_len, e->stage.as<uint2>(), e->counts.as<u32>(),
+                       e->block_sums.as<u64>(), n_reads, not_cov, e->bad_offsets.as<u64>(),
+                       e->bad_regions.as<uint2>(), (u64)(e->bad_regions.cap / sizeof(uint2)),
+                       e->read_type.as<uint8_t>(), e->counters.as<yk::Counters>());
+    HIP_TRY(hipMemcpyAsync(e->h_total, e->block_sums.as<u64>() + nb, sizeof(u64),
+                           hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(e->h_ctr, e->counters.p, sizeof(yk::Counters), hipMemcpyDeviceToHost,
+                           e->stream));
+    return YACRD_OK;
+}
+
+int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u32 *d_len,
+                  uint64_t n_reads64, uint64_t n_iv, uint32_t cov, double not_cov)
+{
+    if (n_reads64 >= 0xFFFFFFFFull) return fail(YACRD_EINVAL, "n_reads must be < 2^32 - 1");
+    const u32 n_reads = (u32)n_reads64;
+    e->has_result = false;
+    e->timing = yacrd_timing{};
+
+    HIP_TRY(e->bad_offsets.reserve((n_reads64 + 1) * sizeof(u64)));
+    if (n_reads == 0) {
+        HIP_TRY(hipMemsetAsync(e->bad_offsets.p, 0, sizeof(u64), e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        e->last_reads = 0;
+        e->last_regions = 0;
+        e->has_result = true;
+        return YACRD_OK;
+    }
+
+    const u32 nb = (n_reads + yk::kScanBlock - 1) / yk::kScanBlock;
+    HIP_TRY(e->lists.reserve((size_t)yk::CLS_COUNT * n_reads * sizeof(u32)));
+    HIP_TRY(e->counters.reserve(sizeof(yk::Counters)));
+    HIP_TRY(e->stage.reserve((size_t)(n_iv + 2 * n_reads64) * sizeof(uint2)));
+    HIP_TRY(e->counts.reserve((size_t)n_reads * sizeof(u32)));
+    HIP_TRY(e->block_sums.reserve((size_t)(nb + 1) * sizeof(u64)));
+    HIP_TRY(e->read_type.reserve((size_t)n_reads));
+    if (e->bad_regions.cap < (size_t)(4 * n_reads64 + 1024) * sizeof(uint2))
+        HIP_TRY(e->bad_regions.reserve((size_t)(4 * n_reads64 + 1024) * sizeof(uint2)));
+
+    u32 *lists = e->lists.as<u32>();
+    yk::Counters *ctr = e->counters.as<yk::Counters>();
+
+    HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(yk::Counters), e->stream));
+    HIP_TRY(hipMemsetAsync(e->counts.p, 0, (size_t)n_reads * sizeof(u32), e->stream));
+
+    HIP_TRY(hipEventRecord(e->ev[EV_START], e->stream));
+    hipLaunchKernelGGL(yk::plan_kernel, dim3((n_reads + yk::kPlanBlock - 1) / yk::kPlanBlock),
+                       dim3(yk::kPlanBlock), 0, e->stream, d_off, n_reads, lists, ctr,
+                       (u32)((e->flags & YACRD_F_FORCE_GENERAL) ? 1 : 0));
+    HIP_TRY(hipEventRecord(e->ev[EV_PLAN], e->stream));
+
+    yk::SweepArgs sa;
+    sa.off = d_off;
+    sa.iv = d_iv;
+    sa.len = d_len;
+    sa.cov = cov;
+    sa.stage = e->stage.as<uint2>();
+    sa.counts = e->counts.as<u32>();
+    sa.gen_list = lists + (size_t)yk::CLS_GENERAL * n_reads;
+    sa.ctr = ctr;
+
+    // small class: one read per wavefront
+    sa.list = lists + (size_t)yk::CLS_SMALL * n_reads;
+    sa.list_n = &ctr->n[yk::CLS_SMALL];
+    if (e->flags & YACRD_F_FORCE_LDS_SORT) {
+        const u32 grid = (u32)std::min<uint64_t>(n_reads, (uint64_t)e->num_cu * 32);
+        hipLaunchKernelGGL((yk::sweep_lds_kernel<64, (int)yk::kSmallEvents>), dim3(grid), dim3(64),
+                           0, e->stream, sa);
+    } else {
+        yk::launch_sweep_wave(sa, n_reads, e->num_cu, e->stream);
+    }
+    HIP_TRY(hipEventRecord(e->ev[EV_SMALL], e->stream));
+
+    // medium classes: one read per workgroup, LDS resident
+    sa.list = lists + (size_t)yk::CLS_MED1 * n_reads;
+    sa.list_n = &ctr->n[yk::CLS_MED1];
+    {
+        const u32 grid = (u32)std::min<uint64_t>(n_reads, (uint64_t)e->num_cu * 4);
+        hipLaunchKernelGGL((yk::sweep_lds_kernel<256, (int)yk::kMedium1Events>), dim3(grid),
+                           dim3(256), 0, e->stream, sa);
+    }
+    HIP_TRY(hipEventRecord(e->ev[EV_MED1], e->stream));
+    sa.list = lists + (size_t)yk::CLS_MED2 * n_reads;
+    sa.list_n = &ctr->n[yk::CLS_MED2];
+    {
+        const u32 grid = (u32)std::min<uint64_t>(n_reads, (uint64_t)e->num_cu);
+        hipLaunchKernelGGL((yk::sweep_lds_kernel<1024, (int)yk::kMedium2Events>), dim3(grid),
+                           dim3(1024), 0, e->stream, sa);
+    }
+    HIP_TRY(hipEventRecord(e->ev[EV_MED2], e->stream));
+
+    // speculative compaction (right when no read needs the general path)
+    int rc = launch_compact(e, d_off, d_len, n_reads, not_cov);
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(e->ev[EV_COMPACT0], e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipGetLastError());
+
+    yk::Counters c0 = *e->h_ctr;
+    bool redo = false;
+    float gen_ms = 0.f, extra_compact_ms = 0.f;
+    if (c0.n[yk::CLS_GENERAL] > 0) {
+        const u32 ng = c0.n[yk::CLS_GENERAL];
+        HIP_TRY(e->gen_sizes.reserve((size_t)ng * sizeof(u64)));
+        HIP_TRY(e->gen_scratch_off.reserve((size_t)ng * sizeof(u64)));
+        hipLaunchKernelGGL(yk::gather_general_sizes_kernel, dim3((ng + 255) / 256), dim3(256), 0,
+                           e->stream, d_off, sa.gen_list, ng, e->gen_sizes.as<u64>());
+        std::vector<u64> sizes(ng), offs(ng);
+        HIP_TRY(hipMemcpyAsync(sizes.data(), e->gen_sizes.p, (size_t)ng * sizeof(u64),
+                               hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        u64 tot = 0, gen_iv = 0;
+        for (u32 i = 0; i < ng; i++) {
+            if (sizes[i] >= 0x7FFFFFFFull)
+                return fail(YACRD_EINVAL, "a read has >= 2^31 - 1 intervals");
+            offs[i] = tot;
+            tot += 3 * sizes[i] + 2;
+            gen_iv += sizes[i];
+        }
+        HIP_TRY(e->gen_scratch.reserve((size_t)tot * sizeof(u64)));
+        HIP_TRY(hipMemcpyAsync(e->gen_scratch_off.p, offs.data(), (size_t)ng * sizeof(u64),
+                               hipMemcpyHostToDevice, e->stream));
+        yk::GeneralArgs ga;
+        ga.off = d_off;
+        ga.iv = d_iv;
+        ga.len = d_len;
+        ga.list = sa.gen_list;
+        ga.scratch_off = e->gen_scratch_off.as<u64>();
+        ga.scratch = e->gen_scratch.as<u64>();
+        ga.cov = cov;
+        ga.stage = e->stage.as<uint2>();
+        ga.counts = e->counts.as<u32>();
+        HIP_TRY(hipEventRecord(e->ev[EV_GEN0], e->stream));
+        hipLaunchKernelGGL(yk::sweep_general_kernel, dim3(ng), dim3(yk::kGenThreads), 0, e->stream,
+                           ga);
+        HIP_TRY(hipEventRecord(e->ev[EV_GEN1], e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream)); // offs/sizes vectors must outlive the copy
+        HIP_TRY(hipGetLastError());
+        gen_ms = ev_ms(e->ev[EV_GEN0], e->ev[EV_GEN1]);
+        e->timing.iv_general = gen_iv;
+        redo = true;
+    }
+    for (int attempt = 0; attempt < 3; attempt++) {
+        if (!redo) {
+            if (!e->h_ctr->region_overflow) break;
+            HIP_TRY(e->bad_regions.reserve((size_t)(*e->h_total + 16) * sizeof(uint2)));
+        }
+        redo = false;
+        HIP_TRY(hipMemsetAsync(&ctr->region_overflow, 0, sizeof(u32), e->stream));
+        HIP_TRY(hipEventRecord(e->ev[EV_GEN0], e->stream));
+        rc = launch_compact(e, d_off, d_len, n_reads, not_cov);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(e->ev[EV_GEN1], e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipGetLastError());
+        extra_compact_ms += ev_ms(e->ev[EV_GEN0], e->ev[EV_GEN1]);
+    }
+    if (e->h_ctr->region_overflow) return fail(YACRD_EINTERNAL, "bad_regions overflow persisted");
+
+    e->last_reads = n_reads;
+    e->last_regions = *e->h_total;
+    e->has_result = true;
+
+    yacrd_timing &t = e->timing;
+    t.plan_ms = ev_ms(e->ev[EV_START], e->ev[EV_PLAN]);
+    t.sweep_small_ms = ev_ms(e->ev[EV_PLAN], e->ev[EV_SMALL]);
+    t.sweep_medium_ms = ev_ms(e->ev[EV_SMALL], e->ev[EV_MED2]);
+    t.sweep_general_ms = gen_ms;
+    t.compact_ms = ev_ms(e->ev[EV_MED2], e->ev[EV_COMPACT0]) + extra_compact_ms;
+    t.total_ms = ev_ms(e->ev[EV_START], e->ev[EV_COMPACT0]) + gen_ms + extra_compact_ms;
+    t.n_small = c0.n[yk::CLS_SMALL];
+    t.n_medium = (uint64_t)c0.n[yk::CLS_MED1] + c0.n[yk::CLS_MED2];
+    t.n_general = c0.n[yk::CLS_GENERAL];
+    t.iv_small = c0.iv[yk::CLS_SMALL];
+    t.iv_medium = c0.iv[yk::CLS_MED1] + c0.iv[yk::CLS_MED2];
+    if (!t.iv_general) t.iv_general = c0.iv[yk::CLS_GENERAL];
+    return YACRD_OK;
+}
+
+int fetch_result(yacrd_engine *e, yacrd_result *out)
+{
+    if (!out) return fail(YACRD_EINVAL, "out is null");
+    std::memset(out, 0, sizeof(*out));
+    if (!e->has_result) return fail(YACRD_EINVAL, "no result to fetch");
+    const uint64_t R = e->last_reads, G = e->last_regions;
+    out->bad_offsets = (uint64_t *)std::malloc((size_t)(R + 1) * sizeof(uint64_t));
+    out->bad_regions = (uint32_t *)std::malloc((size_t)(2 * G + 2) * sizeof(uint32_t));
+    out->read_type = (uint8_t *)std::malloc((size_t)R + 1);
+    if (!out->bad_offsets || !out->bad_regions || !out->read_type) {
+        yacrd_result_free(out);
+        return fail(YACRD_ENOMEM, "host allocation failed");
+    }
+    HIP_TRY(hipEventRecord(e->ev_d2h0, e->stream));
+    HIP_TRY(hipMemcpyAsync(out->bad_offsets, e->bad_offsets.p, (size_t)(R + 1) * sizeof(uint64_t),
+                           hipMemcpyDeviceToHost, e->stream));
+    if (G)
+        HIP_TRY(hipMemcpyAsync(out->bad_regions, e->bad_regions.p, (size_t)G * sizeof(uint2),
+                               hipMemcpyDeviceToHost, e->stream));
+    if (R)
+        HIP_TRY(hipMemcpyAsync(out->read_type, e->read_type.p, (size_t)R, hipMemcpyDeviceToHost,
+                               e->stream));
+    HIP_TRY(hipEventRecord(e->ev_d2h1, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    e->timing.d2h_ms = ev_ms(e->ev_d2h0, e->ev_d2h1);
+    out->n_reads = R;
+    out->n_regions = G;
+    return YACRD_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int yacrd_abi_version(void) { return YACRD_ABI_VERSION; }
+
+const char *yacrd_last_error(void) { return g_err.c_str(); }
+
+int yacrd_engine_create(const yacrd_engine_cfg *cfg, yacrd_engine **out)
+{
+    if (!out) return fail(YACRD_EINVAL, "out is null");
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0)
+        return fail(YACRD_ENODEV, "no HIP device visible (libyacrd_hip needs an MI355X / gfx950)");
+    int dev = cfg ? cfg->device_id : -1;
+    if (dev < 0) HIP_TRY(hipGetDevice(&dev));
+    if (dev >= count) return fail(YACRD_EINVAL, "device_id out of range");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(YACRD_ENODEV, std::string("device is ") + prop.gcnArchName +
+                                      ", this library is built for gfx950 only");
+    DeviceGuard guard(dev);
+    yacrd_engine *e = new (std::nothrow) yacrd_engine();
+    if (!e) return fail(YACRD_ENOMEM, "host allocation failed");
+    e->device = dev;
+    e->flags = cfg ? cfg->flags : 0;
+    e->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    for (int i = 0; i < EV_COUNT && err == hipSuccess; i++) err = hipEventCreate(&e->ev[i]);
+    if (err == hipSuccess) err = hipEventCreate(&e->ev_h2d0);
+    if (err == hipSuccess) err = hipEventCreate(&e->ev_h2d1);
+    if (err == hipSuccess) err = hipEventCreate(&e->ev_d2h0);
+    if (err == hipSuccess) err = hipEventCreate(&e->ev_d2h1);
+    if (err == hipSuccess) err = hipHostMalloc((void **)&e->h_ctr, sizeof(yk::Counters));
+    if (err == hipSuccess) err = hipHostMalloc((void **)&e->h_total, sizeof(uint64_t));
+    if (err != hipSuccess) {
+        yacrd_engine_destroy(e);
+        return fail(YACRD_ENODEV, std::string("engine setup: ") + hipGetErrorString(err));
+    }
+    *out = e;
+    return YACRD_OK;
+}
+
+void yacrd_engine_destroy(yacrd_engine *e)
+{
+    if (!e) return;
+    DeviceGuard guard(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    DevBuf *bufs[] = {&e->in_off, &e->in_iv, &e->in_len, &e->lists, &e->counters, &e->stage,
+                      &e->counts, &e->block_sums, &e->gen_sizes, &e->gen_scratch_off,
+                      &e->gen_scratch, &e->bad_offsets, &e->bad_regions, &e->read_type};
+    for (DevBuf *b : bufs) b->release();
+    if (e->h_ctr) (void)hipHostFree(e->h_ctr);
+    if (e->h_total) (void)hipHostFree(e->h_total);
+    for (int i = 0; i < EV_COUNT; i++)
+        if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
+    hipEvent_t extra[] = {e->ev_h2d0, e->ev_h2d1, e->ev_d2h0, e->ev_d2h1};
+    for (hipEvent_t x : extra)
+        if (x) (void)hipEventDestroy(x);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int yacrd_engine_run_device(yacrd_engine *e, const void *d_offsets, const void *d_intervals,
+                            const void *d_lengths, uint64_t n_reads, uint64_t n_intervals,
+                            uint32_t coverage, double not_coverage, yacrd_device_result *out)
+{
+    if (!e) return fail(YACRD_EINVAL, "engine is null");
+    if (n_reads && (!d_offsets || !d_lengths)) return fail(YACRD_EINVAL, "null device input");
+    if (n_intervals && !d_intervals) return fail(YACRD_EINVAL, "null device intervals");
+    DeviceGuard guard(e->device);
+    int rc = run_on_device(e, (const u64 *)d_offsets, (const uint2 *)d_intervals,
+                           (const u32 *)d_lengths, n_reads, n_intervals, coverage, not_coverage);
+    if (rc) return rc;
+    if (out) {
+        out->n_reads = e->last_reads;
+        out->n_regions = e->last_regions;
+        out->d_bad_offsets = e->bad_offsets.p;
+        out->d_bad_regions = e->bad_regions.p;
+        out->d_read_type = e->read_type.p;
+    }
+    return YACRD_OK;
+}
+
+int yacrd_engine_run(yacrd_engine *e, const uint64_t *offsets, const uint32_t *intervals,
+                     const uint32_t *lengths, uint64_t n_reads, uint32_t coverage,
+                     double not_coverage, yacrd_result *out)
+{
+    if (!e) return fail(YACRD_EINVAL, "engine is null");
+    if (!out) return fail(YACRD_EINVAL, "out is null");
+    std::memset(out, 0, sizeof(*out));
+    if (n_reads && (!offsets || !lengths)) return fail(YACRD_EINVAL, "null input");
+    const uint64_t n_iv = n_reads ? offsets[n_reads] : 0;
+    if (n_reads && offsets[0] != 0) return fail(YACRD_EINVAL, "offsets[0] must be 0");
+    for (uint64_t r = 0; r < n_reads; r++)
+        if (offsets[r + 1] < offsets[r]) return fail(YACRD_EINVAL, "offsets must be non-decreasing");
+    if (n_iv && !intervals) return fail(YACRD_EINVAL, "null intervals");
+    DeviceGuard guard(e->device);
+    HIP_TRY(e->in_off.reserve((size_t)(n_reads + 1) * sizeof(uint64_t)));
+    HIP_TRY(e->in_iv.reserve((size_t)(n_iv + 1) * sizeof(uint2)));
+    HIP_TRY(e->in_len.reserve((size_t)(n_reads + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipEventRecord(e->ev_h2d0, e->stream));
+    if (n_reads) {
+        HIP_TRY(hipMemcpyAsync(e->in_off.p, offsets, (size_t)(n_reads + 1) * sizeof(uint64_t),
+                               hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(e->in_len.p, lengths, (size_t)n_reads * sizeof(uint32_t),
+                               hipMemcpyHostToDevice, e->stream));
+    }
+    if (n_iv)
+        HIP_TRY(hipMemcpyAsync(e->in_iv.p, intervals, (size_t)n_iv * sizeof(uint2),
+                               hipMemcpyHostToDevice, e->stream));
+    HIP_TRY(hipEventRecord(e->ev_h2d1, e->stream));
+    int rc = run_on_device(e, e->in_off.as<u64>(), e->in_iv.as<uint2>(), e->in_len.as<u32>(),
+                           n_reads, n_iv, coverage, not_coverage);
+    if (rc) return rc;
+    e->timing.h2d_ms = ev_ms(e->ev_h2d0, e->ev_h2d1);
+    return fetch_result(e, out);
+}
+
+int yacrd_engine_fetch(yacrd_engine *e, yacrd_result *out)
+{
+    if (!e) return fail(YACRD_EINVAL, "engine is null");
+    DeviceGuard guard(e->device);
+    return fetch_result(e, out);
+}
+
+void yacrd_result_free(yacrd_result *r)
+{
+    if (!r) return;
+    std::free(r->bad_offsets);
+    std::free(r->bad_regions);
+    std::free(r->read_type);
+    std::memset(r, 0, sizeof(*r));
+}
+
+int yacrd_engine_last_timing(const yacrd_engine *e, yacrd_timing *t)
+{
+    if (!e || !t) return fail(YACRD_EINVAL, "null argument");
+    *t = e->timing;
+    return YACRD_OK;
+}
+
+int yacrd_partition_reads(const uint64_t *offsets, uint64_t n_reads, uint32_t n_parts,
+                          uint64_t *cuts)
+{
+    if (!cuts || n_parts == 0 || (n_reads && !offsets)) return fail(YACRD_EINVAL, "bad argument");
+    // Balance by work ~ intervals + a per-read constant (a read costs a wavefront even when tiny).
+    const uint64_t per_read = 8;
+    const uint64_t total = (n_reads ? offsets[n_reads] : 0) + per_read * n_reads;
+    cuts[0] = 0;
+    uint64_t r = 0;
+    for (uint32_t p = 1; p < n_parts; p++) {
+        const uint64_t target = total / n_parts * p + (total % n_parts) * p / n_parts;
+        uint64_t lo = r, hi = n_reads; // first read index whose prefix work >= target
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) / 2;
+            if (offsets[mid] + per_read * mid >= target) hi = mid;
+            else lo = mid + 1;
+        }
+        r = lo;
+        cuts[p] = r;
+    }
+    cuts[n_parts] = n_reads;
+    return YACRD_OK;
+}
+
+int yacrd_engine_classify(yacrd_engine *e, const uint64_t *bad_offsets, const uint32_t *bad_regions,
+                          const uint32_t *lengths, uint64_t n_reads, double not_coverage,
+                          uint8_t *read_type)
+{
+    if (!e) return fail(YACRD_EINVAL, "engine is null");
+    if (n_reads == 0) return YACRD_OK;
+    if (!bad_offsets || !lengths || !read_type) return fail(YACRD_EINVAL, "null argument");
+    if (n_reads >= 0xFFFFFFFFull) return fail(YACRD_EINVAL, "n_reads must be < 2^32 - 1");
+    const uint64_t G = bad_offsets[n_reads];
+    if (G && !bad_regions) return fail(YACRD_EINVAL, "null regions");
+    DeviceGuard guard(e->device);
+    DevBuf d_off, d_reg, d_len, d_type;
+    int rc = YACRD_OK;
+    auto body = [&]() -> int {
+        HIP_TRY(d_off.reserve((size_t)(n_reads + 1) * sizeof(u64)));
+        HIP_TRY(d_reg.reserve((size_t)(G + 1) * sizeof(uint2)));
+        HIP_TRY(d_len.reserve((size_t)n_reads * sizeof(u32)));
+        HIP_TRY(d_type.reserve((size_t)n_reads));
+        HIP_TRY(hipMemcpyAsync(d_off.p, bad_offsets, (size_t)(n_reads + 1) * sizeof(u64),
+                               hipMemcpyHostToDevice, e->stream));
+        if (G)
+            HIP_TRY(hipMemcpyAsync(d_reg.p, bad_regions, (size_t)G * sizeof(uint2),
+                                   hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(d_len.p, lengths, (size_t)n_reads * sizeof(u32),
+                               hipMemcpyHostToDevice, e->stream));
+        hipLaunchKernelGGL(yk::classify_csr_kernel, dim3((u32)((n_reads + 255) / 256)), dim3(256), 0,
+                           e->stream, d_off.as<u64>(), d_reg.as<uint2>(), d_len.as<u32>(),
+                           (u32)n_reads, not_coverage, d_type.as<uint8_t>());
+        HIP_TRY(hipMemcpyAsync(read_type, d_type.p, (size_t)n_reads, hipMemcpyDeviceToHost,
+                               e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipGetLastError());
+        return YACRD_OK;
+    };
+    rc = body();
+    d_off.release();
+    d_reg.release();
+    d_len.release();
+    d_type.release();
+    return rc;
+}
+
+} // extern "C"

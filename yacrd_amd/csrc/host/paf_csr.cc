@@ -1,0 +1,464 @@
+// paf_csr.cc — overlap ingest: PAF / M4 text -> the CSR the engine consumes.
+//
+// Replaces reference Reads2Ovl::init_paf / init_m4 (src/reads2ovl/mod.rs:83-145; column contract
+// src/io.rs:23-50) and FullMemory::add_overlap_and_length (src/reads2ovl/fullmemory.rs:82-90):
+//   * both reads of every record get an interval (mod.rs:108-109 / :140-141)
+//   * a read's length is the FIRST length seen for its id (fullmemory.rs:82-90)
+//   * records may carry extra columns (csv `flexible(true)`), empty lines are skipped
+//   * a short or non-numeric record is an error (the reference bails, mod.rs:93-97)
+// Reads are numbered in first-appearance order.  Parsing is chunk-parallel: each thread interns
+// ids locally, the local tables are merged in file order so numbering and the first-length rule
+// do not depend on the thread count.  csv-crate quoting ("...") is not interpreted (unpinned by
+// the reference's tests): a '"' is an ordinary byte here.
+#include "../../../include/yacrd_host.h"
+#include "host_common.h"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <atomic>
+#include <cerrno>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace yh {
+std::string &err_slot()
+{
+    thread_local std::string s;
+    return s;
+}
+} // namespace yh
+
+struct yacrd_csr {
+    std::vector<uint64_t> offsets;
+    std::vector<uint32_t> intervals;
+    std::vector<uint32_t> lengths;
+    std::vector<uint64_t> name_off;
+    std::vector<char> names;
+    uint64_t n_records = 0;
+    std::vector<uint32_t> table; // open addressing over read ids (value = id + 1)
+    uint64_t mask = 0;
+};
+
+namespace {
+
+enum { FMT_AUTO = 0, FMT_PAF = 1, FMT_M4 = 2 };
+
+struct Rec {
+    uint32_t a, b, sa, ea, sb, eb;
+};
+
+// Interning table local to one chunk.
+struct Names {
+    std::vector<char> arena;
+    std::vector<uint64_t> off;  // start of each name in arena
+    std::vector<uint32_t> nlen; // name length
+    std::vector<uint64_t> hash;
+    std::vector<uint64_t> rlen; // first length seen
+    std::vector<uint32_t> table;
+    uint64_t mask = 0;
+
+    void init(size_t cap_pow2)
+    {
+        table.assign(cap_pow2, 0);
+        mask = cap_pow2 - 1;
+    }
+    void grow()
+    {
+        std::vector<uint32_t> nt(table.size() * 2, 0);
+        const uint64_t nm = nt.size() - 1;
+        for (uint32_t id = 0; id < off.size(); id++) {
+            uint64_t s = hash[id] & nm;
+            while (nt[s]) s = (s + 1) & nm;
+            nt[s] = id + 1;
+        }
+        table.swap(nt);
+        mask = nm;
+    }
+    uint32_t intern(const char *p, size_t n, uint64_t h, uint64_t length)
+    {
+        uint64_t s = h & mask;
+        while (uint32_t v = table[s]) {
+            const uint32_t id = v - 1;
+            if (hash[id] == h && nlen[id] == n && std::memcmp(arena.data() + off[id], p, n) == 0)
+                return id;
+            s = (s + 1) & mask;
+        }
+        const uint32_t id = (uint32_t)off.size();
+        table[s] = id + 1;
+        off.push_back(arena.size());
+        nlen.push_back((uint32_t)n);
+        hash.push_back(h);
+        rlen.push_back(length);
+        arena.insert(arena.end(), p, p + n);
+        if ((off.size() + 1) * 2 > table.size()) grow();
+        return id;
+    }
+};
+
+struct Chunk {
+    const char *begin = nullptr, *end = nullptr;
+    Names names;
+    std::vector<Rec> recs;
+    std::vector<uint32_t> l2g;
+    std::string error;
+    uint64_t error_line = 0; // 1-based within chunk
+    uint64_t lines = 0;
+};
+
+inline bool parse_u64(const char *p, const char *e, uint64_t &out)
+{
+    if (p < e && *p == '+') p++;
+    if (p == e) return false;
+    uint64_t v = 0;
+    for (; p < e; p++) {
+        const unsigned d = (unsigned char)*p - '0';
+        if (d > 9) return false;
+        if (v > (0xFFFFFFFFFFFFFFFFull - d) / 10) return false;
+        v = v * 10 + d;
+    }
+    out = v;
+    return true;
+}
+inline bool parse_u32(const char *p, const char *e, uint32_t &out)
+{
+    uint64_t v;
+    if (!parse_u64(p, e, v) || v > 0xFFFFFFFFull) return false;
+    out = (uint32_t)v;
+    return true;
+}
+inline bool is_one_char(const char *p, const char *e)
+{ // serde `char`: exactly one UTF-8 scalar
+    if (p == e) return false;
+    const unsigned char c = (unsigned char)*p;
+    const int n = c < 0x80 ? 1 : (c >> 5) == 6 ? 2 : (c >> 4) == 14 ? 3 : (c >> 3) == 30 ? 4 : 0;
+    return n != 0 && e - p == n;
+}
+
+void parse_chunk(Chunk &c, int format)
+{
+    const char delim = format == FMT_PAF ? '\t' : ' ';
+    const int need = format == FMT_PAF ? 9 : 12;
+    c.names.init(1 << 12);
+    c.recs.reserve((size_t)(c.end - c.begin) / 96 + 16);
+    const char *p = c.begin;
+    const char *fb[12], *fe[12];
+    while (p < c.end) {
+        const char *eol = (const char *)std::memchr(p, '\n', (size_t)(c.end - p));
+        if (!eol) eol = c.end;
+        const char *le = eol;
+        if (le > p && le[-1] == '\r') le--;
+        c.lines++;
+        if (le == p) { // csv skips empty lines
+            p = eol + 1;
+            continue;
+        }
+        int nf = 0;
+        const char *q = p;
+        while (nf < need) {
+            const char *d = (const char *)std::memchr(q, delim, (size_t)(le - q));
+            fb[nf] = q;
+            fe[nf] = d ? d : le;
+            nf++;
+            if (!d) break;
+            q = d + 1;
+        }
+        bool ok = nf == need;
+        Rec r{};
+        uint64_t la = 0, lb = 0;
+        int ia = 0, ib = 0;
+        if (ok && format == FMT_PAF) { // src/io.rs:23-34
+            ia = 0;
+            ib = 5;
+            ok = parse_u64(fb[1], fe[1], la) && parse_u32(fb[2], fe[2], r.sa) &&
+                 parse_u32(fb[3], fe[3], r.ea) && is_one_char(fb[4], fe[4]) &&
+                 parse_u64(fb[6], fe[6], lb) && parse_u32(fb[7], fe[7], r.sb) &&
+                 parse_u32(fb[8], fe[8], r.eb);
+        } else if (ok) { // src/io.rs:36-50: a b err shared sa ba ea la sb bb eb lb
+            ia = 0;
+            ib = 1;
+            uint64_t shared;
+            char *endp = nullptr;
+            std::string errf(fb[2], fe[2]);
+            errno = 0;
+            (void)std::strtod(errf.c_str(), &endp);
+            ok = !errf.empty() && endp && *endp == '\0' && parse_u64(fb[3], fe[3], shared) &&
+                 is_one_char(fb[4], fe[4]) && parse_u32(fb[5], fe[5], r.sa) &&
+                 parse_u32(fb[6], fe[6], r.ea) && parse_u64(fb[7], fe[7], la) &&
+                 is_one_char(fb[8], fe[8]) && parse_u32(fb[9], fe[9], r.sb) &&
+                 parse_u32(fb[10], fe[10], r.eb) && parse_u64(fb[11], fe[11], lb);
+        }
+        if (ok && (la > 0xFFFFFFFFull || lb > 0xFFFFFFFFull)) {
+            c.error = "read length >= 2^32 is not supported by the engine";
+            c.error_line = c.lines;
+            return;
+        }
+        if (!ok) {
+            c.error = format == FMT_PAF ? "Reading of the file in paf format failed"
+                                        : "Reading of the file in m4 format failed";
+            c.error_line = c.lines;
+            return;
+        }
+        const size_t na = (size_t)(fe[ia] - fb[ia]), nb = (size_t)(fe[ib] - fb[ib]);
+        r.a = c.names.intern(fb[ia], na, yh::hash_bytes(fb[ia], na), la);
+        r.b = c.names.intern(fb[ib], nb, yh::hash_bytes(fb[ib], nb), lb);
+        c.recs.push_back(r);
+        p = eol + 1;
+    }
+}
+
+int build(const char *text, size_t len, int format, int n_threads, yacrd_csr **out)
+{
+    if (format != FMT_PAF && format != FMT_M4) return yh::fail("unknown overlap format");
+    if (n_threads <= 0) n_threads = (int)std::thread::hardware_concurrency();
+    if (n_threads <= 0) n_threads = 1;
+    size_t want = len / (4u << 20) + 1; // >= 4 MiB of text per chunk
+    const size_t T = std::min<size_t>((size_t)n_threads, want);
+
+    std::vector<Chunk> chunks(T);
+    {
+        const char *p = text, *end = text + len;
+        for (size_t t = 0; t < T; t++) {
+            chunks[t].begin = p;
+            const char *q = (t + 1 == T) ? end : text + len / T * (t + 1);
+            if (q < p) q = p;
+            if (t + 1 != T) {
+                const char *nl = (const char *)std::memchr(q, '\n', (size_t)(end - q));
+                q = nl ? nl + 1 : end;
+            }
+            chunks[t].end = q;
+            p = q;
+        }
+    }
+    {
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < T; t++) th.emplace_back(parse_chunk, std::ref(chunks[t]), format);
+        parse_chunk(chunks[0], format);
+        for (auto &x : th) x.join();
+    }
+    uint64_t line0 = 0;
+    for (size_t t = 0; t < T; t++) {
+        if (!chunks[t].error.empty())
+            return yh::fail(chunks[t].error + " (line " +
+                            std::to_string(line0 + chunks[t].error_line) + ")");
+        line0 += chunks[t].lines;
+    }
+
+    // ---- merge local id tables in file order: global numbering = first appearance ----------
+    yacrd_csr *c = new yacrd_csr();
+    {
+        size_t est = 0;
+        for (auto &ch : chunks) est = std::max(est, ch.names.off.size());
+        size_t cap = 1024;
+        while (cap < est * 4) cap <<= 1;
+        c->table.assign(cap, 0);
+        c->mask = cap - 1;
+    }
+    std::vector<uint64_t> ghash;
+    auto grow = [&]() {
+        std::vector<uint32_t> nt(c->table.size() * 2, 0);
+        const uint64_t nm = nt.size() - 1;
+        for (uint32_t id = 0; id < ghash.size(); id++) {
+            uint64_t s = ghash[id] & nm;
+            while (nt[s]) s = (s + 1) & nm;
+            nt[s] = id + 1;
+        }
+        c->table.swap(nt);
+        c->mask = nm;
+    };
+    c->name_off.push_back(0);
+    for (auto &ch : chunks) {
+        Names &ln = ch.names;
+        ch.l2g.resize(ln.off.size());
+        for (uint32_t i = 0; i < ln.off.size(); i++) {
+            const char *p = ln.arena.data() + ln.off[i];
+            const size_t n = ln.nlen[i];
+            const uint64_t h = ln.hash[i];
+            uint64_t s = h & c->mask;
+            uint32_t gid = 0xFFFFFFFFu;
+            while (uint32_t v = c->table[s]) {
+                const uint32_t id = v - 1;
+                if (ghash[id] == h && c->name_off[id + 1] - c->name_off[id] == n &&
+                    std::memcmp(c->names.data() + c->name_off[id], p, n) == 0) {
+                    gid = id;
+                    break;
+                }
+                s = (s + 1) & c->mask;
+            }
+            if (gid == 0xFFFFFFFFu) {
+                gid = (uint32_t)ghash.size();
+                c->table[s] = gid + 1;
+                ghash.push_back(h);
+                c->names.insert(c->names.end(), p, p + n);
+                c->name_off.push_back(c->names.size());
+                c->lengths.push_back((uint32_t)ln.rlen[i]); // first length seen
+                if ((ghash.size() + 1) * 2 > c->table.size()) grow();
+            }
+            ch.l2g[i] = gid;
+        }
+        std::vector<char>().swap(ln.arena);
+        std::vector<uint32_t>().swap(ln.table);
+    }
+    const uint64_t R = ghash.size();
+
+    // ---- counts -> offsets -> fill ------------------------------------------------------------
+    std::vector<std::atomic<uint64_t>> cur(R + 1);
+    for (auto &x : cur) x.store(0, std::memory_order_relaxed);
+    auto for_chunks = [&](auto fn) {
+        std::vector<std::thread> th;
+        for (size_t t = 1; t < T; t++) th.emplace_back(fn, std::ref(chunks[t]));
+        fn(chunks[0]);
+        for (auto &x : th) x.join();
+    };
+    for_chunks([&](Chunk &ch) {
+        for (Rec &r : ch.recs) {
+            r.a = ch.l2g[r.a];
+            r.b = ch.l2g[r.b];
+            cur[r.a].fetch_add(1, std::memory_order_relaxed);
+            cur[r.b].fetch_add(1, std::memory_order_relaxed);
+        }
+    });
+    c->offsets.resize(R + 1);
+    uint64_t acc = 0;
+    for (uint64_t r = 0; r < R; r++) {
+        c->offsets[r] = acc;
+        const uint64_t n = cur[r].load(std::memory_order_relaxed);
+        cur[r].store(acc, std::memory_order_relaxed);
+        acc += n;
+    }
+    c->offsets[R] = acc;
+    c->intervals.resize(2 * acc);
+    uint32_t *iv = c->intervals.data();
+    // With one chunk the fill is in line order; with several, the order inside a read depends on
+    // thread timing (results do not: the sweep sorts).
+    for_chunks([&](Chunk &ch) {
+        for (const Rec &r : ch.recs) {
+            uint64_t p = cur[r.a].fetch_add(1, std::memory_order_relaxed);
+            iv[2 * p] = r.sa;
+            iv[2 * p + 1] = r.ea;
+            p = cur[r.b].fetch_add(1, std::memory_order_relaxed);
+            iv[2 * p] = r.sb;
+            iv[2 * p + 1] = r.eb;
+        }
+    });
+    for (auto &ch : chunks) c->n_records += ch.recs.size();
+    *out = c;
+    return 0;
+}
+
+// src/util.rs:39-55 get_file_type: substring match, .m4/.mhap before .paf
+int sniff_format(const std::string &name)
+{
+    if (name.find(".m4") != std::string::npos || name.find(".mhap") != std::string::npos)
+        return FMT_M4;
+    if (name.find(".paf") != std::string::npos) return FMT_PAF;
+    return FMT_AUTO;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *yacrd_host_last_error(void) { return yh::err_slot().c_str(); }
+
+int yacrd_csr_from_memory(const char *text, size_t len, int format, int n_threads, yacrd_csr **out)
+{
+    if (!out || (!text && len)) return yh::fail("null argument");
+    *out = nullptr;
+    return build(text, len, format, n_threads, out);
+}
+
+int yacrd_csr_from_file(const char *path, int format, int n_threads, yacrd_csr **out)
+{
+    if (!out || !path) return yh::fail("null argument");
+    *out = nullptr;
+    if (format == FMT_AUTO) format = sniff_format(path);
+    if (format == FMT_AUTO)
+        return yh::fail(std::string("Format detection of file ") + path + " failed");
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) return yh::fail(std::string("Can't open file ") + path + " to read");
+    struct stat st;
+    if (fstat(fd, &st) != 0) {
+        ::close(fd);
+        return yh::fail(std::string("Can't stat ") + path);
+    }
+    unsigned char magic[6] = {0};
+    const ssize_t got = ::pread(fd, magic, sizeof magic, 0);
+    // compression is sniffed from magic bytes like niffler (src/util.rs:57-70)
+    if (got >= 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+        ::close(fd);
+        gzFile gz = gzopen(path, "rb");
+        if (!gz) return yh::fail(std::string("Can't open gzip file ") + path);
+        gzbuffer(gz, 1 << 20);
+        std::vector<char> buf;
+        size_t used = 0;
+        for (;;) {
+            if (buf.size() - used < (1u << 20)) buf.resize(buf.size() * 2 + (4u << 20));
+            const int n = gzread(gz, buf.data() + used, 1u << 20);
+            if (n < 0) {
+                gzclose(gz);
+                return yh::fail(std::string("gzip read error in ") + path);
+            }
+            if (n == 0) break;
+            used += (size_t)n;
+        }
+        gzclose(gz);
+        return build(buf.data(), used, format, n_threads, out);
+    }
+    if ((got >= 3 && magic[0] == 'B' && magic[1] == 'Z' && magic[2] == 'h') ||
+        (got >= 6 && magic[0] == 0xFD && std::memcmp(magic + 1, "7zXZ", 4) == 0)) {
+        ::close(fd);
+        return yh::fail(std::string(path) + ": bzip2/xz input is not supported in this build "
+                                             "(no bzlib.h / lzma.h in the image); decompress first");
+    }
+    if (st.st_size == 0) {
+        ::close(fd);
+        return build("", 0, format, n_threads, out);
+    }
+    void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (m == MAP_FAILED) return yh::fail(std::string("mmap failed for ") + path);
+    madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+    const int rc = build((const char *)m, (size_t)st.st_size, format, n_threads, out);
+    munmap(m, (size_t)st.st_size);
+    return rc;
+}
+
+int yacrd_csr_get(const yacrd_csr *c, yacrd_csr_view *v)
+{
+    if (!c || !v) return yh::fail("null argument");
+    v->n_reads = c->lengths.size();
+    v->n_intervals = c->offsets.empty() ? 0 : c->offsets.back();
+    v->n_records = c->n_records;
+    v->offsets = c->offsets.data();
+    v->intervals = c->intervals.data();
+    v->lengths = c->lengths.data();
+    v->name_off = c->name_off.data();
+    v->names = c->names.data();
+    return 0;
+}
+
+int64_t yacrd_csr_find(const yacrd_csr *c, const char *name, size_t n)
+{
+    if (!c || c->table.empty()) return -1;
+    const uint64_t h = yh::hash_bytes(name, n);
+    uint64_t s = h & c->mask;
+    while (uint32_t v = c->table[s]) {
+        const uint32_t id = v - 1;
+        if (c->name_off[id + 1] - c->name_off[id] == n &&
+            std::memcmp(c->names.data() + c->name_off[id], name, n) == 0)
+            return id;
+        s = (s + 1) & c->mask;
+    }
+    return -1;
+}
+
+void yacrd_csr_free(yacrd_csr *c) { delete c; }
+
+} // extern "C"

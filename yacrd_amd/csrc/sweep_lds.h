@@ -1,0 +1,171 @@
+// sweep_lds.h — one read per workgroup, events sorted in LDS.
+//
+// Replaces reference src/stack.rs:61-139 (FromOverlap::compute_bad_part) for *regular* reads
+// (every interval start < end < 2^31).  Instead of the reference's sort + binary-heap sweep it
+// uses the event formulation of DESIGN.md §3:
+//   key(start) = start<<1 | 1, key(end) = end<<1 | 0   (an end sorts before a start at the same
+//   position: the reference pops `head <= interval.0`, stack.rs:72-81)
+//   depth_before(event) = exclusive prefix sum of +1/-1 over the sorted keys
+//   end flagged   <=> depth_before > c   (stack.rs:77-79 and the tail loop :93-105)
+//   start is low  <=> depth_before <= c  (stack.rs:83)
+// A region is closed by the first flagged end after a run of low starts; its begin is the
+// previous flagged end (0 = none -> first_covered, stack.rs:84-88) and its end the last low start
+// of the run (the equal-begin merge of stack.rs:119-136 keeps exactly that one).
+// Reads with a degenerate interval are handed to the general queue untouched.
+#pragma once
+#include "device_common.h"
+
+namespace yk {
+
+template <int T>
+__device__ __forceinline__ void bitonic_sort_lds(u32 *keys, u32 P)
+{
+    for (u32 k = 2; k <= P; k <<= 1) {
+        for (u32 j = k >> 1; j > 0; j >>= 1) {
+            for (u32 p = threadIdx.x; p < (P >> 1); p += T) {
+                const u32 i = ((p & ~(j - 1)) << 1) | (p & (j - 1));
+                const u32 l = i | j;
+                const bool up = (i & k) == 0;
+                const u32 a = keys[i], b = keys[l];
+                if ((a > b) == up) {
+                    keys[i] = b;
+                    keys[l] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// T threads per read, CAP = max events (power of two, CAP % T == 0).
+template <int T, int CAP>
+__global__ __launch_bounds__(T) void sweep_lds_kernel(SweepArgs a)
+{
+    __shared__ u32 keys[CAP];
+    __shared__ u32 sc[T / 64 + 1];
+
+    const u32 tid = threadIdx.x;
+    const u32 list_n = *a.list_n;
+
+    for (u32 b = blockIdx.x; b < list_n; b += gridDim.x) {
+        const u32 r = a.list[b];
+        const u64 o = a.off[r];
+        const u32 n = (u32)(a.off[r + 1] - o);
+        const u32 len = a.len[r];
+        uint2 *slot = a.stage + (o + 2 * (u64)r);
+
+        if (n == 0) { // only reachable through add_length (stack.rs: no loop, tail empty)
+            if (tid == 0) {
+                u32 g = 0;
+                if (len != 0) slot[g++] = make_uint2(0, len);
+                a.counts[r] = g;
+            }
+            continue;
+        }
+
+        const u32 m = 2 * n;
+        u32 P = 2;
+        while (P < m) P <<= 1;
+
+        // ---- stage the read's intervals into LDS as event keys (coalesced 8 B/lane loads)
+        u32 bad = 0, max_start = 0;
+        const uint2 *iv = a.iv + o;
+        for (u32 i = tid; i < n; i += T) {
+            const uint2 v = iv[i];
+            bad |= (u32)(v.x >= v.y) | (v.y >> 31);
+            const u32 ks = (v.x << 1) | 1u;
+            keys[2 * i] = ks;
+            keys[2 * i + 1] = v.y << 1;
+            max_start = max(max_start, ks);
+        }
+        for (u32 i = m + tid; i < P; i += T) keys[i] = kNoKey;
+        bad = block_max<T>(bad, sc);
+        if (bad) { // degenerate interval: exact general path takes the read
+            if (tid == 0) {
+                const u32 idx = atomicAdd(&a.ctr->n[CLS_GENERAL], 1u);
+                a.gen_list[idx] = r;
+                atomicAdd(&a.ctr->rejected, 1u);
+            }
+            __syncthreads();
+            continue;
+        }
+        max_start = block_max<T>(max_start, sc);
+        __syncthreads();
+
+        bitonic_sort_lds<T>(keys, P);
+
+        // ---- blocked chunks: thread t owns events [t*K, t*K+K) of the sorted sequence
+        const u32 K = (P >= (u32)T) ? P / T : 1;
+        const u32 q0 = min(tid * K, m), q1 = min(q0 + K, m);
+
+        // pass A: depth carried into each chunk
+        u32 delta = 0;
+        for (u32 q = q0; q < q1; q++) delta += (keys[q] & 1u) ? 1u : 0xFFFFFFFFu;
+        u32 tot;
+        const u32 depth_in = block_excl_add<T>(delta, sc, tot);
+
+        // pass B: last flagged end / last low start per chunk -> exclusive max scans
+        u32 d = depth_in, mf = 0, ml = 0;
+        for (u32 q = q0; q < q1; q++) {
+            const u32 key = keys[q];
+            if (key & 1u) {
+                if (d <= a.cov) ml = key;
+                d++;
+            } else {
+                if (d > a.cov) mf = key;
+                d--;
+            }
+        }
+        u32 mf_t, ml_t;
+        const u32 mf_in = block_excl_max<T>(mf, sc, mf_t);
+        const u32 ml_in = block_excl_max<T>(ml, sc, ml_t);
+
+        // pass C: count the regions this chunk closes; tail rule (stack.rs:93-105)
+        u32 cnt = 0, min_ge = kNoKey;
+        d = depth_in;
+        mf = mf_in;
+        ml = ml_in;
+        for (u32 q = q0; q < q1; q++) {
+            const u32 key = keys[q];
+            if (key & 1u) {
+                if (d <= a.cov) ml = key;
+                d++;
+            } else {
+                if (d > a.cov) {
+                    if (ml > mf && !(mf == 0 && (ml >> 1) == 0)) cnt++;
+                    mf = key;
+                    if (key > max_start && (key >> 1) >= len) min_ge = min(min_ge, key >> 1);
+                }
+                d--;
+            }
+        }
+        u32 g_closed;
+        u32 pos = block_excl_add<T>(cnt, sc, g_closed);
+        min_ge = block_min<T>(min_ge, sc);
+
+        // pass D: write them, in event order
+        if (cnt) {
+            d = depth_in;
+            mf = mf_in;
+            ml = ml_in;
+            for (u32 q = q0; q < q1; q++) {
+                const u32 key = keys[q];
+                if (key & 1u) {
+                    if (d <= a.cov) ml = key;
+                    d++;
+                } else {
+                    if (d > a.cov) {
+                        if (ml > mf && !(mf == 0 && (ml >> 1) == 0))
+                            slot[pos++] = make_uint2(mf >> 1, ml >> 1);
+                        mf = key;
+                    }
+                    d--;
+                }
+            }
+        }
+        if (tid == 0) a.counts[r] = finish_read(slot, g_closed, mf_t, ml_t, min_ge, len);
+        __syncthreads(); // keys / sc reused by the next read
+    }
+}
+
+} // namespace yk

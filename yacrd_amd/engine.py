@@ -1,0 +1,238 @@
+"""ctypes binding of include/yacrd_engine.h (libyacrd_hip.so).  No CPU fallback."""
+import ctypes
+import os
+import subprocess
+from collections import namedtuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "lib", "libyacrd_hip.so")
+
+NOT_BAD, CHIMERIC, NOT_COVERED = 0, 1, 2
+TYPE_NAMES = {NOT_BAD: "NotBad", CHIMERIC: "Chimeric", NOT_COVERED: "NotCovered"}
+F_FORCE_GENERAL = 1
+F_FORCE_LDS_SORT = 2
+
+# every symbol include/yacrd_engine.h declares
+EXPORTED_SYMBOLS = [
+    "yacrd_abi_version", "yacrd_last_error", "yacrd_engine_create", "yacrd_engine_destroy",
+    "yacrd_engine_run", "yacrd_result_free", "yacrd_engine_run_device", "yacrd_engine_fetch",
+    "yacrd_engine_last_timing", "yacrd_partition_reads", "yacrd_engine_classify",
+]
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class _Cfg(ctypes.Structure):
+    _fields_ = [("device_id", ctypes.c_int32), ("flags", ctypes.c_uint32)]
+
+
+class _Result(ctypes.Structure):
+    _fields_ = [("n_reads", ctypes.c_uint64), ("n_regions", ctypes.c_uint64),
+                ("bad_offsets", ctypes.POINTER(ctypes.c_uint64)),
+                ("bad_regions", ctypes.POINTER(ctypes.c_uint32)),
+                ("read_type", ctypes.POINTER(ctypes.c_uint8))]
+
+
+class _DevResult(ctypes.Structure):
+    _fields_ = [("n_reads", ctypes.c_uint64), ("n_regions", ctypes.c_uint64),
+                ("d_bad_offsets", ctypes.c_void_p), ("d_bad_regions", ctypes.c_void_p),
+                ("d_read_type", ctypes.c_void_p)]
+
+
+class _Timing(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_float) for n in
+                ("h2d_ms", "plan_ms", "sweep_small_ms", "sweep_medium_ms", "sweep_general_ms",
+                 "compact_ms", "d2h_ms", "total_ms")] + \
+               [(n, ctypes.c_uint64) for n in
+                ("n_small", "n_medium", "n_general", "iv_small", "iv_medium", "iv_general")]
+
+
+Result = namedtuple("Result", "bad_offsets bad_regions read_type")
+
+_lib = None
+
+
+def lib_path():
+    return _LIB
+
+
+def build(force=False):
+    """Compile libyacrd_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-s", "-C", os.path.join(_HERE, "csrc")]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd)
+    return _LIB
+
+
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels bundle their own libamdhip64.so.7 (+ HSA runtime).  Two HIP runtimes in one
+    process cannot both own the GPU ("No HIP GPUs are available" for whichever comes second), so
+    when torch is installed we load ITS copy first (RTLD_GLOBAL); our DT_NEEDED libamdhip64.so.7
+    then binds to that already-loaded SONAME.  Without torch (e.g. the C++ CLI) the library uses
+    /opt/rocm's runtime through its RUNPATH.  Set YACRD_HIP_RUNTIME=system to skip this."""
+    if os.environ.get("YACRD_HIP_RUNTIME", "") == "system":
+        return None
+    import importlib.util
+    import sys
+    try:
+        if "torch" in sys.modules:
+            tdir = os.path.dirname(sys.modules["torch"].__file__)
+        else:
+            spec = importlib.util.find_spec("torch")
+            if spec is None or not spec.origin:
+                return None
+            tdir = os.path.dirname(spec.origin)
+    except (ImportError, ValueError):
+        return None
+    cand = os.path.join(tdir, "lib", "libamdhip64.so")
+    if not os.path.exists(cand):
+        return None
+    try:
+        ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    except OSError:
+        return None
+    return cand
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        raise EngineError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(there is no CPU fallback)" % _LIB)
+    _share_hip_runtime_with_torch()
+    lib = ctypes.CDLL(_LIB)
+    u64p, u32p, u8p = (ctypes.POINTER(t) for t in (ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint8))
+    lib.yacrd_abi_version.restype = ctypes.c_int
+    lib.yacrd_last_error.restype = ctypes.c_char_p
+    lib.yacrd_engine_create.argtypes = [ctypes.POINTER(_Cfg), ctypes.POINTER(ctypes.c_void_p)]
+    lib.yacrd_engine_destroy.argtypes = [ctypes.c_void_p]
+    lib.yacrd_engine_destroy.restype = None
+    lib.yacrd_engine_run.argtypes = [ctypes.c_void_p, u64p, u32p, u32p, ctypes.c_uint64,
+                                     ctypes.c_uint32, ctypes.c_double, ctypes.POINTER(_Result)]
+    lib.yacrd_result_free.argtypes = [ctypes.POINTER(_Result)]
+    lib.yacrd_result_free.restype = None
+    lib.yacrd_engine_run_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64,
+                                            ctypes.c_uint32, ctypes.c_double,
+                                            ctypes.POINTER(_DevResult)]
+    lib.yacrd_engine_fetch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_Result)]
+    lib.yacrd_engine_last_timing.argtypes = [ctypes.c_void_p, ctypes.POINTER(_Timing)]
+    lib.yacrd_partition_reads.argtypes = [u64p, ctypes.c_uint64, ctypes.c_uint32, u64p]
+    lib.yacrd_engine_classify.argtypes = [ctypes.c_void_p, u64p, u32p, u32p, ctypes.c_uint64,
+                                          ctypes.c_double, u8p]
+    _lib = lib
+    return lib
+
+
+def _check(lib, rc):
+    if rc != 0:
+        raise EngineError("yacrd engine error %d: %s" % (rc, lib.yacrd_last_error().decode()))
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(ctypes.POINTER(t))
+
+
+def _take(lib, res):
+    R, G = int(res.n_reads), int(res.n_regions)
+    bo = np.ctypeslib.as_array(res.bad_offsets, shape=(R + 1,)).copy()
+    br = (np.ctypeslib.as_array(res.bad_regions, shape=(2 * G,)).copy().reshape(-1, 2)
+          if G else np.zeros((0, 2), dtype=np.uint32))
+    rt = np.ctypeslib.as_array(res.read_type, shape=(R,)).copy() if R else np.zeros(0, np.uint8)
+    lib.yacrd_result_free(ctypes.byref(res))
+    return Result(bo, br, rt)
+
+
+def partition_reads(offsets, n_parts):
+    """Contiguous read ranges balanced by interval count; no GPU needed."""
+    lib = load_library()
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    cuts = np.zeros(n_parts + 1, dtype=np.uint64)
+    _check(lib, lib.yacrd_partition_reads(_ptr(offsets, ctypes.c_uint64), offsets.shape[0] - 1,
+                                          n_parts, _ptr(cuts, ctypes.c_uint64)))
+    return cuts
+
+
+class Engine:
+    """One engine per GPU.  Mirrors the BadPart lifecycle: run() == compute_all_bad_part()."""
+
+    def __init__(self, device_id=-1, flags=0):
+        self._lib = load_library()
+        self._h = ctypes.c_void_p()
+        cfg = _Cfg(device_id, flags)
+        _check(self._lib, self._lib.yacrd_engine_create(ctypes.byref(cfg), ctypes.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            self._lib.yacrd_engine_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def run(self, offsets, intervals, lengths, coverage, not_coverage):
+        """Host CSR in, host CSR out (H2D + kernels + D2H)."""
+        offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+        intervals = np.ascontiguousarray(intervals, dtype=np.uint32).reshape(-1)
+        lengths = np.asarray(lengths)
+        if lengths.size and int(lengths.max()) > 0xFFFFFFFF:
+            raise EngineError("read length >= 2^32 is not supported by the engine ABI")
+        lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+        n_reads = offsets.shape[0] - 1
+        if lengths.shape[0] != n_reads or intervals.shape[0] != 2 * int(offsets[-1]):
+            raise EngineError("malformed CSR")
+        res = _Result()
+        _check(self._lib, self._lib.yacrd_engine_run(
+            self._h, _ptr(offsets, ctypes.c_uint64), _ptr(intervals, ctypes.c_uint32),
+            _ptr(lengths, ctypes.c_uint32), n_reads, min(int(coverage), 0xFFFFFFFF),
+            float(not_coverage), ctypes.byref(res)))
+        return _take(self._lib, res)
+
+    def run_device(self, d_offsets, d_intervals, d_lengths, n_reads, n_intervals, coverage,
+                   not_coverage):
+        """Inputs are raw device pointers (ints).  Returns (n_regions, ptrs) without D2H."""
+        out = _DevResult()
+        _check(self._lib, self._lib.yacrd_engine_run_device(
+            self._h, d_offsets, d_intervals, d_lengths, n_reads, n_intervals,
+            min(int(coverage), 0xFFFFFFFF), float(not_coverage), ctypes.byref(out)))
+        return out
+
+    def fetch(self):
+        res = _Result()
+        _check(self._lib, self._lib.yacrd_engine_fetch(self._h, ctypes.byref(res)))
+        return _take(self._lib, res)
+
+    def timing(self):
+        t = _Timing()
+        _check(self._lib, self._lib.yacrd_engine_last_timing(self._h, ctypes.byref(t)))
+        return {n: getattr(t, n) for n, _ in _Timing._fields_}
+
+    def classify(self, bad_offsets, bad_regions, lengths, not_coverage):
+        bad_offsets = np.ascontiguousarray(bad_offsets, dtype=np.uint64)
+        bad_regions = np.ascontiguousarray(bad_regions, dtype=np.uint32).reshape(-1)
+        lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+        n_reads = lengths.shape[0]
+        out = np.zeros(max(n_reads, 1), dtype=np.uint8)
+        if bad_regions.size == 0:
+            bad_regions = np.zeros(2, dtype=np.uint32)
+        _check(self._lib, self._lib.yacrd_engine_classify(
+            self._h, _ptr(bad_offsets, ctypes.c_uint64), _ptr(bad_regions, ctypes.c_uint32),
+            _ptr(lengths, ctypes.c_uint32), n_reads, float(not_coverage),
+            _ptr(out, ctypes.c_uint8)))
+        return out[:n_reads]

@@ -1,0 +1,168 @@
+"""ctypes binding of include/yacrd_host.h (libyacrd_host.so): ingest, report, synthetic data."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "lib", "libyacrd_host.so")
+
+SYNTH_ONT, SYNTH_SEQUEL, SYNTH_SKEWED = 0, 1, 2
+FMT_AUTO, FMT_PAF, FMT_M4 = 0, 1, 2
+
+EXPORTED_SYMBOLS = [
+    "yacrd_host_last_error", "yacrd_csr_from_file", "yacrd_csr_from_memory", "yacrd_csr_get",
+    "yacrd_csr_find", "yacrd_csr_free", "yacrd_report_write", "yacrd_synth_csr", "yacrd_synth_paf",
+]
+
+
+class HostError(RuntimeError):
+    pass
+
+
+class _View(ctypes.Structure):
+    _fields_ = [("n_reads", ctypes.c_uint64), ("n_intervals", ctypes.c_uint64),
+                ("n_records", ctypes.c_uint64),
+                ("offsets", ctypes.POINTER(ctypes.c_uint64)),
+                ("intervals", ctypes.POINTER(ctypes.c_uint32)),
+                ("lengths", ctypes.POINTER(ctypes.c_uint32)),
+                ("name_off", ctypes.POINTER(ctypes.c_uint64)),
+                ("names", ctypes.POINTER(ctypes.c_char))]
+
+
+class _SynthCfg(ctypes.Structure):
+    _fields_ = [("profile", ctypes.c_uint32), ("flags", ctypes.c_uint32),
+                ("n_reads", ctypes.c_uint64), ("n_overlaps", ctypes.c_uint64),
+                ("seed", ctypes.c_uint64)]
+
+
+_lib = None
+
+
+def build(force=False):
+    cmd = ["make", "-s", "-C", os.path.join(_HERE, "csrc", "host")]
+    if force:
+        cmd.append("-B")
+    subprocess.check_call(cmd)
+    return _LIB
+
+
+def load_library():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            raise HostError("%s is missing: run __graft_entry__.build()" % _LIB)
+        lib = ctypes.CDLL(_LIB)
+        lib.yacrd_host_last_error.restype = ctypes.c_char_p
+        lib.yacrd_csr_from_file.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int,
+                                            ctypes.POINTER(ctypes.c_void_p)]
+        lib.yacrd_csr_from_memory.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int,
+                                              ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        lib.yacrd_csr_get.argtypes = [ctypes.c_void_p, ctypes.POINTER(_View)]
+        lib.yacrd_csr_find.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+        lib.yacrd_csr_find.restype = ctypes.c_int64
+        lib.yacrd_csr_free.argtypes = [ctypes.c_void_p]
+        lib.yacrd_csr_free.restype = None
+        lib.yacrd_report_write.argtypes = [ctypes.c_char_p, ctypes.POINTER(_View),
+                                           ctypes.POINTER(ctypes.c_uint64),
+                                           ctypes.POINTER(ctypes.c_uint32),
+                                           ctypes.POINTER(ctypes.c_uint8)]
+        lib.yacrd_synth_csr.argtypes = [ctypes.POINTER(_SynthCfg), ctypes.POINTER(ctypes.c_uint64),
+                                        ctypes.POINTER(ctypes.c_uint32),
+                                        ctypes.POINTER(ctypes.c_uint32)]
+        lib.yacrd_synth_paf.argtypes = [ctypes.POINTER(_SynthCfg), ctypes.c_char_p]
+        _lib = lib
+    return _lib
+
+
+def _check(lib, rc):
+    if rc != 0:
+        raise HostError(lib.yacrd_host_last_error().decode())
+
+
+class Csr:
+    """Owns a yacrd_csr; numpy views are copies so they outlive it."""
+
+    def __init__(self, handle):
+        self._lib = load_library()
+        self._h = handle
+        v = _View()
+        _check(self._lib, self._lib.yacrd_csr_get(self._h, ctypes.byref(v)))
+        self._view = v
+        R, I = int(v.n_reads), int(v.n_intervals)
+        self.n_reads, self.n_intervals, self.n_records = R, I, int(v.n_records)
+        self.offsets = np.ctypeslib.as_array(v.offsets, shape=(R + 1,)).copy()
+        self.intervals = (np.ctypeslib.as_array(v.intervals, shape=(2 * I,)).copy().reshape(-1, 2)
+                          if I else np.zeros((0, 2), np.uint32))
+        self.lengths = (np.ctypeslib.as_array(v.lengths, shape=(R,)).copy()
+                        if R else np.zeros(0, np.uint32))
+        name_off = np.ctypeslib.as_array(v.name_off, shape=(R + 1,)).copy()
+        blob = ctypes.string_at(v.names, int(name_off[-1])) if R else b""
+        self.names = [blob[int(name_off[i]):int(name_off[i + 1])].decode() for i in range(R)]
+
+    def find(self, name):
+        b = name.encode()
+        return int(self._lib.yacrd_csr_find(self._h, b, len(b)))
+
+    def write_report(self, path, bad_offsets, bad_regions, read_type):
+        bo = np.ascontiguousarray(bad_offsets, dtype=np.uint64)
+        br = np.ascontiguousarray(bad_regions, dtype=np.uint32).reshape(-1)
+        if br.size == 0:
+            br = np.zeros(2, np.uint32)
+        rt = np.ascontiguousarray(read_type, dtype=np.uint8)
+        if rt.size == 0:
+            rt = np.zeros(1, np.uint8)
+        _check(self._lib, self._lib.yacrd_report_write(
+            path.encode(), ctypes.byref(self._view),
+            bo.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
+            br.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+            rt.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8))))
+
+    def close(self):
+        if self._h:
+            self._lib.yacrd_csr_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def csr_from_file(path, fmt=FMT_AUTO, n_threads=0):
+    lib = load_library()
+    h = ctypes.c_void_p()
+    _check(lib, lib.yacrd_csr_from_file(path.encode(), fmt, n_threads, ctypes.byref(h)))
+    return Csr(h)
+
+
+def csr_from_memory(text, fmt, n_threads=0):
+    lib = load_library()
+    if isinstance(text, str):
+        text = text.encode()
+    h = ctypes.c_void_p()
+    _check(lib, lib.yacrd_csr_from_memory(text, len(text), fmt, n_threads, ctypes.byref(h)))
+    return Csr(h)
+
+
+def synth_csr(profile, n_reads, n_overlaps, seed, flags=0):
+    """Deterministic synthetic pile-up straight to CSR.
+    Returns offsets u64[R+1], intervals u32[I,2], lengths u32[R]."""
+    lib = load_library()
+    cfg = _SynthCfg(profile, flags, n_reads, n_overlaps, seed)
+    offsets = np.zeros(n_reads + 1, dtype=np.uint64)
+    intervals = np.zeros(4 * n_overlaps, dtype=np.uint32)
+    lengths = np.zeros(n_reads, dtype=np.uint32)
+    _check(lib, lib.yacrd_synth_csr(ctypes.byref(cfg),
+                                    offsets.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
+                                    intervals.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+                                    lengths.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))))
+    return offsets, intervals.reshape(-1, 2), lengths
+
+
+def synth_paf(profile, n_reads, n_overlaps, seed, path, flags=0):
+    lib = load_library()
+    cfg = _SynthCfg(profile, flags, n_reads, n_overlaps, seed)
+    _check(lib, lib.yacrd_synth_paf(ctypes.byref(cfg), path.encode()))

@@ -15,13 +15,14 @@ constexpr u32 kNoKey = 0xFFFFFFFFu;
 constexpr u32 kSmallEvents = 1024;    // one read per wavefront
 constexpr u32 kMedium1Events = 8192;  // one read per 256-thread workgroup, 32 KiB LDS
 constexpr u32 kMedium2Events = 32768; // one read per 1024-thread workgroup, 128 KiB LDS
-enum { CLS_SMALL = 0, CLS_MED1 = 1, CLS_MED2 = 2, CLS_GENERAL = 3, CLS_COUNT = 4 };
+// small class is split by keys per lane of the register sort (K = 2, 4, 8, 16)
+enum { CLS_W2 = 0, CLS_W4 = 1, CLS_W8 = 2, CLS_W16 = 3, CLS_MED1 = 4, CLS_MED2 = 5, CLS_GENERAL = 6,
+       CLS_COUNT = 7 };
 
 // Device-side counters written by the plan kernel and the sweeps.
 struct Counters {
-    u32 n[CLS_COUNT];        // reads per class (general also receives reads rejected by a sweep)
-    u32 pad0[4];
-    u64 iv[CLS_COUNT];       // intervals per class (plan kernel only)
+    u32 n[8];                // reads per class (general also receives reads rejected by a sweep)
+    u64 iv[8];               // intervals per class (plan kernel only)
     u32 rejected;            // reads a sweep handed to the general queue
     u32 region_overflow;     // compaction ran out of bad_regions capacity
     u32 pad1[2];

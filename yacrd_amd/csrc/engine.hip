@@ -189,15 +189,28 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     sa.gen_list = lists + (size_t)yk::CLS_GENERAL * n_reads;
     sa.ctr = ctr;
 
-    // small class: one read per wavefront
-    sa.list = lists + (size_t)yk::CLS_SMALL * n_reads;
-    sa.list_n = &ctr->n[yk::CLS_SMALL];
+    // small class: one read per wavefront, register sort with K keys per lane
     if (e->flags & YACRD_F_FORCE_LDS_SORT) {
-        const u32 grid = (u32)std::min<uint64_t>(n_reads, (uint64_t)e->num_cu * 32);
-        hipLaunchKernelGGL((yk::sweep_lds_kernel<64, (int)yk::kSmallEvents>), dim3(grid), dim3(64),
-                           0, e->stream, sa);
+        for (int cls = yk::CLS_W2; cls <= yk::CLS_W16; cls++) {
+            sa.list = lists + (size_t)cls * n_reads;
+            sa.list_n = &ctr->n[cls];
+            const u32 grid = (u32)std::min<uint64_t>(n_reads, (uint64_t)e->num_cu * 32);
+            hipLaunchKernelGGL((yk::sweep_lds_kernel<64, (int)yk::kSmallEvents>), dim3(grid),
+                               dim3(64), 0, e->stream, sa);
+        }
     } else {
-        yk::launch_sweep_wave(sa, n_reads, e->num_cu, e->stream);
+        sa.list = lists + (size_t)yk::CLS_W2 * n_reads;
+        sa.list_n = &ctr->n[yk::CLS_W2];
+        yk::launch_sweep_wave<2>(sa, n_reads, e->num_cu, e->stream);
+        sa.list = lists + (size_t)yk::CLS_W4 * n_reads;
+        sa.list_n = &ctr->n[yk::CLS_W4];
+        yk::launch_sweep_wave<4>(sa, n_reads, e->num_cu, e->stream);
+        sa.list = lists + (size_t)yk::CLS_W8 * n_reads;
+        sa.list_n = &ctr->n[yk::CLS_W8];
+        yk::launch_sweep_wave<8>(sa, n_reads, e->num_cu, e->stream);
+        sa.list = lists + (size_t)yk::CLS_W16 * n_reads;
+        sa.list_n = &ctr->n[yk::CLS_W16];
+        yk::launch_sweep_wave<16>(sa, n_reads, e->num_cu, e->stream);
     }
     HIP_TRY(hipEventRecord(e->ev[EV_SMALL], e->stream));
 
@@ -298,10 +311,10 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     t.sweep_general_ms = gen_ms;
     t.compact_ms = ev_ms(e->ev[EV_MED2], e->ev[EV_COMPACT0]) + extra_compact_ms;
     t.total_ms = ev_ms(e->ev[EV_START], e->ev[EV_COMPACT0]) + gen_ms + extra_compact_ms;
-    t.n_small = c0.n[yk::CLS_SMALL];
+    t.n_small = (uint64_t)c0.n[yk::CLS_W2] + c0.n[yk::CLS_W4] + c0.n[yk::CLS_W8] + c0.n[yk::CLS_W16];
     t.n_medium = (uint64_t)c0.n[yk::CLS_MED1] + c0.n[yk::CLS_MED2];
     t.n_general = c0.n[yk::CLS_GENERAL];
-    t.iv_small = c0.iv[yk::CLS_SMALL];
+    t.iv_small = c0.iv[yk::CLS_W2] + c0.iv[yk::CLS_W4] + c0.iv[yk::CLS_W8] + c0.iv[yk::CLS_W16];
     t.iv_medium = c0.iv[yk::CLS_MED1] + c0.iv[yk::CLS_MED2];
     if (!t.iv_general) t.iv_general = c0.iv[yk::CLS_GENERAL];
     return YACRD_OK;

@@ -26,7 +26,10 @@ __global__ __launch_bounds__(kPlanBlock) void plan_kernel(const u64 *off, u32 n_
         const u64 n = off[r + 1] - off[r];
         const u64 m = 2 * n;
         if (force_general) cls = CLS_GENERAL;
-        else if (m <= kSmallEvents) cls = CLS_SMALL;
+        else if (m <= 128) cls = CLS_W2;
+        else if (m <= 256) cls = CLS_W4;
+        else if (m <= 512) cls = CLS_W8;
+        else if (m <= kSmallEvents) cls = CLS_W16;
         else if (m <= kMedium1Events) cls = CLS_MED1;
         else if (m <= kMedium2Events) cls = CLS_MED2;
         else cls = CLS_GENERAL;

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--not-coverage", type=float, default=0.4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lds-sort", action="store_true", help="A/B: LDS-sort kernel for the small class")
+    ap.add_argument("--flags", type=int, default=0, help="extra YACRD_F_* engine flags (A/B)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -70,7 +71,7 @@ def main():
     d_len = torch.from_numpy(lengths.view(np.int32)).to(dev)
     torch.cuda.synchronize()
 
-    flags = yacrd_amd.F_FORCE_LDS_SORT if args.lds_sort else 0
+    flags = (yacrd_amd.F_FORCE_LDS_SORT if args.lds_sort else 0) | args.flags
     eng = yacrd_amd.Engine(device_id=local_rank, flags=flags)
 
     def step():

@@ -60,6 +60,8 @@ typedef struct {
 #define YACRD_F_FORCE_GENERAL 1u
 /* use the LDS-sort kernel for the small class instead of the register-sort kernel; A/B only */
 #define YACRD_F_FORCE_LDS_SORT 2u
+/* cross-lane exchanges of the register sort all through the LDS crossbar (ds_swizzle); A/B only */
+#define YACRD_F_XLANE_DS 4u
 
 /* Host-side result, allocated by the engine, released with yacrd_result_free(). */
 typedef struct {

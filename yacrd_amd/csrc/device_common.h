@@ -21,11 +21,15 @@ enum { CLS_W2 = 0, CLS_W4 = 1, CLS_W8 = 2, CLS_W16 = 3, CLS_MED1 = 4, CLS_MED2 =
 
 // Device-side counters written by the plan kernel and the sweeps.
 struct Counters {
-    u32 n[8];                // reads per class (general also receives reads rejected by a sweep)
-    u64 iv[8];               // intervals per class (plan kernel only)
-    u32 rejected;            // reads a sweep handed to the general queue
+    u32 n[8];                // reads per class (plan kernel)
+    u64 iv[8];               // intervals per class (plan kernel)
+    u32 rej_small;           // reads with a degenerate interval found by a wave sweep (n <= 512)
+    u32 rej_med;             // ... by the 256-thread LDS sweep (n <= 4096)
+    u32 rej_big;             // ... by the 1024-thread LDS sweep (n <= 16384): global-memory path
     u32 region_overflow;     // compaction ran out of bad_regions capacity
-    u32 pad1[2];
+    u32 scan_ticket;         // dynamic workgroup id of the single-pass scan
+    u32 pad1[3];
+    u64 total_regions;       // G, written by the last scan workgroup
 };
 
 struct SweepArgs {
@@ -37,7 +41,8 @@ struct SweepArgs {
     u32 cov;
     uint2 *stage;        // per-read slot of n+2 regions at off[r] + 2r
     u32 *counts;         // [R] regions per read
-    u32 *gen_list;       // general queue (append)
+    u32 *rej_list;       // reads this sweep cannot take (degenerate interval): append here
+    u32 *rej_count;
     Counters *ctr;
 };
 

@@ -1,10 +1,10 @@
 // engine.hip — C ABI of include/yacrd_engine.h: buffer management, launch sequence, timing.
 //
-// Launch sequence per run (one HIP stream per engine, no host sync until the end):
-//   memset(counters, counts) -> plan -> sweep_small -> sweep_med1 -> sweep_med2
-//   -> [speculative] count_block_sums -> scan_block_sums -> compact_classify -> sync
-//   if the general queue is non-empty (huge or degenerate reads): gather sizes, lay out the
-//   scratch, sweep_general, redo the scan/compact.  If bad_regions was too small: grow, redo.
+// Launch sequence per run (one HIP stream per engine):
+//   memset(ctrl) -> plan -> [sync: class counts] -> sweeps of the non-empty classes
+//   -> exact general path (LDS scratch for rejected reads; global scratch for huge reads)
+//   -> compact_classify (single-pass scan) -> sync.
+//   Rare redo: degenerate reads too large for LDS, or bad_regions too small.
 #include "../../include/yacrd_engine.h"
 
 #include <hip/hip_runtime.h>
@@ -71,7 +71,7 @@ struct DevBuf {
     }
 };
 
-enum { EV_START = 0, EV_PLAN, EV_SMALL, EV_MED1, EV_MED2, EV_COMPACT0, EV_GEN0, EV_GEN1, EV_END, EV_COUNT };
+enum { EV_START = 0, EV_PLAN, EV_S0, EV_SMALL, EV_MED, EV_GEN, EV_COMPACT, EV_X0, EV_X1, EV_COUNT };
 
 } // namespace
 
@@ -86,11 +86,10 @@ struct yacrd_engine {
     // inputs staged by yacrd_engine_run
     DevBuf in_off, in_iv, in_len;
     // work buffers
-    DevBuf lists, counters, stage, counts, block_sums, gen_sizes, gen_scratch_off, gen_scratch;
+    DevBuf lists, ctrl, stage, counts, gen_sizes, gen_scratch_off, gen_scratch;
     // results
     DevBuf bad_offsets, bad_regions, read_type;
     yk::Counters *h_ctr = nullptr; // pinned
-    uint64_t *h_total = nullptr;   // pinned
 
     uint64_t last_reads = 0, last_regions = 0;
     bool has_result = false;
@@ -120,22 +119,55 @@ float ev_ms(hipEvent_t a, hipEvent_t b)
     return ms;
 }
 
+// scan + compact + classify: one kernel (decoupled look-back), then the totals come home.
 int launch_compact(yacrd_engine *e, const u64 *d_off, const u32 *d_len, u32 n_reads, double not_cov)
 {
     const u32 nb = (n_reads + yk::kScanBlock - 1) / yk::kScanBlock;
-    hipLaunchKernelGGL(yk::count_block_sums_kernel, dim3(nb), dim3(yk::kScanBlock), 0, e->stream,
-                       e->counts.as<u32>(), n_reads, e->block_sums.as<u64>());
-    hipLaunchKernelGGL(yk::scan_block_sums_kernel, dim3(1), dim3(yk::kScanBlock), 0, e->stream,
-                       e->block_sums.as<u64>(), nb);
+    yk::Counters *ctr = e->ctrl.as<yk::Counters>();
+    u64 *scan_state = reinterpret_cast<u64 *>(ctr + 1);
     hipLaunchKernelGGL(yk::compact_classify_kernel, dim3(nb), dim3(yk::kScanBlock), 0, e->stream,
-                       d_off, d_len, e->stage.as<uint2>(), e->counts.as<u32>(),
-                       e->block_sums.as<u64>(), n_reads, not_cov, e->bad_offsets.as<u64>(),
-                       e->bad_regions.as<uint2>(), (u64)(e->bad_regions.cap / sizeof(uint2)),
-                       e->read_type.as<uint8_t>(), e->counters.as<yk::Counters>());
-    HIP_TRY(hipMemcpyAsync(e->h_total, e->block_sums.as<u64>() + nb, sizeof(u64),
-                           hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipMemcpyAsync(e->h_ctr, e->counters.p, sizeof(yk::Counters), hipMemcpyDeviceToHost,
-                           e->stream));
+                       d_off, d_len, e->stage.as<uint2>(), e->counts.as<u32>(), scan_state, n_reads,
+                       not_cov, e->bad_offsets.as<u64>(), e->bad_regions.as<uint2>(),
+                       (u64)(e->bad_regions.cap / sizeof(uint2)), e->read_type.as<uint8_t>(), ctr);
+    HIP_TRY(hipMemcpyAsync(e->h_ctr, ctr, sizeof(yk::Counters), hipMemcpyDeviceToHost, e->stream));
+    return YACRD_OK;
+}
+
+// Global-memory exact path over `count` reads listed at d_list (host knows the count).
+int run_general_global(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u32 *d_len,
+                       const u32 *d_list, u32 count, u32 cov, hipStream_t stream, u64 *iv_total)
+{
+    HIP_TRY(e->gen_sizes.reserve((size_t)count * sizeof(u64)));
+    HIP_TRY(e->gen_scratch_off.reserve((size_t)count * sizeof(u64)));
+    hipLaunchKernelGGL(yk::gather_general_sizes_kernel, dim3((count + 255) / 256), dim3(256), 0,
+                       stream, d_off, d_list, count, e->gen_sizes.as<u64>());
+    std::vector<u64> sizes(count), offs(count);
+    HIP_TRY(hipMemcpyAsync(sizes.data(), e->gen_sizes.p, (size_t)count * sizeof(u64),
+                           hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    u64 tot = 0, gen_iv = 0;
+    for (u32 i = 0; i < count; i++) {
+        if (sizes[i] >= 0x7FFFFFFFull) return fail(YACRD_EINVAL, "a read has >= 2^31 - 1 intervals");
+        offs[i] = tot;
+        tot += 3 * sizes[i] + 2;
+        gen_iv += sizes[i];
+    }
+    if (iv_total) *iv_total = gen_iv;
+    HIP_TRY(e->gen_scratch.reserve((size_t)tot * sizeof(u64)));
+    HIP_TRY(hipMemcpyAsync(e->gen_scratch_off.p, offs.data(), (size_t)count * sizeof(u64),
+                           hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream)); // `offs` must outlive the copy
+    yk::GeneralArgs ga;
+    ga.off = d_off;
+    ga.iv = d_iv;
+    ga.len = d_len;
+    ga.list = d_list;
+    ga.scratch_off = e->gen_scratch_off.as<u64>();
+    ga.scratch = e->gen_scratch.as<u64>();
+    ga.cov = cov;
+    ga.stage = e->stage.as<uint2>();
+    ga.counts = e->counts.as<u32>();
+    hipLaunchKernelGGL(yk::sweep_general_kernel, dim3(count), dim3(yk::kGenThreads), 0, stream, ga);
     return YACRD_OK;
 }
 
@@ -158,26 +190,33 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     }
 
     const u32 nb = (n_reads + yk::kScanBlock - 1) / yk::kScanBlock;
-    HIP_TRY(e->lists.reserve((size_t)yk::CLS_COUNT * n_reads * sizeof(u32)));
-    HIP_TRY(e->counters.reserve(sizeof(yk::Counters)));
+    constexpr int kLists = yk::CLS_COUNT + 3; // class lists + three rejection lists
+    HIP_TRY(e->lists.reserve((size_t)kLists * n_reads * sizeof(u32)));
+    const size_t ctrl_bytes = sizeof(yk::Counters) + (size_t)nb * sizeof(u64);
+    HIP_TRY(e->ctrl.reserve(ctrl_bytes));
     HIP_TRY(e->stage.reserve((size_t)(n_iv + 2 * n_reads64) * sizeof(uint2)));
     HIP_TRY(e->counts.reserve((size_t)n_reads * sizeof(u32)));
-    HIP_TRY(e->block_sums.reserve((size_t)(nb + 1) * sizeof(u64)));
     HIP_TRY(e->read_type.reserve((size_t)n_reads));
     if (e->bad_regions.cap < (size_t)(4 * n_reads64 + 1024) * sizeof(uint2))
         HIP_TRY(e->bad_regions.reserve((size_t)(4 * n_reads64 + 1024) * sizeof(uint2)));
 
     u32 *lists = e->lists.as<u32>();
-    yk::Counters *ctr = e->counters.as<yk::Counters>();
+    auto list_of = [&](int i) { return lists + (size_t)i * n_reads; };
+    u32 *rej_small = list_of(yk::CLS_COUNT), *rej_med = list_of(yk::CLS_COUNT + 1),
+        *rej_big = list_of(yk::CLS_COUNT + 2);
+    yk::Counters *ctr = e->ctrl.as<yk::Counters>();
 
-    HIP_TRY(hipMemsetAsync(ctr, 0, sizeof(yk::Counters), e->stream));
-    HIP_TRY(hipMemsetAsync(e->counts.p, 0, (size_t)n_reads * sizeof(u32), e->stream));
-
+    // ---- plan: bin reads by size class; the host needs the class counts to launch only what
+    // exists (an empty launch costs ~4 us, there are seven classes)
+    HIP_TRY(hipMemsetAsync(ctr, 0, ctrl_bytes, e->stream));
     HIP_TRY(hipEventRecord(e->ev[EV_START], e->stream));
     hipLaunchKernelGGL(yk::plan_kernel, dim3((n_reads + yk::kPlanBlock - 1) / yk::kPlanBlock),
                        dim3(yk::kPlanBlock), 0, e->stream, d_off, n_reads, lists, ctr,
                        (u32)((e->flags & YACRD_F_FORCE_GENERAL) ? 1 : 0));
     HIP_TRY(hipEventRecord(e->ev[EV_PLAN], e->stream));
+    HIP_TRY(hipMemcpyAsync(e->h_ctr, ctr, sizeof(yk::Counters), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    const yk::Counters c0 = *e->h_ctr;
 
     yk::SweepArgs sa;
     sa.off = d_off;
@@ -186,137 +225,137 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     sa.cov = cov;
     sa.stage = e->stage.as<uint2>();
     sa.counts = e->counts.as<u32>();
-    sa.gen_list = lists + (size_t)yk::CLS_GENERAL * n_reads;
     sa.ctr = ctr;
 
-    // small class: one read per wavefront, register sort with K keys per lane
-    if (e->flags & YACRD_F_FORCE_LDS_SORT) {
-        for (int cls = yk::CLS_W2; cls <= yk::CLS_W16; cls++) {
-            sa.list = lists + (size_t)cls * n_reads;
-            sa.list_n = &ctr->n[cls];
-            const u32 grid = (u32)std::min<uint64_t>(n_reads, (uint64_t)e->num_cu * 32);
+    // ---- small classes: one read per wavefront, register sort with K keys per lane
+    HIP_TRY(hipEventRecord(e->ev[EV_S0], e->stream));
+    sa.rej_list = rej_small;
+    sa.rej_count = &ctr->rej_small;
+    const int xm = (e->flags & YACRD_F_XLANE_DS) ? 1 : 0;
+    bool any_small = false;
+    for (int cls = yk::CLS_W2; cls <= yk::CLS_W16; cls++) {
+        if (!c0.n[cls]) continue;
+        any_small = true;
+        sa.list = list_of(cls);
+        sa.list_n = &ctr->n[cls];
+        if (e->flags & YACRD_F_FORCE_LDS_SORT) {
+            const u32 grid = (u32)std::min<uint64_t>(c0.n[cls], (uint64_t)e->num_cu * 32);
             hipLaunchKernelGGL((yk::sweep_lds_kernel<64, (int)yk::kSmallEvents>), dim3(grid),
                                dim3(64), 0, e->stream, sa);
+        } else if (cls == yk::CLS_W2) {
+            yk::launch_sweep_wave<2>(sa, c0.n[cls], e->num_cu, e->stream, xm);
+        } else if (cls == yk::CLS_W4) {
+            yk::launch_sweep_wave<4>(sa, c0.n[cls], e->num_cu, e->stream, xm);
+        } else if (cls == yk::CLS_W8) {
+            yk::launch_sweep_wave<8>(sa, c0.n[cls], e->num_cu, e->stream, xm);
+        } else {
+            yk::launch_sweep_wave<16>(sa, c0.n[cls], e->num_cu, e->stream, xm);
         }
-    } else {
-        sa.list = lists + (size_t)yk::CLS_W2 * n_reads;
-        sa.list_n = &ctr->n[yk::CLS_W2];
-        yk::launch_sweep_wave<2>(sa, n_reads, e->num_cu, e->stream);
-        sa.list = lists + (size_t)yk::CLS_W4 * n_reads;
-        sa.list_n = &ctr->n[yk::CLS_W4];
-        yk::launch_sweep_wave<4>(sa, n_reads, e->num_cu, e->stream);
-        sa.list = lists + (size_t)yk::CLS_W8 * n_reads;
-        sa.list_n = &ctr->n[yk::CLS_W8];
-        yk::launch_sweep_wave<8>(sa, n_reads, e->num_cu, e->stream);
-        sa.list = lists + (size_t)yk::CLS_W16 * n_reads;
-        sa.list_n = &ctr->n[yk::CLS_W16];
-        yk::launch_sweep_wave<16>(sa, n_reads, e->num_cu, e->stream);
     }
     HIP_TRY(hipEventRecord(e->ev[EV_SMALL], e->stream));
 
-    // medium classes: one read per workgroup, LDS resident
-    sa.list = lists + (size_t)yk::CLS_MED1 * n_reads;
-    sa.list_n = &ctr->n[yk::CLS_MED1];
-    {
-        const u32 grid = (u32)std::min<uint64_t>(n_reads, (uint64_t)e->num_cu * 4);
+    // ---- medium classes: one read per workgroup, LDS resident
+    if (c0.n[yk::CLS_MED1]) {
+        sa.list = list_of(yk::CLS_MED1);
+        sa.list_n = &ctr->n[yk::CLS_MED1];
+        sa.rej_list = rej_med;
+        sa.rej_count = &ctr->rej_med;
+        const u32 grid = (u32)std::min<uint64_t>(c0.n[yk::CLS_MED1], (uint64_t)e->num_cu * 4);
         hipLaunchKernelGGL((yk::sweep_lds_kernel<256, (int)yk::kMedium1Events>), dim3(grid),
                            dim3(256), 0, e->stream, sa);
     }
-    HIP_TRY(hipEventRecord(e->ev[EV_MED1], e->stream));
-    sa.list = lists + (size_t)yk::CLS_MED2 * n_reads;
-    sa.list_n = &ctr->n[yk::CLS_MED2];
-    {
-        const u32 grid = (u32)std::min<uint64_t>(n_reads, (uint64_t)e->num_cu);
+    if (c0.n[yk::CLS_MED2]) {
+        sa.list = list_of(yk::CLS_MED2);
+        sa.list_n = &ctr->n[yk::CLS_MED2];
+        sa.rej_list = rej_big;
+        sa.rej_count = &ctr->rej_big;
+        const u32 grid = (u32)std::min<uint64_t>(c0.n[yk::CLS_MED2], (uint64_t)e->num_cu);
         hipLaunchKernelGGL((yk::sweep_lds_kernel<1024, (int)yk::kMedium2Events>), dim3(grid),
                            dim3(1024), 0, e->stream, sa);
     }
-    HIP_TRY(hipEventRecord(e->ev[EV_MED2], e->stream));
+    HIP_TRY(hipEventRecord(e->ev[EV_MED], e->stream));
 
-    // speculative compaction (right when no read needs the general path)
+    // ---- exact general path
+    // (a) reads a sweep rejected (degenerate interval), scratch in LDS, no host round trip
+    if (any_small) {
+        sa.list = rej_small;
+        sa.list_n = &ctr->rej_small;
+        sa.rej_list = rej_med; // cannot happen (n <= 512), kept well defined
+        sa.rej_count = &ctr->rej_med;
+        hipLaunchKernelGGL((yk::sweep_general_lds_kernel<256, 512>), dim3(e->num_cu * 2), dim3(256),
+                           0, e->stream, sa);
+    }
+    if (c0.n[yk::CLS_MED1]) {
+        sa.list = rej_med;
+        sa.list_n = &ctr->rej_med;
+        sa.rej_list = rej_big;
+        sa.rej_count = &ctr->rej_big;
+        hipLaunchKernelGGL((yk::sweep_general_lds_kernel<1024, 4096>), dim3(e->num_cu), dim3(1024),
+                           0, e->stream, sa);
+    }
+    // (b) reads too large for LDS (or every read under YACRD_F_FORCE_GENERAL): global scratch
+    u64 gen_iv = 0;
+    if (c0.n[yk::CLS_GENERAL]) {
+        int rc = run_general_global(e, d_off, d_iv, d_len, list_of(yk::CLS_GENERAL),
+                                    c0.n[yk::CLS_GENERAL], cov, e->stream, &gen_iv);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipEventRecord(e->ev[EV_GEN], e->stream));
+
+    // ---- follow-on kernel: scan + compact + classify
     int rc = launch_compact(e, d_off, d_len, n_reads, not_cov);
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(e->ev[EV_COMPACT0], e->stream));
+    HIP_TRY(hipEventRecord(e->ev[EV_COMPACT], e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipGetLastError());
 
-    yk::Counters c0 = *e->h_ctr;
+    // ---- rare slow paths: degenerate reads too large for the LDS exact path; region overflow
+    float extra_ms = 0.f;
+    u32 n_rej_big = e->h_ctr->rej_big;
     bool redo = false;
-    float gen_ms = 0.f, extra_compact_ms = 0.f;
-    if (c0.n[yk::CLS_GENERAL] > 0) {
-        const u32 ng = c0.n[yk::CLS_GENERAL];
-        HIP_TRY(e->gen_sizes.reserve((size_t)ng * sizeof(u64)));
-        HIP_TRY(e->gen_scratch_off.reserve((size_t)ng * sizeof(u64)));
-        hipLaunchKernelGGL(yk::gather_general_sizes_kernel, dim3((ng + 255) / 256), dim3(256), 0,
-                           e->stream, d_off, sa.gen_list, ng, e->gen_sizes.as<u64>());
-        std::vector<u64> sizes(ng), offs(ng);
-        HIP_TRY(hipMemcpyAsync(sizes.data(), e->gen_sizes.p, (size_t)ng * sizeof(u64),
-                               hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        u64 tot = 0, gen_iv = 0;
-        for (u32 i = 0; i < ng; i++) {
-            if (sizes[i] >= 0x7FFFFFFFull)
-                return fail(YACRD_EINVAL, "a read has >= 2^31 - 1 intervals");
-            offs[i] = tot;
-            tot += 3 * sizes[i] + 2;
-            gen_iv += sizes[i];
-        }
-        HIP_TRY(e->gen_scratch.reserve((size_t)tot * sizeof(u64)));
-        HIP_TRY(hipMemcpyAsync(e->gen_scratch_off.p, offs.data(), (size_t)ng * sizeof(u64),
-                               hipMemcpyHostToDevice, e->stream));
-        yk::GeneralArgs ga;
-        ga.off = d_off;
-        ga.iv = d_iv;
-        ga.len = d_len;
-        ga.list = sa.gen_list;
-        ga.scratch_off = e->gen_scratch_off.as<u64>();
-        ga.scratch = e->gen_scratch.as<u64>();
-        ga.cov = cov;
-        ga.stage = e->stage.as<uint2>();
-        ga.counts = e->counts.as<u32>();
-        HIP_TRY(hipEventRecord(e->ev[EV_GEN0], e->stream));
-        hipLaunchKernelGGL(yk::sweep_general_kernel, dim3(ng), dim3(yk::kGenThreads), 0, e->stream,
-                           ga);
-        HIP_TRY(hipEventRecord(e->ev[EV_GEN1], e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream)); // offs/sizes vectors must outlive the copy
-        HIP_TRY(hipGetLastError());
-        gen_ms = ev_ms(e->ev[EV_GEN0], e->ev[EV_GEN1]);
-        e->timing.iv_general = gen_iv;
+    if (n_rej_big) {
+        HIP_TRY(hipEventRecord(e->ev[EV_X0], e->stream));
+        rc = run_general_global(e, d_off, d_iv, d_len, rej_big, n_rej_big, cov, e->stream, nullptr);
+        if (rc) return rc;
         redo = true;
     }
     for (int attempt = 0; attempt < 3; attempt++) {
         if (!redo) {
             if (!e->h_ctr->region_overflow) break;
-            HIP_TRY(e->bad_regions.reserve((size_t)(*e->h_total + 16) * sizeof(uint2)));
+            HIP_TRY(e->bad_regions.reserve((size_t)(e->h_ctr->total_regions + 16) * sizeof(uint2)));
+            HIP_TRY(hipEventRecord(e->ev[EV_X0], e->stream));
         }
         redo = false;
-        HIP_TRY(hipMemsetAsync(&ctr->region_overflow, 0, sizeof(u32), e->stream));
-        HIP_TRY(hipEventRecord(e->ev[EV_GEN0], e->stream));
+        // reset the scan state, the ticket and the overflow flag (keep the class counters)
+        HIP_TRY(hipMemsetAsync(&ctr->region_overflow, 0, 2 * sizeof(u32), e->stream));
+        HIP_TRY(hipMemsetAsync(ctr + 1, 0, (size_t)nb * sizeof(u64), e->stream));
         rc = launch_compact(e, d_off, d_len, n_reads, not_cov);
         if (rc) return rc;
-        HIP_TRY(hipEventRecord(e->ev[EV_GEN1], e->stream));
+        HIP_TRY(hipEventRecord(e->ev[EV_X1], e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
         HIP_TRY(hipGetLastError());
-        extra_compact_ms += ev_ms(e->ev[EV_GEN0], e->ev[EV_GEN1]);
+        extra_ms += ev_ms(e->ev[EV_X0], e->ev[EV_X1]);
     }
     if (e->h_ctr->region_overflow) return fail(YACRD_EINTERNAL, "bad_regions overflow persisted");
 
+    const yk::Counters c1 = *e->h_ctr;
     e->last_reads = n_reads;
-    e->last_regions = *e->h_total;
+    e->last_regions = c1.total_regions;
     e->has_result = true;
 
     yacrd_timing &t = e->timing;
     t.plan_ms = ev_ms(e->ev[EV_START], e->ev[EV_PLAN]);
-    t.sweep_small_ms = ev_ms(e->ev[EV_PLAN], e->ev[EV_SMALL]);
-    t.sweep_medium_ms = ev_ms(e->ev[EV_SMALL], e->ev[EV_MED2]);
-    t.sweep_general_ms = gen_ms;
-    t.compact_ms = ev_ms(e->ev[EV_MED2], e->ev[EV_COMPACT0]) + extra_compact_ms;
-    t.total_ms = ev_ms(e->ev[EV_START], e->ev[EV_COMPACT0]) + gen_ms + extra_compact_ms;
+    t.sweep_small_ms = ev_ms(e->ev[EV_S0], e->ev[EV_SMALL]);
+    t.sweep_medium_ms = ev_ms(e->ev[EV_SMALL], e->ev[EV_MED]);
+    t.sweep_general_ms = ev_ms(e->ev[EV_MED], e->ev[EV_GEN]);
+    t.compact_ms = ev_ms(e->ev[EV_GEN], e->ev[EV_COMPACT]);
+    t.total_ms = t.plan_ms + ev_ms(e->ev[EV_S0], e->ev[EV_COMPACT]) + extra_ms;
     t.n_small = (uint64_t)c0.n[yk::CLS_W2] + c0.n[yk::CLS_W4] + c0.n[yk::CLS_W8] + c0.n[yk::CLS_W16];
     t.n_medium = (uint64_t)c0.n[yk::CLS_MED1] + c0.n[yk::CLS_MED2];
-    t.n_general = c0.n[yk::CLS_GENERAL];
+    t.n_general = (uint64_t)c0.n[yk::CLS_GENERAL] + c1.rej_small + c1.rej_med + c1.rej_big;
     t.iv_small = c0.iv[yk::CLS_W2] + c0.iv[yk::CLS_W4] + c0.iv[yk::CLS_W8] + c0.iv[yk::CLS_W16];
     t.iv_medium = c0.iv[yk::CLS_MED1] + c0.iv[yk::CLS_MED2];
-    if (!t.iv_general) t.iv_general = c0.iv[yk::CLS_GENERAL];
+    t.iv_general = c0.iv[yk::CLS_GENERAL];
     return YACRD_OK;
 }
 
@@ -386,7 +425,6 @@ int yacrd_engine_create(const yacrd_engine_cfg *cfg, yacrd_engine **out)
     if (err == hipSuccess) err = hipEventCreate(&e->ev_d2h0);
     if (err == hipSuccess) err = hipEventCreate(&e->ev_d2h1);
     if (err == hipSuccess) err = hipHostMalloc((void **)&e->h_ctr, sizeof(yk::Counters));
-    if (err == hipSuccess) err = hipHostMalloc((void **)&e->h_total, sizeof(uint64_t));
     if (err != hipSuccess) {
         yacrd_engine_destroy(e);
         return fail(YACRD_ENODEV, std::string("engine setup: ") + hipGetErrorString(err));
@@ -400,12 +438,11 @@ void yacrd_engine_destroy(yacrd_engine *e)
     if (!e) return;
     DeviceGuard guard(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    DevBuf *bufs[] = {&e->in_off, &e->in_iv, &e->in_len, &e->lists, &e->counters, &e->stage,
-                      &e->counts, &e->block_sums, &e->gen_sizes, &e->gen_scratch_off,
+    DevBuf *bufs[] = {&e->in_off, &e->in_iv, &e->in_len, &e->lists, &e->ctrl, &e->stage,
+                      &e->counts, &e->gen_sizes, &e->gen_scratch_off,
                       &e->gen_scratch, &e->bad_offsets, &e->bad_regions, &e->read_type};
     for (DevBuf *b : bufs) b->release();
     if (e->h_ctr) (void)hipHostFree(e->h_ctr);
-    if (e->h_total) (void)hipHostFree(e->h_total);
     for (int i = 0; i < EV_COUNT; i++)
         if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
     hipEvent_t extra[] = {e->ev_h2d0, e->ev_h2d1, e->ev_d2h0, e->ev_d2h1};

@@ -45,46 +45,7 @@ __global__ __launch_bounds__(kPlanBlock) void plan_kernel(const u64 *off, u32 n_
     if (r < n_reads) lists[(u64)cls * n_reads + s_base[cls] + local] = r;
 }
 
-// ---- bad_offsets = exclusive scan of per-read region counts (three small kernels) -----------
 constexpr int kScanBlock = 1024;
-
-__global__ __launch_bounds__(kScanBlock) void count_block_sums_kernel(const u32 *counts,
-                                                                      u32 n_reads, u64 *block_sums)
-{
-    __shared__ u32 sc[kScanBlock / 64];
-    const u32 r = blockIdx.x * kScanBlock + threadIdx.x;
-    u32 v = (r < n_reads) ? counts[r] : 0u;
-    u32 tot;
-    block_excl_add<kScanBlock>(v, sc, tot);
-    if (threadIdx.x == 0) block_sums[blockIdx.x] = tot;
-}
-
-// single workgroup: in-place exclusive scan of block_sums[nb]; total -> block_sums[nb]
-__global__ __launch_bounds__(kScanBlock) void scan_block_sums_kernel(u64 *block_sums, u32 nb)
-{
-    __shared__ u64 sh[kScanBlock];
-    __shared__ u64 carry_s;
-    if (threadIdx.x == 0) carry_s = 0;
-    __syncthreads();
-    for (u32 base = 0; base < nb; base += kScanBlock) {
-        const u32 i = base + threadIdx.x;
-        const u64 v = (i < nb) ? block_sums[i] : 0;
-        sh[threadIdx.x] = v;
-        __syncthreads();
-        for (u32 d = 1; d < kScanBlock; d <<= 1) { // Hillis-Steele, inclusive
-            u64 t = (threadIdx.x >= d) ? sh[threadIdx.x - d] : 0;
-            __syncthreads();
-            sh[threadIdx.x] += t;
-            __syncthreads();
-        }
-        const u64 carry = carry_s;
-        if (i < nb) block_sums[i] = carry + sh[threadIdx.x] - v;
-        __syncthreads();
-        if (threadIdx.x == kScanBlock - 1) carry_s = carry + sh[kScanBlock - 1];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) block_sums[nb] = carry_s;
-}
 
 // ---- follow-on kernel: compact each read's regions into the CSR and tag the read ------------
 // Classification is reference src/editor/mod.rs:85-100 (type_of_read): u32 wrapping sum of
@@ -95,18 +56,50 @@ __device__ __forceinline__ u32 classify(u32 bad, bool middle_gap, u32 len, doubl
     return middle_gap ? 1u : 0u;                        // YACRD_CHIMERIC : YACRD_NOT_BAD
 }
 
+// bad_offsets is the exclusive scan of the per-read region counts: single pass, decoupled
+// look-back over workgroup aggregates.  scan_state[i] = flag<<62 | value, flag 1 = aggregate of
+// workgroup i, 2 = inclusive prefix through workgroup i (one 64-bit word, so relaxed agent-scope
+// atomics are enough); workgroup ids come from a ticket so a predecessor is always running.
 __global__ __launch_bounds__(kScanBlock) void compact_classify_kernel(
-    const u64 *off, const u32 *len, const uint2 *stage, const u32 *counts, const u64 *block_base,
+    const u64 *off, const u32 *len, const uint2 *stage, const u32 *counts, u64 *scan_state,
     u32 n_reads, double not_cov, u64 *bad_offsets, uint2 *bad_regions, u64 region_cap,
     uint8_t *read_type, Counters *ctr)
 {
     __shared__ u32 sc[kScanBlock / 64];
-    const u32 r = blockIdx.x * kScanBlock + threadIdx.x;
+    __shared__ u32 s_bid;
+    __shared__ u64 s_base;
+    if (threadIdx.x == 0) s_bid = atomicAdd(&ctr->scan_ticket, 1u);
+    __syncthreads();
+    const u32 bid = s_bid;
+    const u32 r = bid * kScanBlock + threadIdx.x;
     const u32 g = (r < n_reads) ? counts[r] : 0u;
     u32 tot;
     const u32 local = block_excl_add<kScanBlock>(g, sc, tot);
+    if (threadIdx.x == 0) {
+        constexpr u64 kAgg = 1ull << 62, kPre = 2ull << 62, kVal = (1ull << 62) - 1;
+        u64 base = 0;
+        if (bid > 0) {
+            __hip_atomic_store(&scan_state[bid], kAgg | tot, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            for (u32 i = bid; i-- > 0;) {
+                u64 v;
+                do {
+                    v = __hip_atomic_load(&scan_state[i], __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT);
+                    if (!(v >> 62)) __builtin_amdgcn_s_sleep(1);
+                } while (!(v >> 62));
+                base += v & kVal;
+                if ((v >> 62) == 2) break;
+            }
+        }
+        __hip_atomic_store(&scan_state[bid], kPre | (base + tot), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        s_base = base;
+        if ((u64)(bid + 1) * kScanBlock >= n_reads) ctr->total_regions = base + tot;
+    }
+    __syncthreads();
     if (r >= n_reads) return;
-    const u64 dst = block_base[blockIdx.x] + local;
+    const u64 dst = s_base + local;
     bad_offsets[r] = dst;
     if (r == n_reads - 1) bad_offsets[n_reads] = dst + g;
 

@@ -74,35 +74,23 @@ __device__ __forceinline__ void bitonic_sort_global_u64(u64 *a, u32 n)
     }
 }
 
-__global__ __launch_bounds__(kGenThreads) void sweep_general_kernel(GeneralArgs a)
+// One read, T threads, scratch K[n+2] / EV[2n] of u64 anywhere (global memory or LDS).
+template <int T>
+__device__ __forceinline__ void general_read(const uint2 *iv, u32 n, u32 len, u32 cov, uint2 *slot,
+                                             u32 *count_out, u64 *K, u64 *EV, u32 *sc, u32 *s_misc)
 {
-    constexpr int T = kGenThreads;
-    __shared__ u32 sc[T / 64];
-    __shared__ u32 s_misc[4];
-
     const u32 tid = threadIdx.x;
-    const u32 r = a.list[blockIdx.x];
-    const u64 o = a.off[r];
-    const u32 n = (u32)(a.off[r + 1] - o);
-    const u32 len = a.len[r];
-    const u32 cov = a.cov;
-    uint2 *slot = a.stage + (o + 2 * (u64)r);
-
     if (n == 0) {
         if (tid == 0) {
             u32 g = 0;
             if (len != 0) slot[g++] = make_uint2(0, len);
-            a.counts[r] = g;
+            *count_out = g;
         }
         return;
     }
-
-    u64 *K = a.scratch + a.scratch_off[blockIdx.x];
-    u64 *EV = K + (n + 2);
     const u32 M = 2 * n;
 
     // 1. interval keys
-    const uint2 *iv = a.iv + o;
     for (u32 i = tid; i < n; i += T) {
         const uint2 v = iv[i];
         K[i] = ((u64)v.x << 32) | v.y;
@@ -235,7 +223,47 @@ __global__ __launch_bounds__(kGenThreads) void sweep_general_kernel(GeneralArgs 
             slot[w++] = make_uint2(cur.x, e);
         }
     }
-    if (tid == 0) a.counts[r] = g;
+    if (tid == 0) *count_out = g;
+    __syncthreads(); // scratch may be reused by the caller's next read
+}
+
+// Global-memory scratch: any read size.  One workgroup per list entry.
+__global__ __launch_bounds__(kGenThreads) void sweep_general_kernel(GeneralArgs a)
+{
+    __shared__ u32 sc[kGenThreads / 64];
+    __shared__ u32 s_misc[4];
+    const u32 r = a.list[blockIdx.x];
+    const u64 o = a.off[r];
+    const u32 n = (u32)(a.off[r + 1] - o);
+    u64 *K = a.scratch + a.scratch_off[blockIdx.x];
+    general_read<kGenThreads>(a.iv + o, n, a.len[r], a.cov, a.stage + (o + 2 * (u64)r),
+                              a.counts + r, K, K + (n + 2), sc, s_misc);
+}
+
+// LDS scratch: the exact path for reads a sweep rejected (degenerate interval), without a host
+// round trip.  T threads per read, reads of at most CAPN intervals; grid-strides over the
+// device-side rejection list.  Reads larger than CAPN are forwarded to `big_list`.
+template <int T, int CAPN>
+__global__ __launch_bounds__(T) void sweep_general_lds_kernel(SweepArgs a)
+{
+    __shared__ u64 scratch[3 * CAPN + 2];
+    __shared__ u32 sc[T / 64 + 1];
+    __shared__ u32 s_misc[4];
+    const u32 list_n = *a.list_n;
+    for (u32 b = blockIdx.x; b < list_n; b += gridDim.x) {
+        const u32 r = a.list[b];
+        const u64 o = a.off[r];
+        const u32 n = (u32)(a.off[r + 1] - o);
+        if (n > (u32)CAPN) {
+            if (threadIdx.x == 0) {
+                a.rej_list[atomicAdd(a.rej_count, 1u)] = r;
+                a.counts[r] = 0;
+            }
+            continue;
+        }
+        general_read<T>(a.iv + o, n, a.len[r], a.cov, a.stage + (o + 2 * (u64)r), a.counts + r,
+                        scratch, scratch + (n + 2), sc, s_misc);
+    }
 }
 
 // n per general read, for the host-side scratch layout

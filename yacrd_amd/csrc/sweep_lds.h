@@ -82,9 +82,8 @@ __global__ __launch_bounds__(T) void sweep_lds_kernel(SweepArgs a)
         bad = block_max<T>(bad, sc);
         if (bad) { // degenerate interval: exact general path takes the read
             if (tid == 0) {
-                const u32 idx = atomicAdd(&a.ctr->n[CLS_GENERAL], 1u);
-                a.gen_list[idx] = r;
-                atomicAdd(&a.ctr->rejected, 1u);
+                a.rej_list[atomicAdd(a.rej_count, 1u)] = r;
+                a.counts[r] = 0; // keeps the compaction well defined until the exact path ran
             }
             __syncthreads();
             continue;

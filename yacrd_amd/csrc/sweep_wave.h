@@ -30,16 +30,17 @@ constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114,
               DPP_ROW_SHR8 = 0x118, DPP_WAVE_SHR1 = 0x138, DPP_BCAST15 = 0x142,
               DPP_BCAST31 = 0x143;
 
-// value of lane ^ D
-template <int D>
+// value of lane ^ D.  XM (cross-lane mode): 0 = DPP for xor 1/2/8, LDS crossbar for 4/16/32;
+// 1 = LDS crossbar (ds_swizzle / ds_bpermute) for every stride (fewest VALU instructions).
+template <int D, int XM>
 __device__ __forceinline__ u32 lane_xor(u32 x, u32 bperm_addr32)
 {
-    if constexpr (D == 1) return (u32)__builtin_amdgcn_mov_dpp((int)x, DPP_XOR1, 0xF, 0xF, false);
+    if constexpr (D == 32) return (u32)__builtin_amdgcn_ds_bpermute((int)bperm_addr32, (int)x);
+    else if constexpr (XM == 1 || D == 4 || D == 16)
+        return (u32)__builtin_amdgcn_ds_swizzle((int)x, (D << 10) | 0x1F);
+    else if constexpr (D == 1) return (u32)__builtin_amdgcn_mov_dpp((int)x, DPP_XOR1, 0xF, 0xF, false);
     else if constexpr (D == 2) return (u32)__builtin_amdgcn_mov_dpp((int)x, DPP_XOR2, 0xF, 0xF, false);
-    else if constexpr (D == 4) return (u32)__builtin_amdgcn_ds_swizzle((int)x, 0x101F);
-    else if constexpr (D == 8) return (u32)__builtin_amdgcn_mov_dpp((int)x, DPP_ROR8, 0xF, 0xF, false);
-    else if constexpr (D == 16) return (u32)__builtin_amdgcn_ds_swizzle((int)x, 0x401F);
-    else return (u32)__builtin_amdgcn_ds_bpermute((int)bperm_addr32, (int)x);
+    else return (u32)__builtin_amdgcn_mov_dpp((int)x, DPP_ROR8, 0xF, 0xF, false);
 }
 
 // wave64 inclusive scans on DPP (row_shr 1/2/4/8, row_bcast 15/31); identity 0
@@ -74,7 +75,7 @@ struct LaneConst {
 constexpr int ilog2c(int v) { return v <= 1 ? 0 : 1 + ilog2c(v >> 1); }
 
 // ---- bitonic sort of 64*K keys held as x[K] per lane, element index = lane*K + r ------------
-template <int K, int M, int J>
+template <int K, int M, int J, int XM>
 __device__ __forceinline__ void bitonic_step(u32 (&x)[K], const LaneConst &lc)
 {
     constexpr int P = 64 * K;
@@ -85,7 +86,7 @@ __device__ __forceinline__ void bitonic_step(u32 (&x)[K], const LaneConst &lc)
         const u32 sel = lc.k[ilog2c(D)] ^ dirm; // ~0: this lane keeps the larger key
 #pragma unroll
         for (int r = 0; r < K; r++) {
-            const u32 t = lane_xor<D>(x[r], lc.addr32);
+            const u32 t = lane_xor<D, XM>(x[r], lc.addr32);
             x[r] = umed3(x[r], t, sel);
         }
     } else { // partner in another register of the same lane
@@ -108,22 +109,22 @@ __device__ __forceinline__ void bitonic_step(u32 (&x)[K], const LaneConst &lc)
         }
     }
 }
-template <int K, int M, int J>
+template <int K, int M, int J, int XM>
 __device__ __forceinline__ void bitonic_level(u32 (&x)[K], const LaneConst &lc)
 {
-    bitonic_step<K, M, J>(x, lc);
-    if constexpr (J > 1) bitonic_level<K, M, J / 2>(x, lc);
+    bitonic_step<K, M, J, XM>(x, lc);
+    if constexpr (J > 1) bitonic_level<K, M, J / 2, XM>(x, lc);
 }
-template <int K, int M>
+template <int K, int M, int XM>
 __device__ __forceinline__ void bitonic_sort(u32 (&x)[K], const LaneConst &lc)
 {
-    bitonic_level<K, M, M / 2>(x, lc);
-    if constexpr (M < 64 * K) bitonic_sort<K, M * 2>(x, lc);
+    bitonic_level<K, M, M / 2, XM>(x, lc);
+    if constexpr (M < 64 * K) bitonic_sort<K, M * 2, XM>(x, lc);
 }
 
 // ---- one read, K keys per lane --------------------------------------------------------------
 // Returns false when the read has a degenerate interval (caller queues it for the general path).
-template <int K>
+template <int K, int XM>
 __device__ __forceinline__ bool sweep_wave_read(const uint2 *__restrict__ iv, u32 n, u32 len,
                                                 u32 cov, uint2 *slot, u32 *count_out,
                                                 const LaneConst &lc)
@@ -147,7 +148,7 @@ __device__ __forceinline__ bool sweep_wave_read(const uint2 *__restrict__ iv, u3
     }
     if (__builtin_amdgcn_ballot_w64(bad != 0) != 0) return false;
 
-    bitonic_sort<K, 2>(x, lc);
+    bitonic_sort<K, 2, XM>(x, lc);
 
     // ---- pass 1: depth carried into each lane
     u32 delta = 0;
@@ -229,7 +230,7 @@ __device__ __forceinline__ bool sweep_wave_read(const uint2 *__restrict__ iv, u3
 }
 
 // One kernel per K so the small K get small register footprints (8 waves/SIMD).
-template <int K>
+template <int K, int XM>
 __global__ __launch_bounds__(256) void sweep_wave_kernel(SweepArgs a)
 {
     const u32 lane = lane_id();
@@ -256,23 +257,26 @@ __global__ __launch_bounds__(256) void sweep_wave_kernel(SweepArgs a)
                 a.counts[r] = g;
             }
         } else {
-            ok = sweep_wave_read<K>(a.iv + o, n, len, a.cov, slot, a.counts + r, lc);
+            ok = sweep_wave_read<K, XM>(a.iv + o, n, len, a.cov, slot, a.counts + r, lc);
         }
-        if (!ok && lane == 0) { // degenerate interval: exact general path takes the read
-            const u32 idx = atomicAdd(&a.ctr->n[CLS_GENERAL], 1u);
-            a.gen_list[idx] = r;
-            atomicAdd(&a.ctr->rejected, 1u);
+        if (!ok && lane == 0) { // degenerate interval: the exact general path takes the read
+            a.rej_list[atomicAdd(a.rej_count, 1u)] = r;
+            a.counts[r] = 0;
         }
     }
 }
 
 template <int K>
-inline void launch_sweep_wave(const SweepArgs &sa, u32 n_reads, int num_cu, hipStream_t stream)
+inline void launch_sweep_wave(const SweepArgs &sa, u32 n_reads, int num_cu, hipStream_t stream,
+                              int xlane_mode)
 {
     // persistent waves: 8 workgroups of 4 waves per CU (32 waves/CU) grid-striding over the list
     const u64 want = ((u64)n_reads + 3) / 4;
     const u32 grid = (u32)(want < (u64)num_cu * 8 ? want : (u64)num_cu * 8);
-    hipLaunchKernelGGL(sweep_wave_kernel<K>, dim3(grid ? grid : 1), dim3(256), 0, stream, sa);
+    if (xlane_mode == 1)
+        hipLaunchKernelGGL((sweep_wave_kernel<K, 1>), dim3(grid ? grid : 1), dim3(256), 0, stream, sa);
+    else
+        hipLaunchKernelGGL((sweep_wave_kernel<K, 0>), dim3(grid ? grid : 1), dim3(256), 0, stream, sa);
 }
 
 } // namespace yk

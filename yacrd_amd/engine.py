@@ -13,6 +13,7 @@ NOT_BAD, CHIMERIC, NOT_COVERED = 0, 1, 2
 TYPE_NAMES = {NOT_BAD: "NotBad", CHIMERIC: "Chimeric", NOT_COVERED: "NotCovered"}
 F_FORCE_GENERAL = 1
 F_FORCE_LDS_SORT = 2
+F_XLANE_DS = 4
 
 # every symbol include/yacrd_engine.h declares
 EXPORTED_SYMBOLS = [

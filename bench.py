@@ -48,16 +48,11 @@ def main():
     yacrd_amd.load_library()  # binds to torch's HIP runtime before torch initialises it
 
     import torch
-    import torch.distributed as dist
+    from yacrd_amd import dist as ydist
 
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        try:
-            dist.init_process_group("nccl", device_id=dev)
-        except Exception:
-            dist.init_process_group("gloo")
+    dist = ydist.init(device=dev)  # None when WORLD_SIZE == 1; nccl (RCCL) else, gloo fallback
 
     prof = {"ont": host.SYNTH_ONT, "sequel": host.SYNTH_SEQUEL, "skewed": host.SYNTH_SKEWED}[args.profile]
     cov = args.coverage if args.coverage is not None else (3 if args.profile == "sequel" else 4)
@@ -79,7 +74,7 @@ def main():
                               args.not_coverage)
 
     def barrier():
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -98,10 +93,7 @@ def main():
     elapsed = time.perf_counter() - t0
 
     G = int(out.n_regions)
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = ydist.max_over_ranks(dist, elapsed, dev)
 
     if rank == 0:
         K = args.steps
@@ -167,7 +159,7 @@ def main():
             line["parity"] = "bit-exact vs oracle on all %d reads" % R if parity else "MISMATCH vs oracle"
         print(json.dumps(line), flush=True)
     eng.close()
-    if world > 1:
+    if dist is not None:
         dist.destroy_process_group()
 
 

@@ -125,6 +125,15 @@ int yacrd_engine_last_timing(const yacrd_engine *e, yacrd_timing *t);
 int yacrd_partition_reads(const uint64_t *offsets, uint64_t n_reads, uint32_t n_parts,
                           uint64_t *cuts);
 
+/* Read-partitioned run over several GPUs of one node: contiguous read ranges from
+ * yacrd_partition_reads(), one host thread per engine (one engine per device; the same device
+ * may appear twice, useful for testing), no collective — results are concatenated in read order,
+ * so the output is identical to a single-engine run. */
+int yacrd_engines_run_partitioned(yacrd_engine *const *engines, uint32_t n_engines,
+                                  const uint64_t *offsets, const uint32_t *intervals,
+                                  const uint32_t *lengths, uint64_t n_reads, uint32_t coverage,
+                                  double not_coverage, yacrd_result *out);
+
 /* Standalone classification of an existing region CSR (the reference calls type_of_read
  * again in every editor, e.g. src/editor/scrubbing.rs:181).  Host buffers in, host out. */
 int yacrd_engine_classify(yacrd_engine *e, const uint64_t *bad_offsets,

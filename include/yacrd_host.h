@@ -52,6 +52,32 @@ void yacrd_csr_free(yacrd_csr *c);
 int yacrd_report_write(const char *path, const yacrd_csr_view *reads, const uint64_t *bad_offsets,
                        const uint32_t *bad_regions, const uint8_t *read_type);
 
+/* ---- editors and the .yacrd re-reader ----------------------------------------------------------- */
+/* What BadPart::get_bad_part answers (src/stack.rs:164-169) plus the engine's read type, over
+ * all reads: names (concatenated, name_off[R+1]), lengths, region CSR, read_type. */
+typedef struct {
+    uint64_t n_reads;
+    const uint64_t *name_off;
+    const char *names;
+    const uint32_t *lengths;
+    const uint64_t *bad_offsets;
+    const uint32_t *bad_regions;
+    const uint8_t *read_type; /* from the engine: yacrd_engine_run / yacrd_engine_classify */
+} yacrd_badparts_view;
+
+enum { YACRD_OP_SCRUBB = 0, YACRD_OP_FILTER = 1, YACRD_OP_EXTRACT = 2, YACRD_OP_SPLIT = 3 };
+
+/* editor::{scrubbing,filter,extract,split} (src/editor/ scrubbing.rs, filter.rs, extract.rs, split.rs): FASTA/FASTQ for all four, PAF/M4
+ * for filter and extract; gzip in -> gzip out.  Reads unknown to `bp` are NotBad with no region. */
+int yacrd_edit_file(int op, const char *in_path, const char *out_path, const yacrd_badparts_view *bp);
+
+/* FromReport (src/stack.rs:176-257): a .yacrd report back into the BadPart table.  read_type is
+ * left NULL: classify with yacrd_engine_classify() and the -n of the current invocation. */
+typedef struct yacrd_report yacrd_report;
+int yacrd_report_read(const char *path, yacrd_report **out);
+int yacrd_report_get(const yacrd_report *r, yacrd_badparts_view *v);
+void yacrd_report_free(yacrd_report *r);
+
 /* ---- synthetic workloads ------------------------------------------------------ */
 enum { YACRD_SYNTH_ONT = 0, YACRD_SYNTH_SEQUEL = 1, YACRD_SYNTH_SKEWED = 2 };
 

@@ -1,0 +1,79 @@
+"""The `yacrd` drop-in CLI end to end on the GPU box: the reference's own integration tests
+(tests/run.rs:95-300) replayed against yacrd_amd/bin/yacrd."""
+import gzip
+import os
+import shutil
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "yacrd_amd", "bin", "yacrd")
+
+
+def run(*args):
+    p = subprocess.run([BIN] + list(args), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    return p
+
+
+@pytest.fixture(scope="module")
+def work(golden_dir, tmp_path_factory):
+    d = tmp_path_factory.mktemp("cli")
+    shutil.copy(os.path.join(golden_dir, "reads.paf"), d / "reads.paf")
+    with gzip.open(os.path.join(golden_dir, "reads.fastq.gz"), "rb") as i, open(d / "reads.fastq", "wb") as o:
+        shutil.copyfileobj(i, o)
+    return d
+
+
+def lines(path):
+    with open(path) as f:
+        return [l.rstrip("\n") for l in f]
+
+
+def test_detection(work, golden_dir):  # run.rs:95-117, compared as a set (diff_unorder)
+    run("-i", str(work / "reads.paf"), "-o", str(work / "result.yacrd"))
+    assert set(lines(work / "result.yacrd")) == set(lines(os.path.join(golden_dir, "truth.yacrd")))
+    assert len(lines(work / "result.yacrd")) == 230
+
+
+def test_detection_ondisk_flag_and_gpus(work, golden_dir):  # run.rs:120-160
+    run("-i", str(work / "reads.paf"), "-o", str(work / "result.ondisk.yacrd"), "-d",
+        str(work / "ondisk"), "--gpus", "1", "-t", "2")
+    assert set(lines(work / "result.ondisk.yacrd")) == set(lines(os.path.join(golden_dir, "truth.yacrd")))
+
+
+@pytest.mark.parametrize("op", ["filter", "extract", "split", "scrubb"])
+def test_editors(work, golden_dir, op):  # run.rs:162-300, ordered comparison (diff)
+    out = work / ("result.%s.fastq" % op)
+    run("-i", str(work / "reads.paf"), "-o", str(work / ("result.%s.yacrd" % op)), op, "-i",
+        str(work / "reads.fastq"), "-o", str(out))
+    with gzip.open(os.path.join(golden_dir, "truth.%s.fastq.gz" % op), "rt") as f:
+        truth = [l.rstrip("\n") for l in f]
+    assert lines(out) == truth
+
+
+def test_report_as_input(work, golden_dir):  # src/main.rs:43-45: FromReport bypass + editor
+    rep = os.path.join(golden_dir, "truth.yacrd")
+    out = work / "from_report.scrubb.fastq"
+    run("-i", rep, "-o", str(work / "again.yacrd"), "scrubb", "-i", str(work / "reads.fastq"), "-o", str(out))
+    assert set(lines(work / "again.yacrd")) == set(lines(rep))
+    with gzip.open(os.path.join(golden_dir, "truth.scrubb.fastq.gz"), "rt") as f:
+        assert lines(out) == [l.rstrip("\n") for l in f]
+
+
+def test_thresholds_match_secondary_vectors(work):
+    import hashlib
+    run("-i", str(work / "reads.paf"), "-o", str(work / "c3.yacrd"), "-c", "3", "-n", "0.4")
+    body = b"".join(sorted(l.encode() + b"\n" for l in lines(work / "c3.yacrd")))
+    assert hashlib.sha256(body).hexdigest() == \
+        "0b207320f179e75a93862fded411651225dfc94e982b1afa2f3e8ea3c113dce2"
+
+
+def test_bad_usage_is_loud(work):
+    p = subprocess.run([BIN, "-i", str(work / "reads.paf")], capture_output=True, text=True)
+    assert p.returncode != 0
+    p = subprocess.run([BIN, "-i", str(work / "nope.paf"), "-o", str(work / "x")], capture_output=True, text=True)
+    assert p.returncode != 0 and "nope.paf" in p.stderr

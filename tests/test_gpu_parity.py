@@ -191,3 +191,14 @@ def test_device_resident_entry_point(engine):
     assert_same(got, want, "run_device")
     t = engine.timing()
     assert t["n_small"] == len(lengths) and t["total_ms"] > 0
+
+
+def test_read_partitioned_multi_engine(engine):
+    """contiguous read ranges, one engine each, no collective; identical output."""
+    csr = make_csr(1100, np.random.default_rng(11).integers(0, 700, size=3000),
+                   REGULAR_MODES + ("degenerate",))
+    want = oracle.run(csr[0], csr[1], csr[2].astype(np.uint64), 3, 0.4, n_threads=4)
+    with yacrd_amd.Engine() as e2, yacrd_amd.Engine() as e3:
+        for engines in ([engine], [engine, e2], [engine, e2, e3]):
+            got = yacrd_amd.run_partitioned(engines, *csr, 3, 0.4)
+            assert_same(got, want, "partitioned x%d" % len(engines))

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "device_common.h"
@@ -552,6 +553,72 @@ int yacrd_partition_reads(const uint64_t *offsets, uint64_t n_reads, uint32_t n_
         cuts[p] = r;
     }
     cuts[n_parts] = n_reads;
+    return YACRD_OK;
+}
+
+int yacrd_engines_run_partitioned(yacrd_engine *const *engines, uint32_t n_engines,
+                                  const uint64_t *offsets, const uint32_t *intervals,
+                                  const uint32_t *lengths, uint64_t n_reads, uint32_t coverage,
+                                  double not_coverage, yacrd_result *out)
+{
+    if (!engines || n_engines == 0 || !out) return fail(YACRD_EINVAL, "bad argument");
+    std::memset(out, 0, sizeof(*out));
+    for (uint32_t p = 0; p < n_engines; p++)
+        if (!engines[p]) return fail(YACRD_EINVAL, "null engine");
+    std::vector<uint64_t> cuts(n_engines + 1);
+    int rc = yacrd_partition_reads(offsets, n_reads, n_engines, cuts.data());
+    if (rc) return rc;
+
+    std::vector<yacrd_result> parts(n_engines);
+    std::vector<int> codes(n_engines, YACRD_OK);
+    std::vector<std::string> errs(n_engines);
+    auto work = [&](uint32_t p) {
+        const uint64_t r0 = cuts[p], r1 = cuts[p + 1];
+        const uint64_t base = n_reads ? offsets[r0] : 0;
+        std::vector<uint64_t> loc(r1 - r0 + 1);
+        for (uint64_t r = r0; r <= r1; r++) loc[r - r0] = offsets[r] - base;
+        codes[p] = yacrd_engine_run(engines[p], loc.data(), intervals ? intervals + 2 * base : nullptr,
+                                    lengths ? lengths + r0 : nullptr, r1 - r0, coverage,
+                                    not_coverage, &parts[p]);
+        if (codes[p]) errs[p] = g_err; // thread-local message of this worker
+    };
+    {
+        std::vector<std::thread> th;
+        for (uint32_t p = 1; p < n_engines; p++) th.emplace_back(work, p);
+        work(0);
+        for (auto &t : th) t.join();
+    }
+    for (uint32_t p = 0; p < n_engines; p++)
+        if (codes[p]) {
+            const int code = codes[p];
+            const std::string msg = "partition " + std::to_string(p) + ": " + errs[p];
+            for (auto &r : parts) yacrd_result_free(&r);
+            return fail(code, msg);
+        }
+    uint64_t G = 0;
+    for (auto &r : parts) G += r.n_regions;
+    out->bad_offsets = (uint64_t *)std::malloc((size_t)(n_reads + 1) * sizeof(uint64_t));
+    out->bad_regions = (uint32_t *)std::malloc((size_t)(2 * G + 2) * sizeof(uint32_t));
+    out->read_type = (uint8_t *)std::malloc((size_t)n_reads + 1);
+    if (!out->bad_offsets || !out->bad_regions || !out->read_type) {
+        for (auto &r : parts) yacrd_result_free(&r);
+        yacrd_result_free(out);
+        return fail(YACRD_ENOMEM, "host allocation failed");
+    }
+    uint64_t g0 = 0;
+    for (uint32_t p = 0; p < n_engines; p++) {
+        const uint64_t r0 = cuts[p], nr = cuts[p + 1] - cuts[p];
+        for (uint64_t r = 0; r < nr; r++) out->bad_offsets[r0 + r] = g0 + parts[p].bad_offsets[r];
+        if (parts[p].n_regions)
+            std::memcpy(out->bad_regions + 2 * g0, parts[p].bad_regions,
+                        (size_t)parts[p].n_regions * 2 * sizeof(uint32_t));
+        if (nr) std::memcpy(out->read_type + r0, parts[p].read_type, (size_t)nr);
+        g0 += parts[p].n_regions;
+        yacrd_result_free(&parts[p]);
+    }
+    out->bad_offsets[n_reads] = G;
+    out->n_reads = n_reads;
+    out->n_regions = G;
     return YACRD_OK;
 }
 

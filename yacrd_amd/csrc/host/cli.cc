@@ -1,0 +1,192 @@
+// cli.cc — `yacrd` drop-in command line over the MI355X engine.
+//
+// Same flags, defaults, file-type rules and outputs as the reference binary
+// (src/cli.rs:33-137, src/main.rs:36-137):
+//   yacrd -i <overlaps.paf|.m4|.mhap|report.yacrd> -o <report.yacrd> [-t N] [-c COV] [-n RATIO]
+//         [--read-buffer-size N] [-d PREFIX] [--ondisk-buffer-size N]
+//         [scrubb|filter|extract|split -i <in> -o <out>]
+// Additive flags only: --gpus N (read-partitioned over N GPUs, default 1).
+// The bad-region computation and the read classification run on the GPU through
+// include/yacrd_engine.h; there is no CPU fallback — without a gfx950 device this exits non-zero.
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../../include/yacrd_engine.h"
+#include "../../../include/yacrd_host.h"
+
+namespace {
+
+const char *kVersion = "1.0.0 Magby";
+
+[[noreturn]] void die(const std::string &msg, int code = 1)
+{
+    std::fprintf(stderr, "Error: %s\n", msg.c_str());
+    std::exit(code);
+}
+
+void usage(FILE *f)
+{
+    std::fprintf(f,
+                 "yacrd %s (MI355X engine)\n"
+                 "USAGE:\n    yacrd [OPTIONS] --input <INPUT> --output <OUTPUT> [SUBCOMMAND]\n\n"
+                 "OPTIONS:\n"
+                 "    -i, --input <INPUT>                  overlap file (.paf|.m4|.mhap) or yacrd report (.yacrd)\n"
+                 "    -o, --output <OUTPUT>                path output file\n"
+                 "    -t, --thread <THREADS>               host threads (overlap parsing); 0 = all [default: 1]\n"
+                 "    -c, --coverage <COVERAGE>            if coverage reach this value region is marked as bad [default: 0]\n"
+                 "    -n, --not-coverage <NOT_COVERAGE>    bad-region ratio above which a read is NotCovered [default: 0.8]\n"
+                 "        --read-buffer-size <N>           accepted for compatibility [default: 8192]\n"
+                 "    -d, --ondisk <PREFIX>                accepted for compatibility (HBM + host RAM hold the overlaps)\n"
+                 "        --ondisk-buffer-size <N>         accepted for compatibility [default: 64000000]\n"
+                 "        --gpus <N>                       GPUs to partition the reads over [default: 1]\n"
+                 "    -h, --help    -V, --version\n\n"
+                 "SUBCOMMANDS (each takes -i <input> -o <output>):\n"
+                 "    scrubb     all bad region of read is removed\n"
+                 "    filter     record mark as chimeric or NotCovered is filter\n"
+                 "    extract    record mark as chimeric or NotCovered is extract\n"
+                 "    split      record mark as chimeric or NotCovered is split\n",
+                 kVersion);
+}
+
+bool parse_u64(const char *s, unsigned long long &v)
+{
+    if (!*s) return false;
+    errno = 0;
+    char *end = nullptr;
+    if (*s == '-') return false;
+    v = std::strtoull(s, &end, 10);
+    return errno == 0 && end && *end == '\0';
+}
+
+bool has(const std::string &s, const char *needle) { return s.find(needle) != std::string::npos; }
+
+} // namespace
+
+int main(int argc, char **argv)
+{
+    std::string input, output, sub, sub_in, sub_out, ondisk;
+    unsigned long long threads = 1, coverage = 0, gpus = 1, tmp = 0;
+    double not_coverage = 0.8;
+
+    int i = 1;
+    auto value = [&](const char *flag) -> const char * {
+        if (i + 1 >= argc) die(std::string("The argument '") + flag + "' requires a value", 2);
+        return argv[++i];
+    };
+    for (; i < argc; i++) {
+        const std::string a = argv[i];
+        if (a == "-h" || a == "--help") {
+            usage(stdout);
+            return 0;
+        } else if (a == "-V" || a == "--version") {
+            std::printf("yacrd %s\n", kVersion);
+            return 0;
+        } else if (a == "-i" || a == "--input") input = value("--input");
+        else if (a == "-o" || a == "--output") output = value("--output");
+        else if (a == "-t" || a == "--thread") {
+            if (!parse_u64(value("--thread"), threads)) die("Invalid value for '--thread'", 2);
+        } else if (a == "-c" || a == "--coverage") {
+            if (!parse_u64(value("--coverage"), coverage)) die("Invalid value for '--coverage'", 2);
+        } else if (a == "-n" || a == "--not-coverage") {
+            char *end = nullptr;
+            const char *v = value("--not-coverage");
+            not_coverage = std::strtod(v, &end);
+            if (!*v || (end && *end)) die("Invalid value for '--not-coverage'", 2);
+        } else if (a == "--read-buffer-size") {
+            if (!parse_u64(value("--read-buffer-size"), tmp)) die("Invalid value for '--read-buffer-size'", 2);
+        } else if (a == "-d" || a == "--ondisk") ondisk = value("--ondisk");
+        else if (a == "--ondisk-buffer-size") (void)value("--ondisk-buffer-size");
+        else if (a == "--gpus") {
+            if (!parse_u64(value("--gpus"), gpus) || gpus == 0) die("Invalid value for '--gpus'", 2);
+        } else if (a == "scrubb" || a == "filter" || a == "extract" || a == "split") {
+            sub = a;
+            for (i++; i < argc; i++) {
+                const std::string b = argv[i];
+                if (b == "-i" || b == "--input") sub_in = value("--input");
+                else if (b == "-o" || b == "--output") sub_out = value("--output");
+                else die("Found argument '" + b + "' which wasn't expected in subcommand " + sub, 2);
+            }
+            if (sub_in.empty() || sub_out.empty())
+                die("The following required arguments were not provided: --input --output (" + sub + ")", 2);
+        } else {
+            die("Found argument '" + a + "' which wasn't expected", 2);
+        }
+    }
+    if (input.empty() || output.empty()) {
+        usage(stderr);
+        die("The following required arguments were not provided: --input <INPUT> --output <OUTPUT>", 2);
+    }
+    if (!ondisk.empty())
+        std::fprintf(stderr, "[INFO] --ondisk is accepted for compatibility; overlaps are kept in "
+                             "host memory and HBM (same results, reference tests/run.rs:120-160)\n");
+
+    // ---- engines (one per GPU)
+    std::vector<yacrd_engine *> engines;
+    for (unsigned long long g = 0; g < gpus; g++) {
+        yacrd_engine_cfg cfg = {(int32_t)g, YACRD_F_DEFAULT};
+        yacrd_engine *e = nullptr;
+        if (yacrd_engine_create(&cfg, &e) != YACRD_OK) die(yacrd_last_error());
+        engines.push_back(e);
+    }
+    const uint32_t cov32 = coverage > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)coverage;
+
+    yacrd_csr *csr = nullptr;
+    yacrd_report *rep = nullptr;
+    yacrd_result res{};
+    std::vector<uint8_t> rep_types;
+    yacrd_badparts_view bp{};
+    yacrd_csr_view view{};
+
+    // src/main.rs:43-60: a .yacrd input bypasses detection (FromReport), anything else is overlaps
+    const bool m4 = has(input, ".m4") || has(input, ".mhap"), paf = has(input, ".paf");
+    if (!m4 && !paf && has(input, ".yacrd")) {
+        if (yacrd_report_read(input.c_str(), &rep)) die(yacrd_host_last_error());
+        yacrd_report_get(rep, &bp);
+        rep_types.resize((size_t)bp.n_reads + 1);
+        // type_of_read with this invocation's -n, on the GPU (kernel #2)
+        if (yacrd_engine_classify(engines[0], bp.bad_offsets, bp.bad_regions, bp.lengths, bp.n_reads,
+                                  not_coverage, rep_types.data()) != YACRD_OK)
+            die(yacrd_last_error());
+        bp.read_type = rep_types.data();
+        view.n_reads = bp.n_reads;
+        view.name_off = bp.name_off;
+        view.names = bp.names;
+        view.lengths = bp.lengths;
+    } else {
+        if (yacrd_csr_from_file(input.c_str(), 0, (int)threads, &csr)) die(yacrd_host_last_error());
+        yacrd_csr_get(csr, &view);
+        if (yacrd_engines_run_partitioned(engines.data(), (uint32_t)engines.size(), view.offsets,
+                                          view.intervals, view.lengths, view.n_reads, cov32,
+                                          not_coverage, &res) != YACRD_OK)
+            die(yacrd_last_error());
+        bp.n_reads = view.n_reads;
+        bp.name_off = view.name_off;
+        bp.names = view.names;
+        bp.lengths = view.lengths;
+        bp.bad_offsets = res.bad_offsets;
+        bp.bad_regions = res.bad_regions;
+        bp.read_type = res.read_type;
+    }
+
+    // src/main.rs:62-84: the report, one line per read
+    if (yacrd_report_write(output.c_str(), &view, bp.bad_offsets, bp.bad_regions, bp.read_type))
+        die(yacrd_host_last_error());
+
+    // src/main.rs:86-118: optional post operation
+    if (!sub.empty()) {
+        const int op = sub == "scrubb" ? YACRD_OP_SCRUBB
+                                       : sub == "filter" ? YACRD_OP_FILTER
+                                                         : sub == "extract" ? YACRD_OP_EXTRACT : YACRD_OP_SPLIT;
+        if (yacrd_edit_file(op, sub_in.c_str(), sub_out.c_str(), &bp)) die(yacrd_host_last_error());
+    }
+
+    yacrd_result_free(&res);
+    if (csr) yacrd_csr_free(csr);
+    if (rep) yacrd_report_free(rep);
+    for (yacrd_engine *e : engines) yacrd_engine_destroy(e);
+    return 0;
+}

@@ -1,0 +1,577 @@
+// editors.cc — post-detection operations on sequence / overlap files and the .yacrd re-reader.
+//
+// Reference (paths relative to the reference root):
+//   scrubb   src/editor/scrubbing.rs:33-236    split    src/editor/split.rs:33-226
+//   filter   src/editor/filter.rs:32-228       extract  src/editor/extract.rs:32-232
+//   FromReport (a .yacrd given as -i)          src/stack.rs:176-257
+// The editors consume `BadPart::get_bad_part` (unknown id -> (vec![], 0), src/stack.rs:164-169) and
+// the read type.  The reference recomputes type_of_read per record (e.g. scrubbing.rs:181); here
+// the type comes from the engine (GPU kernel #2), an unknown read being NotBad by construction
+// (0/0 = NaN > n is false, editor/mod.rs:88).  Pure byte shuffling, I/O bound: host C++.
+//
+// Sequence formats follow what the reference's golden files pin for noodles 0.84: FASTQ
+// "@name[ description]\nseq\n+\nqual\n"; FASTA ">name[ description]\n" + sequence wrapped at 80
+// columns (the wrap width is unpinned by the reference's tests).
+#include "../../../include/yacrd_host.h"
+#include "host_common.h"
+
+#include <zlib.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace {
+
+enum FileType { FT_NONE, FT_FASTA, FT_FASTQ, FT_YACRD, FT_PAF, FT_M4, FT_YOVL };
+
+// src/util.rs:39-55 get_file_type: substring match, in this priority
+FileType file_type(const std::string &n)
+{
+    auto has = [&](const char *s) { return n.find(s) != std::string::npos; };
+    if (has(".m4") || has(".mhap")) return FT_M4;
+    if (has(".paf")) return FT_PAF;
+    if (has(".yacrd")) return FT_YACRD;
+    if (has(".fastq") || has(".fq")) return FT_FASTQ;
+    if (has(".fasta") || has(".fa")) return FT_FASTA;
+    if (has(".yovl")) return FT_YOVL;
+    return FT_NONE;
+}
+const char *type_name(FileType t)
+{
+    switch (t) {
+    case FT_FASTA: return "fasta";
+    case FT_FASTQ: return "fastq";
+    case FT_YACRD: return "yacrd";
+    case FT_PAF: return "paf";
+    case FT_M4: return "m4";
+    default: return "yacrd overlap";
+    }
+}
+
+// ---- input: plain or gzip, sniffed from magic bytes like niffler (src/util.rs:57-70) ---------
+struct Reader {
+    gzFile gz = nullptr; // zlib reads plain files transparently
+    bool compressed = false;
+    std::vector<char> buf;
+    size_t pos = 0, end = 0;
+    bool eof = false;
+
+    int open(const char *path)
+    {
+        FILE *f = std::fopen(path, "rb");
+        if (!f) return yh::fail(std::string("Can't open file ") + path + " to read");
+        unsigned char m[6] = {0};
+        const size_t got = std::fread(m, 1, sizeof m, f);
+        std::fclose(f);
+        if (got >= 2 && m[0] == 0x1f && m[1] == 0x8b) compressed = true;
+        if ((got >= 3 && m[0] == 'B' && m[1] == 'Z' && m[2] == 'h') ||
+            (got >= 6 && m[0] == 0xFD && std::memcmp(m + 1, "7zXZ", 4) == 0))
+            return yh::fail(std::string(path) + ": bzip2/xz input is not supported in this build "
+                                                "(no bzlib.h / lzma.h in the image)");
+        gz = gzopen(path, "rb");
+        if (!gz) return yh::fail(std::string("Can't open file ") + path + " to read");
+        gzbuffer(gz, 1 << 20);
+        buf.resize(1 << 20);
+        return 0;
+    }
+    ~Reader()
+    {
+        if (gz) gzclose(gz);
+    }
+    bool fill()
+    {
+        if (eof) return false;
+        const int n = gzread(gz, buf.data(), (unsigned)buf.size());
+        if (n <= 0) {
+            eof = true;
+            return false;
+        }
+        pos = 0;
+        end = (size_t)n;
+        return true;
+    }
+    // next line without its terminator; false at end of input
+    bool line(std::string &out)
+    {
+        out.clear();
+        bool any = false;
+        for (;;) {
+            if (pos == end && !fill()) break;
+            any = true;
+            const char *p = buf.data() + pos;
+            const char *nl = (const char *)std::memchr(p, '\n', end - pos);
+            if (nl) {
+                out.append(p, (size_t)(nl - p));
+                pos = (size_t)(nl - buf.data()) + 1;
+                return true;
+            }
+            out.append(p, end - pos);
+            pos = end;
+        }
+        return any && !out.empty();
+    }
+    int peek()
+    {
+        if (pos == end && !fill()) return -1;
+        return (unsigned char)buf[pos];
+    }
+};
+
+// ---- output: same compression as the input, gzip level 1 (src/util.rs:72-87) ------------------
+struct Writer {
+    FILE *f = nullptr;
+    gzFile gz = nullptr;
+    std::vector<char> buf;
+    bool failed = false;
+    int open(const char *path, bool gzip)
+    {
+        if (gzip) {
+            gz = gzopen(path, "wb1");
+            if (!gz) return yh::fail(std::string("Can't open file ") + path + " to write");
+            gzbuffer(gz, 1 << 20);
+        } else {
+            f = std::fopen(path, "wb");
+            if (!f) return yh::fail(std::string("Can't open file ") + path + " to write");
+        }
+        buf.reserve(1 << 20);
+        return 0;
+    }
+    void flush()
+    {
+        if (buf.empty()) return;
+        if (gz) failed |= gzwrite(gz, buf.data(), (unsigned)buf.size()) != (int)buf.size();
+        else failed |= std::fwrite(buf.data(), 1, buf.size(), f) != buf.size();
+        buf.clear();
+    }
+    void put(const char *p, size_t n)
+    {
+        buf.insert(buf.end(), p, p + n);
+        if (buf.size() > (1u << 20) - 4096) flush();
+    }
+    void put(const std::string &s) { put(s.data(), s.size()); }
+    void put(char c) { put(&c, 1); }
+    int close()
+    {
+        flush();
+        if (gz) failed |= gzclose(gz) != Z_OK;
+        if (f) failed |= std::fclose(f) != 0;
+        gz = nullptr;
+        f = nullptr;
+        return failed ? yh::fail("Error during writing of the output file") : 0;
+    }
+    ~Writer()
+    {
+        if (gz) gzclose(gz);
+        if (f) std::fclose(f);
+    }
+};
+
+// ---- BadPart lookups ---------------------------------------------------------------------------
+struct BadParts {
+    const yacrd_badparts_view *v;
+    std::unordered_map<std::string, uint32_t> index;
+    explicit BadParts(const yacrd_badparts_view *view) : v(view)
+    {
+        index.reserve((size_t)v->n_reads * 2 + 16);
+        for (uint64_t r = 0; r < v->n_reads; r++)
+            index.emplace(std::string(v->names + v->name_off[r],
+                                      (size_t)(v->name_off[r + 1] - v->name_off[r])),
+                          (uint32_t)r);
+    }
+    // get_bad_part + type: unknown id -> (empty, 0, NotBad)
+    void get(const std::string &id, const uint32_t *&reg, size_t &n, uint32_t &len, int &type) const
+    {
+        auto it = index.find(id);
+        if (it == index.end()) {
+            reg = nullptr;
+            n = 0;
+            len = 0;
+            type = 0;
+            return;
+        }
+        const uint32_t r = it->second;
+        reg = v->bad_regions + 2 * v->bad_offsets[r];
+        n = (size_t)(v->bad_offsets[r + 1] - v->bad_offsets[r]);
+        len = v->lengths[r];
+        type = v->read_type[r];
+    }
+};
+
+inline bool is_ws(char c) { return c == ' ' || c == '\t' || c == '\n' || c == '\x0c' || c == '\r'; }
+
+struct SeqRecord {
+    std::string name, desc, seq, qual;
+};
+
+void write_fastq(Writer &w, const std::string &name, const std::string &desc, const char *seq,
+                 const char *qual, size_t n)
+{
+    w.put('@');
+    w.put(name);
+    if (!desc.empty()) {
+        w.put(' ');
+        w.put(desc);
+    }
+    w.put('\n');
+    w.put(seq, n);
+    w.put("\n+\n", 3);
+    w.put(qual, n);
+    w.put('\n');
+}
+void write_fasta(Writer &w, const std::string &name, const std::string &desc, const char *seq,
+                 size_t n)
+{
+    w.put('>');
+    w.put(name);
+    if (!desc.empty()) {
+        w.put(' ');
+        w.put(desc);
+    }
+    w.put('\n');
+    for (size_t i = 0; i < n; i += 80) {
+        w.put(seq + i, std::min<size_t>(80, n - i));
+        w.put('\n');
+    }
+}
+
+void split_definition(const std::string &line, bool any_ws, std::string &name, std::string &desc)
+{ // line without the leading '@' / '>'
+    size_t i = 0;
+    while (i < line.size() && !(any_ws ? is_ws(line[i]) : line[i] == ' ')) i++;
+    name.assign(line, 0, i);
+    desc.assign(line, i < line.size() ? i + 1 : i, std::string::npos);
+}
+
+bool next_fastq(Reader &r, SeqRecord &rec, std::string &err)
+{
+    std::string l1, plus;
+    for (;;) {
+        if (!r.line(l1)) return false;
+        if (!l1.empty()) break;
+    }
+    if (!l1.empty() && l1.back() == '\r') l1.pop_back();
+    if (l1.empty() || l1[0] != '@') {
+        err = "Reading of the file in fastq format failed";
+        return false;
+    }
+    split_definition(l1.substr(1), false, rec.name, rec.desc);
+    rec.seq.clear();
+    rec.qual.clear();
+    const bool got_seq = r.line(rec.seq);
+    const bool got_plus = r.line(plus);
+    const bool got_qual = r.line(rec.qual);
+    if (!rec.seq.empty() && rec.seq.back() == '\r') rec.seq.pop_back();
+    if (!rec.qual.empty() && rec.qual.back() == '\r') rec.qual.pop_back();
+    if (!got_seq || !got_plus || plus.empty() || plus[0] != '+' || (!got_qual && !rec.seq.empty()) ||
+        rec.seq.size() != rec.qual.size()) {
+        err = "Reading of the file in fastq format failed";
+        return false;
+    }
+    return true;
+}
+
+bool next_fasta(Reader &r, SeqRecord &rec, std::string &err)
+{
+    std::string l;
+    for (;;) {
+        if (!r.line(l)) return false;
+        if (!l.empty()) break;
+    }
+    if (!l.empty() && l.back() == '\r') l.pop_back();
+    if (l.empty() || l[0] != '>') {
+        err = "Reading of the file in fasta format failed";
+        return false;
+    }
+    split_definition(l.substr(1), true, rec.name, rec.desc);
+    rec.seq.clear();
+    for (;;) {
+        const int c = r.peek();
+        if (c < 0 || c == '>') break;
+        if (!r.line(l)) break;
+        if (!l.empty() && l.back() == '\r') l.pop_back();
+        rec.seq += l;
+    }
+    return true;
+}
+
+enum Op { OP_SCRUBB = 0, OP_FILTER = 1, OP_EXTRACT = 2, OP_SPLIT = 3 };
+const char *op_name(int op)
+{
+    static const char *n[] = {"scrubbing", "filter", "extract", "split"};
+    return n[op];
+}
+
+// cut positions: scrubbing.rs:195-209 (every region) / split.rs:189-198 (middle regions only)
+void cut_positions(int op, const uint32_t *reg, size_t n, uint32_t len, std::vector<uint32_t> &poss,
+                   size_t &first)
+{
+    poss.clear();
+    poss.push_back(0);
+    first = 0;
+    if (op == OP_SCRUBB) {
+        for (size_t i = 0; i < n; i++) {
+            poss.push_back(reg[2 * i]);
+            poss.push_back(reg[2 * i + 1]);
+        }
+        if (poss.back() != len) poss.push_back(len);
+        if (poss.size() >= 2 && poss[0] == 0 && poss[1] == 0) first = 2;
+        // chunks_exact(2): a trailing odd element is ignored
+    } else {
+        for (size_t i = 0; i < n; i++) {
+            if (reg[2 * i] == 0 || reg[2 * i + 1] == len) continue;
+            poss.push_back(reg[2 * i]);
+            poss.push_back(reg[2 * i + 1]);
+        }
+        poss.push_back(len);
+    }
+}
+
+int edit_sequences(int op, bool fastq, Reader &in, Writer &out, const BadParts &bp)
+{
+    SeqRecord rec;
+    std::string err, key, piece;
+    std::vector<uint32_t> poss;
+    for (;;) {
+        const bool ok = fastq ? next_fastq(in, rec, err) : next_fasta(in, rec, err);
+        if (!ok) {
+            if (!err.empty()) return yh::fail(err);
+            break;
+        }
+        // FASTQ: first whitespace token of the name (scrubbing.rs:174-179); FASTA: the name
+        key = rec.name;
+        if (fastq) {
+            size_t i = 0;
+            while (i < key.size() && !is_ws(key[i])) i++;
+            key.resize(i);
+        }
+        const uint32_t *reg;
+        size_t n;
+        uint32_t len;
+        int type;
+        bp.get(key, reg, n, len, type);
+        auto copy = [&]() {
+            if (fastq) write_fastq(out, rec.name, rec.desc, rec.seq.data(), rec.qual.data(), rec.seq.size());
+            else write_fasta(out, rec.name, rec.desc, rec.seq.data(), rec.seq.size());
+        };
+        if (op == OP_FILTER) {
+            if (type == 0) copy();
+            continue;
+        }
+        if (op == OP_EXTRACT) {
+            if (type != 0) copy();
+            continue;
+        }
+        if (type == 2) continue; // NotCovered reads are dropped
+        if (op == OP_SCRUBB ? n == 0 : type == 0) {
+            copy();
+            continue;
+        }
+        size_t first;
+        cut_positions(op, reg, n, len, poss, first);
+        for (size_t k = first; k + 1 < poss.size(); k += 2) {
+            const uint32_t p0 = poss[k], p1 = poss[k + 1];
+            if (p0 > rec.seq.size() || p1 > rec.seq.size()) {
+                std::fprintf(stderr,
+                             "[ERROR] For read %s %s position is larger than read, it's strange check "
+                             "your data. For this read, this split position and next are ignore.\n",
+                             rec.name.c_str(), op == OP_SCRUBB ? "scrubb" : "split");
+                break;
+            }
+            if (p0 > p1) // the reference panics on seq[p0..p1] with p0 > p1
+                return yh::fail("bad region with begin > end while cutting read " + rec.name);
+            piece = rec.name + "_" + std::to_string(p0) + "_" + std::to_string(p1);
+            if (fastq)
+                write_fastq(out, piece, rec.desc, rec.seq.data() + p0, rec.qual.data() + p0, p1 - p0);
+            else
+                write_fasta(out, piece, std::string(), rec.seq.data() + p0, p1 - p0);
+        }
+    }
+    return 0;
+}
+
+// filter / extract on overlap files: filter.rs:140-228, extract.rs:144-232 (csv reader, not flexible)
+int edit_overlaps(int op, bool paf, Reader &in, Writer &out, const BadParts &bp)
+{
+    const char delim = paf ? '\t' : ' ';
+    const size_t ib = paf ? 5 : 1;
+    std::string l, a, b;
+    size_t n_fields = 0;
+    while (in.line(l)) {
+        if (!l.empty() && l.back() == '\r') l.pop_back();
+        if (l.empty()) continue;
+        size_t nf = 1, start_b = std::string::npos, end_a = l.find(delim);
+        size_t p = 0;
+        for (size_t i = 0; i < l.size(); i++)
+            if (l[i] == delim) {
+                if (nf == ib) start_b = i + 1;
+                nf++;
+                (void)p;
+            }
+        if (n_fields == 0) n_fields = nf;
+        if (nf != n_fields || nf <= ib)
+            return yh::fail(paf ? "Reading of the file in paf format failed"
+                                : "Reading of the file in m4 format failed");
+        a.assign(l, 0, end_a);
+        const size_t end_b = l.find(delim, start_b);
+        b.assign(l, start_b, end_b == std::string::npos ? std::string::npos : end_b - start_b);
+        const uint32_t *reg;
+        size_t n;
+        uint32_t len;
+        int ta, tb;
+        bp.get(a, reg, n, len, ta);
+        bp.get(b, reg, n, len, tb);
+        const bool both_good = ta == 0 && tb == 0;
+        if (op == OP_FILTER ? both_good : !both_good) {
+            out.put(l);
+            out.put('\n');
+        }
+    }
+    return 0;
+}
+
+} // namespace
+
+// ---- .yacrd re-reader (FromReport, src/stack.rs:176-257) ---------------------------------------
+struct yacrd_report {
+    std::vector<uint64_t> name_off{0};
+    std::vector<char> names;
+    std::vector<uint32_t> lengths;
+    std::vector<uint64_t> bad_offsets{0};
+    std::vector<uint32_t> bad_regions;
+};
+
+extern "C" {
+
+int yacrd_report_read(const char *path, yacrd_report **out)
+{
+    if (!path || !out) return yh::fail("null argument");
+    *out = nullptr;
+    Reader in;
+    if (in.open(path)) return 1;
+    yacrd_report *rep = new yacrd_report();
+    std::unordered_map<std::string, uint32_t> seen; // HashMap::insert: the last line for an id wins
+    std::string l;
+    uint64_t line_no = 0;
+    auto corrupt = [&](const std::string &why) {
+        delete rep;
+        return yh::fail("Your yacrd file " + std::string(path) + " seems corrupt at line " +
+                        std::to_string(line_no) + " (" + why + ")");
+    };
+    struct Row {
+        std::string id;
+        uint32_t len;
+        std::vector<uint32_t> reg;
+    };
+    std::vector<Row> rows;
+    while (in.line(l)) {
+        if (!l.empty() && l.back() == '\r') l.pop_back();
+        if (l.empty()) continue;
+        // type \t id \t len \t regions
+        size_t t1 = l.find('\t'), t2 = t1 == std::string::npos ? t1 : l.find('\t', t1 + 1),
+               t3 = t2 == std::string::npos ? t2 : l.find('\t', t2 + 1);
+        if (t3 == std::string::npos) return corrupt("expected 4 tab separated columns");
+        Row row;
+        row.id.assign(l, t1 + 1, t2 - t1 - 1);
+        uint64_t len = 0;
+        {
+            const std::string s(l, t2 + 1, t3 - t2 - 1);
+            if (s.empty()) return corrupt("length");
+            for (char c : s) {
+                if (c < '0' || c > '9') return corrupt("length");
+                len = len * 10 + (uint64_t)(c - '0');
+                if (len > 0xFFFFFFFFull) return corrupt("read length >= 2^32 is not supported");
+            }
+        }
+        row.len = (uint32_t)len;
+        const std::string body(l, t3 + 1);
+        if (!body.empty()) { // parse_bad_string, stack.rs:217-241: "len,begin,end;..."
+            size_t p = 0;
+            while (p <= body.size()) {
+                size_t e = body.find(';', p);
+                if (e == std::string::npos) e = body.size();
+                const std::string sub(body, p, e - p);
+                size_t c1 = sub.find(','), c2 = c1 == std::string::npos ? c1 : sub.find(',', c1 + 1);
+                if (c2 == std::string::npos) return corrupt("position");
+                size_t c3 = sub.find(',', c2 + 1);
+                auto num = [&](const std::string &s, uint32_t &v) {
+                    if (s.empty()) return false;
+                    uint64_t x = 0;
+                    for (char c : s) {
+                        if (c < '0' || c > '9') return false;
+                        x = x * 10 + (uint64_t)(c - '0');
+                        if (x > 0xFFFFFFFFull) return false;
+                    }
+                    v = (uint32_t)x;
+                    return true;
+                };
+                uint32_t bgn, end;
+                if (!num(sub.substr(c1 + 1, c2 - c1 - 1), bgn) ||
+                    !num(sub.substr(c2 + 1, c3 == std::string::npos ? std::string::npos : c3 - c2 - 1), end))
+                    return corrupt("position");
+                row.reg.push_back(bgn);
+                row.reg.push_back(end);
+                p = e + 1;
+                if (e == body.size()) break;
+            }
+        }
+        line_no++;
+        auto it = seen.find(row.id);
+        if (it != seen.end()) rows[it->second] = std::move(row);
+        else {
+            seen.emplace(row.id, (uint32_t)rows.size());
+            rows.push_back(std::move(row));
+        }
+    }
+    for (const Row &row : rows) {
+        rep->names.insert(rep->names.end(), row.id.begin(), row.id.end());
+        rep->name_off.push_back(rep->names.size());
+        rep->lengths.push_back(row.len);
+        rep->bad_regions.insert(rep->bad_regions.end(), row.reg.begin(), row.reg.end());
+        rep->bad_offsets.push_back(rep->bad_regions.size() / 2);
+    }
+    *out = rep;
+    return 0;
+}
+
+int yacrd_report_get(const yacrd_report *r, yacrd_badparts_view *v)
+{
+    if (!r || !v) return yh::fail("null argument");
+    v->n_reads = r->lengths.size();
+    v->name_off = r->name_off.data();
+    v->names = r->names.data();
+    v->lengths = r->lengths.data();
+    v->bad_offsets = r->bad_offsets.data();
+    v->bad_regions = r->bad_regions.data();
+    v->read_type = nullptr; // classify with the engine (yacrd_engine_classify) before editing
+    return 0;
+}
+
+void yacrd_report_free(yacrd_report *r) { delete r; }
+
+int yacrd_edit_file(int op, const char *in_path, const char *out_path, const yacrd_badparts_view *bp)
+{
+    if (op < 0 || op > 3 || !in_path || !out_path || !bp) return yh::fail("bad argument");
+    if (bp->n_reads && (!bp->read_type || !bp->bad_offsets || !bp->lengths || !bp->name_off))
+        return yh::fail("bad parts table is incomplete (read_type comes from the engine)");
+    const FileType ft = file_type(in_path);
+    const bool seq = ft == FT_FASTA || ft == FT_FASTQ, ovl = ft == FT_PAF || ft == FT_M4;
+    if (ft == FT_NONE || ft == FT_YOVL)
+        return yh::fail(std::string("Format detection of file ") + in_path + " failed");
+    if (!(seq || (ovl && (op == OP_FILTER || op == OP_EXTRACT))))
+        return yh::fail(std::string("Can't run ") + op_name(op) + " on " + type_name(ft) +
+                        " file " + in_path);
+    Reader in;
+    if (in.open(in_path)) return 1;
+    Writer out;
+    if (out.open(out_path, in.compressed)) return 1;
+    const BadParts table(bp);
+    const int rc = seq ? edit_sequences(op, ft == FT_FASTQ, in, out, table)
+                       : edit_overlaps(op, ft == FT_PAF, in, out, table);
+    if (rc) return rc;
+    return out.close();
+}
+
+} // extern "C"

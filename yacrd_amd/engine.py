@@ -20,6 +20,7 @@ EXPORTED_SYMBOLS = [
     "yacrd_abi_version", "yacrd_last_error", "yacrd_engine_create", "yacrd_engine_destroy",
     "yacrd_engine_run", "yacrd_result_free", "yacrd_engine_run_device", "yacrd_engine_fetch",
     "yacrd_engine_last_timing", "yacrd_partition_reads", "yacrd_engine_classify",
+    "yacrd_engines_run_partitioned",
 ]
 
 
@@ -128,6 +129,10 @@ def load_library():
     lib.yacrd_partition_reads.argtypes = [u64p, ctypes.c_uint64, ctypes.c_uint32, u64p]
     lib.yacrd_engine_classify.argtypes = [ctypes.c_void_p, u64p, u32p, u32p, ctypes.c_uint64,
                                           ctypes.c_double, u8p]
+    lib.yacrd_engines_run_partitioned.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32,
+                                                  u64p, u32p, u32p, ctypes.c_uint64,
+                                                  ctypes.c_uint32, ctypes.c_double,
+                                                  ctypes.POINTER(_Result)]
     _lib = lib
     return lib
 
@@ -159,6 +164,23 @@ def partition_reads(offsets, n_parts):
     _check(lib, lib.yacrd_partition_reads(_ptr(offsets, ctypes.c_uint64), offsets.shape[0] - 1,
                                           n_parts, _ptr(cuts, ctypes.c_uint64)))
     return cuts
+
+
+def run_partitioned(engines, offsets, intervals, lengths, coverage, not_coverage):
+    """Read-partitioned run over several engines (one per GPU); same output as one engine."""
+    lib = load_library()
+    offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
+    intervals = np.ascontiguousarray(intervals, dtype=np.uint32).reshape(-1)
+    lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+    if intervals.size == 0:
+        intervals = np.zeros(2, dtype=np.uint32)
+    handles = (ctypes.c_void_p * len(engines))(*[e._h for e in engines])
+    res = _Result()
+    _check(lib, lib.yacrd_engines_run_partitioned(
+        handles, len(engines), _ptr(offsets, ctypes.c_uint64), _ptr(intervals, ctypes.c_uint32),
+        _ptr(lengths, ctypes.c_uint32), offsets.shape[0] - 1, min(int(coverage), 0xFFFFFFFF),
+        float(not_coverage), ctypes.byref(res)))
+    return _take(lib, res)
 
 
 class Engine:

@@ -14,7 +14,10 @@ FMT_AUTO, FMT_PAF, FMT_M4 = 0, 1, 2
 EXPORTED_SYMBOLS = [
     "yacrd_host_last_error", "yacrd_csr_from_file", "yacrd_csr_from_memory", "yacrd_csr_get",
     "yacrd_csr_find", "yacrd_csr_free", "yacrd_report_write", "yacrd_synth_csr", "yacrd_synth_paf",
+    "yacrd_edit_file", "yacrd_report_read", "yacrd_report_get", "yacrd_report_free",
 ]
+
+OP_SCRUBB, OP_FILTER, OP_EXTRACT, OP_SPLIT = 0, 1, 2, 3
 
 
 class HostError(RuntimeError):
@@ -29,6 +32,16 @@ class _View(ctypes.Structure):
                 ("lengths", ctypes.POINTER(ctypes.c_uint32)),
                 ("name_off", ctypes.POINTER(ctypes.c_uint64)),
                 ("names", ctypes.POINTER(ctypes.c_char))]
+
+
+class _BadParts(ctypes.Structure):
+    _fields_ = [("n_reads", ctypes.c_uint64),
+                ("name_off", ctypes.POINTER(ctypes.c_uint64)),
+                ("names", ctypes.c_char_p),
+                ("lengths", ctypes.POINTER(ctypes.c_uint32)),
+                ("bad_offsets", ctypes.POINTER(ctypes.c_uint64)),
+                ("bad_regions", ctypes.POINTER(ctypes.c_uint32)),
+                ("read_type", ctypes.POINTER(ctypes.c_uint8))]
 
 
 class _SynthCfg(ctypes.Structure):
@@ -72,6 +85,12 @@ def load_library():
                                         ctypes.POINTER(ctypes.c_uint32),
                                         ctypes.POINTER(ctypes.c_uint32)]
         lib.yacrd_synth_paf.argtypes = [ctypes.POINTER(_SynthCfg), ctypes.c_char_p]
+        lib.yacrd_edit_file.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p,
+                                        ctypes.POINTER(_BadParts)]
+        lib.yacrd_report_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
+        lib.yacrd_report_get.argtypes = [ctypes.c_void_p, ctypes.POINTER(_BadParts)]
+        lib.yacrd_report_free.argtypes = [ctypes.c_void_p]
+        lib.yacrd_report_free.restype = None
         _lib = lib
     return _lib
 
@@ -166,3 +185,46 @@ def synth_paf(profile, n_reads, n_overlaps, seed, path, flags=0):
     lib = load_library()
     cfg = _SynthCfg(profile, flags, n_reads, n_overlaps, seed)
     _check(lib, lib.yacrd_synth_paf(ctypes.byref(cfg), path.encode()))
+
+
+def edit_file(op, in_path, out_path, names, lengths, bad_offsets, bad_regions, read_type):
+    """editor::{scrubbing,filter,extract,split} over the BadPart table (names, lengths, region CSR,
+    engine read types)."""
+    lib = load_library()
+    blob = b"".join(n.encode() for n in names)
+    name_off = np.zeros(len(names) + 1, dtype=np.uint64)
+    np.cumsum([len(n.encode()) for n in names], out=name_off[1:])
+    lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+    bo = np.ascontiguousarray(bad_offsets, dtype=np.uint64)
+    br = np.ascontiguousarray(bad_regions, dtype=np.uint32).reshape(-1)
+    if br.size == 0:
+        br = np.zeros(2, np.uint32)
+    rt = np.ascontiguousarray(read_type, dtype=np.uint8)
+    view = _BadParts(len(names), name_off.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)), blob,
+                     lengths.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+                     bo.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
+                     br.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+                     rt.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)))
+    _check(lib, lib.yacrd_edit_file(op, in_path.encode(), out_path.encode(), ctypes.byref(view)))
+
+
+def report_read(path):
+    """FromReport: .yacrd -> (names, lengths u32, bad_offsets u64, bad_regions u32[G,2])."""
+    lib = load_library()
+    h = ctypes.c_void_p()
+    _check(lib, lib.yacrd_report_read(path.encode(), ctypes.byref(h)))
+    try:
+        v = _BadParts()
+        _check(lib, lib.yacrd_report_get(h, ctypes.byref(v)))
+        R = int(v.n_reads)
+        name_off = np.ctypeslib.as_array(v.name_off, shape=(R + 1,)).copy()
+        blob = ctypes.string_at(v.names, int(name_off[-1])) if R else b""
+        names = [blob[int(name_off[i]):int(name_off[i + 1])].decode() for i in range(R)]
+        lengths = np.ctypeslib.as_array(v.lengths, shape=(R,)).copy() if R else np.zeros(0, np.uint32)
+        bo = np.ctypeslib.as_array(v.bad_offsets, shape=(R + 1,)).copy()
+        G = int(bo[-1])
+        br = (np.ctypeslib.as_array(v.bad_regions, shape=(2 * G,)).copy().reshape(-1, 2)
+              if G else np.zeros((0, 2), np.uint32))
+    finally:
+        lib.yacrd_report_free(h)
+    return names, lengths, bo, br

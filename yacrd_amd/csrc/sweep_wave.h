@@ -270,9 +270,16 @@ template <int K>
 inline void launch_sweep_wave(const SweepArgs &sa, u32 n_reads, int num_cu, hipStream_t stream,
                               int xlane_mode)
 {
-    // persistent waves: 8 workgroups of 4 waves per CU (32 waves/CU) grid-striding over the list
+    // One read per wavefront, four wavefronts per workgroup; the dispatcher balances the tail
+    // better than persistent waves did (76 vs 82 us on configs[1], profiles/README.md).
+    // YACRD_WAVE_BLOCKS_PER_CU=n caps the grid at n workgroups per CU (grid-stride loop) for A/B.
+    static const int per_cu = [] {
+        const char *s = getenv("YACRD_WAVE_BLOCKS_PER_CU");
+        return s ? atoi(s) : 0;
+    }();
     const u64 want = ((u64)n_reads + 3) / 4;
-    const u32 grid = (u32)(want < (u64)num_cu * 8 ? want : (u64)num_cu * 8);
+    const u64 cap = per_cu > 0 ? (u64)num_cu * (u64)per_cu : want;
+    const u32 grid = (u32)(want < cap ? want : cap);
     if (xlane_mode == 1)
         hipLaunchKernelGGL((sweep_wave_kernel<K, 1>), dim3(grid ? grid : 1), dim3(256), 0, stream, sa);
     else

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""tools/ingest_bench.py — overlaps/s ingested: synthetic PAF text -> CSR (host parser), by threads."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from yacrd_amd import host  # noqa: E402
+
+reads, overlaps = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000, int(sys.argv[2]) if len(sys.argv) > 2 else 5_000_000
+path = "/tmp/ingest_%d_%d.paf" % (reads, overlaps)
+t0 = time.perf_counter()
+host.synth_paf(host.SYNTH_ONT, reads, overlaps, 20241110, path)
+size = os.path.getsize(path)
+res = {"paf_bytes": size, "write_s": round(time.perf_counter() - t0, 2), "runs": []}
+for th in (1, 8, 32, 64, 128, 0):
+    t0 = time.perf_counter()
+    c = host.csr_from_file(path, n_threads=th)
+    dt = time.perf_counter() - t0
+    res["runs"].append({"threads": th or (os.cpu_count() or 0), "s": round(dt, 3),
+                        "overlaps_per_s": round(c.n_records / dt), "GB_per_s": round(size / dt / 1e9, 3)})
+    c.close()
+os.remove(path)
+print(json.dumps(res))

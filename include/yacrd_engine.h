@@ -62,6 +62,8 @@ typedef struct {
 #define YACRD_F_FORCE_LDS_SORT 2u
 /* cross-lane exchanges of the register sort all through the LDS crossbar (ds_swizzle); A/B only */
 #define YACRD_F_XLANE_DS 4u
+/* no four-reads-per-wavefront row layout: every small read gets a whole wavefront; A/B only */
+#define YACRD_F_WAVE_ONLY 8u
 
 /* Host-side result, allocated by the engine, released with yacrd_result_free(). */
 typedef struct {

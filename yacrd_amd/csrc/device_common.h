@@ -15,14 +15,15 @@ constexpr u32 kNoKey = 0xFFFFFFFFu;
 constexpr u32 kSmallEvents = 1024;    // one read per wavefront
 constexpr u32 kMedium1Events = 8192;  // one read per 256-thread workgroup, 32 KiB LDS
 constexpr u32 kMedium2Events = 32768; // one read per 1024-thread workgroup, 128 KiB LDS
-// small class is split by keys per lane of the register sort (K = 2, 4, 8, 16)
-enum { CLS_W2 = 0, CLS_W4 = 1, CLS_W8 = 2, CLS_W16 = 3, CLS_MED1 = 4, CLS_MED2 = 5, CLS_GENERAL = 6,
-       CLS_COUNT = 7 };
+// Small reads sort in registers.  R<K>: four reads per wavefront, one per 16-lane DPP row, K keys
+// per lane (<= 16*K events); W<K>: one read per wavefront, K keys per lane (<= 64*K events).
+enum { CLS_R2 = 0, CLS_R4, CLS_R8, CLS_R16, CLS_W2, CLS_W4, CLS_W8, CLS_W16, CLS_MED1, CLS_MED2,
+       CLS_GENERAL, CLS_COUNT };
 
 // Device-side counters written by the plan kernel and the sweeps.
 struct Counters {
-    u32 n[8];                // reads per class (plan kernel)
-    u64 iv[8];               // intervals per class (plan kernel)
+    u32 n[12];               // reads per class (plan kernel)
+    u64 iv[12];              // intervals per class (plan kernel)
     u32 rej_small;           // reads with a degenerate interval found by a wave sweep (n <= 512)
     u32 rej_med;             // ... by the 256-thread LDS sweep (n <= 4096)
     u32 rej_big;             // ... by the 1024-thread LDS sweep (n <= 16384): global-memory path

@@ -213,7 +213,8 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     HIP_TRY(hipEventRecord(e->ev[EV_START], e->stream));
     hipLaunchKernelGGL(yk::plan_kernel, dim3((n_reads + yk::kPlanBlock - 1) / yk::kPlanBlock),
                        dim3(yk::kPlanBlock), 0, e->stream, d_off, n_reads, lists, ctr,
-                       (u32)((e->flags & YACRD_F_FORCE_GENERAL) ? 1 : 0));
+                       (u32)((e->flags & YACRD_F_FORCE_GENERAL) ? 1
+                             : (e->flags & (YACRD_F_WAVE_ONLY | YACRD_F_FORCE_LDS_SORT)) ? 2 : 0));
     HIP_TRY(hipEventRecord(e->ev[EV_PLAN], e->stream));
     HIP_TRY(hipMemcpyAsync(e->h_ctr, ctr, sizeof(yk::Counters), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -234,7 +235,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     sa.rej_count = &ctr->rej_small;
     const int xm = (e->flags & YACRD_F_XLANE_DS) ? 1 : 0;
     bool any_small = false;
-    for (int cls = yk::CLS_W2; cls <= yk::CLS_W16; cls++) {
+    for (int cls = yk::CLS_R2; cls <= yk::CLS_W16; cls++) {
         if (!c0.n[cls]) continue;
         any_small = true;
         sa.list = list_of(cls);
@@ -243,14 +244,17 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
             const u32 grid = (u32)std::min<uint64_t>(c0.n[cls], (uint64_t)e->num_cu * 32);
             hipLaunchKernelGGL((yk::sweep_lds_kernel<64, (int)yk::kSmallEvents>), dim3(grid),
                                dim3(64), 0, e->stream, sa);
-        } else if (cls == yk::CLS_W2) {
-            yk::launch_sweep_wave<2>(sa, c0.n[cls], e->num_cu, e->stream, xm);
-        } else if (cls == yk::CLS_W4) {
-            yk::launch_sweep_wave<4>(sa, c0.n[cls], e->num_cu, e->stream, xm);
-        } else if (cls == yk::CLS_W8) {
-            yk::launch_sweep_wave<8>(sa, c0.n[cls], e->num_cu, e->stream, xm);
         } else {
-            yk::launch_sweep_wave<16>(sa, c0.n[cls], e->num_cu, e->stream, xm);
+            switch (cls) {
+            case yk::CLS_R2: yk::launch_sweep_group<16, 2>(sa, c0.n[cls], e->stream, xm); break;
+            case yk::CLS_R4: yk::launch_sweep_group<16, 4>(sa, c0.n[cls], e->stream, xm); break;
+            case yk::CLS_R8: yk::launch_sweep_group<16, 8>(sa, c0.n[cls], e->stream, xm); break;
+            case yk::CLS_R16: yk::launch_sweep_group<16, 16>(sa, c0.n[cls], e->stream, xm); break;
+            case yk::CLS_W2: yk::launch_sweep_group<64, 2>(sa, c0.n[cls], e->stream, xm); break;
+            case yk::CLS_W4: yk::launch_sweep_group<64, 4>(sa, c0.n[cls], e->stream, xm); break;
+            case yk::CLS_W8: yk::launch_sweep_group<64, 8>(sa, c0.n[cls], e->stream, xm); break;
+            default: yk::launch_sweep_group<64, 16>(sa, c0.n[cls], e->stream, xm); break;
+            }
         }
     }
     HIP_TRY(hipEventRecord(e->ev[EV_SMALL], e->stream));
@@ -351,10 +355,14 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     t.sweep_general_ms = ev_ms(e->ev[EV_MED], e->ev[EV_GEN]);
     t.compact_ms = ev_ms(e->ev[EV_GEN], e->ev[EV_COMPACT]);
     t.total_ms = t.plan_ms + ev_ms(e->ev[EV_S0], e->ev[EV_COMPACT]) + extra_ms;
-    t.n_small = (uint64_t)c0.n[yk::CLS_W2] + c0.n[yk::CLS_W4] + c0.n[yk::CLS_W8] + c0.n[yk::CLS_W16];
+    t.n_small = 0;
+    t.iv_small = 0;
+    for (int cls = yk::CLS_R2; cls <= yk::CLS_W16; cls++) {
+        t.n_small += c0.n[cls];
+        t.iv_small += c0.iv[cls];
+    }
     t.n_medium = (uint64_t)c0.n[yk::CLS_MED1] + c0.n[yk::CLS_MED2];
     t.n_general = (uint64_t)c0.n[yk::CLS_GENERAL] + c1.rej_small + c1.rej_med + c1.rej_big;
-    t.iv_small = c0.iv[yk::CLS_W2] + c0.iv[yk::CLS_W4] + c0.iv[yk::CLS_W8] + c0.iv[yk::CLS_W16];
     t.iv_medium = c0.iv[yk::CLS_MED1] + c0.iv[yk::CLS_MED2];
     t.iv_general = c0.iv[yk::CLS_GENERAL];
     return YACRD_OK;

@@ -9,8 +9,9 @@ namespace yk {
 // workgroup, so the global counters see ~4 atomics per 1024 reads.
 constexpr int kPlanBlock = 1024;
 
+// mode: 0 = default, 1 = every read to the general path, 2 = no row layout (one read per wave)
 __global__ __launch_bounds__(kPlanBlock) void plan_kernel(const u64 *off, u32 n_reads, u32 *lists,
-                                                          Counters *ctr, u32 force_general)
+                                                          Counters *ctr, u32 mode)
 {
     __shared__ u32 s_cnt[CLS_COUNT];
     __shared__ u32 s_base[CLS_COUNT];
@@ -25,7 +26,11 @@ __global__ __launch_bounds__(kPlanBlock) void plan_kernel(const u64 *off, u32 n_
     if (r < n_reads) {
         const u64 n = off[r + 1] - off[r];
         const u64 m = 2 * n;
-        if (force_general) cls = CLS_GENERAL;
+        if (mode == 1) cls = CLS_GENERAL;
+        else if (mode != 2 && m <= 32) cls = CLS_R2;
+        else if (mode != 2 && m <= 64) cls = CLS_R4;
+        else if (mode != 2 && m <= 128) cls = CLS_R8;
+        else if (mode != 2 && m <= 256) cls = CLS_R16;
         else if (m <= 128) cls = CLS_W2;
         else if (m <= 256) cls = CLS_W4;
         else if (m <= 512) cls = CLS_W8;

@@ -11,7 +11,8 @@
 //     "upper lane of the pair" xor "descending block".
 // No LDS allocation, no barriers: a 256-thread workgroup is four independent wavefronts.
 // Pads are end-like keys (0xFFFFFFFE) and depth compares are signed, so nothing after the sort
-// needs a validity mask.
+// needs a validity mask (a read without intervals falls out as [(0,len)] on its own).
+// Reads of <= 128 intervals use 16-lane groups: four reads per wavefront (see sweep_group_read).
 #pragma once
 #include "device_common.h"
 
@@ -67,6 +68,33 @@ __device__ __forceinline__ u32 wscan_max(u32 v)
 }
 __device__ __forceinline__ u32 wshift_up1(u32 v) { return YK_DPP0(v, DPP_WAVE_SHR1, 0xF); }
 
+// 16-lane (DPP row) inclusive scans: four reads per wavefront, one per row
+__device__ __forceinline__ u32 rscan_add(u32 v)
+{
+    v += YK_DPP0(v, DPP_ROW_SHR1, 0xF);
+    v += YK_DPP0(v, DPP_ROW_SHR2, 0xF);
+    v += YK_DPP0(v, DPP_ROW_SHR4, 0xF);
+    v += YK_DPP0(v, DPP_ROW_SHR8, 0xF);
+    return v;
+}
+__device__ __forceinline__ u32 rscan_max(u32 v)
+{
+    v = max(v, YK_DPP0(v, DPP_ROW_SHR1, 0xF));
+    v = max(v, YK_DPP0(v, DPP_ROW_SHR2, 0xF));
+    v = max(v, YK_DPP0(v, DPP_ROW_SHR4, 0xF));
+    v = max(v, YK_DPP0(v, DPP_ROW_SHR8, 0xF));
+    return v;
+}
+__device__ __forceinline__ u32 rscan_min(u32 v) // identity ~0: shifted-in lanes must not win
+{
+    v = min(v, (u32)__builtin_amdgcn_update_dpp(-1, (int)v, DPP_ROW_SHR1, 0xF, 0xF, false));
+    v = min(v, (u32)__builtin_amdgcn_update_dpp(-1, (int)v, DPP_ROW_SHR2, 0xF, 0xF, false));
+    v = min(v, (u32)__builtin_amdgcn_update_dpp(-1, (int)v, DPP_ROW_SHR4, 0xF, 0xF, false));
+    v = min(v, (u32)__builtin_amdgcn_update_dpp(-1, (int)v, DPP_ROW_SHR8, 0xF, 0xF, false));
+    return v;
+}
+__device__ __forceinline__ u32 rshift_up1(u32 v) { return YK_DPP0(v, DPP_ROW_SHR1, 0xF); }
+
 struct LaneConst {
     u32 k[7];   // k[i] = (lane & (1<<i)) ? ~0u : 0u for i < 6; k[6] = 0
     u32 addr32; // byte address of lane ^ 32 for ds_bpermute
@@ -74,11 +102,12 @@ struct LaneConst {
 
 constexpr int ilog2c(int v) { return v <= 1 ? 0 : 1 + ilog2c(v >> 1); }
 
-// ---- bitonic sort of 64*K keys held as x[K] per lane, element index = lane*K + r ------------
-template <int K, int M, int J, int XM>
+// ---- bitonic sort of LANES*K keys held as x[K] per lane, element index = lane_in_group*K + r --
+// LANES = 64: one sequence per wavefront; LANES = 16: four independent sequences, one per DPP row.
+template <int LANES, int K, int M, int J, int XM>
 __device__ __forceinline__ void bitonic_step(u32 (&x)[K], const LaneConst &lc)
 {
-    constexpr int P = 64 * K;
+    constexpr int P = LANES * K;
     constexpr bool lane_dir = (M >= K) && (M < P); // direction bit lives in the lane id
     const u32 dirm = lane_dir ? lc.k[ilog2c(M / K)] : 0u;
     if constexpr (J >= K) { // partner in another lane
@@ -109,27 +138,47 @@ __device__ __forceinline__ void bitonic_step(u32 (&x)[K], const LaneConst &lc)
         }
     }
 }
-template <int K, int M, int J, int XM>
+template <int LANES, int K, int M, int J, int XM>
 __device__ __forceinline__ void bitonic_level(u32 (&x)[K], const LaneConst &lc)
 {
-    bitonic_step<K, M, J, XM>(x, lc);
-    if constexpr (J > 1) bitonic_level<K, M, J / 2, XM>(x, lc);
+    bitonic_step<LANES, K, M, J, XM>(x, lc);
+    if constexpr (J > 1) bitonic_level<LANES, K, M, J / 2, XM>(x, lc);
 }
-template <int K, int M, int XM>
+template <int LANES, int K, int M, int XM>
 __device__ __forceinline__ void bitonic_sort(u32 (&x)[K], const LaneConst &lc)
 {
-    bitonic_level<K, M, M / 2, XM>(x, lc);
-    if constexpr (M < 64 * K) bitonic_sort<K, M * 2, XM>(x, lc);
+    bitonic_level<LANES, K, M, M / 2, XM>(x, lc);
+    if constexpr (M < LANES * K) bitonic_sort<LANES, K, M * 2, XM>(x, lc);
 }
 
-// ---- one read, K keys per lane --------------------------------------------------------------
-// Returns false when the read has a degenerate interval (caller queues it for the general path).
-template <int K, int XM>
-__device__ __forceinline__ bool sweep_wave_read(const uint2 *__restrict__ iv, u32 n, u32 len,
-                                                u32 cov, uint2 *slot, u32 *count_out,
-                                                const LaneConst &lc)
+// ---- one read per group of LANES lanes, K keys per lane ------------------------------------
+// LANES = 64: one read per wavefront.  LANES = 16: four reads per wavefront, one per DPP row — every
+// cross-lane step then stays inside a row (10 cross-lane sort stages instead of 21, 4-step scans
+// instead of 6) and is shared by four reads.  Arguments are per lane but uniform inside a group.
+// The last lane of the group owns the inclusive scan totals and finishes the read.
+template <int LANES>
+__device__ __forceinline__ u32 gscan_add(u32 v) { return LANES == 64 ? wscan_add(v) : rscan_add(v); }
+template <int LANES>
+__device__ __forceinline__ u32 gscan_max(u32 v) { return LANES == 64 ? wscan_max(v) : rscan_max(v); }
+template <int LANES>
+__device__ __forceinline__ u32 gshift_up1(u32 v) { return LANES == 64 ? wshift_up1(v) : rshift_up1(v); }
+template <int LANES>
+__device__ __forceinline__ u32 gscan_min(u32 v)
 {
-    const u32 lane = lane_id();
+    v = rscan_min(v);
+    if (LANES == 64) {
+        v = min(v, (u32)__builtin_amdgcn_update_dpp(-1, (int)v, DPP_BCAST15, 0xA, 0xF, false));
+        v = min(v, (u32)__builtin_amdgcn_update_dpp(-1, (int)v, DPP_BCAST31, 0xC, 0xF, false));
+    }
+    return v;
+}
+
+template <int LANES, int K, int XM>
+__device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u32 n, u32 len,
+                                                 u32 cov, uint2 *slot, bool active, u32 r,
+                                                 const SweepArgs &a, const LaneConst &lc)
+{
+    const u32 lane = lane_id(), lig = lane & (u32)(LANES - 1);
     const u32 m = 2 * n;
     const i32 c = (i32)min(cov, 0x7FFFFFFFu);
 
@@ -138,7 +187,7 @@ __device__ __forceinline__ bool sweep_wave_read(const uint2 *__restrict__ iv, u3
     u32 bad = 0;
 #pragma unroll
     for (int j = 0; j < K / 2; j++) {
-        const u32 i = lane + 64u * j;
+        const u32 i = lig + (u32)LANES * j;
         uint2 v = make_uint2(0x7FFFFFFFu, 0x7FFFFFFFu);
         if (i < n) v = iv[i];
         const bool pad = i >= n;
@@ -146,92 +195,104 @@ __device__ __forceinline__ bool sweep_wave_read(const uint2 *__restrict__ iv, u3
         x[2 * j] = pad ? kPadKey : ((v.x << 1) | 1u);
         x[2 * j + 1] = pad ? kPadKey : (v.y << 1);
     }
-    if (__builtin_amdgcn_ballot_w64(bad != 0) != 0) return false;
+    const u64 badmask = __builtin_amdgcn_ballot_w64(bad != 0);
+    const bool group_bad =
+        LANES == 64 ? badmask != 0 : ((u32)(badmask >> (lane & 48u)) & 0xFFFFu) != 0;
+    if (LANES == 64 && group_bad) { // wave-uniform: skip the work, queue for the exact path
+        if (lig == LANES - 1 && active) {
+            a.rej_list[atomicAdd(a.rej_count, 1u)] = r;
+            a.counts[r] = 0;
+        }
+        return;
+    }
 
-    bitonic_sort<K, 2, XM>(x, lc);
+    bitonic_sort<LANES, K, 2, XM>(x, lc);
 
     // ---- pass 1: depth carried into each lane
     u32 delta = 0;
 #pragma unroll
-    for (int r = 0; r < K; r++) delta += (x[r] & 1u) ? 1u : 0xFFFFFFFFu;
-    const u32 dincl = wscan_add(delta);
+    for (int q = 0; q < K; q++) delta += (x[q] & 1u) ? 1u : 0xFFFFFFFFu;
+    const u32 dincl = gscan_add<LANES>(delta);
     const i32 depth_in = (i32)(dincl - delta);
 
-    // ---- pass 2: flagged ends / low starts, per-lane last of each
-    u32 fbits = 0, lbits = 0, mf = 0, ml = 0;
+    // ---- pass 2: last flagged end / last low start of the lane (keys ascend, so last = max)
+    u32 mf = 0, ml = 0;
     i32 d = depth_in;
 #pragma unroll
-    for (int r = 0; r < K; r++) {
-        const u32 key = x[r];
-        const bool is_s = (key & 1u) != 0;
-        const bool low = is_s && d <= c;
-        const bool fl = !is_s && d > c;
-        ml = low ? key : ml;
-        mf = fl ? key : mf;
-        lbits |= (low ? 1u : 0u) << r;
-        fbits |= (fl ? 1u : 0u) << r;
+    for (int q = 0; q < K; q++) {
+        const u32 key = x[q];
+        const bool is_s = (key & 1u) != 0, gt = d > c;
+        ml = (is_s && !gt) ? key : ml;
+        mf = (!is_s && gt) ? key : mf;
         d += is_s ? 1 : -1;
     }
-    const u32 mf_incl = wscan_max(mf), ml_incl = wscan_max(ml);
-    const u32 mf_in = wshift_up1(mf_incl), ml_in = wshift_up1(ml_incl);
-    const u32 mf_t = (u32)__builtin_amdgcn_readlane((int)mf_incl, 63);
-    const u32 ml_t = (u32)__builtin_amdgcn_readlane((int)ml_incl, 63);
+    const u32 mf_incl = gscan_max<LANES>(mf), ml_incl = gscan_max<LANES>(ml);
+    // "no flagged end yet" is carried as 1 instead of 0: a run whose only low starts sit at
+    // position 0 (key 1) then fails `cml > cmf`, which is the reference's `first_covered != 0`.
+    const u32 mf_in = max(gshift_up1<LANES>(mf_incl), 1u), ml_in = gshift_up1<LANES>(ml_incl);
 
     // ---- pass 3: regions closed in this lane; tail rule candidates (stack.rs:93-105)
-    u32 cnt = 0, first_b = 0, first_e = 0, cand = kNoKey;
+    // an end is in the tail when every start precedes it: starts before = (index + depth) / 2
+    const u32 tail_base = m - lig * (u32)K;
+    const u32 len_key = len >= 0x7FFFFFFFu ? 0xFFFFFFFFu : (len << 1);
+    u32 cnt = 0, fb = 0, fe = 0, cand = kNoKey;
     {
         u32 cmf = mf_in, cml = ml_in;
         d = depth_in;
 #pragma unroll
-        for (int r = 0; r < K; r++) {
-            const u32 key = x[r];
-            const bool fl = (fbits >> r) & 1u, low = (lbits >> r) & 1u;
-            const bool close = fl && cml > cmf && !(cmf == 0 && (cml >> 1) == 0);
-            if (close && cnt == 0) {
-                first_b = cmf >> 1;
-                first_e = cml >> 1;
-            }
+        for (int q = 0; q < K; q++) {
+            const u32 key = x[q];
+            const bool is_s = (key & 1u) != 0, gt = d > c;
+            const bool fl = !is_s && gt, low = is_s && !gt;
+            const bool close = fl && cml > cmf;
             cnt += close ? 1u : 0u;
-            // an end is in the tail when every start precedes it: starts before = (idx + depth)/2
-            const bool tail = fl && (lane * K + r + (u32)d == m) && (key >> 1) >= len;
-            cand = (tail && cand == kNoKey) ? (key >> 1) : cand;
+            fb = close ? cmf : fb;
+            fe = close ? cml : fe;
+            const bool tail = fl && ((u32)d + (u32)q == tail_base) && key >= len_key;
+            cand = min(cand, tail ? (key >> 1) : kNoKey);
             cmf = fl ? key : cmf;
             cml = low ? key : cml;
-            d += (key & 1u) ? 1 : -1;
+            d += is_s ? 1 : -1;
         }
     }
+    const bool live = active && !group_bad;
     u32 g_closed = 0;
-    const u64 any_close = __builtin_amdgcn_ballot_w64(cnt != 0);
-    if (any_close) {
-        const u32 cincl = wscan_add(cnt);
+    if (__builtin_amdgcn_ballot_w64(cnt != 0) != 0) {
+        const u32 cincl = gscan_add<LANES>(cnt);
+        g_closed = cincl; // meaningful on the group's last lane
         u32 pos = cincl - cnt;
-        g_closed = (u32)__builtin_amdgcn_readlane((int)cincl, 63);
-        if (cnt == 1) {
-            slot[pos] = make_uint2(first_b, first_e);
-        } else if (cnt > 1) { // several regions close inside one lane: replay it
+        if (live && cnt == 1) {
+            slot[pos] = make_uint2(fb >> 1, fe >> 1);
+        } else if (live && cnt > 1) { // several regions close inside one lane: replay it
             u32 cmf = mf_in, cml = ml_in;
+            d = depth_in;
 #pragma unroll
-            for (int r = 0; r < K; r++) {
-                const u32 key = x[r];
-                const bool fl = (fbits >> r) & 1u, low = (lbits >> r) & 1u;
-                if (fl && cml > cmf && !(cmf == 0 && (cml >> 1) == 0))
-                    slot[pos++] = make_uint2(cmf >> 1, cml >> 1);
+            for (int q = 0; q < K; q++) {
+                const u32 key = x[q];
+                const bool is_s = (key & 1u) != 0, gt = d > c;
+                const bool fl = !is_s && gt, low = is_s && !gt;
+                if (fl && cml > cmf) slot[pos++] = make_uint2(cmf >> 1, cml >> 1);
                 cmf = fl ? key : cmf;
                 cml = low ? key : cml;
+                d += is_s ? 1 : -1;
             }
         }
     }
     u32 min_ge = kNoKey;
-    const u64 any_cand = __builtin_amdgcn_ballot_w64(cand != kNoKey);
-    if (any_cand) // keys ascend with the lane id: the first lane holding a candidate has the minimum
-        min_ge = (u32)__builtin_amdgcn_readlane((int)cand, (int)__builtin_ctzll(any_cand));
-    if (lane == 0) *count_out = finish_read(slot, g_closed, mf_t, ml_t, min_ge, len);
-    return true;
+    if (__builtin_amdgcn_ballot_w64(cand != kNoKey) != 0) min_ge = gscan_min<LANES>(cand);
+    if (lig == LANES - 1 && active) { // the group's last lane holds every inclusive total
+        if (group_bad) {
+            a.rej_list[atomicAdd(a.rej_count, 1u)] = r;
+            a.counts[r] = 0;
+        } else {
+            a.counts[r] = finish_read(slot, g_closed, mf_incl, ml_incl, min_ge, len);
+        }
+    }
 }
 
-// One kernel per K so the small K get small register footprints (8 waves/SIMD).
-template <int K, int XM>
-__global__ __launch_bounds__(256) void sweep_wave_kernel(SweepArgs a)
+// One kernel per (LANES, K): small K keep small register footprints.
+template <int LANES, int K, int XM>
+__global__ __launch_bounds__(256) void sweep_group_kernel(SweepArgs a)
 {
     const u32 lane = lane_id();
     LaneConst lc;
@@ -240,50 +301,34 @@ __global__ __launch_bounds__(256) void sweep_wave_kernel(SweepArgs a)
     lc.k[6] = 0;
     lc.addr32 = (lane ^ 32u) << 2;
 
+    constexpr u32 GROUPS = 64 / LANES; // reads per wavefront
     const u32 list_n = *a.list_n;
-    const u32 wave = (u32)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const u32 nwaves = gridDim.x * 4u;
-    for (u32 w = blockIdx.x * 4u + wave; w < list_n; w += nwaves) {
-        const u32 r = a.list[w];
-        const u64 o = a.off[r];
-        const u32 n = (u32)(a.off[r + 1] - o);
-        const u32 len = a.len[r];
-        uint2 *slot = a.stage + (o + 2 * (u64)r);
-        bool ok = true;
-        if (n == 0) {
-            if (lane == 0) {
-                u32 g = 0;
-                if (len != 0) slot[g++] = make_uint2(0, len);
-                a.counts[r] = g;
-            }
-        } else {
-            ok = sweep_wave_read<K, XM>(a.iv + o, n, len, a.cov, slot, a.counts + r, lc);
-        }
-        if (!ok && lane == 0) { // degenerate interval: the exact general path takes the read
-            a.rej_list[atomicAdd(a.rej_count, 1u)] = r;
-            a.counts[r] = 0;
-        }
+    const u32 wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const u32 idx = wave * GROUPS + lane / (u32)LANES;
+    const bool active = idx < list_n;
+    u32 r = 0, n = 0, len = 0;
+    u64 o = 0;
+    if (active) {
+        r = a.list[idx];
+        o = a.off[r];
+        n = (u32)(a.off[r + 1] - o);
+        len = a.len[r];
     }
+    sweep_group_read<LANES, K, XM>(a.iv + o, n, len, a.cov, a.stage + (o + 2 * (u64)r), active, r,
+                                   a, lc);
 }
 
-template <int K>
-inline void launch_sweep_wave(const SweepArgs &sa, u32 n_reads, int num_cu, hipStream_t stream,
-                              int xlane_mode)
+template <int LANES, int K>
+inline void launch_sweep_group(const SweepArgs &sa, u32 n_reads, hipStream_t stream, int xlane_mode)
 {
-    // One read per wavefront, four wavefronts per workgroup; the dispatcher balances the tail
-    // better than persistent waves did (76 vs 82 us on configs[1], profiles/README.md).
-    // YACRD_WAVE_BLOCKS_PER_CU=n caps the grid at n workgroups per CU (grid-stride loop) for A/B.
-    static const int per_cu = [] {
-        const char *s = getenv("YACRD_WAVE_BLOCKS_PER_CU");
-        return s ? atoi(s) : 0;
-    }();
-    const u64 want = ((u64)n_reads + 3) / 4;
-    const u64 cap = per_cu > 0 ? (u64)num_cu * (u64)per_cu : want;
-    const u32 grid = (u32)(want < cap ? want : cap);
+    constexpr u32 per_block = 4u * (64 / LANES); // reads per 256-thread workgroup
+    const u32 grid = (n_reads + per_block - 1) / per_block;
     if (xlane_mode == 1)
-        hipLaunchKernelGGL((sweep_wave_kernel<K, 1>), dim3(grid ? grid : 1), dim3(256), 0, stream, sa);
+        hipLaunchKernelGGL((sweep_group_kernel<LANES, K, 1>), dim3(grid ? grid : 1), dim3(256), 0,
+                           stream, sa);
     else
-        hipLaunchKernelGGL((sweep_wave_kernel<K, 0>), dim3(grid ? grid : 1), dim3(256), 0, stream, sa);
+        hipLaunchKernelGGL((sweep_group_kernel<LANES, K, 0>), dim3(grid ? grid : 1), dim3(256), 0,
+                           stream, sa);
 }
 
 } // namespace yk

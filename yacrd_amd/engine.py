@@ -14,6 +14,7 @@ TYPE_NAMES = {NOT_BAD: "NotBad", CHIMERIC: "Chimeric", NOT_COVERED: "NotCovered"
 F_FORCE_GENERAL = 1
 F_FORCE_LDS_SORT = 2
 F_XLANE_DS = 4
+F_WAVE_ONLY = 8
 
 # every symbol include/yacrd_engine.h declares
 EXPORTED_SYMBOLS = [

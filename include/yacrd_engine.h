@@ -64,6 +64,8 @@ typedef struct {
 #define YACRD_F_XLANE_DS 4u
 /* no four-reads-per-wavefront row layout: every small read gets a whole wavefront; A/B only */
 #define YACRD_F_WAVE_ONLY 8u
+/* no two-reads-per-wavefront layout for reads of 129..256 intervals; A/B only */
+#define YACRD_F_NO_HALVES 16u
 
 /* Host-side result, allocated by the engine, released with yacrd_result_free(). */
 typedef struct {

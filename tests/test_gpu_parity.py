@@ -95,6 +95,14 @@ def test_general_class_large_reads(engine, cov):
                            len_hi=1000000), cov, 0.4, "large c=%d" % cov)
 
 
+@pytest.mark.parametrize("cov", [0, 3])
+def test_big_path_with_degenerate_reads(engine, cov):
+    """> 16384 intervals: device-wide segmented sort; degenerate giants fall back to the exact kernel."""
+    sizes = [20000, 17000, 33000, 16385, 131072, 100, 65536]
+    check(engine, make_csr(350 + cov, sizes, ("degenerate", "regular", "huge_pos", "dups", "sparse"),
+                           len_lo=300000, len_hi=900000), cov, 0.4, "big+degenerate c=%d" % cov)
+
+
 @pytest.mark.parametrize("cov", [0, 1, 2, 4])
 def test_degenerate_and_huge_positions(engine, cov):
     rng = np.random.default_rng(4)

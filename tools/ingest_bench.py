@@ -15,12 +15,19 @@ t0 = time.perf_counter()
 host.synth_paf(host.SYNTH_ONT, reads, overlaps, 20241110, path)
 size = os.path.getsize(path)
 res = {"paf_bytes": size, "write_s": round(time.perf_counter() - t0, 2), "runs": []}
+import ctypes
+lib = host.load_library()
 for th in (1, 8, 32, 64, 128, 0):
-    t0 = time.perf_counter()
-    c = host.csr_from_file(path, n_threads=th)
-    dt = time.perf_counter() - t0
-    res["runs"].append({"threads": th or (os.cpu_count() or 0), "s": round(dt, 3),
-                        "overlaps_per_s": round(c.n_records / dt), "GB_per_s": round(size / dt / 1e9, 3)})
-    c.close()
+    best = None
+    for rep in range(3):  # the raw C call (no numpy copies, no name decoding), best of 3
+        h = ctypes.c_void_p()
+        t0 = time.perf_counter()
+        rc = lib.yacrd_csr_from_file(path.encode(), 0, th, ctypes.byref(h))
+        dt = time.perf_counter() - t0
+        assert rc == 0
+        lib.yacrd_csr_free(h)
+        best = dt if best is None else min(best, dt)
+    res["runs"].append({"threads": th or (os.cpu_count() or 0), "s": round(best, 4),
+                        "overlaps_per_s": round(overlaps / best), "GB_per_s": round(size / best / 1e9, 3)})
 os.remove(path)
 print(json.dumps(res))

@@ -38,9 +38,10 @@ def main():
         cfg = CONFIGS[c]
         R, O = int(cfg["reads"] * scale), int(cfg["overlaps"] * scale)
         t0 = time.perf_counter()
-        offsets, intervals, lengths = host.synth_csr(cfg["profile"], R, O, 20241108 + c)
+        sflags = int(os.environ.get("YACRD_SYNTH_FLAGS", "0"))  # 1 = no abutting/degenerate injection
+        offsets, intervals, lengths = host.synth_csr(cfg["profile"], R, O, 20241108 + c, sflags)
         t_gen = time.perf_counter() - t0
-        out = {"config": c, "reads": R, "overlaps": O, "intervals": int(offsets[-1]),
+        out = {"config": c, "synth_flags": sflags, "reads": R, "overlaps": O, "intervals": int(offsets[-1]),
                "max_intervals_per_read": int(np.diff(offsets.astype(np.int64)).max()),
                "gen_s": round(t_gen, 2)}
         with yacrd_amd.Engine(device_id=0) as e:

@@ -17,13 +17,14 @@ constexpr u32 kMedium1Events = 8192;  // one read per 256-thread workgroup, 32 K
 constexpr u32 kMedium2Events = 32768; // one read per 1024-thread workgroup, 128 KiB LDS
 // Small reads sort in registers.  R<K>: four reads per wavefront, one per 16-lane DPP row, K keys
 // per lane (<= 16*K events); W<K>: one read per wavefront, K keys per lane (<= 64*K events).
-enum { CLS_R2 = 0, CLS_R4, CLS_R8, CLS_R16, CLS_W2, CLS_W4, CLS_W8, CLS_W16, CLS_MED1, CLS_MED2,
-       CLS_GENERAL, CLS_COUNT };
+// H16: two reads per wavefront (32-lane halves), 16 keys per lane (<= 512 events).
+enum { CLS_R2 = 0, CLS_R4, CLS_R8, CLS_R16, CLS_H16, CLS_W2, CLS_W4, CLS_W8, CLS_W16, CLS_MED1,
+       CLS_MED2, CLS_GENERAL, CLS_COUNT };
 
 // Device-side counters written by the plan kernel and the sweeps.
 struct Counters {
-    u32 n[12];               // reads per class (plan kernel)
-    u64 iv[12];              // intervals per class (plan kernel)
+    u32 n[16];               // reads per class (plan kernel)
+    u64 iv[16];              // intervals per class (plan kernel)
     u32 rej_small;           // reads with a degenerate interval found by a wave sweep (n <= 512)
     u32 rej_med;             // ... by the 256-thread LDS sweep (n <= 4096)
     u32 rej_big;             // ... by the 1024-thread LDS sweep (n <= 16384): global-memory path

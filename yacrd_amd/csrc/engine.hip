@@ -19,6 +19,7 @@
 
 #include "device_common.h"
 #include "plan_compact.h"
+#include "sweep_big.h"
 #include "sweep_general.h"
 #include "sweep_lds.h"
 #include "sweep_wave.h"
@@ -87,7 +88,7 @@ struct yacrd_engine {
     // inputs staged by yacrd_engine_run
     DevBuf in_off, in_iv, in_len;
     // work buffers
-    DevBuf lists, ctrl, stage, counts, gen_sizes, gen_scratch_off, gen_scratch;
+    DevBuf lists, ctrl, stage, counts, gen_sizes, gen_scratch_off, gen_scratch, big_tab, big_keys, big_redo;
     // results
     DevBuf bad_offsets, bad_regions, read_type;
     yk::Counters *h_ctr = nullptr; // pinned
@@ -134,24 +135,36 @@ int launch_compact(yacrd_engine *e, const u64 *d_off, const u32 *d_len, u32 n_re
     return YACRD_OK;
 }
 
+// Sizes / offsets of `count` listed reads, to the host (one sync).
+int gather_reads(yacrd_engine *e, const u64 *d_off, const u32 *d_len, const u32 *d_list, u32 count,
+                 hipStream_t stream, std::vector<yk::GatherOut> &out)
+{
+    HIP_TRY(e->gen_sizes.reserve((size_t)count * sizeof(yk::GatherOut)));
+    hipLaunchKernelGGL(yk::gather_general_sizes_kernel, dim3((count + 255) / 256), dim3(256), 0,
+                       stream, d_off, d_len, d_list, count, e->gen_sizes.as<yk::GatherOut>());
+    out.resize(count);
+    HIP_TRY(hipMemcpyAsync(out.data(), e->gen_sizes.p, (size_t)count * sizeof(yk::GatherOut),
+                           hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    for (const auto &g : out)
+        if (g.n >= 0x7FFFFFFFull) return fail(YACRD_EINVAL, "a read has >= 2^31 - 1 intervals");
+    return YACRD_OK;
+}
+
 // Global-memory exact path over `count` reads listed at d_list (host knows the count).
 int run_general_global(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u32 *d_len,
                        const u32 *d_list, u32 count, u32 cov, hipStream_t stream, u64 *iv_total)
 {
-    HIP_TRY(e->gen_sizes.reserve((size_t)count * sizeof(u64)));
+    std::vector<yk::GatherOut> info;
+    int rc = gather_reads(e, d_off, d_len, d_list, count, stream, info);
+    if (rc) return rc;
     HIP_TRY(e->gen_scratch_off.reserve((size_t)count * sizeof(u64)));
-    hipLaunchKernelGGL(yk::gather_general_sizes_kernel, dim3((count + 255) / 256), dim3(256), 0,
-                       stream, d_off, d_list, count, e->gen_sizes.as<u64>());
-    std::vector<u64> sizes(count), offs(count);
-    HIP_TRY(hipMemcpyAsync(sizes.data(), e->gen_sizes.p, (size_t)count * sizeof(u64),
-                           hipMemcpyDeviceToHost, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
+    std::vector<u64> offs(count);
     u64 tot = 0, gen_iv = 0;
     for (u32 i = 0; i < count; i++) {
-        if (sizes[i] >= 0x7FFFFFFFull) return fail(YACRD_EINVAL, "a read has >= 2^31 - 1 intervals");
         offs[i] = tot;
-        tot += 3 * sizes[i] + 2;
-        gen_iv += sizes[i];
+        tot += 3 * info[i].n + 2;
+        gen_iv += info[i].n;
     }
     if (iv_total) *iv_total = gen_iv;
     HIP_TRY(e->gen_scratch.reserve((size_t)tot * sizeof(u64)));
@@ -169,6 +182,91 @@ int run_general_global(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, con
     ga.stage = e->stage.as<uint2>();
     ga.counts = e->counts.as<u32>();
     hipLaunchKernelGGL(yk::sweep_general_kernel, dim3(count), dim3(yk::kGenThreads), 0, stream, ga);
+    return YACRD_OK;
+}
+
+// Reads with more than 16 384 intervals: device-wide segmented sort + chunked sweep
+// (sweep_big.h).  Reads that turn out to hold a degenerate interval are redone by the exact
+// general kernel afterwards.
+int run_big(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u32 *d_len,
+            const u32 *d_list, u32 count, u32 cov, hipStream_t stream, u64 *iv_total)
+{
+    std::vector<yk::GatherOut> info;
+    int rc = gather_reads(e, d_off, d_len, d_list, count, stream, info);
+    if (rc) return rc;
+    std::vector<yk::BigSeg> segs(count);
+    std::vector<u32> chunk_seg;
+    u64 key_off = 0, gen_iv = 0;
+    u32 max_P = 0;
+    for (u32 i = 0; i < count; i++) {
+        u64 P = yk::kBigC;
+        while (P < 2 * info[i].n) P <<= 1;
+        if (P > 0x80000000ull) return fail(YACRD_EINVAL, "a read has more than 2^30 intervals");
+        yk::BigSeg &sg = segs[i];
+        sg.key_off = key_off;
+        sg.iv_off = info[i].iv_off;
+        sg.P = (u32)P;
+        sg.n = (u32)info[i].n;
+        sg.len = info[i].len;
+        sg.read = info[i].read;
+        sg.chunk_off = (u32)chunk_seg.size();
+        sg.pad = 0;
+        for (u64 c = 0; c < P / yk::kBigC; c++) chunk_seg.push_back(i);
+        key_off += P;
+        gen_iv += info[i].n;
+        max_P = std::max(max_P, (u32)P);
+    }
+    if (iv_total) *iv_total = gen_iv;
+    const size_t n_chunks = chunk_seg.size();
+    if (n_chunks >= 0x7FFFFFFFull / (yk::kBigC / 2)) return fail(YACRD_EINVAL, "big path: too many keys");
+    const size_t tab_bytes = (size_t)count * sizeof(yk::BigSeg) + n_chunks * sizeof(u32) +
+                             9 * n_chunks * sizeof(u32) + (size_t)count * sizeof(u32) + 64;
+    HIP_TRY(e->big_tab.reserve(tab_bytes));
+    HIP_TRY(e->big_keys.reserve((size_t)key_off * sizeof(u32)));
+    char *base = e->big_tab.as<char>();
+    yk::BigArgs a;
+    a.seg = reinterpret_cast<yk::BigSeg *>(base);
+    u32 *w = reinterpret_cast<u32 *>(base + (size_t)count * sizeof(yk::BigSeg));
+    a.chunk_seg = w;
+    w += n_chunks;
+    u32 **per_chunk[] = {&a.c_delta, &a.c_depth_in, &a.c_mf, &a.c_ml, &a.c_mf_in,
+                         &a.c_ml_in, &a.c_cnt, &a.c_pos, &a.c_cand};
+    for (u32 **pp : per_chunk) {
+        *pp = w;
+        w += n_chunks;
+    }
+    a.seg_bad = w;
+    a.keys = e->big_keys.as<u32>();
+    a.iv = d_iv;
+    a.n_chunks = (u32)n_chunks;
+    a.n_segs = count;
+    a.cov = cov;
+    a.stage = e->stage.as<uint2>();
+    a.counts = e->counts.as<u32>();
+    HIP_TRY(hipMemcpyAsync((void *)a.seg, segs.data(), (size_t)count * sizeof(yk::BigSeg),
+                           hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync((void *)a.chunk_seg, chunk_seg.data(), n_chunks * sizeof(u32),
+                           hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemsetAsync(a.seg_bad, 0, (size_t)count * sizeof(u32), stream));
+    hipLaunchKernelGGL(yk::big_fill_kernel, dim3((u32)n_chunks), dim3(yk::kBigT), 0, stream, a);
+    yk::launch_big(a, max_P, stream);
+    std::vector<u32> bad(count);
+    HIP_TRY(hipMemcpyAsync(bad.data(), a.seg_bad, (size_t)count * sizeof(u32), hipMemcpyDeviceToHost,
+                           stream));
+    HIP_TRY(hipStreamSynchronize(stream)); // host tables must outlive the copies
+    HIP_TRY(hipGetLastError());
+    std::vector<u32> redo;
+    for (u32 i = 0; i < count; i++)
+        if (bad[i]) redo.push_back(info[i].read);
+    if (!redo.empty()) { // degenerate interval in a huge read: exact path, single workgroup each
+        HIP_TRY(e->big_redo.reserve(redo.size() * sizeof(u32)));
+        HIP_TRY(hipMemcpyAsync(e->big_redo.p, redo.data(), redo.size() * sizeof(u32),
+                               hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        rc = run_general_global(e, d_off, d_iv, d_len, e->big_redo.as<u32>(), (u32)redo.size(), cov,
+                                stream, nullptr);
+        if (rc) return rc;
+    }
     return YACRD_OK;
 }
 
@@ -214,7 +312,8 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     hipLaunchKernelGGL(yk::plan_kernel, dim3((n_reads + yk::kPlanBlock - 1) / yk::kPlanBlock),
                        dim3(yk::kPlanBlock), 0, e->stream, d_off, n_reads, lists, ctr,
                        (u32)((e->flags & YACRD_F_FORCE_GENERAL) ? 1
-                             : (e->flags & (YACRD_F_WAVE_ONLY | YACRD_F_FORCE_LDS_SORT)) ? 2 : 0));
+                             : (e->flags & (YACRD_F_WAVE_ONLY | YACRD_F_FORCE_LDS_SORT)) ? 2
+                             : (e->flags & YACRD_F_NO_HALVES) ? 3 : 0));
     HIP_TRY(hipEventRecord(e->ev[EV_PLAN], e->stream));
     HIP_TRY(hipMemcpyAsync(e->h_ctr, ctr, sizeof(yk::Counters), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
@@ -250,6 +349,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
             case yk::CLS_R4: yk::launch_sweep_group<16, 4>(sa, c0.n[cls], e->stream, xm); break;
             case yk::CLS_R8: yk::launch_sweep_group<16, 8>(sa, c0.n[cls], e->stream, xm); break;
             case yk::CLS_R16: yk::launch_sweep_group<16, 16>(sa, c0.n[cls], e->stream, xm); break;
+            case yk::CLS_H16: yk::launch_sweep_group<32, 16>(sa, c0.n[cls], e->stream, xm); break;
             case yk::CLS_W2: yk::launch_sweep_group<64, 2>(sa, c0.n[cls], e->stream, xm); break;
             case yk::CLS_W4: yk::launch_sweep_group<64, 4>(sa, c0.n[cls], e->stream, xm); break;
             case yk::CLS_W8: yk::launch_sweep_group<64, 8>(sa, c0.n[cls], e->stream, xm); break;
@@ -301,8 +401,11 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     // (b) reads too large for LDS (or every read under YACRD_F_FORCE_GENERAL): global scratch
     u64 gen_iv = 0;
     if (c0.n[yk::CLS_GENERAL]) {
-        int rc = run_general_global(e, d_off, d_iv, d_len, list_of(yk::CLS_GENERAL),
-                                    c0.n[yk::CLS_GENERAL], cov, e->stream, &gen_iv);
+        int rc = (e->flags & YACRD_F_FORCE_GENERAL)
+                     ? run_general_global(e, d_off, d_iv, d_len, list_of(yk::CLS_GENERAL),
+                                          c0.n[yk::CLS_GENERAL], cov, e->stream, &gen_iv)
+                     : run_big(e, d_off, d_iv, d_len, list_of(yk::CLS_GENERAL),
+                               c0.n[yk::CLS_GENERAL], cov, e->stream, &gen_iv);
         if (rc) return rc;
     }
     HIP_TRY(hipEventRecord(e->ev[EV_GEN], e->stream));
@@ -449,7 +552,8 @@ void yacrd_engine_destroy(yacrd_engine *e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     DevBuf *bufs[] = {&e->in_off, &e->in_iv, &e->in_len, &e->lists, &e->ctrl, &e->stage,
                       &e->counts, &e->gen_sizes, &e->gen_scratch_off,
-                      &e->gen_scratch, &e->bad_offsets, &e->bad_regions, &e->read_type};
+                      &e->gen_scratch, &e->big_tab, &e->big_keys, &e->big_redo,
+                      &e->bad_offsets, &e->bad_regions, &e->read_type};
     for (DevBuf *b : bufs) b->release();
     if (e->h_ctr) (void)hipHostFree(e->h_ctr);
     for (int i = 0; i < EV_COUNT; i++)

@@ -9,7 +9,8 @@ namespace yk {
 // workgroup, so the global counters see ~4 atomics per 1024 reads.
 constexpr int kPlanBlock = 1024;
 
-// mode: 0 = default, 1 = every read to the general path, 2 = no row layout (one read per wave)
+// mode: 0 = default, 1 = every read to the general path, 2 = one read per wavefront only,
+// 3 = rows (<= 128 intervals) but no 32-lane halves
 __global__ __launch_bounds__(kPlanBlock) void plan_kernel(const u64 *off, u32 n_reads, u32 *lists,
                                                           Counters *ctr, u32 mode)
 {
@@ -31,6 +32,7 @@ __global__ __launch_bounds__(kPlanBlock) void plan_kernel(const u64 *off, u32 n_
         else if (mode != 2 && m <= 64) cls = CLS_R4;
         else if (mode != 2 && m <= 128) cls = CLS_R8;
         else if (mode != 2 && m <= 256) cls = CLS_R16;
+        else if (mode == 0 && m <= 512) cls = CLS_H16;
         else if (m <= 128) cls = CLS_W2;
         else if (m <= 256) cls = CLS_W4;
         else if (m <= 512) cls = CLS_W8;

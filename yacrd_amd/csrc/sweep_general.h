@@ -266,12 +266,26 @@ __global__ __launch_bounds__(T) void sweep_general_lds_kernel(SweepArgs a)
     }
 }
 
-// n per general read, for the host-side scratch layout
-__global__ __launch_bounds__(256) void gather_general_sizes_kernel(const u64 *off, const u32 *list,
-                                                                   u32 count, u64 *sizes)
+// what the host needs to lay out scratch / key buffers for the listed reads
+struct GatherOut {
+    u64 iv_off;
+    u64 n;
+    u32 len;
+    u32 read;
+};
+__global__ __launch_bounds__(256) void gather_general_sizes_kernel(const u64 *off, const u32 *len,
+                                                                   const u32 *list, u32 count,
+                                                                   GatherOut *out)
 {
     const u32 i = blockIdx.x * 256u + threadIdx.x;
-    if (i < count) sizes[i] = off[list[i] + 1] - off[list[i]];
+    if (i >= count) return;
+    const u32 r = list[i];
+    GatherOut g;
+    g.iv_off = off[r];
+    g.n = off[r + 1] - off[r];
+    g.len = len[r];
+    g.read = r;
+    out[i] = g;
 }
 
 } // namespace yk

@@ -156,20 +156,39 @@ __device__ __forceinline__ void bitonic_sort(u32 (&x)[K], const LaneConst &lc)
 // cross-lane step then stays inside a row (10 cross-lane sort stages instead of 21, 4-step scans
 // instead of 6) and is shared by four reads.  Arguments are per lane but uniform inside a group.
 // The last lane of the group owns the inclusive scan totals and finishes the read.
+// 32-lane groups (two reads per wavefront) are row scans plus the row_bcast:15 step.
 template <int LANES>
-__device__ __forceinline__ u32 gscan_add(u32 v) { return LANES == 64 ? wscan_add(v) : rscan_add(v); }
+__device__ __forceinline__ u32 gscan_add(u32 v)
+{
+    if (LANES == 64) return wscan_add(v);
+    v = rscan_add(v);
+    if (LANES == 32) v += YK_DPP0(v, DPP_BCAST15, 0xA);
+    return v;
+}
 template <int LANES>
-__device__ __forceinline__ u32 gscan_max(u32 v) { return LANES == 64 ? wscan_max(v) : rscan_max(v); }
+__device__ __forceinline__ u32 gscan_max(u32 v)
+{
+    if (LANES == 64) return wscan_max(v);
+    v = rscan_max(v);
+    if (LANES == 32) v = max(v, YK_DPP0(v, DPP_BCAST15, 0xA));
+    return v;
+}
 template <int LANES>
-__device__ __forceinline__ u32 gshift_up1(u32 v) { return LANES == 64 ? wshift_up1(v) : rshift_up1(v); }
+__device__ __forceinline__ u32 gshift_up1(u32 v)
+{
+    if (LANES == 16) return rshift_up1(v);
+    const u32 t = wshift_up1(v);
+    if (LANES == 32) return (lane_id() == 32u) ? 0u : t; // lane 32 opens the second group
+    return t;
+}
 template <int LANES>
 __device__ __forceinline__ u32 gscan_min(u32 v)
 {
     v = rscan_min(v);
-    if (LANES == 64) {
+    if (LANES >= 32)
         v = min(v, (u32)__builtin_amdgcn_update_dpp(-1, (int)v, DPP_BCAST15, 0xA, 0xF, false));
+    if (LANES == 64)
         v = min(v, (u32)__builtin_amdgcn_update_dpp(-1, (int)v, DPP_BCAST31, 0xC, 0xF, false));
-    }
     return v;
 }
 
@@ -196,8 +215,9 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
         x[2 * j + 1] = pad ? kPadKey : (v.y << 1);
     }
     const u64 badmask = __builtin_amdgcn_ballot_w64(bad != 0);
-    const bool group_bad =
-        LANES == 64 ? badmask != 0 : ((u32)(badmask >> (lane & 48u)) & 0xFFFFu) != 0;
+    const bool group_bad = LANES == 64   ? badmask != 0
+                           : LANES == 32 ? (u32)(badmask >> (lane & 32u)) != 0
+                                         : ((u32)(badmask >> (lane & 48u)) & 0xFFFFu) != 0;
     if (LANES == 64 && group_bad) { // wave-uniform: skip the work, queue for the exact path
         if (lig == LANES - 1 && active) {
             a.rej_list[atomicAdd(a.rej_count, 1u)] = r;
@@ -209,9 +229,10 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
     bitonic_sort<LANES, K, 2, XM>(x, lc);
 
     // ---- pass 1: depth carried into each lane
-    u32 delta = 0;
+    u32 n_starts = 0; // net depth change of the lane = starts - ends = 2 * starts - K
 #pragma unroll
-    for (int q = 0; q < K; q++) delta += (x[q] & 1u) ? 1u : 0xFFFFFFFFu;
+    for (int q = 0; q < K; q++) n_starts += x[q] & 1u;
+    const u32 delta = 2u * n_starts - (u32)K;
     const u32 dincl = gscan_add<LANES>(delta);
     const i32 depth_in = (i32)(dincl - delta);
 

@@ -15,6 +15,7 @@ F_FORCE_GENERAL = 1
 F_FORCE_LDS_SORT = 2
 F_XLANE_DS = 4
 F_WAVE_ONLY = 8
+F_NO_HALVES = 16
 
 # every symbol include/yacrd_engine.h declares
 EXPORTED_SYMBOLS = [

@@ -14,8 +14,102 @@
 // Reads with a degenerate interval are handed to the general queue untouched.
 #pragma once
 #include "device_common.h"
+#include "sweep_wave.h"
 
 namespace yk {
+
+// ---- register-resident pieces of the workgroup sort ------------------------------------------
+// A wavefront holds a 1024-key block striped over its lanes (element = r*64 + lane, r < 16), so
+// LDS loads/stores are conflict-free, strides >= 64 are register-to-register and strides < 64
+// are DPP / ds_swizzle exchanges (same primitives as sweep_wave.h).  Blocks that must come out
+// descending are complemented before and after, so every step below is ascending-only at the
+// block level; directions inside a block are compile-time (register bits) or lane constants.
+template <int M, int J, int XM>
+__device__ __forceinline__ void striped_step(u32 (&x)[16], const LaneConst &lc)
+{
+    constexpr int K = 16, P = 64 * K;
+    if constexpr (J >= 64) {
+        constexpr int R = J / 64;
+#pragma unroll
+        for (int r = 0; r < K; r++) {
+            if ((r & R) == 0) {
+                const u32 a = x[r], b = x[r | R];
+                const bool desc = (M < P) && ((r & (M / 64)) != 0);
+                x[r] = desc ? max(a, b) : min(a, b);
+                x[r | R] = desc ? min(a, b) : max(a, b);
+            }
+        }
+    } else {
+        const u32 kj = lc.k[ilog2c(J)];
+        const u32 dir_lane = (M < 64) ? lc.k[ilog2c(M)] : 0u;
+#pragma unroll
+        for (int r = 0; r < K; r++) {
+            const bool desc_r = (M >= 64) && (M < P) && ((r & (M / 64)) != 0);
+            const u32 sel = desc_r ? ~kj : (kj ^ dir_lane);
+            const u32 t = lane_xor<J, XM>(x[r], lc.addr32);
+            x[r] = umed3(x[r], t, sel);
+        }
+    }
+}
+template <int M, int J, int XM>
+__device__ __forceinline__ void striped_level(u32 (&x)[16], const LaneConst &lc)
+{
+    striped_step<M, J, XM>(x, lc);
+    if constexpr (J > 1) striped_level<M, J / 2, XM>(x, lc);
+}
+template <int M, int XM>
+__device__ __forceinline__ void striped_sort(u32 (&x)[16], const LaneConst &lc)
+{
+    striped_level<M, M / 2, XM>(x, lc);
+    if constexpr (M < 1024) striped_sort<M * 2, XM>(x, lc);
+}
+
+// Workgroup sort of P >= 1024 keys in LDS: 1024-key runs sorted in registers, then per level the
+// strides >= 1024 as LDS compare-exchange stages and the strides < 1024 again in registers.
+// For P = 32768 that is 15 LDS stages instead of 120.
+template <int T>
+__device__ __forceinline__ void hybrid_sort_lds(u32 *keys, u32 P, const LaneConst &lc)
+{
+    const u32 lane = lane_id(), wave = threadIdx.x >> 6;
+    constexpr u32 NW = T / 64;
+    const u32 n_blocks = P >> 10;
+    for (u32 b = wave; b < n_blocks; b += NW) {
+        u32 *kb = keys + (b << 10) + lane;
+        const u32 flip = (b & 1u) ? 0xFFFFFFFFu : 0u; // level 1024 direction = bit 10 of the index
+        u32 x[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) x[r] = kb[r * 64] ^ flip;
+        striped_sort<2, 0>(x, lc);
+#pragma unroll
+        for (int r = 0; r < 16; r++) kb[r * 64] = x[r] ^ flip;
+    }
+    __syncthreads();
+    for (u32 M = 2048; M <= P; M <<= 1) {
+        for (u32 j = M >> 1; j >= 1024; j >>= 1) {
+            for (u32 p = threadIdx.x; p < (P >> 1); p += T) {
+                const u32 i = ((p & ~(j - 1)) << 1) | (p & (j - 1)), l = i | j;
+                const bool up = (i & M) == 0;
+                const u32 a = keys[i], c = keys[l];
+                if ((a > c) == up) {
+                    keys[i] = c;
+                    keys[l] = a;
+                }
+            }
+            __syncthreads();
+        }
+        for (u32 b = wave; b < n_blocks; b += NW) {
+            u32 *kb = keys + (b << 10) + lane;
+            const u32 flip = ((b << 10) & M) ? 0xFFFFFFFFu : 0u;
+            u32 x[16];
+#pragma unroll
+            for (int r = 0; r < 16; r++) x[r] = kb[r * 64] ^ flip;
+            striped_level<1024, 512, 0>(x, lc);
+#pragma unroll
+            for (int r = 0; r < 16; r++) kb[r * 64] = x[r] ^ flip;
+        }
+        __syncthreads();
+    }
+}
 
 template <int T>
 __device__ __forceinline__ void bitonic_sort_lds(u32 *keys, u32 P)
@@ -46,6 +140,11 @@ __global__ __launch_bounds__(T) void sweep_lds_kernel(SweepArgs a)
 
     const u32 tid = threadIdx.x;
     const u32 list_n = *a.list_n;
+    LaneConst lc;
+#pragma unroll
+    for (int i = 0; i < 6; i++) lc.k[i] = (tid & (1u << i)) ? 0xFFFFFFFFu : 0u;
+    lc.k[6] = 0;
+    lc.addr32 = ((tid & 63u) ^ 32u) << 2;
 
     for (u32 b = blockIdx.x; b < list_n; b += gridDim.x) {
         const u32 r = a.list[b];
@@ -91,7 +190,8 @@ __global__ __launch_bounds__(T) void sweep_lds_kernel(SweepArgs a)
         max_start = block_max<T>(max_start, sc);
         __syncthreads();
 
-        bitonic_sort_lds<T>(keys, P);
+        if (T >= 256 && P >= 1024) hybrid_sort_lds<T>(keys, P, lc);
+        else bitonic_sort_lds<T>(keys, P);
 
         // ---- blocked chunks: thread t owns events [t*K, t*K+K) of the sorted sequence
         const u32 K = (P >= (u32)T) ? P / T : 1;

@@ -387,6 +387,8 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         sa.list_n = &ctr->rej_small;
         sa.rej_list = rej_med; // cannot happen (n <= 512), kept well defined
         sa.rej_count = &ctr->rej_med;
+        // (a single wavefront per read was tried: 23.9 us vs 20.2 us — the stages are latency
+        // chains, more threads shorten each one)
         hipLaunchKernelGGL((yk::sweep_general_lds_kernel<256, 512>), dim3(e->num_cu * 2), dim3(256),
                            0, e->stream, sa);
     }

@@ -58,6 +58,16 @@ def make_read(rng, n, length, mode="regular"):
             iv[idx[0]] = (rng.integers(0, max(1, L)), 0)
         if rng.random() < 0.3:
             iv[idx[-1]] = iv[idx[0]]
+    elif mode == "zero_len":  # start == end only (the fast paths take these)
+        k = max(1, n // 6)
+        idx = rng.choice(n, size=k, replace=False)
+        iv[idx, 1] = iv[idx, 0]
+        if rng.random() < 0.3:
+            iv[idx[0]] = (0, 0)
+        if rng.random() < 0.3:
+            iv[idx[-1]] = (L, L)
+        if rng.random() < 0.2 and k > 1:
+            iv[idx[1]] = iv[idx[0]]  # duplicate zero-length interval -> exact path
     elif mode == "huge_pos":  # positions >= 2^31 (32-bit event keys cannot hold them)
         k = max(1, n // 8)
         idx = rng.choice(n, size=k, replace=False)

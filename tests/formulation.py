@@ -5,10 +5,13 @@ formulations be fuzzed against the oracle on CPU (tests/test_formulation.py)."""
 NO = 0xFFFFFFFF
 
 
+SH = 2  # key = pos << 2 | class: 0 end, 1 zero-length start, 2 zero-length end, 3 start
+
+
 def finish_read(slot, mf_t, ml_t, min_ge, length):
-    lcf = min_ge if min_ge != NO else (mf_t >> 1)
+    lcf = min_ge if min_ge != NO else (mf_t >> SH)
     if ml_t > mf_t:
-        b, e = mf_t >> 1, ml_t >> 1
+        b, e = mf_t >> SH, ml_t >> SH
         if mf_t == 0:
             if e != 0 and length != 0:
                 slot.append((0, max(e, length)))
@@ -24,23 +27,41 @@ def finish_read(slot, mf_t, ml_t, min_ge, length):
 
 
 def regular_events(intervals, length, cov):
-    """Event formulation for regular reads (start < end < 2^31); None if not regular."""
+    """Event formulation for regular reads (start <= end < 2^30 - 1, no two zero-length
+    intervals at one position); None if the read must take the exact general path."""
     n = len(intervals)
     if n == 0:
         return [(0, length)] if length != 0 else []
     keys = []
     max_start = 0
     for s, e in intervals:
-        if s >= e or e >= 2**31:
+        if s > e or e >= 2**30 - 1:
             return None
-        keys.append((s << 1) | 1)
-        keys.append(e << 1)
-        max_start = max(max_start, (s << 1) | 1)
+        if s == e:
+            keys.append((s << SH) | 1)
+            keys.append((s << SH) | 2)
+        else:
+            keys.append((s << SH) | 3)
+            keys.append(e << SH)
+        max_start = max(max_start, keys[-2])
     keys.sort()
+    for a, b in zip(keys, keys[1:]):
+        if a == b and (a & 3) == 1 and a != 1:
+            return None  # duplicate zero-length interval: S,S,E,E would not be S,E,S,E
+        # (0,0) intervals are inert in the reference (their pop re-assigns last_covered = 0 while it
+        # still is 0) and in the keys (flipped end key 0 never beats "none" = 1): no exception needed
+    # Flagged ends are tracked in a "flipped" domain tk = key ^ 2 (class 0 <-> 2): at one position
+    # a regular end then beats a zero-length interval's own end under max, i.e. the FIRST flagged
+    # end of a position is the effective one (later ones leave last_covered unchanged, so an open
+    # run of low starts at that position must stay open).  tc = 1 means "none": its true key 1 ^ 2
+    # = 3 is the key of a start at position 0, which makes `ml > true(tc)` the reference's
+    # `first_covered != 0` test.
     d = 0
-    mf = ml = 0
+    tc = 1
+    ml = 0
     min_ge = NO
     slot = []
+    any_flag = False
     for key in keys:
         if key & 1:
             if d <= cov:
@@ -48,13 +69,16 @@ def regular_events(intervals, length, cov):
             d += 1
         else:
             if d > cov:
-                if ml > mf and not (mf == 0 and (ml >> 1) == 0):
-                    slot.append((mf >> 1, ml >> 1))
-                mf = key
-                if key > max_start and (key >> 1) >= length:
-                    min_ge = min(min_ge, key >> 1)
+                tk = key ^ 2
+                if tk > tc:
+                    if ml > (tc ^ 2):
+                        slot.append(((tc ^ 2) >> SH, ml >> SH))
+                    tc = tk
+                    any_flag = True
+                if key > max_start and (key >> SH) >= length:
+                    min_ge = min(min_ge, key >> SH)
             d -= 1
-    return finish_read(slot, mf, ml, min_ge, length)
+    return finish_read(slot, (tc ^ 2) if any_flag else 0, ml, min_ge, length)
 
 
 def general_events(intervals, length, cov):

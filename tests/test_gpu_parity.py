@@ -61,7 +61,7 @@ def test_fixture_truth(engine, golden_dir, cov, nc):
 
 
 # ---- size classes x coverage ------------------------------------------------------------------
-REGULAR_MODES = ("regular", "abutting", "dups", "beyond", "sparse")
+REGULAR_MODES = ("regular", "abutting", "dups", "beyond", "sparse", "zero_len")
 
 
 @pytest.mark.parametrize("cov", [0, 1, 3, 4, 9])

@@ -11,6 +11,33 @@ namespace yk {
 
 constexpr u32 kNoKey = 0xFFFFFFFFu;
 
+// Event keys of the regular sweeps: position << 2 | class, so that sorting the keys reproduces
+// the reference's push/pop order (src/stack.rs:66-91) at one position:
+//   0 end of a regular interval     (popped first: `head <= interval.0`, stack.rs:72-81)
+//   1 start of a zero-length interval (start == end sorts before the regular intervals that
+//   2 end   of a zero-length interval  start there, and is popped first at the next step)
+//   3 start of a regular interval
+// Reads with start > end, a position >= 2^30 - 1, or two zero-length intervals at one position
+// > 0 (S,S,E,E would not be S,E,S,E) go to the exact general path instead.  (0,0) intervals are
+// inert in the reference (their pop re-assigns last_covered = 0 while it still is 0) and in the
+// keys (their flipped end key 0 never beats "none" = 1), duplicates included.
+constexpr u32 kKeyShift = 2;
+constexpr u32 kMaxKeyPos = 0x3FFFFFFEu;
+__device__ __forceinline__ void make_event_keys(uint2 v, u32 &ks, u32 &ke, u32 &bad, u32 &zero_len)
+{
+    const u32 z = (v.x == v.y) ? 2u : 0u;
+    bad |= (v.x > v.y || v.y > kMaxKeyPos) ? 1u : 0u;
+    zero_len += z;              // 2 per zero-length interval
+    ks = ((v.x << kKeyShift) | 3u) - z; // class 3, or 1 when zero-length
+    ke = (v.y << kKeyShift) + z;        // class 0, or 2 when zero-length
+}
+// Flagged ends are tracked as tk = key ^ 2 (class 0 <-> 2): under max, the FIRST flagged end of
+// a position wins (a regular end beats the zero-length interval's own end), because later
+// flagged ends at that position leave last_covered unchanged and must not close the run of low
+// starts sitting there.  tk = 1 is "none": its true key 1 ^ 2 = 3 is the key of a start at
+// position 0, which turns `last_low > true(tk)` into the reference's `first_covered != 0`.
+constexpr u32 kNoFlag = 1u;
+
 // Size classes by events per read (m = 2 * intervals).
 constexpr u32 kSmallEvents = 1024;    // one read per wavefront
 constexpr u32 kMedium1Events = 8192;  // one read per 256-thread workgroup, 32 KiB LDS
@@ -168,16 +195,16 @@ __device__ __forceinline__ u32 block_max(u32 v, u32 *sc)
 // ---- final assembly shared by every regular-read sweep --------------------------------------
 // After the event sweep a read is described by:
 //   g      closed regions already written to slot[0..g)
-//   mf_t   key of the last flagged end (0 = none);   ml_t  key of the last low start
+//   mf_t   true key of the last effective flagged end (0 = none);  ml_t  key of the last low start
 //   min_ge smallest flagged tail end >= len (kNoKey = none)
 // This reproduces reference src/stack.rs:93-113 (tail loop, prepend, append) and the part of
 // the equal-begin merge (:119-136) that touches the last region.  Returns the region count.
 __device__ __forceinline__ u32 finish_read(uint2 *slot, u32 g, u32 mf_t, u32 ml_t, u32 min_ge,
                                            u32 len)
 {
-    const u32 lcf = (min_ge != kNoKey) ? min_ge : (mf_t >> 1);
+    const u32 lcf = (min_ge != kNoKey) ? min_ge : (mf_t >> kKeyShift);
     if (ml_t > mf_t) { // the last low start comes after the last flagged end: open run
-        const u32 b = mf_t >> 1, e = ml_t >> 1;
+        const u32 b = mf_t >> kKeyShift, e = ml_t >> kKeyShift;
         if (mf_t == 0) { // nothing ever exceeded the coverage threshold
             if (e != 0 && len != 0) slot[g++] = make_uint2(0, max(e, len));
             else if (e != 0) slot[g++] = make_uint2(0, e);

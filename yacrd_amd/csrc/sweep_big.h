@@ -2,8 +2,8 @@
 // device works on them.  Same event formulation as sweep_lds.h (reference src/stack.rs:61-139),
 // but the 2n keys of a read live in global memory as `P/C` chunks of C = 8192 keys and every
 // step is a grid over chunks:
-//   fill        keys (start<<1|1, end<<1) + end-like pads up to P = pow2 >= 2n; flags degenerate
-//               reads (those go to the exact general kernel instead)
+//   fill        event keys (position<<2 | class, device_common.h) + end-like pads up to
+//               P = pow2 >= 2n; flags reads the keys cannot express (exact general kernel instead)
 //   sort        segmented bitonic: chunk_sort (levels <= C in LDS), then per level M = 2C..P:
 //               global_stage for strides >= C, lds_merge for strides < C.  A read stops at M = P.
 //   sweep       the chunked passes of sweep_lds.h with the carries between chunks going through
@@ -53,16 +53,11 @@ __global__ __launch_bounds__(kBigT) void big_fill_kernel(BigArgs a)
     const BigSeg s = a.seg[a.chunk_seg[c]];
     const u32 e0 = (c - s.chunk_off) * kBigC; // first local key index of this chunk
     u32 *out = a.keys + s.key_off + e0;
-    u32 bad = 0;
+    u32 bad = 0, nz = 0;
     for (u32 t = threadIdx.x; t < kBigC / 2; t += kBigT) { // one interval -> two keys
         const u32 i = e0 / 2 + t;
         u32 ks = kNoKey - 1, ke = kNoKey - 1; // end-like pads (0xFFFFFFFE)
-        if (i < s.n) {
-            const uint2 v = a.iv[s.iv_off + i];
-            bad |= (v.x >= v.y || v.y >= 0x7FFFFFFFu) ? 1u : 0u;
-            ks = (v.x << 1) | 1u;
-            ke = v.y << 1;
-        }
+        if (i < s.n) make_event_keys(a.iv[s.iv_off + i], ks, ke, bad, nz);
         out[2 * t] = ks;
         out[2 * t + 1] = ke;
     }
@@ -161,11 +156,18 @@ __global__ __launch_bounds__(kBigT) void big_pass_a_kernel(BigArgs a)
 {
     __shared__ u32 sc[kBigT / 64];
     const BigChunk b = big_chunk(a);
-    u32 delta = 0;
-    for (int q = 0; q < kBigKT; q++) delta += (b.k[q] & 1u) ? 1u : 0xFFFFFFFFu;
+    u32 delta = 0, dup = 0;
+    u32 prev = b.e0 ? b.k[-1] : 0u; // last key before this thread's run (same read)
+    for (int q = 0; q < kBigKT; q++) {
+        const u32 key = b.k[q];
+        delta += (key & 1u) ? 1u : 0xFFFFFFFFu;
+        dup |= (key == prev && (key & 3u) == 1u && key != 1u) ? 1u : 0u; // two zero-length intervals, one position
+        prev = key;
+    }
     u32 tot;
     block_excl_add<kBigT>(delta, sc, tot);
     if (threadIdx.x == 0) a.c_delta[blockIdx.x] = tot;
+    if (__syncthreads_or((int)dup) && threadIdx.x == 0) a.seg_bad[a.chunk_seg[blockIdx.x]] = 1;
 }
 
 // one workgroup per read: carries between its chunks.  which: 0 depth (sum), 1 mf/ml (max),
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(kBigT) void big_scan_kernel(BigArgs a, u32 which)
         const u32 last = s.chunk_off + nc - 1;
         const u32 mf_t = max(a.c_mf_in[last], a.c_mf[last]), ml_t = max(a.c_ml_in[last], a.c_ml[last]);
         uint2 *slot = a.stage + (s.iv_off + 2 * (u64)s.read);
-        a.counts[s.read] = finish_read(slot, carry[0], mf_t, ml_t, carry[2], s.len);
+        a.counts[s.read] = finish_read(slot, carry[0], mf_t ? (mf_t ^ 2u) : 0u, ml_t, carry[2], s.len);
     }
 }
 
@@ -237,13 +239,13 @@ __global__ __launch_bounds__(kBigT) void big_pass_kernel(BigArgs a)
     u32 tot;
     const i32 depth_in = (i32)(a.c_depth_in[c] + block_excl_add<kBigT>(delta, sc, tot));
 
-    u32 mf = 0, ml = 0;
+    u32 mf = 0, ml = 0; // mf: flagged ends in the flipped domain (device_common.h)
     i32 d = depth_in;
     for (int q = 0; q < kBigKT; q++) {
         const u32 key = b.k[q];
         const bool is_s = key & 1u, gt = d > cov;
         ml = (is_s && !gt) ? key : ml;
-        mf = (!is_s && gt) ? key : mf;
+        mf = (!is_s && gt) ? max(mf, key ^ 2u) : mf;
         d += is_s ? 1 : -1;
     }
     u32 mf_t, ml_t;
@@ -256,10 +258,9 @@ __global__ __launch_bounds__(kBigT) void big_pass_kernel(BigArgs a)
         }
         return;
     }
-    // "no flagged end yet" is carried as 1 (see sweep_wave.h): excludes a run at position 0 only
-    u32 cmf = max(max(a.c_mf_in[c], mf_ex), 1u), cml = max(a.c_ml_in[c], ml_ex);
+    u32 cmf = max(max(a.c_mf_in[c], mf_ex), kNoFlag), cml = max(a.c_ml_in[c], ml_ex);
     const u32 m = 2 * b.s.n;
-    const u32 len_key = b.s.len >= 0x7FFFFFFFu ? 0xFFFFFFFFu : (b.s.len << 1);
+    const u32 len_key = b.s.len > kMaxKeyPos ? 0xFFFFFFFFu : (b.s.len << kKeyShift);
     uint2 *slot = a.stage + (b.s.iv_off + 2 * (u64)b.s.read);
     u32 cnt = 0, cand = kNoKey;
     if (PASS == 1) {
@@ -267,9 +268,10 @@ __global__ __launch_bounds__(kBigT) void big_pass_kernel(BigArgs a)
         for (int q = 0; q < kBigKT; q++) {
             const u32 key = b.k[q];
             const bool is_s = key & 1u, gt = d > cov, fl = !is_s && gt;
-            cnt += (fl && cml > cmf) ? 1u : 0u;
-            if (fl && (b.e0 + q + (u32)d == m) && key >= len_key) cand = min(cand, key >> 1);
-            cmf = fl ? key : cmf;
+            const bool eff = fl && (key ^ 2u) > cmf;
+            cnt += (eff && cml > (cmf ^ 2u)) ? 1u : 0u;
+            if (fl && (b.e0 + q + (u32)d == m) && key >= len_key) cand = min(cand, key >> kKeyShift);
+            cmf = eff ? (key ^ 2u) : cmf;
             cml = (is_s && !gt) ? key : cml;
             d += is_s ? 1 : -1;
         }
@@ -287,8 +289,9 @@ __global__ __launch_bounds__(kBigT) void big_pass_kernel(BigArgs a)
         for (int q = 0; q < kBigKT; q++) {
             const u32 key = b.k[q];
             const bool is_s = key & 1u, gt = d > cov, fl = !is_s && gt;
-            cnt += (fl && cl2 > cm2) ? 1u : 0u;
-            cm2 = fl ? key : cm2;
+            const bool eff = fl && (key ^ 2u) > cm2;
+            cnt += (eff && cl2 > (cm2 ^ 2u)) ? 1u : 0u;
+            cm2 = eff ? (key ^ 2u) : cm2;
             cl2 = (is_s && !gt) ? key : cl2;
             d += is_s ? 1 : -1;
         }
@@ -299,8 +302,10 @@ __global__ __launch_bounds__(kBigT) void big_pass_kernel(BigArgs a)
             for (int q = 0; q < kBigKT; q++) {
                 const u32 key = b.k[q];
                 const bool is_s = key & 1u, gt = d > cov, fl = !is_s && gt;
-                if (fl && cml > cmf) slot[pos++] = make_uint2(cmf >> 1, cml >> 1);
-                cmf = fl ? key : cmf;
+                const bool eff = fl && (key ^ 2u) > cmf;
+                if (eff && cml > (cmf ^ 2u))
+                    slot[pos++] = make_uint2((cmf ^ 2u) >> kKeyShift, cml >> kKeyShift);
+                cmf = eff ? (key ^ 2u) : cmf;
                 cml = (is_s && !gt) ? key : cml;
                 d += is_s ? 1 : -1;
             }

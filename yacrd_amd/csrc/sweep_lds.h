@@ -3,8 +3,8 @@
 // Replaces reference src/stack.rs:61-139 (FromOverlap::compute_bad_part) for *regular* reads
 // (every interval start < end < 2^31).  Instead of the reference's sort + binary-heap sweep it
 // uses the event formulation of DESIGN.md §3:
-//   key(start) = start<<1 | 1, key(end) = end<<1 | 0   (an end sorts before a start at the same
-//   position: the reference pops `head <= interval.0`, stack.rs:72-81)
+//   key = position<<2 | class (device_common.h): an end sorts before a start at the same position
+//   (the reference pops `head <= interval.0`, stack.rs:72-81); zero-length intervals sit between
 //   depth_before(event) = exclusive prefix sum of +1/-1 over the sorted keys
 //   end flagged   <=> depth_before > c   (stack.rs:77-79 and the tail loop :93-105)
 //   start is low  <=> depth_before <= c  (stack.rs:83)
@@ -167,18 +167,19 @@ __global__ __launch_bounds__(T) void sweep_lds_kernel(SweepArgs a)
         while (P < m) P <<= 1;
 
         // ---- stage the read's intervals into LDS as event keys (coalesced 8 B/lane loads)
-        u32 bad = 0, max_start = 0;
+        u32 bad = 0, max_start = 0, nz = 0;
         const uint2 *iv = a.iv + o;
         for (u32 i = tid; i < n; i += T) {
-            const uint2 v = iv[i];
-            bad |= (u32)(v.x >= v.y) | (v.y >> 31);
-            const u32 ks = (v.x << 1) | 1u;
+            u32 ks, ke;
+            make_event_keys(iv[i], ks, ke, bad, nz);
             keys[2 * i] = ks;
-            keys[2 * i + 1] = v.y << 1;
+            keys[2 * i + 1] = ke;
             max_start = max(max_start, ks);
         }
         for (u32 i = m + tid; i < P; i += T) keys[i] = kNoKey;
         bad = block_max<T>(bad, sc);
+        u32 nz_total;
+        block_excl_add<T>(nz, sc, nz_total);
         if (bad) { // degenerate interval: exact general path takes the read
             if (tid == 0) {
                 a.rej_list[atomicAdd(a.rej_count, 1u)] = r;
@@ -193,6 +194,20 @@ __global__ __launch_bounds__(T) void sweep_lds_kernel(SweepArgs a)
         if (T >= 256 && P >= 1024) hybrid_sort_lds<T>(keys, P, lc);
         else bitonic_sort_lds<T>(keys, P);
 
+        if (nz_total > 2) { // two zero-length intervals at one position > 0: exact path (see keys)
+            u32 dup = 0;
+            for (u32 i = tid; i + 1 < m; i += T)
+                dup |= (keys[i] == keys[i + 1] && (keys[i] & 3u) == 1u && keys[i] != 1u);
+            if (block_max<T>(dup, sc)) {
+                if (tid == 0) {
+                    a.rej_list[atomicAdd(a.rej_count, 1u)] = r;
+                    a.counts[r] = 0;
+                }
+                __syncthreads();
+                continue;
+            }
+        }
+
         // ---- blocked chunks: thread t owns events [t*K, t*K+K) of the sorted sequence
         const u32 K = (P >= (u32)T) ? P / T : 1;
         const u32 q0 = min(tid * K, m), q1 = min(q0 + K, m);
@@ -203,7 +218,7 @@ __global__ __launch_bounds__(T) void sweep_lds_kernel(SweepArgs a)
         u32 tot;
         const u32 depth_in = block_excl_add<T>(delta, sc, tot);
 
-        // pass B: last flagged end / last low start per chunk -> exclusive max scans
+        // pass B: last flagged end (flipped domain, device_common.h) / last low start per chunk
         u32 d = depth_in, mf = 0, ml = 0;
         for (u32 q = q0; q < q1; q++) {
             const u32 key = keys[q];
@@ -211,12 +226,12 @@ __global__ __launch_bounds__(T) void sweep_lds_kernel(SweepArgs a)
                 if (d <= a.cov) ml = key;
                 d++;
             } else {
-                if (d > a.cov) mf = key;
+                if (d > a.cov) mf = max(mf, key ^ 2u);
                 d--;
             }
         }
         u32 mf_t, ml_t;
-        const u32 mf_in = block_excl_max<T>(mf, sc, mf_t);
+        const u32 mf_in = max(block_excl_max<T>(mf, sc, mf_t), kNoFlag);
         const u32 ml_in = block_excl_max<T>(ml, sc, ml_t);
 
         // pass C: count the regions this chunk closes; tail rule (stack.rs:93-105)
@@ -231,9 +246,12 @@ __global__ __launch_bounds__(T) void sweep_lds_kernel(SweepArgs a)
                 d++;
             } else {
                 if (d > a.cov) {
-                    if (ml > mf && !(mf == 0 && (ml >> 1) == 0)) cnt++;
-                    mf = key;
-                    if (key > max_start && (key >> 1) >= len) min_ge = min(min_ge, key >> 1);
+                    if ((key ^ 2u) > mf) {
+                        if (ml > (mf ^ 2u)) cnt++;
+                        mf = key ^ 2u;
+                    }
+                    if (key > max_start && (key >> kKeyShift) >= len)
+                        min_ge = min(min_ge, key >> kKeyShift);
                 }
                 d--;
             }
@@ -253,16 +271,17 @@ __global__ __launch_bounds__(T) void sweep_lds_kernel(SweepArgs a)
                     if (d <= a.cov) ml = key;
                     d++;
                 } else {
-                    if (d > a.cov) {
-                        if (ml > mf && !(mf == 0 && (ml >> 1) == 0))
-                            slot[pos++] = make_uint2(mf >> 1, ml >> 1);
-                        mf = key;
+                    if (d > a.cov && (key ^ 2u) > mf) {
+                        if (ml > (mf ^ 2u))
+                            slot[pos++] = make_uint2((mf ^ 2u) >> kKeyShift, ml >> kKeyShift);
+                        mf = key ^ 2u;
                     }
                     d--;
                 }
             }
         }
-        if (tid == 0) a.counts[r] = finish_read(slot, g_closed, mf_t, ml_t, min_ge, len);
+        if (tid == 0)
+            a.counts[r] = finish_read(slot, g_closed, mf_t ? (mf_t ^ 2u) : 0u, ml_t, min_ge, len);
         __syncthreads(); // keys / sc reused by the next read
     }
 }

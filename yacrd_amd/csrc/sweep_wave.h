@@ -14,6 +14,8 @@
 // needs a validity mask (a read without intervals falls out as [(0,len)] on its own).
 // Reads of <= 128 intervals use 16-lane groups: four reads per wavefront (see sweep_group_read).
 #pragma once
+#include <type_traits>
+
 #include "device_common.h"
 
 namespace yk {
@@ -203,22 +205,31 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
 
     // ---- coalesced interval loads (8 B/lane), keys straight into registers
     u32 x[K];
-    u32 bad = 0;
+    u32 bad = 0, nz = 0;
+    {
+        // issue every load before the first use: one memory latency per read, not K/2 of them
+        uint2 v[K / 2];
 #pragma unroll
-    for (int j = 0; j < K / 2; j++) {
-        const u32 i = lig + (u32)LANES * j;
-        uint2 v = make_uint2(0x7FFFFFFFu, 0x7FFFFFFFu);
-        if (i < n) v = iv[i];
-        const bool pad = i >= n;
-        bad |= (!pad && (v.x >= v.y || v.y >= 0x7FFFFFFFu)) ? 1u : 0u;
-        x[2 * j] = pad ? kPadKey : ((v.x << 1) | 1u);
-        x[2 * j + 1] = pad ? kPadKey : (v.y << 1);
+        for (int j = 0; j < K / 2; j++) {
+            const u32 i = lig + (u32)LANES * j;
+            v[j] = make_uint2(1u, 2u);
+            if (i < n) v[j] = iv[i];
+        }
+#pragma unroll
+        for (int j = 0; j < K / 2; j++) {
+            const u32 i = lig + (u32)LANES * j;
+            u32 ks, ke, b = 0, z = 0;
+            make_event_keys(v[j], ks, ke, b, z);
+            const bool real = i < n;
+            x[2 * j] = real ? ks : kPadKey;
+            x[2 * j + 1] = real ? ke : kPadKey;
+            bad |= real ? b : 0u;
+            nz += real ? z : 0u;
+        }
     }
-    const u64 badmask = __builtin_amdgcn_ballot_w64(bad != 0);
-    const bool group_bad = LANES == 64   ? badmask != 0
-                           : LANES == 32 ? (u32)(badmask >> (lane & 32u)) != 0
-                                         : ((u32)(badmask >> (lane & 48u)) & 0xFFFFu) != 0;
-    if (LANES == 64 && group_bad) { // wave-uniform: skip the work, queue for the exact path
+    u64 badmask = __builtin_amdgcn_ballot_w64(bad != 0);
+    const u64 zmask = __builtin_amdgcn_ballot_w64(nz != 0);
+    if (LANES == 64 && badmask != 0) { // wave-uniform: skip the work, queue for the exact path
         if (lig == LANES - 1 && active) {
             a.rej_list[atomicAdd(a.rej_count, 1u)] = r;
             a.counts[r] = 0;
@@ -227,6 +238,20 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
     }
 
     bitonic_sort<LANES, K, 2, XM>(x, lc);
+
+    // two zero-length intervals at one position cannot be expressed by the keys: after the sort
+    // they are adjacent equal class-1 keys.  Only looked for when the wavefront saw >= 2 of them.
+    if ((zmask & (zmask - 1)) != 0 || __builtin_amdgcn_ballot_w64(nz > 2) != 0) {
+        bool dup = false;
+#pragma unroll
+        for (int q = 0; q + 1 < K; q++) dup |= x[q] == x[q + 1] && (x[q] & 3u) == 1u && x[q] != 1u;
+        const u32 prev = gshift_up1<LANES>(x[K - 1]);
+        dup |= lig != 0 && prev == x[0] && (prev & 3u) == 1u && prev != 1u;
+        badmask |= __builtin_amdgcn_ballot_w64(dup);
+    }
+    const bool group_bad = LANES == 64   ? badmask != 0
+                           : LANES == 32 ? (u32)(badmask >> (lane & 32u)) != 0
+                                         : ((u32)(badmask >> (lane & 48u)) & 0xFFFFu) != 0;
 
     // ---- pass 1: depth carried into each lane
     u32 n_starts = 0; // net depth change of the lane = starts - ends = 2 * starts - K
@@ -237,45 +262,62 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
     const i32 depth_in = (i32)(dincl - delta);
 
     // ---- pass 2: last flagged end / last low start of the lane (keys ascend, so last = max)
-    u32 mf = 0, ml = 0;
-    i32 d = depth_in;
-#pragma unroll
-    for (int q = 0; q < K; q++) {
-        const u32 key = x[q];
-        const bool is_s = (key & 1u) != 0, gt = d > c;
-        ml = (is_s && !gt) ? key : ml;
-        mf = (!is_s && gt) ? key : mf;
-        d += is_s ? 1 : -1;
-    }
-    const u32 mf_incl = gscan_max<LANES>(mf), ml_incl = gscan_max<LANES>(ml);
-    // "no flagged end yet" is carried as 1 instead of 0: a run whose only low starts sit at
-    // position 0 (key 1) then fails `cml > cmf`, which is the reference's `first_covered != 0`.
-    const u32 mf_in = max(gshift_up1<LANES>(mf_incl), 1u), ml_in = gshift_up1<LANES>(ml_incl);
-
-    // ---- pass 3: regions closed in this lane; tail rule candidates (stack.rs:93-105)
+    // Passes 2 and 3 (straight-line per variant so the per-key depth / flag values are shared):
+    //   pass 2  last flagged end / last low start of the lane (keys ascend, so last = max)
+    //   pass 3  regions closed in this lane; tail rule candidates (stack.rs:93-105)
+    // Flagged ends are carried between lanes in the flipped domain tk = key ^ 2
+    // (device_common.h).  A wavefront without zero-length intervals (all but ~0.1 % of them) only
+    // holds classes 0 and 3, where "effective" is plain "flagged" and the loops stay in the true
+    // key domain (ZL = false).
     // an end is in the tail when every start precedes it: starts before = (index + depth) / 2
     const u32 tail_base = m - lig * (u32)K;
-    const u32 len_key = len >= 0x7FFFFFFFu ? 0xFFFFFFFFu : (len << 1);
+    const u32 len_key = len > kMaxKeyPos ? 0xFFFFFFFFu : (len << kKeyShift);
+    u32 mf_incl, ml_incl, mf_in, ml_in;
     u32 cnt = 0, fb = 0, fe = 0, cand = kNoKey;
-    {
-        u32 cmf = mf_in, cml = ml_in;
+    auto passes = [&](auto zl_tag) {
+        constexpr bool ZL = decltype(zl_tag)::value;
+        u32 mf = 0, ml = 0;
+        i32 d = depth_in;
+#pragma unroll
+        for (int q = 0; q < K; q++) {
+            const u32 key = x[q];
+            const bool is_s = (key & 1u) != 0, gt = d > c;
+            ml = (is_s && !gt) ? key : ml;
+            if (ZL) mf = (!is_s && gt) ? max(mf, key ^ 2u) : mf;
+            else mf = (!is_s && gt) ? key : mf;
+            d += is_s ? 1 : -1;
+        }
+        if (!ZL) mf = mf ? (mf ^ 2u) : 0u;
+        mf_incl = gscan_max<LANES>(mf);
+        ml_incl = gscan_max<LANES>(ml);
+        mf_in = max(gshift_up1<LANES>(mf_incl), kNoFlag);
+        ml_in = gshift_up1<LANES>(ml_incl);
+
+        u32 tc = ZL ? mf_in : (mf_in ^ 2u); // ZL: flipped domain; else true key, "none" = 3
+        u32 cml = ml_in;
         d = depth_in;
 #pragma unroll
         for (int q = 0; q < K; q++) {
             const u32 key = x[q];
             const bool is_s = (key & 1u) != 0, gt = d > c;
             const bool fl = !is_s && gt, low = is_s && !gt;
-            const bool close = fl && cml > cmf;
+            const bool eff = ZL ? (fl && (key ^ 2u) > tc) : fl;
+            const u32 begin = ZL ? (tc ^ 2u) : tc;
+            const bool close = eff && cml > begin;
             cnt += close ? 1u : 0u;
-            fb = close ? cmf : fb;
+            fb = close ? begin : fb;
             fe = close ? cml : fe;
             const bool tail = fl && ((u32)d + (u32)q == tail_base) && key >= len_key;
-            cand = min(cand, tail ? (key >> 1) : kNoKey);
-            cmf = fl ? key : cmf;
+            cand = min(cand, tail ? (key >> kKeyShift) : kNoKey);
+            tc = eff ? (ZL ? (key ^ 2u) : key) : tc;
             cml = low ? key : cml;
             d += is_s ? 1 : -1;
         }
-    }
+    };
+    if (zmask == 0) passes(std::false_type{}); // wave-uniform
+    else passes(std::true_type{});
+    i32 d;
+
     const bool live = active && !group_bad;
     u32 g_closed = 0;
     if (__builtin_amdgcn_ballot_w64(cnt != 0) != 0) {
@@ -283,17 +325,19 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
         g_closed = cincl; // meaningful on the group's last lane
         u32 pos = cincl - cnt;
         if (live && cnt == 1) {
-            slot[pos] = make_uint2(fb >> 1, fe >> 1);
+            slot[pos] = make_uint2(fb >> kKeyShift, fe >> kKeyShift);
         } else if (live && cnt > 1) { // several regions close inside one lane: replay it
-            u32 cmf = mf_in, cml = ml_in;
+            u32 tc = mf_in, cml = ml_in;
             d = depth_in;
 #pragma unroll
             for (int q = 0; q < K; q++) {
                 const u32 key = x[q];
                 const bool is_s = (key & 1u) != 0, gt = d > c;
                 const bool fl = !is_s && gt, low = is_s && !gt;
-                if (fl && cml > cmf) slot[pos++] = make_uint2(cmf >> 1, cml >> 1);
-                cmf = fl ? key : cmf;
+                const bool eff = fl && (key ^ 2u) > tc;
+                if (eff && cml > (tc ^ 2u))
+                    slot[pos++] = make_uint2((tc ^ 2u) >> kKeyShift, cml >> kKeyShift);
+                tc = eff ? (key ^ 2u) : tc;
                 cml = low ? key : cml;
                 d += is_s ? 1 : -1;
             }
@@ -306,7 +350,7 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
             a.rej_list[atomicAdd(a.rej_count, 1u)] = r;
             a.counts[r] = 0;
         } else {
-            a.counts[r] = finish_read(slot, g_closed, mf_incl, ml_incl, min_ge, len);
+            a.counts[r] = finish_read(slot, g_closed, mf_incl ? (mf_incl ^ 2u) : 0u, ml_incl, min_ge, len);
         }
     }
 }

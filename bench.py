@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lds-sort", action="store_true", help="A/B: LDS-sort kernel for the small class")
     ap.add_argument("--flags", type=int, default=0, help="extra YACRD_F_* engine flags (A/B)")
+    ap.add_argument("--full-timing", action="store_true",
+                    help="HIP events around every phase and class kernel (slower steps)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -50,9 +52,12 @@ def main():
     import torch
     from yacrd_amd import dist as ydist
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = ydist.init(device=dev)  # None when WORLD_SIZE == 1; nccl (RCCL) else, gloo fallback
+    # YACRD_BENCH_DEVICE / YACRD_BENCH_BACKEND: plumbing test of the N>1 path on a 1-GPU box
+    # (all ranks on one device, gloo); never set by the driver
+    dev_index = int(os.environ.get("YACRD_BENCH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    dist = ydist.init(backend=os.environ.get("YACRD_BENCH_BACKEND"), device=dev)  # None when WORLD_SIZE == 1
 
     prof = {"ont": host.SYNTH_ONT, "sequel": host.SYNTH_SEQUEL, "skewed": host.SYNTH_SKEWED}[args.profile]
     cov = args.coverage if args.coverage is not None else (3 if args.profile == "sequel" else 4)
@@ -67,7 +72,9 @@ def main():
     torch.cuda.synchronize()
 
     flags = (yacrd_amd.F_FORCE_LDS_SORT if args.lds_sort else 0) | args.flags
-    eng = yacrd_amd.Engine(device_id=local_rank, flags=flags)
+    if args.full_timing:
+        flags |= yacrd_amd.F_TIMING_FULL
+    eng = yacrd_amd.Engine(device_id=dev_index, flags=flags)
 
     def step():
         return eng.run_device(d_off.data_ptr(), d_iv.data_ptr(), d_len.data_ptr(), R, I, cov,
@@ -82,6 +89,7 @@ def main():
         step()
     keys = ("plan_ms", "sweep_small_ms", "sweep_medium_ms", "sweep_general_ms", "compact_ms", "total_ms")
     acc = dict.fromkeys(keys, 0.0)
+    cls_ms = [0.0] * 12
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -89,6 +97,8 @@ def main():
         t = eng.timing()  # HIP events recorded on the engine's stream inside run_device
         for k in keys:
             acc[k] += t[k]
+        for i in range(12):
+            cls_ms[i] += t["class_ms"][i]
     barrier()
     elapsed = time.perf_counter() - t0
 
@@ -97,13 +107,20 @@ def main():
 
     if rank == 0:
         K = args.steps
-        avg = {k: acc[k] / K for k in keys}
-        # algorithmic bytes per pass, SURVEY.md §8(d): 16 B per overlap + 29 B per read + 8 B per region
+        avg = {k: acc[k] / K for k in keys if acc[k] > 0}  # per-phase fields need --full-timing
+        # algorithmic bytes per pass, SURVEY.md §8(d): 16 B per overlap + 21 B per read + 8 B per region
+        # (8(R+1) + 4R read, 8(R+1) + R written; the survey's "29 B per read" shorthand over-counts)
         b_alg = 8 * I + 8 * (R + 1) + 4 * R + 8 * (R + 1) + 8 * G + R
-        dom = "sweep_small" if avg["sweep_small_ms"] >= max(avg["sweep_medium_ms"], avg["sweep_general_ms"]) else (
-            "sweep_medium" if avg["sweep_medium_ms"] >= avg["sweep_general_ms"] else "sweep_general")
-        dom_ms = avg[dom + "_ms"]
-        achieved = b_alg / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        # dominant kernel = the size class with the largest own kernel time (HIP events around that
+        # launch on the engine's stream); its algorithmic bytes are those of the reads it processed
+        ci = max(range(12), key=lambda i: cls_ms[i])
+        cname = yacrd_amd.CLASS_NAMES[ci]
+        dom = yacrd_amd.CLASS_KERNELS[cname]
+        dom_ms = cls_ms[ci] / K
+        c_reads, c_iv = t["class_reads"][ci], t["class_intervals"][ci]
+        b_dom = 8 * c_iv + 21 * c_reads + 16 + 8 * (G * c_reads // max(R, 1))
+        achieved = b_dom / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        avg["class_ms"] = {yacrd_amd.CLASS_NAMES[i]: cls_ms[i] / K for i in range(12) if cls_ms[i] > 0}
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -130,10 +147,12 @@ def main():
                        "regions_per_gpu": G, "parallelism": "read-partition x%d, no collective" % world},
             "overlaps_per_sec": world * args.overlaps * K / elapsed,
             "kernel_ms": avg,
-            "path_gbps": b_alg / (avg["total_ms"] * 1e-3) / 1e9 if avg["total_ms"] > 0 else None,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes": b_alg, "kernel_ms": dom_ms},
+            "path_gbps": b_alg / (avg["total_ms"] * 1e-3) / 1e9 if avg.get("total_ms") else None,
+            "roofline": {"bound": "hbm", "kernel": dom, "size_class": cname, "achieved": achieved,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "algorithmic_bytes": b_dom, "kernel_ms": dom_ms,
+                         "kernel_reads": c_reads, "kernel_intervals": c_iv,
+                         "whole_path_algorithmic_bytes": b_alg},
         }
         if world == 1 and not args.no_cpu_baseline:
             import oracle

@@ -66,6 +66,9 @@ typedef struct {
 #define YACRD_F_WAVE_ONLY 8u
 /* no two-reads-per-wavefront layout for reads of 129..256 intervals; A/B only */
 #define YACRD_F_NO_HALVES 16u
+/* record HIP events around every phase and every class kernel (costs ~3 us of stream time per
+ * event); by default only the total and the dominant class kernel are bracketed */
+#define YACRD_F_TIMING_FULL 32u
 
 /* Host-side result, allocated by the engine, released with yacrd_result_free(). */
 typedef struct {
@@ -85,7 +88,8 @@ typedef struct {
     const void *d_read_type;   /* u8[R]   */
 } yacrd_device_result;
 
-/* Per-phase wall times of the last run, measured with HIP events on the engine's stream. */
+/* Wall times of the last run, measured with HIP events on the engine's stream.  The per-phase
+ * fields (sweep_*_ms, compact_ms) and class_ms of non-dominant classes need YACRD_F_TIMING_FULL. */
 typedef struct {
     float h2d_ms;
     float plan_ms;          /* size-class binning */
@@ -97,7 +101,16 @@ typedef struct {
     float total_ms;         /* first kernel start -> last kernel end */
     uint64_t n_small, n_medium, n_general;     /* reads per class */
     uint64_t iv_small, iv_medium, iv_general;  /* intervals per class */
+    /* per size class (YACRD_CLASS_NAMES order): own kernel time, reads, intervals */
+    float class_ms[12];
+    uint64_t class_reads[12];
+    uint64_t class_intervals[12];
 } yacrd_timing;
+
+/* size classes, in the order of yacrd_timing.class_*: R<K> = four reads per wavefront (16-lane
+ * rows, K keys per lane), H16 = two per wavefront, W<K> = one per wavefront, M1/M2 = one per
+ * workgroup (LDS), BIG = device-wide path (> 16384 intervals) */
+#define YACRD_CLASS_NAMES "R2,R4,R8,R16,H16,W2,W4,W8,W16,M1,M2,BIG"
 
 int yacrd_abi_version(void);
 const char *yacrd_last_error(void);

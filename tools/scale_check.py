@@ -44,7 +44,7 @@ def main():
         out = {"config": c, "synth_flags": sflags, "reads": R, "overlaps": O, "intervals": int(offsets[-1]),
                "max_intervals_per_read": int(np.diff(offsets.astype(np.int64)).max()),
                "gen_s": round(t_gen, 2)}
-        with yacrd_amd.Engine(device_id=0) as e:
+        with yacrd_amd.Engine(device_id=0, flags=yacrd_amd.F_TIMING_FULL) as e:
             t0 = time.perf_counter()
             got = e.run(offsets, intervals, lengths, cfg["cov"], cfg["nc"])
             out["gpu_run_s_incl_pcie"] = round(time.perf_counter() - t0, 3)

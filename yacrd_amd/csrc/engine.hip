@@ -83,6 +83,7 @@ struct yacrd_engine {
     hipStream_t stream = nullptr;
     hipEvent_t ev[EV_COUNT] = {};
     hipEvent_t ev_h2d0 = nullptr, ev_h2d1 = nullptr, ev_d2h0 = nullptr, ev_d2h1 = nullptr;
+    hipEvent_t ev_cls[24] = {}; // brackets around class kernels
     int num_cu = 256;
 
     // inputs staged by yacrd_engine_run
@@ -334,9 +335,34 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     sa.rej_count = &ctr->rej_small;
     const int xm = (e->flags & YACRD_F_XLANE_DS) ? 1 : 0;
     bool any_small = false;
+    // Kernel-level timing.  An event costs ~3 us of stream time, so by default only the class
+    // with the most intervals (the dominant kernel) is bracketed; YACRD_F_TIMING_FULL brackets
+    // every launched class and the phases.
+    const bool full = (e->flags & YACRD_F_TIMING_FULL) != 0;
+    int dom_cls = -1;
+    for (int cls = 0; cls < yk::CLS_GENERAL; cls++)
+        if (c0.n[cls] && (dom_cls < 0 || c0.iv[cls] > c0.iv[dom_cls])) dom_cls = cls;
+    int cls_b[12], cls_e[12]; // event indices bracketing each class, -1 = not recorded
+    for (int i = 0; i < 12; i++) cls_b[i] = cls_e[i] = -1;
+    int n_cls_ev = 0;
+    auto before_class = [&](int cls) -> hipError_t {
+        if (!(full || cls == dom_cls)) return hipSuccess;
+        if (n_cls_ev > 0 && full) { // the previous class's end mark is this one's begin mark
+            cls_b[cls] = n_cls_ev - 1;
+            return hipSuccess;
+        }
+        cls_b[cls] = n_cls_ev;
+        return hipEventRecord(e->ev_cls[n_cls_ev++], e->stream);
+    };
+    auto mark_class = [&](int cls) -> hipError_t {
+        if (!(full || cls == dom_cls)) return hipSuccess;
+        cls_e[cls] = n_cls_ev;
+        return hipEventRecord(e->ev_cls[n_cls_ev++], e->stream);
+    };
     for (int cls = yk::CLS_R2; cls <= yk::CLS_W16; cls++) {
         if (!c0.n[cls]) continue;
         any_small = true;
+        HIP_TRY(before_class(cls));
         sa.list = list_of(cls);
         sa.list_n = &ctr->n[cls];
         if (e->flags & YACRD_F_FORCE_LDS_SORT) {
@@ -356,11 +382,13 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
             default: yk::launch_sweep_group<64, 16>(sa, c0.n[cls], e->stream, xm); break;
             }
         }
+        HIP_TRY(mark_class(cls));
     }
-    HIP_TRY(hipEventRecord(e->ev[EV_SMALL], e->stream));
+    if (full) HIP_TRY(hipEventRecord(e->ev[EV_SMALL], e->stream));
 
     // ---- medium classes: one read per workgroup, LDS resident
     if (c0.n[yk::CLS_MED1]) {
+        HIP_TRY(before_class(yk::CLS_MED1));
         sa.list = list_of(yk::CLS_MED1);
         sa.list_n = &ctr->n[yk::CLS_MED1];
         sa.rej_list = rej_med;
@@ -368,8 +396,10 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         const u32 grid = (u32)std::min<uint64_t>(c0.n[yk::CLS_MED1], (uint64_t)e->num_cu * 4);
         hipLaunchKernelGGL((yk::sweep_lds_kernel<256, (int)yk::kMedium1Events>), dim3(grid),
                            dim3(256), 0, e->stream, sa);
+        HIP_TRY(mark_class(yk::CLS_MED1));
     }
     if (c0.n[yk::CLS_MED2]) {
+        HIP_TRY(before_class(yk::CLS_MED2));
         sa.list = list_of(yk::CLS_MED2);
         sa.list_n = &ctr->n[yk::CLS_MED2];
         sa.rej_list = rej_big;
@@ -377,8 +407,9 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         const u32 grid = (u32)std::min<uint64_t>(c0.n[yk::CLS_MED2], (uint64_t)e->num_cu);
         hipLaunchKernelGGL((yk::sweep_lds_kernel<1024, (int)yk::kMedium2Events>), dim3(grid),
                            dim3(1024), 0, e->stream, sa);
+        HIP_TRY(mark_class(yk::CLS_MED2));
     }
-    HIP_TRY(hipEventRecord(e->ev[EV_MED], e->stream));
+    if (full) HIP_TRY(hipEventRecord(e->ev[EV_MED], e->stream));
 
     // ---- exact general path
     // (a) reads a sweep rejected (degenerate interval), scratch in LDS, no host round trip
@@ -410,7 +441,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
                                c0.n[yk::CLS_GENERAL], cov, e->stream, &gen_iv);
         if (rc) return rc;
     }
-    HIP_TRY(hipEventRecord(e->ev[EV_GEN], e->stream));
+    if (full) HIP_TRY(hipEventRecord(e->ev[EV_GEN], e->stream));
 
     // ---- follow-on kernel: scan + compact + classify
     int rc = launch_compact(e, d_off, d_len, n_reads, not_cov);
@@ -455,10 +486,12 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
 
     yacrd_timing &t = e->timing;
     t.plan_ms = ev_ms(e->ev[EV_START], e->ev[EV_PLAN]);
-    t.sweep_small_ms = ev_ms(e->ev[EV_S0], e->ev[EV_SMALL]);
-    t.sweep_medium_ms = ev_ms(e->ev[EV_SMALL], e->ev[EV_MED]);
-    t.sweep_general_ms = ev_ms(e->ev[EV_MED], e->ev[EV_GEN]);
-    t.compact_ms = ev_ms(e->ev[EV_GEN], e->ev[EV_COMPACT]);
+    if (full) {
+        t.sweep_small_ms = ev_ms(e->ev[EV_S0], e->ev[EV_SMALL]);
+        t.sweep_medium_ms = ev_ms(e->ev[EV_SMALL], e->ev[EV_MED]);
+        t.sweep_general_ms = ev_ms(e->ev[EV_MED], e->ev[EV_GEN]);
+        t.compact_ms = ev_ms(e->ev[EV_GEN], e->ev[EV_COMPACT]);
+    }
     t.total_ms = t.plan_ms + ev_ms(e->ev[EV_S0], e->ev[EV_COMPACT]) + extra_ms;
     t.n_small = 0;
     t.iv_small = 0;
@@ -470,6 +503,15 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     t.n_general = (uint64_t)c0.n[yk::CLS_GENERAL] + c1.rej_small + c1.rej_med + c1.rej_big;
     t.iv_medium = c0.iv[yk::CLS_MED1] + c0.iv[yk::CLS_MED2];
     t.iv_general = c0.iv[yk::CLS_GENERAL];
+    static_assert(yk::CLS_GENERAL == 11, "yacrd_timing.class_* follows the CLS_ order");
+    for (int cls = 0; cls <= yk::CLS_GENERAL; cls++) {
+        t.class_reads[cls] = c0.n[cls];
+        t.class_intervals[cls] = c0.iv[cls];
+        t.class_ms[cls] = 0.f;
+        if (cls < yk::CLS_GENERAL && cls_b[cls] >= 0 && cls_e[cls] >= 0)
+            t.class_ms[cls] = ev_ms(e->ev_cls[cls_b[cls]], e->ev_cls[cls_e[cls]]);
+    }
+    t.class_ms[yk::CLS_GENERAL] = (full && c0.n[yk::CLS_GENERAL]) ? t.sweep_general_ms : 0.f;
     return YACRD_OK;
 }
 
@@ -534,6 +576,7 @@ int yacrd_engine_create(const yacrd_engine_cfg *cfg, yacrd_engine **out)
     e->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     for (int i = 0; i < EV_COUNT && err == hipSuccess; i++) err = hipEventCreate(&e->ev[i]);
+    for (int i = 0; i < 24 && err == hipSuccess; i++) err = hipEventCreate(&e->ev_cls[i]);
     if (err == hipSuccess) err = hipEventCreate(&e->ev_h2d0);
     if (err == hipSuccess) err = hipEventCreate(&e->ev_h2d1);
     if (err == hipSuccess) err = hipEventCreate(&e->ev_d2h0);
@@ -560,6 +603,8 @@ void yacrd_engine_destroy(yacrd_engine *e)
     if (e->h_ctr) (void)hipHostFree(e->h_ctr);
     for (int i = 0; i < EV_COUNT; i++)
         if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
+    for (int i = 0; i < 24; i++)
+        if (e->ev_cls[i]) (void)hipEventDestroy(e->ev_cls[i]);
     hipEvent_t extra[] = {e->ev_h2d0, e->ev_h2d1, e->ev_d2h0, e->ev_d2h1};
     for (hipEvent_t x : extra)
         if (x) (void)hipEventDestroy(x);

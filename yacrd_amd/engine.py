@@ -16,6 +16,7 @@ F_FORCE_LDS_SORT = 2
 F_XLANE_DS = 4
 F_WAVE_ONLY = 8
 F_NO_HALVES = 16
+F_TIMING_FULL = 32
 
 # every symbol include/yacrd_engine.h declares
 EXPORTED_SYMBOLS = [
@@ -52,7 +53,19 @@ class _Timing(ctypes.Structure):
                 ("h2d_ms", "plan_ms", "sweep_small_ms", "sweep_medium_ms", "sweep_general_ms",
                  "compact_ms", "d2h_ms", "total_ms")] + \
                [(n, ctypes.c_uint64) for n in
-                ("n_small", "n_medium", "n_general", "iv_small", "iv_medium", "iv_general")]
+                ("n_small", "n_medium", "n_general", "iv_small", "iv_medium", "iv_general")] + \
+               [("class_ms", ctypes.c_float * 12), ("class_reads", ctypes.c_uint64 * 12),
+                ("class_intervals", ctypes.c_uint64 * 12)]
+
+CLASS_NAMES = "R2,R4,R8,R16,H16,W2,W4,W8,W16,M1,M2,BIG".split(",")
+CLASS_KERNELS = {  # the HIP kernel behind each class, as rocprofv3 prints it
+    "R2": "sweep_group_kernel<16, 2, 0>", "R4": "sweep_group_kernel<16, 4, 0>",
+    "R8": "sweep_group_kernel<16, 8, 0>", "R16": "sweep_group_kernel<16, 16, 0>",
+    "H16": "sweep_group_kernel<32, 16, 0>", "W2": "sweep_group_kernel<64, 2, 0>",
+    "W4": "sweep_group_kernel<64, 4, 0>", "W8": "sweep_group_kernel<64, 8, 0>",
+    "W16": "sweep_group_kernel<64, 16, 0>", "M1": "sweep_lds_kernel<256, 8192>",
+    "M2": "sweep_lds_kernel<1024, 32768>", "BIG": "big_* kernels (sweep_big.h)",
+}
 
 
 Result = namedtuple("Result", "bad_offsets bad_regions read_type")
@@ -246,7 +259,11 @@ class Engine:
     def timing(self):
         t = _Timing()
         _check(self._lib, self._lib.yacrd_engine_last_timing(self._h, ctypes.byref(t)))
-        return {n: getattr(t, n) for n, _ in _Timing._fields_}
+        out = {}
+        for n, _ in _Timing._fields_:
+            v = getattr(t, n)
+            out[n] = list(v) if n.startswith("class_") else v
+        return out
 
     def classify(self, bad_offsets, bad_regions, lengths, not_coverage):
         bad_offsets = np.ascontiguousarray(bad_offsets, dtype=np.uint64)

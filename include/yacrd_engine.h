@@ -69,6 +69,8 @@ typedef struct {
 /* record HIP events around every phase and every class kernel (costs ~3 us of stream time per
  * event); by default only the total and the dominant class kernel are bracketed */
 #define YACRD_F_TIMING_FULL 32u
+/* always wait for the plan's class counts (no prediction from the previous run); A/B only */
+#define YACRD_F_NO_PREDICTION 64u
 
 /* Host-side result, allocated by the engine, released with yacrd_result_free(). */
 typedef struct {
@@ -136,6 +138,9 @@ int yacrd_engine_run_device(yacrd_engine *e, const void *d_offsets, const void *
 int yacrd_engine_fetch(yacrd_engine *e, yacrd_result *out);
 
 int yacrd_engine_last_timing(const yacrd_engine *e, yacrd_timing *t);
+/* Sums of the float fields over the runs since the last reset (count fields are those of the
+ * last run), and how many runs: lets a caller time K runs without K round trips. */
+int yacrd_engine_timing_total(yacrd_engine *e, yacrd_timing *sum, uint64_t *n_runs, int reset);
 
 /* Read-id partitioning for multi-GPU: cuts[n_parts+1], contiguous read
  * ranges balanced by interval count; reads are independent so there is no exchange step. */

@@ -210,3 +210,20 @@ def test_read_partitioned_multi_engine(engine):
         for engines in ([engine], [engine, e2], [engine, e2, e3]):
             got = yacrd_amd.run_partitioned(engines, *csr, 3, 0.4)
             assert_same(got, want, "partitioned x%d" % len(engines))
+
+
+def test_class_prediction_is_validated():
+    """Runs of identical shape (reads, intervals) reuse the previous run's class set instead of
+    waiting for the plan; a batch whose classes differ must still come out bit-exact."""
+    R = 600
+    a_sizes = [100] * R                                    # everything in one class
+    b_sizes = [10] * 300 + [190] * 299 + [60000 - 3000 - 299 * 190]  # same totals, other classes
+    assert sum(a_sizes) == sum(b_sizes) == 60000
+    c_sizes = [2] * 599 + [60000 - 2 * 599]                # one read beyond the LDS classes
+    with yacrd_amd.Engine() as e, yacrd_amd.Engine(flags=yacrd_amd.F_NO_PREDICTION) as ref:
+        for rep, sizes in enumerate([a_sizes, a_sizes, b_sizes, b_sizes, c_sizes, a_sizes, c_sizes]):
+            csr = make_csr(1200 + rep, sizes, REGULAR_MODES + ("degenerate",), len_lo=300000,
+                           len_hi=900000)
+            want = oracle.run(csr[0], csr[1], csr[2].astype(np.uint64), 3, 0.4, n_threads=4)
+            assert_same(e.run(*csr, 3, 0.4), want, "predicted run %d" % rep)
+            assert_same(ref.run(*csr, 3, 0.4), want, "unpredicted run %d" % rep)

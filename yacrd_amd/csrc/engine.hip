@@ -96,7 +96,13 @@ struct yacrd_engine {
 
     uint64_t last_reads = 0, last_regions = 0;
     bool has_result = false;
+    // class counts of the previous run: the prediction that lets the next one skip the plan sync
+    yk::Counters pred{};
+    uint64_t pred_reads = 0, pred_iv = 0;
+    bool pred_valid = false;
     yacrd_timing timing = {};
+    yacrd_timing timing_sum = {};
+    uint64_t timing_runs = 0;
 };
 
 namespace {
@@ -305,9 +311,16 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     u32 *rej_small = list_of(yk::CLS_COUNT), *rej_med = list_of(yk::CLS_COUNT + 1),
         *rej_big = list_of(yk::CLS_COUNT + 2);
     yk::Counters *ctr = e->ctrl.as<yk::Counters>();
+    const bool full = (e->flags & YACRD_F_TIMING_FULL) != 0;
+    const int xm = (e->flags & YACRD_F_XLANE_DS) ? 1 : 0;
 
-    // ---- plan: bin reads by size class; the host needs the class counts to launch only what
-    // exists (an empty launch costs ~4 us, there are seven classes)
+    // ---- plan: bin reads by size class.  Only classes that hold reads are launched (an empty
+    // launch costs ~4 us and there are twelve classes), so the host needs the class counts.
+    // Normally that is one sync right here.  When the previous run on this engine had the same
+    // shape (reads, intervals, flags) its class set is used as a PREDICTION instead: the sweeps
+    // are launched without waiting, sized for n_reads, and the prediction is validated against
+    // the real counts at the final sync (a class that was not predicted is launched then and
+    // the compaction redone).  Streams of similar batches never pay the mid-pipeline sync.
     HIP_TRY(hipMemsetAsync(ctr, 0, ctrl_bytes, e->stream));
     HIP_TRY(hipEventRecord(e->ev[EV_START], e->stream));
     hipLaunchKernelGGL(yk::plan_kernel, dim3((n_reads + yk::kPlanBlock - 1) / yk::kPlanBlock),
@@ -316,9 +329,30 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
                              : (e->flags & (YACRD_F_WAVE_ONLY | YACRD_F_FORCE_LDS_SORT)) ? 2
                              : (e->flags & YACRD_F_NO_HALVES) ? 3 : 0));
     HIP_TRY(hipEventRecord(e->ev[EV_PLAN], e->stream));
-    HIP_TRY(hipMemcpyAsync(e->h_ctr, ctr, sizeof(yk::Counters), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    const yk::Counters c0 = *e->h_ctr;
+
+    const bool predicted = e->pred_valid && e->pred_reads == n_reads64 && e->pred_iv == n_iv &&
+                           e->pred.n[yk::CLS_GENERAL] == 0 &&
+                           !(e->flags & (YACRD_F_FORCE_GENERAL | YACRD_F_NO_PREDICTION));
+    struct LaunchSet {
+        u32 n[12];  // reads used to size the grid; 0 = class not launched
+        u64 iv[12]; // intervals (to pick the dominant class)
+    } ls{};
+    yk::Counters c0{};
+    if (predicted) {
+        for (int cls = 0; cls < yk::CLS_GENERAL; cls++) {
+            ls.n[cls] = e->pred.n[cls] ? n_reads : 0;
+            ls.iv[cls] = e->pred.iv[cls];
+        }
+    } else {
+        HIP_TRY(hipMemcpyAsync(e->h_ctr, ctr, sizeof(yk::Counters), hipMemcpyDeviceToHost,
+                               e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        c0 = *e->h_ctr;
+        for (int cls = 0; cls < yk::CLS_GENERAL; cls++) {
+            ls.n[cls] = c0.n[cls];
+            ls.iv[cls] = c0.iv[cls];
+        }
+    }
 
     yk::SweepArgs sa;
     sa.off = d_off;
@@ -329,24 +363,15 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     sa.counts = e->counts.as<u32>();
     sa.ctr = ctr;
 
-    // ---- small classes: one read per wavefront, register sort with K keys per lane
-    HIP_TRY(hipEventRecord(e->ev[EV_S0], e->stream));
-    sa.rej_list = rej_small;
-    sa.rej_count = &ctr->rej_small;
-    const int xm = (e->flags & YACRD_F_XLANE_DS) ? 1 : 0;
-    bool any_small = false;
     // Kernel-level timing.  An event costs ~3 us of stream time, so by default only the class
     // with the most intervals (the dominant kernel) is bracketed; YACRD_F_TIMING_FULL brackets
     // every launched class and the phases.
-    const bool full = (e->flags & YACRD_F_TIMING_FULL) != 0;
-    int dom_cls = -1;
-    for (int cls = 0; cls < yk::CLS_GENERAL; cls++)
-        if (c0.n[cls] && (dom_cls < 0 || c0.iv[cls] > c0.iv[dom_cls])) dom_cls = cls;
     int cls_b[12], cls_e[12]; // event indices bracketing each class, -1 = not recorded
     for (int i = 0; i < 12; i++) cls_b[i] = cls_e[i] = -1;
-    int n_cls_ev = 0;
+    int n_cls_ev = 0, dom_cls = -1;
+    bool timing_on = true;
     auto before_class = [&](int cls) -> hipError_t {
-        if (!(full || cls == dom_cls)) return hipSuccess;
+        if (!timing_on || !(full || cls == dom_cls)) return hipSuccess;
         if (n_cls_ev > 0 && full) { // the previous class's end mark is this one's begin mark
             cls_b[cls] = n_cls_ev - 1;
             return hipSuccess;
@@ -355,107 +380,144 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         return hipEventRecord(e->ev_cls[n_cls_ev++], e->stream);
     };
     auto mark_class = [&](int cls) -> hipError_t {
-        if (!(full || cls == dom_cls)) return hipSuccess;
+        if (!timing_on || !(full || cls == dom_cls)) return hipSuccess;
         cls_e[cls] = n_cls_ev;
         return hipEventRecord(e->ev_cls[n_cls_ev++], e->stream);
     };
-    for (int cls = yk::CLS_R2; cls <= yk::CLS_W16; cls++) {
-        if (!c0.n[cls]) continue;
-        any_small = true;
-        HIP_TRY(before_class(cls));
-        sa.list = list_of(cls);
-        sa.list_n = &ctr->n[cls];
-        if (e->flags & YACRD_F_FORCE_LDS_SORT) {
-            const u32 grid = (u32)std::min<uint64_t>(c0.n[cls], (uint64_t)e->num_cu * 32);
-            hipLaunchKernelGGL((yk::sweep_lds_kernel<64, (int)yk::kSmallEvents>), dim3(grid),
-                               dim3(64), 0, e->stream, sa);
-        } else {
-            switch (cls) {
-            case yk::CLS_R2: yk::launch_sweep_group<16, 2>(sa, c0.n[cls], e->stream, xm); break;
-            case yk::CLS_R4: yk::launch_sweep_group<16, 4>(sa, c0.n[cls], e->stream, xm); break;
-            case yk::CLS_R8: yk::launch_sweep_group<16, 8>(sa, c0.n[cls], e->stream, xm); break;
-            case yk::CLS_R16: yk::launch_sweep_group<16, 16>(sa, c0.n[cls], e->stream, xm); break;
-            case yk::CLS_H16: yk::launch_sweep_group<32, 16>(sa, c0.n[cls], e->stream, xm); break;
-            case yk::CLS_W2: yk::launch_sweep_group<64, 2>(sa, c0.n[cls], e->stream, xm); break;
-            case yk::CLS_W4: yk::launch_sweep_group<64, 4>(sa, c0.n[cls], e->stream, xm); break;
-            case yk::CLS_W8: yk::launch_sweep_group<64, 8>(sa, c0.n[cls], e->stream, xm); break;
-            default: yk::launch_sweep_group<64, 16>(sa, c0.n[cls], e->stream, xm); break;
+
+    // sweeps of the classes in `set`, then the LDS exact path for what they rejected
+    auto launch_sweeps = [&](const LaunchSet &set) -> int {
+        bool any_small = false;
+        sa.rej_list = rej_small;
+        sa.rej_count = &ctr->rej_small;
+        for (int cls = yk::CLS_R2; cls <= yk::CLS_W16; cls++) { // register sort per lane group
+            if (!set.n[cls]) continue;
+            any_small = true;
+            HIP_TRY(before_class(cls));
+            sa.list = list_of(cls);
+            sa.list_n = &ctr->n[cls];
+            if (e->flags & YACRD_F_FORCE_LDS_SORT) {
+                const u32 grid = (u32)std::min<uint64_t>(set.n[cls], (uint64_t)e->num_cu * 32);
+                hipLaunchKernelGGL((yk::sweep_lds_kernel<64, (int)yk::kSmallEvents>), dim3(grid),
+                                   dim3(64), 0, e->stream, sa);
+            } else {
+                switch (cls) {
+                case yk::CLS_R2: yk::launch_sweep_group<16, 2>(sa, set.n[cls], e->stream, xm); break;
+                case yk::CLS_R4: yk::launch_sweep_group<16, 4>(sa, set.n[cls], e->stream, xm); break;
+                case yk::CLS_R8: yk::launch_sweep_group<16, 8>(sa, set.n[cls], e->stream, xm); break;
+                case yk::CLS_R16: yk::launch_sweep_group<16, 16>(sa, set.n[cls], e->stream, xm); break;
+                case yk::CLS_H16: yk::launch_sweep_group<32, 16>(sa, set.n[cls], e->stream, xm); break;
+                case yk::CLS_W2: yk::launch_sweep_group<64, 2>(sa, set.n[cls], e->stream, xm); break;
+                case yk::CLS_W4: yk::launch_sweep_group<64, 4>(sa, set.n[cls], e->stream, xm); break;
+                case yk::CLS_W8: yk::launch_sweep_group<64, 8>(sa, set.n[cls], e->stream, xm); break;
+                default: yk::launch_sweep_group<64, 16>(sa, set.n[cls], e->stream, xm); break;
+                }
             }
+            HIP_TRY(mark_class(cls));
         }
-        HIP_TRY(mark_class(cls));
-    }
-    if (full) HIP_TRY(hipEventRecord(e->ev[EV_SMALL], e->stream));
+        if (full && timing_on) HIP_TRY(hipEventRecord(e->ev[EV_SMALL], e->stream));
 
-    // ---- medium classes: one read per workgroup, LDS resident
-    if (c0.n[yk::CLS_MED1]) {
-        HIP_TRY(before_class(yk::CLS_MED1));
-        sa.list = list_of(yk::CLS_MED1);
-        sa.list_n = &ctr->n[yk::CLS_MED1];
-        sa.rej_list = rej_med;
-        sa.rej_count = &ctr->rej_med;
-        const u32 grid = (u32)std::min<uint64_t>(c0.n[yk::CLS_MED1], (uint64_t)e->num_cu * 4);
-        hipLaunchKernelGGL((yk::sweep_lds_kernel<256, (int)yk::kMedium1Events>), dim3(grid),
-                           dim3(256), 0, e->stream, sa);
-        HIP_TRY(mark_class(yk::CLS_MED1));
-    }
-    if (c0.n[yk::CLS_MED2]) {
-        HIP_TRY(before_class(yk::CLS_MED2));
-        sa.list = list_of(yk::CLS_MED2);
-        sa.list_n = &ctr->n[yk::CLS_MED2];
-        sa.rej_list = rej_big;
-        sa.rej_count = &ctr->rej_big;
-        const u32 grid = (u32)std::min<uint64_t>(c0.n[yk::CLS_MED2], (uint64_t)e->num_cu);
-        hipLaunchKernelGGL((yk::sweep_lds_kernel<1024, (int)yk::kMedium2Events>), dim3(grid),
-                           dim3(1024), 0, e->stream, sa);
-        HIP_TRY(mark_class(yk::CLS_MED2));
-    }
-    if (full) HIP_TRY(hipEventRecord(e->ev[EV_MED], e->stream));
+        if (set.n[yk::CLS_MED1]) { // one read per workgroup, LDS resident
+            HIP_TRY(before_class(yk::CLS_MED1));
+            sa.list = list_of(yk::CLS_MED1);
+            sa.list_n = &ctr->n[yk::CLS_MED1];
+            sa.rej_list = rej_med;
+            sa.rej_count = &ctr->rej_med;
+            const u32 grid = (u32)std::min<uint64_t>(set.n[yk::CLS_MED1], (uint64_t)e->num_cu * 4);
+            hipLaunchKernelGGL((yk::sweep_lds_kernel<256, (int)yk::kMedium1Events>), dim3(grid),
+                               dim3(256), 0, e->stream, sa);
+            HIP_TRY(mark_class(yk::CLS_MED1));
+        }
+        if (set.n[yk::CLS_MED2]) {
+            HIP_TRY(before_class(yk::CLS_MED2));
+            sa.list = list_of(yk::CLS_MED2);
+            sa.list_n = &ctr->n[yk::CLS_MED2];
+            sa.rej_list = rej_big;
+            sa.rej_count = &ctr->rej_big;
+            const u32 grid = (u32)std::min<uint64_t>(set.n[yk::CLS_MED2], (uint64_t)e->num_cu);
+            hipLaunchKernelGGL((yk::sweep_lds_kernel<1024, (int)yk::kMedium2Events>), dim3(grid),
+                               dim3(1024), 0, e->stream, sa);
+            HIP_TRY(mark_class(yk::CLS_MED2));
+        }
+        if (full && timing_on) HIP_TRY(hipEventRecord(e->ev[EV_MED], e->stream));
 
-    // ---- exact general path
-    // (a) reads a sweep rejected (degenerate interval), scratch in LDS, no host round trip
-    if (any_small) {
-        sa.list = rej_small;
-        sa.list_n = &ctr->rej_small;
-        sa.rej_list = rej_med; // cannot happen (n <= 512), kept well defined
-        sa.rej_count = &ctr->rej_med;
-        // (a single wavefront per read was tried: 23.9 us vs 20.2 us — the stages are latency
-        // chains, more threads shorten each one)
-        hipLaunchKernelGGL((yk::sweep_general_lds_kernel<256, 512>), dim3(e->num_cu * 2), dim3(256),
-                           0, e->stream, sa);
-    }
-    if (c0.n[yk::CLS_MED1]) {
-        sa.list = rej_med;
-        sa.list_n = &ctr->rej_med;
-        sa.rej_list = rej_big;
-        sa.rej_count = &ctr->rej_big;
-        hipLaunchKernelGGL((yk::sweep_general_lds_kernel<1024, 4096>), dim3(e->num_cu), dim3(1024),
-                           0, e->stream, sa);
-    }
-    // (b) reads too large for LDS (or every read under YACRD_F_FORCE_GENERAL): global scratch
+        // exact path for reads a sweep rejected, scratch in LDS, no host round trip
+        if (any_small) {
+            sa.list = rej_small;
+            sa.list_n = &ctr->rej_small;
+            sa.rej_list = rej_med; // cannot happen (n <= 512), kept well defined
+            sa.rej_count = &ctr->rej_med;
+            // (a single wavefront per read was tried: 23.9 us vs 20.2 us — the stages are latency
+            // chains, more threads shorten each one)
+            hipLaunchKernelGGL((yk::sweep_general_lds_kernel<256, 512>), dim3(e->num_cu * 2),
+                               dim3(256), 0, e->stream, sa);
+        }
+        if (set.n[yk::CLS_MED1]) {
+            sa.list = rej_med;
+            sa.list_n = &ctr->rej_med;
+            sa.rej_list = rej_big;
+            sa.rej_count = &ctr->rej_big;
+            hipLaunchKernelGGL((yk::sweep_general_lds_kernel<1024, 4096>), dim3(e->num_cu),
+                               dim3(1024), 0, e->stream, sa);
+        }
+        return YACRD_OK;
+    };
+    // reads beyond the LDS classes (or every read under YACRD_F_FORCE_GENERAL); host-driven
+    auto launch_huge = [&](u32 count, u64 *iv_total) -> int {
+        return (e->flags & YACRD_F_FORCE_GENERAL)
+                   ? run_general_global(e, d_off, d_iv, d_len, list_of(yk::CLS_GENERAL), count, cov,
+                                        e->stream, iv_total)
+                   : run_big(e, d_off, d_iv, d_len, list_of(yk::CLS_GENERAL), count, cov, e->stream,
+                             iv_total);
+    };
+
+    for (int cls = 0; cls < yk::CLS_GENERAL; cls++)
+        if (ls.n[cls] && (dom_cls < 0 || ls.iv[cls] > ls.iv[dom_cls])) dom_cls = cls;
+    HIP_TRY(hipEventRecord(e->ev[EV_S0], e->stream));
+    int rc = launch_sweeps(ls);
+    if (rc) return rc;
     u64 gen_iv = 0;
-    if (c0.n[yk::CLS_GENERAL]) {
-        int rc = (e->flags & YACRD_F_FORCE_GENERAL)
-                     ? run_general_global(e, d_off, d_iv, d_len, list_of(yk::CLS_GENERAL),
-                                          c0.n[yk::CLS_GENERAL], cov, e->stream, &gen_iv)
-                     : run_big(e, d_off, d_iv, d_len, list_of(yk::CLS_GENERAL),
-                               c0.n[yk::CLS_GENERAL], cov, e->stream, &gen_iv);
+    if (!predicted && c0.n[yk::CLS_GENERAL]) {
+        rc = launch_huge(c0.n[yk::CLS_GENERAL], &gen_iv);
         if (rc) return rc;
     }
     if (full) HIP_TRY(hipEventRecord(e->ev[EV_GEN], e->stream));
 
     // ---- follow-on kernel: scan + compact + classify
-    int rc = launch_compact(e, d_off, d_len, n_reads, not_cov);
+    rc = launch_compact(e, d_off, d_len, n_reads, not_cov);
     if (rc) return rc;
     HIP_TRY(hipEventRecord(e->ev[EV_COMPACT], e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipGetLastError());
+    timing_on = false;
 
-    // ---- rare slow paths: degenerate reads too large for the LDS exact path; region overflow
+    // ---- rare slow paths: a class the prediction missed; degenerate reads too large for the
+    // LDS exact path; region overflow.  Each ends with a redo of the compaction.
     float extra_ms = 0.f;
-    u32 n_rej_big = e->h_ctr->rej_big;
     bool redo = false;
+    if (predicted) {
+        c0 = *e->h_ctr; // the plan's real counts
+        LaunchSet missing{};
+        bool any_missing = false;
+        for (int cls = 0; cls < yk::CLS_GENERAL; cls++)
+            if (c0.n[cls] && !ls.n[cls]) {
+                missing.n[cls] = c0.n[cls];
+                any_missing = true;
+            }
+        if (any_missing || c0.n[yk::CLS_GENERAL]) {
+            HIP_TRY(hipEventRecord(e->ev[EV_X0], e->stream));
+            if (any_missing && (rc = launch_sweeps(missing))) return rc;
+            if (c0.n[yk::CLS_GENERAL] && (rc = launch_huge(c0.n[yk::CLS_GENERAL], &gen_iv))) return rc;
+            // the rejection counters may have grown: bring them home before looking at rej_big
+            HIP_TRY(hipMemcpyAsync(e->h_ctr, ctr, sizeof(yk::Counters), hipMemcpyDeviceToHost,
+                                   e->stream));
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            redo = true;
+        }
+    }
+    const u32 n_rej_big = e->h_ctr->rej_big;
     if (n_rej_big) {
-        HIP_TRY(hipEventRecord(e->ev[EV_X0], e->stream));
+        if (!redo) HIP_TRY(hipEventRecord(e->ev[EV_X0], e->stream));
         rc = run_general_global(e, d_off, d_iv, d_len, rej_big, n_rej_big, cov, e->stream, nullptr);
         if (rc) return rc;
         redo = true;
@@ -480,9 +542,14 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     if (e->h_ctr->region_overflow) return fail(YACRD_EINTERNAL, "bad_regions overflow persisted");
 
     const yk::Counters c1 = *e->h_ctr;
+    if (predicted) c0 = c1; // class counts are final either way
     e->last_reads = n_reads;
     e->last_regions = c1.total_regions;
     e->has_result = true;
+    e->pred = c1;
+    e->pred_reads = n_reads64;
+    e->pred_iv = n_iv;
+    e->pred_valid = true;
 
     yacrd_timing &t = e->timing;
     t.plan_ms = ev_ms(e->ev[EV_START], e->ev[EV_PLAN]);
@@ -492,7 +559,8 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         t.sweep_general_ms = ev_ms(e->ev[EV_MED], e->ev[EV_GEN]);
         t.compact_ms = ev_ms(e->ev[EV_GEN], e->ev[EV_COMPACT]);
     }
-    t.total_ms = t.plan_ms + ev_ms(e->ev[EV_S0], e->ev[EV_COMPACT]) + extra_ms;
+    t.total_ms = (predicted ? ev_ms(e->ev[EV_START], e->ev[EV_COMPACT])
+                            : t.plan_ms + ev_ms(e->ev[EV_S0], e->ev[EV_COMPACT])) + extra_ms;
     t.n_small = 0;
     t.iv_small = 0;
     for (int cls = yk::CLS_R2; cls <= yk::CLS_W16; cls++) {
@@ -512,6 +580,20 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
             t.class_ms[cls] = ev_ms(e->ev_cls[cls_b[cls]], e->ev_cls[cls_e[cls]]);
     }
     t.class_ms[yk::CLS_GENERAL] = (full && c0.n[yk::CLS_GENERAL]) ? t.sweep_general_ms : 0.f;
+
+    yacrd_timing &ts = e->timing_sum;
+    const yacrd_timing keep = ts;
+    ts = t; // count fields follow the last run
+    ts.h2d_ms = keep.h2d_ms;
+    ts.d2h_ms = keep.d2h_ms;
+    ts.plan_ms = keep.plan_ms + t.plan_ms;
+    ts.sweep_small_ms = keep.sweep_small_ms + t.sweep_small_ms;
+    ts.sweep_medium_ms = keep.sweep_medium_ms + t.sweep_medium_ms;
+    ts.sweep_general_ms = keep.sweep_general_ms + t.sweep_general_ms;
+    ts.compact_ms = keep.compact_ms + t.compact_ms;
+    ts.total_ms = keep.total_ms + t.total_ms;
+    for (int i = 0; i < 12; i++) ts.class_ms[i] = keep.class_ms[i] + t.class_ms[i];
+    e->timing_runs++;
     return YACRD_OK;
 }
 
@@ -688,6 +770,18 @@ int yacrd_engine_last_timing(const yacrd_engine *e, yacrd_timing *t)
 {
     if (!e || !t) return fail(YACRD_EINVAL, "null argument");
     *t = e->timing;
+    return YACRD_OK;
+}
+
+int yacrd_engine_timing_total(yacrd_engine *e, yacrd_timing *sum, uint64_t *n_runs, int reset)
+{
+    if (!e) return fail(YACRD_EINVAL, "null argument");
+    if (sum) *sum = e->timing_sum;
+    if (n_runs) *n_runs = e->timing_runs;
+    if (reset) {
+        e->timing_sum = yacrd_timing{};
+        e->timing_runs = 0;
+    }
     return YACRD_OK;
 }
 

@@ -369,6 +369,7 @@ __global__ __launch_bounds__(256) void sweep_group_kernel(SweepArgs a)
     constexpr u32 GROUPS = 64 / LANES; // reads per wavefront
     const u32 list_n = *a.list_n;
     const u32 wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (wave * GROUPS >= list_n) return; // grids may be sized for more reads than the class holds
     const u32 idx = wave * GROUPS + lane / (u32)LANES;
     const bool active = idx < list_n;
     u32 r = 0, n = 0, len = 0;

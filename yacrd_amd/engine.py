@@ -17,13 +17,14 @@ F_XLANE_DS = 4
 F_WAVE_ONLY = 8
 F_NO_HALVES = 16
 F_TIMING_FULL = 32
+F_NO_PREDICTION = 64
 
 # every symbol include/yacrd_engine.h declares
 EXPORTED_SYMBOLS = [
     "yacrd_abi_version", "yacrd_last_error", "yacrd_engine_create", "yacrd_engine_destroy",
     "yacrd_engine_run", "yacrd_result_free", "yacrd_engine_run_device", "yacrd_engine_fetch",
     "yacrd_engine_last_timing", "yacrd_partition_reads", "yacrd_engine_classify",
-    "yacrd_engines_run_partitioned",
+    "yacrd_engines_run_partitioned", "yacrd_engine_timing_total",
 ]
 
 
@@ -144,6 +145,8 @@ def load_library():
     lib.yacrd_partition_reads.argtypes = [u64p, ctypes.c_uint64, ctypes.c_uint32, u64p]
     lib.yacrd_engine_classify.argtypes = [ctypes.c_void_p, u64p, u32p, u32p, ctypes.c_uint64,
                                           ctypes.c_double, u8p]
+    lib.yacrd_engine_timing_total.argtypes = [ctypes.c_void_p, ctypes.POINTER(_Timing),
+                                              ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
     lib.yacrd_engines_run_partitioned.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32,
                                                   u64p, u32p, u32p, ctypes.c_uint64,
                                                   ctypes.c_uint32, ctypes.c_double,
@@ -264,6 +267,18 @@ class Engine:
             v = getattr(t, n)
             out[n] = list(v) if n.startswith("class_") else v
         return out
+
+    def timing_total(self, reset=False):
+        """(sums over the runs since the last reset, number of runs)."""
+        t = _Timing()
+        n = ctypes.c_uint64()
+        _check(self._lib, self._lib.yacrd_engine_timing_total(self._h, ctypes.byref(t),
+                                                              ctypes.byref(n), 1 if reset else 0))
+        out = {}
+        for name, _ in _Timing._fields_:
+            v = getattr(t, name)
+            out[name] = list(v) if name.startswith("class_") else v
+        return out, int(n.value)
 
     def classify(self, bad_offsets, bad_regions, lengths, not_coverage):
         bad_offsets = np.ascontiguousarray(bad_offsets, dtype=np.uint64)

@@ -117,13 +117,20 @@ def main():
         # dominant kernel = the size class with the largest own kernel time (HIP events around that
         # launch on the engine's stream); its algorithmic bytes are those of the reads it processed
         ci = max(range(12), key=lambda i: cls_ms[i])
-        cname = yacrd_amd.CLASS_NAMES[ci]
-        dom = yacrd_amd.CLASS_KERNELS[cname]
-        dom_ms = cls_ms[ci] / K
-        c_reads, c_iv = t["class_reads"][ci], t["class_intervals"][ci]
+        if t["fused_ms"] >= cls_ms[ci]:  # the row / half-wavefront classes run as one launch
+            cname, dom = "R2..H16", "sweep_small_fused_kernel"
+            dom_ms = t["fused_ms"] / K
+            c_reads, c_iv = t["fused_reads"], t["fused_intervals"]
+        else:
+            cname = yacrd_amd.CLASS_NAMES[ci]
+            dom = yacrd_amd.CLASS_KERNELS[cname]
+            dom_ms = cls_ms[ci] / K
+            c_reads, c_iv = t["class_reads"][ci], t["class_intervals"][ci]
         b_dom = 8 * c_iv + 21 * c_reads + 16 + 8 * (G * c_reads // max(R, 1))
         achieved = b_dom / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         avg["class_ms"] = {yacrd_amd.CLASS_NAMES[i]: cls_ms[i] / K for i in range(12) if cls_ms[i] > 0}
+        if t["fused_ms"] > 0:
+            avg["class_ms"]["R2..H16 (one launch)"] = t["fused_ms"] / K
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):

@@ -71,6 +71,8 @@ typedef struct {
 #define YACRD_F_TIMING_FULL 32u
 /* always wait for the plan's class counts (no prediction from the previous run); A/B only */
 #define YACRD_F_NO_PREDICTION 64u
+/* one launch per register-sort class instead of the fused launch; A/B only */
+#define YACRD_F_NO_FUSED_LAUNCH 128u
 
 /* Host-side result, allocated by the engine, released with yacrd_result_free(). */
 typedef struct {
@@ -107,6 +109,10 @@ typedef struct {
     float class_ms[12];
     uint64_t class_reads[12];
     uint64_t class_intervals[12];
+    /* the classes R2..H16 run as ONE launch (sweep_small_fused_kernel): its time and what it
+     * processed; class_ms of those classes is then 0 */
+    float fused_ms;
+    uint64_t fused_reads, fused_intervals;
 } yacrd_timing;
 
 /* size classes, in the order of yacrd_timing.class_*: R<K> = four reads per wavefront (16-lane

@@ -57,7 +57,8 @@ struct Counters {
     u32 rej_big;             // ... by the 1024-thread LDS sweep (n <= 16384): global-memory path
     u32 region_overflow;     // compaction ran out of bad_regions capacity
     u32 scan_ticket;         // dynamic workgroup id of the single-pass scan
-    u32 pad1[3];
+    u32 scan_done;           // workgroups of the scan kernel that finished
+    u32 pad1[2];
     u64 total_regions;       // G, written by the last scan workgroup
 };
 

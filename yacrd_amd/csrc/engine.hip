@@ -138,6 +138,8 @@ int launch_compact(yacrd_engine *e, const u64 *d_off, const u32 *d_len, u32 n_re
                        d_off, d_len, e->stage.as<uint2>(), e->counts.as<u32>(), scan_state, n_reads,
                        not_cov, e->bad_offsets.as<u64>(), e->bad_regions.as<uint2>(),
                        (u64)(e->bad_regions.cap / sizeof(uint2)), e->read_type.as<uint8_t>(), ctr);
+    // (handing the counters over through mapped pinned memory from the kernel's last workgroup
+    // was tried: the system-scope stores made the kernel 8 us slower than this 4 us copy)
     HIP_TRY(hipMemcpyAsync(e->h_ctr, ctr, sizeof(yk::Counters), hipMemcpyDeviceToHost, e->stream));
     return YACRD_OK;
 }
@@ -385,13 +387,47 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         return hipEventRecord(e->ev_cls[n_cls_ev++], e->stream);
     };
 
+    bool skip_rejected_small = predicted && e->pred.rej_small == 0, skipped_small = false;
+    bool fused_marked = false;
     // sweeps of the classes in `set`, then the LDS exact path for what they rejected
     auto launch_sweeps = [&](const LaunchSet &set) -> int {
         bool any_small = false;
         sa.rej_list = rej_small;
         sa.rej_count = &ctr->rej_small;
+        // the row / half-wavefront classes in one launch
+        const bool fuse = !(e->flags & (YACRD_F_FORCE_LDS_SORT | YACRD_F_XLANE_DS |
+                                        YACRD_F_NO_FUSED_LAUNCH));
+        if (fuse) {
+            yk::FusedArgs fa;
+            fa.base = sa;
+            fa.n_entries = 0;
+            u32 blocks = 0;
+            bool has_dom = false;
+            for (int cls = yk::CLS_R2; cls <= yk::CLS_H16; cls++) {
+                if (!set.n[cls]) continue;
+                const u32 per = yk::sweep_group_reads_per_block(cls);
+                blocks += (set.n[cls] + per - 1) / per;
+                fa.cls[fa.n_entries] = (u32)cls;
+                fa.block_end[fa.n_entries] = blocks;
+                fa.list[fa.n_entries] = list_of(cls);
+                fa.list_n[fa.n_entries] = &ctr->n[cls];
+                fa.n_entries++;
+                has_dom |= cls == dom_cls;
+            }
+            if (fa.n_entries) {
+                any_small = true;
+                const bool mark = timing_on && (full || has_dom);
+                if (mark) HIP_TRY(hipEventRecord(e->ev_cls[22], e->stream));
+                hipLaunchKernelGGL(yk::sweep_small_fused_kernel, dim3(blocks), dim3(256), 0,
+                                   e->stream, fa);
+                if (mark) {
+                    HIP_TRY(hipEventRecord(e->ev_cls[23], e->stream));
+                    fused_marked = true;
+                }
+            }
+        }
         for (int cls = yk::CLS_R2; cls <= yk::CLS_W16; cls++) { // register sort per lane group
-            if (!set.n[cls]) continue;
+            if (!set.n[cls] || (fuse && cls <= yk::CLS_H16)) continue;
             any_small = true;
             HIP_TRY(before_class(cls));
             sa.list = list_of(cls);
@@ -441,8 +477,10 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         }
         if (full && timing_on) HIP_TRY(hipEventRecord(e->ev[EV_MED], e->stream));
 
-        // exact path for reads a sweep rejected, scratch in LDS, no host round trip
-        if (any_small) {
+        // exact path for reads a sweep rejected, scratch in LDS, no host round trip (skipped when
+        // the prediction says nothing gets rejected; checked at the final sync)
+        if (any_small && skip_rejected_small) skipped_small = true;
+        else if (any_small) {
             sa.list = rej_small;
             sa.list_n = &ctr->rej_small;
             sa.rej_list = rej_med; // cannot happen (n <= 512), kept well defined
@@ -495,8 +533,19 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     // LDS exact path; region overflow.  Each ends with a redo of the compaction.
     float extra_ms = 0.f;
     bool redo = false;
+    skip_rejected_small = false;
     if (predicted) {
         c0 = *e->h_ctr; // the plan's real counts
+        if (skipped_small && c0.rej_small) { // rejections the prediction did not expect
+            HIP_TRY(hipEventRecord(e->ev[EV_X0], e->stream));
+            sa.list = rej_small;
+            sa.list_n = &ctr->rej_small;
+            sa.rej_list = rej_med;
+            sa.rej_count = &ctr->rej_med;
+            hipLaunchKernelGGL((yk::sweep_general_lds_kernel<256, 512>), dim3(e->num_cu * 2),
+                               dim3(256), 0, e->stream, sa);
+            redo = true;
+        }
         LaunchSet missing{};
         bool any_missing = false;
         for (int cls = 0; cls < yk::CLS_GENERAL; cls++)
@@ -505,7 +554,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
                 any_missing = true;
             }
         if (any_missing || c0.n[yk::CLS_GENERAL]) {
-            HIP_TRY(hipEventRecord(e->ev[EV_X0], e->stream));
+            if (!redo) HIP_TRY(hipEventRecord(e->ev[EV_X0], e->stream));
             if (any_missing && (rc = launch_sweeps(missing))) return rc;
             if (c0.n[yk::CLS_GENERAL] && (rc = launch_huge(c0.n[yk::CLS_GENERAL], &gen_iv))) return rc;
             // the rejection counters may have grown: bring them home before looking at rej_big
@@ -530,7 +579,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         }
         redo = false;
         // reset the scan state, the ticket and the overflow flag (keep the class counters)
-        HIP_TRY(hipMemsetAsync(&ctr->region_overflow, 0, 2 * sizeof(u32), e->stream));
+        HIP_TRY(hipMemsetAsync(&ctr->region_overflow, 0, 3 * sizeof(u32), e->stream));
         HIP_TRY(hipMemsetAsync(ctr + 1, 0, (size_t)nb * sizeof(u64), e->stream));
         rc = launch_compact(e, d_off, d_len, n_reads, not_cov);
         if (rc) return rc;
@@ -580,6 +629,15 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
             t.class_ms[cls] = ev_ms(e->ev_cls[cls_b[cls]], e->ev_cls[cls_e[cls]]);
     }
     t.class_ms[yk::CLS_GENERAL] = (full && c0.n[yk::CLS_GENERAL]) ? t.sweep_general_ms : 0.f;
+    t.fused_ms = 0.f;
+    t.fused_reads = t.fused_intervals = 0;
+    if (fused_marked) {
+        t.fused_ms = ev_ms(e->ev_cls[22], e->ev_cls[23]);
+        for (int cls = yk::CLS_R2; cls <= yk::CLS_H16; cls++) {
+            t.fused_reads += c0.n[cls];
+            t.fused_intervals += c0.iv[cls];
+        }
+    }
 
     yacrd_timing &ts = e->timing_sum;
     const yacrd_timing keep = ts;
@@ -593,6 +651,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     ts.compact_ms = keep.compact_ms + t.compact_ms;
     ts.total_ms = keep.total_ms + t.total_ms;
     for (int i = 0; i < 12; i++) ts.class_ms[i] = keep.class_ms[i] + t.class_ms[i];
+    ts.fused_ms = keep.fused_ms + t.fused_ms;
     e->timing_runs++;
     return YACRD_OK;
 }

@@ -355,9 +355,9 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
     }
 }
 
-// One kernel per (LANES, K): small K keep small register footprints.
+// Body of one workgroup (four wavefronts, 4 * 64/LANES reads) of class (LANES, K).
 template <int LANES, int K, int XM>
-__global__ __launch_bounds__(256) void sweep_group_kernel(SweepArgs a)
+__device__ __forceinline__ void sweep_group_block(const SweepArgs &a, u32 block)
 {
     const u32 lane = lane_id();
     LaneConst lc;
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void sweep_group_kernel(SweepArgs a)
 
     constexpr u32 GROUPS = 64 / LANES; // reads per wavefront
     const u32 list_n = *a.list_n;
-    const u32 wave = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const u32 wave = block * 4u + (threadIdx.x >> 6);
     if (wave * GROUPS >= list_n) return; // grids may be sized for more reads than the class holds
     const u32 idx = wave * GROUPS + lane / (u32)LANES;
     const bool active = idx < list_n;
@@ -384,6 +384,13 @@ __global__ __launch_bounds__(256) void sweep_group_kernel(SweepArgs a)
                                    a, lc);
 }
 
+// One kernel per (LANES, K): small K keep small register footprints.
+template <int LANES, int K, int XM>
+__global__ __launch_bounds__(256) void sweep_group_kernel(SweepArgs a)
+{
+    sweep_group_block<LANES, K, XM>(a, blockIdx.x);
+}
+
 template <int LANES, int K>
 inline void launch_sweep_group(const SweepArgs &sa, u32 n_reads, hipStream_t stream, int xlane_mode)
 {
@@ -395,6 +402,44 @@ inline void launch_sweep_group(const SweepArgs &sa, u32 n_reads, hipStream_t str
     else
         hipLaunchKernelGGL((sweep_group_kernel<LANES, K, 0>), dim3(grid ? grid : 1), dim3(256), 0,
                            stream, sa);
+}
+
+// ---- every register-sort class in ONE launch ------------------------------------------------
+// The classes R2..H16 are independent; launched one after the other each pays its own ramp-up
+// and drain (~4-7 us for the minor ones on configs[1]).  Here the grid is the concatenation of
+// the per-class grids and a workgroup looks up its class (<= 5 uniform compares).
+struct FusedArgs {
+    SweepArgs base;           // list / list_n filled per class from the table below
+    u32 n_entries;
+    u32 cls[5];               // CLS_R2 .. CLS_H16
+    u32 block_end[5];         // running end of the per-class grids
+    const u32 *list[5];
+    const u32 *list_n[5];
+};
+
+__global__ __launch_bounds__(256, 5) void sweep_small_fused_kernel(FusedArgs f)
+{
+    u32 e = 0, first = 0;
+    while (e + 1 < f.n_entries && blockIdx.x >= f.block_end[e]) {
+        first = f.block_end[e];
+        e++;
+    }
+    SweepArgs a = f.base;
+    a.list = f.list[e];
+    a.list_n = f.list_n[e];
+    const u32 b = blockIdx.x - first;
+    switch (f.cls[e]) { // the one-read-per-wavefront classes stay separate kernels (registers)
+    case CLS_R2: sweep_group_block<16, 2, 0>(a, b); break;
+    case CLS_R4: sweep_group_block<16, 4, 0>(a, b); break;
+    case CLS_R8: sweep_group_block<16, 8, 0>(a, b); break;
+    case CLS_R16: sweep_group_block<16, 16, 0>(a, b); break;
+    default: sweep_group_block<32, 16, 0>(a, b); break;
+    }
+}
+
+inline u32 sweep_group_reads_per_block(int cls)
+{
+    return (cls <= CLS_R16) ? 16u : (cls == CLS_H16) ? 8u : 4u;
 }
 
 } // namespace yk

@@ -24,6 +24,7 @@
 #include <cerrno>
 #include <chrono>
 #include <cstdio>
+#include <memory>
 #include <mutex>
 #include <cstdlib>
 #include <cstring>
@@ -41,7 +42,7 @@ std::string &err_slot()
 
 struct yacrd_csr {
     std::vector<uint64_t> offsets;
-    std::vector<uint32_t> intervals;
+    std::unique_ptr<uint32_t[]> intervals; // 2 * n_intervals, deliberately not zero-filled
     std::vector<uint32_t> lengths;
     std::vector<uint64_t> name_off;
     std::vector<char> names;
@@ -524,8 +525,10 @@ int build(const char *text, size_t len, int format, int n_threads, yacrd_csr **o
         acc += n;
     }
     c->offsets[R] = acc;
-    c->intervals.resize(2 * acc);
-    uint32_t *iv = c->intervals.data();
+    // new[] without () leaves the 8 B/interval buffer untouched: a vector would zero it on one
+    // thread (tens of ms for 10^7 intervals) before the parallel fill overwrites every word
+    c->intervals.reset(new uint32_t[2 * acc + 2]);
+    uint32_t *iv = c->intervals.get();
     // With one chunk the fill is in line order; with several, the order inside a read depends on
     // thread timing (results do not: the sweep sorts).
     parallel_for(T, NT, [&](size_t t) {
@@ -646,7 +649,7 @@ int yacrd_csr_get(const yacrd_csr *c, yacrd_csr_view *v)
     v->n_intervals = c->offsets.empty() ? 0 : c->offsets.back();
     v->n_records = c->n_records;
     v->offsets = c->offsets.data();
-    v->intervals = c->intervals.data();
+    v->intervals = c->intervals.get();
     v->lengths = c->lengths.data();
     v->name_off = c->name_off.data();
     v->names = c->names.data();

@@ -94,6 +94,10 @@ int yacrd_synth_csr(const yacrd_synth_cfg *cfg, uint64_t *offsets, uint32_t *int
                     uint32_t *lengths);
 /* Same overlaps as PAF text (12 columns + tp:A:S), read ids r%09u. */
 int yacrd_synth_paf(const yacrd_synth_cfg *cfg, const char *path);
+/* Matching reads as FASTQ (bases from the PRNG, quality '?', a description on every record),
+ * plus `extra_reads` reads x%09u that appear in no overlap (they must pass through editors
+ * untouched, src/stack.rs:164-169). */
+int yacrd_synth_fastq(const yacrd_synth_cfg *cfg, uint64_t extra_reads, const char *path);
 
 #ifdef __cplusplus
 }

@@ -77,3 +77,31 @@ def test_bad_usage_is_loud(work):
     assert p.returncode != 0
     p = subprocess.run([BIN, "-i", str(work / "nope.paf"), "-o", str(work / "x")], capture_output=True, text=True)
     assert p.returncode != 0 and "nope.paf" in p.stderr
+
+
+def test_synthetic_pipeline_config5_shape(tmp_path):
+    """configs[4] at reduced scale through the whole drop-in: PAF text -> ingest -> engine ->
+    report -> scrubb of a FASTQ, against the CPU restatements (oracle ingest + sweep + editor)."""
+    import numpy as np
+    import oracle
+    from oracle import editors
+    from yacrd_amd import host
+    R, O, seed = 4000, 200000, 20241113
+    paf, fq = str(tmp_path / "s.paf"), str(tmp_path / "s.fastq")
+    host.synth_paf(host.SYNTH_SEQUEL, R, O, seed, paf)
+    host.synth_fastq(host.SYNTH_SEQUEL, R, O, seed, 20, fq)   # 20 reads that no overlap mentions
+    for op in ("scrubb", "split"):
+        rep, out = str(tmp_path / ("%s.yacrd" % op)), str(tmp_path / ("%s.fastq" % op))
+        run("-i", paf, "-o", rep, "-c", "3", "-n", "0.4", "-t", "4", op, "-i", fq, "-o", out)
+        with open(paf) as f:
+            reads = oracle.parse_paf(f)
+        table = {k: (oracle.compute_bad_part(v[0], v[1], 3), v[1]) for k, v in reads.items()}
+        want_report = set(oracle.report_line(k, ln, reg, oracle.type_of_read(ln, reg, 0.4))
+                          for k, (reg, ln) in table.items())
+        assert set(lines(rep)) == want_report and len(lines(rep)) == len(table)
+        with open(fq, "rb") as f:
+            want = editors.edit_fastq(op, f.read(), table, 0.4)
+        with open(out, "rb") as f:
+            assert f.read() == want
+    types = [l.split("\t")[0] for l in lines(rep)]
+    assert types.count("Chimeric") > 0 and types.count("NotCovered") > 0

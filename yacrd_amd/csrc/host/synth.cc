@@ -250,4 +250,44 @@ int yacrd_synth_paf(const yacrd_synth_cfg *cfg, const char *path)
     return 0;
 }
 
+int yacrd_synth_fastq(const yacrd_synth_cfg *cfg, uint64_t extra_reads, const char *path)
+{
+    if (check_cfg(cfg)) return 1;
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return yh::fail(std::string("cannot open ") + path);
+    std::vector<char> buf(1 << 20);
+    std::setvbuf(f, buf.data(), _IOFBF, buf.size());
+    Gen g(*cfg); // same lengths as the overlaps
+    Rng rng(cfg->seed ^ 0x5eedf00dull);
+    std::string seq, qual;
+    const uint64_t total = cfg->n_reads + extra_reads;
+    uint64_t next_extra = extra_reads ? total / extra_reads / 2 : total; // spread the extras
+    uint64_t emitted_extra = 0, r = 0;
+    for (uint64_t i = 0; i < total; i++) {
+        const bool extra = emitted_extra < extra_reads && (i == next_extra || r >= cfg->n_reads);
+        uint32_t len;
+        if (extra) {
+            len = 200 + (uint32_t)rng.below(3000);
+            next_extra += total / extra_reads;
+        } else {
+            len = g.len[r];
+        }
+        seq.resize(len);
+        for (uint32_t k = 0; k < len; k += 32) { // 2 bits per base
+            uint64_t w = rng.next();
+            const uint32_t m = std::min<uint32_t>(32, len - k);
+            for (uint32_t j = 0; j < m; j++, w >>= 2) seq[k + j] = "ACGT"[w & 3];
+        }
+        qual.assign(len, '?');
+        if (extra) std::fprintf(f, "@x%09llu no overlap len=%u\n", (unsigned long long)emitted_extra++, len);
+        else std::fprintf(f, "@r%09llu synthetic len=%u\n", (unsigned long long)r++, len);
+        std::fwrite(seq.data(), 1, len, f);
+        std::fwrite("\n+\n", 1, 3, f);
+        std::fwrite(qual.data(), 1, len, f);
+        std::fputc('\n', f);
+    }
+    if (std::fclose(f) != 0) return yh::fail("write error");
+    return 0;
+}
+
 } // extern "C"

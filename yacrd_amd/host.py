@@ -15,6 +15,7 @@ EXPORTED_SYMBOLS = [
     "yacrd_host_last_error", "yacrd_csr_from_file", "yacrd_csr_from_memory", "yacrd_csr_get",
     "yacrd_csr_find", "yacrd_csr_free", "yacrd_report_write", "yacrd_synth_csr", "yacrd_synth_paf",
     "yacrd_edit_file", "yacrd_report_read", "yacrd_report_get", "yacrd_report_free",
+    "yacrd_synth_fastq",
 ]
 
 OP_SCRUBB, OP_FILTER, OP_EXTRACT, OP_SPLIT = 0, 1, 2, 3
@@ -85,6 +86,7 @@ def load_library():
                                         ctypes.POINTER(ctypes.c_uint32),
                                         ctypes.POINTER(ctypes.c_uint32)]
         lib.yacrd_synth_paf.argtypes = [ctypes.POINTER(_SynthCfg), ctypes.c_char_p]
+        lib.yacrd_synth_fastq.argtypes = [ctypes.POINTER(_SynthCfg), ctypes.c_uint64, ctypes.c_char_p]
         lib.yacrd_edit_file.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p,
                                         ctypes.POINTER(_BadParts)]
         lib.yacrd_report_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
@@ -185,6 +187,12 @@ def synth_paf(profile, n_reads, n_overlaps, seed, path, flags=0):
     lib = load_library()
     cfg = _SynthCfg(profile, flags, n_reads, n_overlaps, seed)
     _check(lib, lib.yacrd_synth_paf(ctypes.byref(cfg), path.encode()))
+
+
+def synth_fastq(profile, n_reads, n_overlaps, seed, extra_reads, path, flags=0):
+    lib = load_library()
+    cfg = _SynthCfg(profile, flags, n_reads, n_overlaps, seed)
+    _check(lib, lib.yacrd_synth_fastq(ctypes.byref(cfg), extra_reads, path.encode()))
 
 
 def edit_file(op, in_path, out_path, names, lengths, bad_offsets, bad_regions, read_type):

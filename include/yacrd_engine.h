@@ -73,6 +73,11 @@ typedef struct {
 #define YACRD_F_NO_PREDICTION 64u
 /* one launch per register-sort class instead of the fused launch; A/B only */
 #define YACRD_F_NO_FUSED_LAUNCH 128u
+/* sort every event: skip the coverage pre-filter of the register-sort classes (A/B, tests) */
+#define YACRD_F_NO_PREFILTER 256u
+/* count the reads the pre-filter thinned (yacrd_timing.prefiltered_reads); one global atomic per
+ * read, so only for tests */
+#define YACRD_F_COUNT_PREFILTERED 512u
 
 /* Host-side result, allocated by the engine, released with yacrd_result_free(). */
 typedef struct {
@@ -113,6 +118,9 @@ typedef struct {
      * processed; class_ms of those classes is then 0 */
     float fused_ms;
     uint64_t fused_reads, fused_intervals;
+    /* reads whose events were thinned by the coverage pre-filter before the sort (counted only
+     * under YACRD_F_COUNT_PREFILTERED) */
+    uint64_t prefiltered_reads;
 } yacrd_timing;
 
 /* size classes, in the order of yacrd_timing.class_*: R<K> = four reads per wavefront (16-lane

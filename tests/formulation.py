@@ -26,14 +26,9 @@ def finish_read(slot, mf_t, ml_t, min_ge, length):
     return slot
 
 
-def regular_events(intervals, length, cov):
-    """Event formulation for regular reads (start <= end < 2^30 - 1, no two zero-length
-    intervals at one position); None if the read must take the exact general path."""
-    n = len(intervals)
-    if n == 0:
-        return [(0, length)] if length != 0 else []
+def regular_keys(intervals):
+    """Sorted event keys of a regular read; None if the read must take the exact general path."""
     keys = []
-    max_start = 0
     for s, e in intervals:
         if s > e or e >= 2**30 - 1:
             return None
@@ -43,30 +38,37 @@ def regular_events(intervals, length, cov):
         else:
             keys.append((s << SH) | 3)
             keys.append(e << SH)
-        max_start = max(max_start, keys[-2])
     keys.sort()
     for a, b in zip(keys, keys[1:]):
         if a == b and (a & 3) == 1 and a != 1:
             return None  # duplicate zero-length interval: S,S,E,E would not be S,E,S,E
         # (0,0) intervals are inert in the reference (their pop re-assigns last_covered = 0 while it
         # still is 0) and in the keys (flipped end key 0 never beats "none" = 1): no exception needed
+    return keys
+
+
+def sweep_keys(keys, length, cov):
+    """The post-sort sweep over sorted event keys (sweep_wave.h passes 1-3 + finish_read)."""
     # Flagged ends are tracked in a "flipped" domain tk = key ^ 2 (class 0 <-> 2): at one position
     # a regular end then beats a zero-length interval's own end under max, i.e. the FIRST flagged
     # end of a position is the effective one (later ones leave last_covered unchanged, so an open
     # run of low starts at that position must stay open).  tc = 1 means "none": its true key 1 ^ 2
     # = 3 is the key of a start at position 0, which makes `ml > true(tc)` the reference's
     # `first_covered != 0` test.
+    n_starts = sum(1 for k in keys if k & 1)
     d = 0
     tc = 1
     ml = 0
     min_ge = NO
     slot = []
     any_flag = False
+    seen = 0
     for key in keys:
         if key & 1:
             if d <= cov:
                 ml = key
             d += 1
+            seen += 1
         else:
             if d > cov:
                 tk = key ^ 2
@@ -75,10 +77,78 @@ def regular_events(intervals, length, cov):
                         slot.append(((tc ^ 2) >> SH, ml >> SH))
                     tc = tk
                     any_flag = True
-                if key > max_start and (key >> SH) >= length:
+                if seen == n_starts and (key >> SH) >= length:  # tail: every start precedes it
                     min_ge = min(min_ge, key >> SH)
             d -= 1
     return finish_read(slot, (tc ^ 2) if any_flag else 0, ml, min_ge, length)
+
+
+def regular_events(intervals, length, cov):
+    """Event formulation for regular reads (start <= end < 2^30 - 1, no two zero-length
+    intervals at one position); None if the read must take the exact general path."""
+    if len(intervals) == 0:
+        return [(0, length)] if length != 0 else []
+    keys = regular_keys(intervals)
+    return None if keys is None else sweep_keys(keys, length, cov)
+
+
+def bin_shift(length, nb):
+    """Smallest shift with (length >> shift) < nb: bins of 2^shift positions, the bin that holds
+    `length` (and every later one) exists inside the table."""
+    sh = 0
+    while (length >> sh) >= nb:
+        sh += 1
+    return sh
+
+
+def prefilter_keys(intervals, length, cov, nb):
+    """Coverage pre-filter (sweep_wave.h `prefilter`): drop every event inside a *safe* bin — one
+    that more than `cov` intervals span completely — and stand in for each maximal run of safe
+    bins with |net| start (net > 0) or end (net < 0) keys at the run's first position, so that the
+    depth of every surviving event is unchanged.  Returns the (unsorted) surviving keys."""
+    sh = bin_shift(length, nb)
+    S, E = [0] * nb, [0] * nb
+    keys = []
+    for s, e in intervals:
+        S[min(s >> sh, nb - 1)] += 1
+        E[min(e >> sh, nb - 1)] += 1
+        keys += [(s << SH) | 1, (s << SH) | 2] if s == e else [(s << SH) | 3, e << SH]
+    first_unsafe = length >> sh           # bins holding positions >= length are never safe
+    safe, depth_at, cs, ce = [], [], 0, 0
+    for b in range(nb):
+        depth_at.append(cs - ce)          # depth at the bin's first position
+        ce += E[b]
+        safe.append(cs - ce > cov and b < first_unsafe)  # <= #intervals spanning the whole bin
+        cs += S[b]
+    depth_at.append(cs - ce)
+    out = [k for k in keys if not safe[min((k >> SH) >> sh, nb - 1)]]
+    b = 0
+    while b < nb:
+        if safe[b]:
+            b2 = b
+            while b2 + 1 < nb and safe[b2 + 1]:
+                b2 += 1
+            net = depth_at[b2 + 1] - depth_at[b]
+            pos = b << sh
+            out += [(pos << SH) | 3] * net if net > 0 else [pos << SH] * (-net)
+            b = b2 + 1
+        else:
+            b += 1
+    return out
+
+
+def prefiltered_events(intervals, length, cov, nb=16):
+    """regular_events with the coverage pre-filter in front of the sort.  As on the GPU, duplicate
+    zero-length intervals are only looked for among the keys that survive the filter."""
+    if len(intervals) == 0:
+        return [(0, length)] if length != 0 else []
+    if any(s > e or e >= 2**30 - 1 for s, e in intervals):
+        return None
+    keys = sorted(prefilter_keys(intervals, length, cov, nb))
+    for a, b in zip(keys, keys[1:]):
+        if a == b and (a & 3) == 1 and a != 1:
+            return None
+    return sweep_keys(keys, length, cov)
 
 
 def general_events(intervals, length, cov):

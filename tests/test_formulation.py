@@ -4,7 +4,7 @@ import pytest
 
 import oracle
 from cases import make_read
-from formulation import general_events, regular_events
+from formulation import general_events, prefilter_keys, prefiltered_events, regular_events
 
 MODES = ("regular", "abutting", "dups", "beyond", "sparse", "degenerate", "huge_pos", "zero_len")
 
@@ -24,6 +24,10 @@ def test_formulations_match_oracle(mode):
             if reg is not None:
                 n_reg += 1
                 assert reg == want, (mode, iv, L, cov)
+            for nb in (4, 16, 32):  # may accept reads whose duplicate zero-length pair sits in a safe bin
+                pre = prefiltered_events(iv, L, cov, nb)
+                assert pre is None or pre == want, (mode, iv, L, cov, nb)
+                assert reg is None or pre is not None
     if mode not in ("huge_pos",):
         assert n_reg > 0
 
@@ -41,3 +45,31 @@ def test_tiny_exhaustive():
                     reg = regular_events(list(iv), L, cov)
                     if reg is not None:
                         assert reg == want, (iv, L, cov)
+                    pre = prefiltered_events(list(iv), L, cov, 4)
+                    assert pre is None or pre == want, (iv, L, cov)
+                    assert reg is None or pre is not None
+
+
+def test_prefilter_deep_pileups():
+    """Deep pile-ups at small c: most bins are safe, the filter drops most events and the result
+    must not change (modes with ties, zero-length intervals and ends beyond the read included)."""
+    rng = np.random.default_rng(77)
+    dropped = total = 0
+    for it in range(600):
+        n = int(rng.integers(20, 260))
+        L = int(rng.integers(16, 40000)) if it % 5 else int(rng.integers(1, 64))
+        mode = ("regular", "abutting", "dups", "beyond", "zero_len")[it % 5]
+        iv = [tuple(int(x) for x in p) for p in make_read(rng, n, L, mode)]
+        if it % 7 == 0:  # positions on a coarse grid: many ties on bin boundaries
+            g = max(1, L // 16)
+            iv = [((s // g) * g, max((e // g) * g, (s // g) * g + (1 if e > s else 0))) for s, e in iv]
+        for cov in (0, 1, 4, 9):
+            want = oracle.compute_bad_part(iv, L, cov)
+            for nb in (8, 16, 32):
+                got = prefiltered_events(iv, L, cov, nb)
+                if got is not None:
+                    assert got == want, (mode, iv, L, cov, nb)
+            if regular_events(iv, L, cov) is not None:
+                total += 2 * len(iv)
+                dropped += 2 * len(iv) - len(prefilter_keys(iv, L, cov, 16))
+    assert dropped > total // 4  # the filter really fires in this test

@@ -72,6 +72,37 @@ def test_small_class(engine, cov):
     check(engine, make_csr(100 + cov, sizes, REGULAR_MODES), cov, 0.4, "small c=%d" % cov)
 
 
+# ---- coverage pre-filter (sweep_wave.h `prefilter`) -------------------------------------------
+@pytest.mark.parametrize("cov", [0, 1, 4, 9, 40])
+def test_prefilter_on_deep_pileups(cov):
+    """Reads of 65..256 intervals (classes R16 / H16) piled deep: most bins are safe at small c.
+    Same results with the filter (default), without it, and from the oracle; the filter fires."""
+    rng = np.random.default_rng(5)
+    sizes = np.concatenate([rng.integers(65, 257, size=3000), [65, 128, 129, 256, 96, 200]])
+    lengths = np.concatenate([rng.integers(1, 200, size=300), rng.integers(200, 150000, size=2706)])
+    csr = make_csr(900 + cov, sizes, REGULAR_MODES, lengths=lengths)
+    with yacrd_amd.Engine(flags=yacrd_amd.F_COUNT_PREFILTERED) as e:
+        got = check(e, csr, cov, 0.4, "prefilter c=%d" % cov)
+        fired = e.timing()["prefiltered_reads"]
+    with yacrd_amd.Engine(flags=yacrd_amd.F_NO_PREFILTER | yacrd_amd.F_COUNT_PREFILTERED) as e:
+        ref = e.run(*csr, cov, 0.4)
+        assert e.timing()["prefiltered_reads"] == 0
+    assert_same(got, (ref.bad_offsets, ref.bad_regions, ref.read_type), "prefilter on/off")
+    if cov <= 9:
+        assert fired > 1000, fired
+    if cov == 40:   # depth never exceeds c on most of these reads: nothing is safe, nothing dropped
+        assert fired < 3006
+
+
+def test_prefilter_on_synthetic_profiles():
+    from yacrd_amd import host
+    for prof, R, O, cov in ((host.SYNTH_ONT, 4000, 200000, 4), (host.SYNTH_SEQUEL, 3000, 300000, 3)):
+        off, iv, ln = host.synth_csr(prof, R, O, 99)
+        with yacrd_amd.Engine(flags=yacrd_amd.F_COUNT_PREFILTERED) as e:
+            check(e, (off, iv.reshape(-1, 2), ln), cov, 0.4, "synthetic profile %d" % prof)
+            assert e.timing()["prefiltered_reads"] > R // 2
+
+
 @pytest.mark.parametrize("cov", [0, 4])
 def test_small_class_lds_variant(engine_lds, cov):
     rng = np.random.default_rng(2)

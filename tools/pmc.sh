@@ -2,7 +2,7 @@
 # tools/pmc.sh <outdir> -- <bench args>: rocprofv3 PMC passes for the bench (run on the GPU box).
 # Counters go in their own runs (no sys/hip traces), as the MI355X guide prescribes.
 set -u
-out=$1; shift; shift
+out=$(realpath -m "$1"); shift; shift
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 run() { # name counters...

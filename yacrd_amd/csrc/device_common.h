@@ -58,7 +58,8 @@ struct Counters {
     u32 region_overflow;     // compaction ran out of bad_regions capacity
     u32 scan_ticket;         // dynamic workgroup id of the single-pass scan
     u32 scan_done;           // workgroups of the scan kernel that finished
-    u32 pad1[2];
+    u32 prefiltered;         // reads that took the pre-filtered sort (only counted when asked)
+    u32 pad1;
     u64 total_regions;       // G, written by the last scan workgroup
 };
 
@@ -69,6 +70,7 @@ struct SweepArgs {
     const u32 *list;     // read ids of this class
     const u32 *list_n;   // device-side count
     u32 cov;
+    u32 prefilter;       // 1: drop events in bins deeper than cov before the sort (sweep_wave.h); 2: and count
     uint2 *stage;        // per-read slot of n+2 regions at off[r] + 2r
     u32 *counts;         // [R] regions per read
     u32 *rej_list;       // reads this sweep cannot take (degenerate interval): append here

@@ -361,6 +361,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     sa.iv = d_iv;
     sa.len = d_len;
     sa.cov = cov;
+    sa.prefilter = (e->flags & YACRD_F_NO_PREFILTER) ? 0u : (e->flags & YACRD_F_COUNT_PREFILTERED) ? 2u : 1u;
     sa.stage = e->stage.as<uint2>();
     sa.counts = e->counts.as<u32>();
     sa.ctr = ctr;
@@ -631,6 +632,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     t.class_ms[yk::CLS_GENERAL] = (full && c0.n[yk::CLS_GENERAL]) ? t.sweep_general_ms : 0.f;
     t.fused_ms = 0.f;
     t.fused_reads = t.fused_intervals = 0;
+    t.prefiltered_reads = c1.prefiltered;
     if (fused_marked) {
         t.fused_ms = ev_ms(e->ev_cls[22], e->ev_cls[23]);
         for (int cls = yk::CLS_R2; cls <= yk::CLS_H16; cls++) {

@@ -194,54 +194,22 @@ __device__ __forceinline__ u32 gscan_min(u32 v)
     return v;
 }
 
+// ---- everything after the event keys are in registers: sort, sweep, regions out ---------------
+// m = number of real keys of the group (the rest are pads); zl_check = the wavefront holds >= 2
+// zero-length intervals (duplicates must be looked for after the sort).
 template <int LANES, int K, int XM>
-__device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u32 n, u32 len,
-                                                 u32 cov, uint2 *slot, bool active, u32 r,
-                                                 const SweepArgs &a, const LaneConst &lc)
+__device__ __forceinline__ void sweep_group_keys(u32 (&x)[K], u32 m, u32 len, i32 c, uint2 *slot,
+                                                 bool active, u32 r, u64 badmask, u64 zmask,
+                                                 bool zl_check, const SweepArgs &a,
+                                                 const LaneConst &lc)
 {
     const u32 lane = lane_id(), lig = lane & (u32)(LANES - 1);
-    const u32 m = 2 * n;
-    const i32 c = (i32)min(cov, 0x7FFFFFFFu);
-
-    // ---- coalesced interval loads (8 B/lane), keys straight into registers
-    u32 x[K];
-    u32 bad = 0, nz = 0;
-    {
-        // issue every load before the first use: one memory latency per read, not K/2 of them
-        uint2 v[K / 2];
-#pragma unroll
-        for (int j = 0; j < K / 2; j++) {
-            const u32 i = lig + (u32)LANES * j;
-            v[j] = make_uint2(1u, 2u);
-            if (i < n) v[j] = iv[i];
-        }
-#pragma unroll
-        for (int j = 0; j < K / 2; j++) {
-            const u32 i = lig + (u32)LANES * j;
-            u32 ks, ke, b = 0, z = 0;
-            make_event_keys(v[j], ks, ke, b, z);
-            const bool real = i < n;
-            x[2 * j] = real ? ks : kPadKey;
-            x[2 * j + 1] = real ? ke : kPadKey;
-            bad |= real ? b : 0u;
-            nz += real ? z : 0u;
-        }
-    }
-    u64 badmask = __builtin_amdgcn_ballot_w64(bad != 0);
-    const u64 zmask = __builtin_amdgcn_ballot_w64(nz != 0);
-    if (LANES == 64 && badmask != 0) { // wave-uniform: skip the work, queue for the exact path
-        if (lig == LANES - 1 && active) {
-            a.rej_list[atomicAdd(a.rej_count, 1u)] = r;
-            a.counts[r] = 0;
-        }
-        return;
-    }
 
     bitonic_sort<LANES, K, 2, XM>(x, lc);
 
     // two zero-length intervals at one position cannot be expressed by the keys: after the sort
     // they are adjacent equal class-1 keys.  Only looked for when the wavefront saw >= 2 of them.
-    if ((zmask & (zmask - 1)) != 0 || __builtin_amdgcn_ballot_w64(nz > 2) != 0) {
+    if (zl_check) {
         bool dup = false;
 #pragma unroll
         for (int q = 0; q + 1 < K; q++) dup |= x[q] == x[q + 1] && (x[q] & 3u) == 1u && x[q] != 1u;
@@ -353,6 +321,185 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
             a.counts[r] = finish_read(slot, g_closed, mf_incl ? (mf_incl ^ 2u) : 0u, ml_incl, min_ge, len);
         }
     }
+}
+
+// ---- coverage pre-filter (emulated and fuzzed in tests/formulation.py) -----------
+// Most of a well-covered read lies deeper than `c`: nothing there can open, close or bound a bad
+// region.  The read is cut into NB = LANES bins of 2^sh positions (one bin per lane).  A bin is
+// *safe* when more than c intervals span it completely (start in an earlier bin, end in a later
+// one): every event inside then has depth_before > c, so its starts are never low and its flagged
+// ends are always superseded by a later flagged end outside (the spanning intervals still have
+// to end before the depth can reach c).  Every event in a safe bin is dropped; each maximal run
+// of safe bins is stood in for by |net| start (net > 0) or end (net < 0) keys at the run's first
+// position, net = depth after the run - depth before it, so the depth of every surviving event is
+// unchanged.  The per-bin counts come from an LDS histogram (starts | ends << 16, LDS atomics:
+// the LDS pipe is otherwise idle here) and one packed row scan.  Survivors are compacted through
+// LDS; if every group of the wavefront keeps <= LANES*K/2 keys the caller sorts K/2 keys per lane.
+// Exactness does not depend on the bins (any under-estimate of "safe" is fine); reference
+// semantics: src/stack.rs:61-139 via the event formulation above.
+__device__ __forceinline__ void wave_lds_sync()
+{
+    // LDS operations of one wavefront execute in order; this only stops the compiler from moving
+    // LDS accesses across the point where lanes exchange data through LDS.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// LDS scratch of one wavefront for the pre-filter: bin counters of every group + compacted keys.
+// A bin has four counters (one per lane & 3): the reads' hot bins (dovetails start at 0 and end at
+// len) would otherwise serialise the LDS atomics of a row.
+constexpr int kFilterTabWords = 272, kFilterKeyWords = 512;
+__device__ __forceinline__ u32 *wave_filter_scratch()
+{
+    __shared__ __attribute__((aligned(16))) u32 s_scratch[4][kFilterTabWords + kFilterKeyWords];
+    return s_scratch[threadIdx.x >> 6];
+}
+
+template <int LANES, int K>
+__device__ __forceinline__ bool prefilter(const u32 (&x)[K], u32 n, u32 len, i32 c, u32 (&y)[K / 2],
+                                          u32 &m_out)
+{
+    static_assert(LANES == 16 || LANES == 32, "one bin per lane, bin mask in 32 bits");
+    static_assert(K == 16, "a lane reads its K/2 = 8 compacted keys as two 16-byte vectors");
+    constexpr int NB = LANES, CAP = LANES * K / 2, GROUPS = 64 / LANES;
+    static_assert(GROUPS * (NB + 1) * 4 <= kFilterTabWords && GROUPS * CAP <= kFilterKeyWords, "scratch");
+    const u32 lane = lane_id(), lig = lane & (u32)(LANES - 1), grp = lane / (u32)LANES;
+    u32 *scratch = wave_filter_scratch();
+    u32 *tab = scratch + grp * (u32)((NB + 1) * 4);        // (NB bins + one for the pads) x 4 copies
+    u32 *keys = scratch + kFilterTabWords + grp * (u32)CAP;
+    uint4 *my_bin = reinterpret_cast<uint4 *>(tab) + lig;
+    uint4 *my_keys = reinterpret_cast<uint4 *>(keys) + lig * 2u;
+
+    // smallest shift with (len >> sh) < NB: the bin holding `len` and every later one stay unsafe
+    const i32 bits = 32 - (i32)__builtin_clz(len | 1u) - ilog2c(NB) + (len != 0 ? 0 : -1);
+    const u32 sh = (u32)max(bits, 0), ksh = sh + kKeyShift;
+
+    // ---- histogram: starts in the low half of a counter, ends in the high half (LDS atomics).
+    // The compacted-key area starts out as pads.
+    *my_bin = make_uint4(0u, 0u, 0u, 0u);
+    my_keys[0] = make_uint4(kPadKey, kPadKey, kPadKey, kPadKey);
+    my_keys[1] = make_uint4(kPadKey, kPadKey, kPadKey, kPadKey);
+    wave_lds_sync();
+    u32 *cell0 = tab + (lig & 3u);        // this lane's copy of bin 0
+    u32 *pad_cell = cell0 + NB * 4;
+    u32 *cell[K];
+#pragma unroll
+    for (int q = 0; q < K; q++) {
+        const bool real = lig + (u32)LANES * (q / 2) < n;
+        u32 *p = cell0 + min(x[q] >> ksh, (u32)(NB - 1)) * 4u;
+        cell[q] = real ? p : pad_cell;
+        atomicAdd(cell[q], (q & 1) ? 0x10000u : 1u);
+    }
+    wave_lds_sync();
+    const uint4 w4 = *my_bin;
+    const u32 w = w4.x + w4.y + w4.z + w4.w;
+    const u32 incl = gscan_add<LANES>(w); // packed: both halves scanned at once
+    const i32 S = (i32)(w & 0xFFFFu), E = (i32)(w >> 16);
+    const i32 cs = (i32)(incl & 0xFFFFu), ce = (i32)(incl >> 16);
+    const i32 depth_after = cs - ce, depth_at = depth_after - (S - E);
+    const bool safe = (cs - S) - ce > c && lig < (len >> sh);
+    const u64 sball = __builtin_amdgcn_ballot_w64(safe);
+    if (sball == 0) return false; // wave-uniform: nothing to drop
+    const u32 smask = (u32)(sball >> (lane & (u32)(64 - LANES))) & (LANES == 16 ? 0xFFFFu : 0xFFFFFFFFu);
+    const bool head = safe && (((smask << 1) >> lig) & 1u) == 0;
+    const bool tail = safe && (((smask >> 1) >> lig) & 1u) == 0;
+    const u32 hv = gscan_max<LANES>(head ? (((lig + 1u) << 16) | (u32)depth_at) : 0u);
+    const i32 net = tail ? depth_after - (i32)(hv & 0xFFFFu) : 0;
+    const u32 nsyn = min((u32)(net < 0 ? -net : net), (u32)CAP + 1u);
+    const u32 synkey = (((hv >> 16) - 1u) << ksh) | (net > 0 ? 3u : 0u);
+
+    // ---- slots: a bin's survivors go to [base, base + S + E), a run's stand-ins to the tail
+    // lane's range; counters of safe bins (and of the pads) start at CAP = "nowhere"
+    const u32 mine = safe ? nsyn : (u32)(S + E);
+    const u32 rincl = gscan_add<LANES>(mine);
+    const u32 m = (u32)__builtin_amdgcn_ds_bpermute((int)((lane | (u32)(LANES - 1)) << 2), (int)rincl);
+    if (__builtin_amdgcn_ballot_w64(m > (u32)CAP) != 0) return false; // some group keeps too much
+    const u32 base = rincl - mine;
+    {
+        uint4 b4;
+        b4.x = base;
+        b4.y = b4.x + (w4.x & 0xFFFFu) + (w4.x >> 16);
+        b4.z = b4.y + (w4.y & 0xFFFFu) + (w4.y >> 16);
+        b4.w = b4.z + (w4.z & 0xFFFFu) + (w4.z >> 16);
+        *my_bin = safe ? make_uint4(CAP, CAP, CAP, CAP) : b4;
+        if (lig < 4u) tab[NB * 4 + lig] = (u32)CAP;
+    }
+#pragma unroll 1
+    for (u32 t = 0; t < nsyn; t++) keys[base + t] = synkey;
+    wave_lds_sync();
+    u32 pos[K]; // every slot request in flight before the first store needs its answer
+#pragma unroll
+    for (int q = 0; q < K; q++) pos[q] = atomicAdd(cell[q], 1u);
+#pragma unroll
+    for (int q = 0; q < K; q++) {
+        if (pos[q] < (u32)CAP) keys[pos[q]] = x[q];
+    }
+    wave_lds_sync();
+    const uint4 lo = my_keys[0], hi = my_keys[1];
+    y[0] = lo.x, y[1] = lo.y, y[2] = lo.z, y[3] = lo.w;
+    y[4] = hi.x, y[5] = hi.y, y[6] = hi.z, y[7] = hi.w;
+    m_out = m;
+    return true;
+}
+
+// ---- one read per group of LANES lanes: loads, keys, (pre-filter,) sweep ------------------------
+template <int LANES, int K, int XM>
+__device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u32 n, u32 len,
+                                                 u32 cov, uint2 *slot, bool active, u32 r,
+                                                 const SweepArgs &a, const LaneConst &lc)
+{
+    const u32 lane = lane_id(), lig = lane & (u32)(LANES - 1);
+    const i32 c = (i32)min(cov, 0x7FFFFFFFu);
+
+    // ---- coalesced interval loads (8 B/lane), keys straight into registers
+    u32 x[K];
+    u32 bad = 0, nz = 0;
+    {
+        // issue every load before the first use: one memory latency per read, not K/2 of them
+        uint2 v[K / 2];
+#pragma unroll
+        for (int j = 0; j < K / 2; j++) {
+            const u32 i = lig + (u32)LANES * j;
+            v[j] = make_uint2(1u, 2u);
+            if (i < n) v[j] = iv[i];
+        }
+#pragma unroll
+        for (int j = 0; j < K / 2; j++) {
+            const u32 i = lig + (u32)LANES * j;
+            u32 ks, ke, b = 0, z = 0;
+            make_event_keys(v[j], ks, ke, b, z);
+            const bool real = i < n;
+            x[2 * j] = real ? ks : kPadKey;
+            x[2 * j + 1] = real ? ke : kPadKey;
+            bad |= real ? b : 0u;
+            nz += real ? z : 0u;
+        }
+    }
+    const u64 badmask = __builtin_amdgcn_ballot_w64(bad != 0);
+    const u64 zmask = __builtin_amdgcn_ballot_w64(nz != 0);
+    if (LANES == 64 && badmask != 0) { // wave-uniform: skip the work, queue for the exact path
+        if (lig == LANES - 1 && active) {
+            a.rej_list[atomicAdd(a.rej_count, 1u)] = r;
+            a.counts[r] = 0;
+        }
+        return;
+    }
+    // two zero-length intervals at one position: only looked for when the wavefront saw >= 2
+    const bool zl_check = (zmask & (zmask - 1)) != 0 || __builtin_amdgcn_ballot_w64(nz > 2) != 0;
+
+    if constexpr (K == 16 && LANES < 64) {
+        if (a.prefilter) { // uniform
+            u32 y[K / 2], mf;
+            if (prefilter<LANES, K>(x, n, len, c, y, mf)) {
+                if (a.prefilter == 2 && lig == 0 && active) atomicAdd(&a.ctr->prefiltered, 1u);
+                sweep_group_keys<LANES, K / 2, XM>(y, mf, len, c, slot, active, r, badmask, zmask,
+                                                   zl_check, a, lc);
+                return;
+            }
+        }
+    }
+    sweep_group_keys<LANES, K, XM>(x, 2 * n, len, c, slot, active, r, badmask, zmask, zl_check, a, lc);
 }
 
 // Body of one workgroup (four wavefronts, 4 * 64/LANES reads) of class (LANES, K).

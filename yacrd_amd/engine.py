@@ -19,6 +19,8 @@ F_NO_HALVES = 16
 F_TIMING_FULL = 32
 F_NO_PREDICTION = 64
 F_NO_FUSED_LAUNCH = 128
+F_NO_PREFILTER = 256
+F_COUNT_PREFILTERED = 512
 
 # every symbol include/yacrd_engine.h declares
 EXPORTED_SYMBOLS = [
@@ -58,7 +60,8 @@ class _Timing(ctypes.Structure):
                 ("n_small", "n_medium", "n_general", "iv_small", "iv_medium", "iv_general")] + \
                [("class_ms", ctypes.c_float * 12), ("class_reads", ctypes.c_uint64 * 12),
                 ("class_intervals", ctypes.c_uint64 * 12), ("fused_ms", ctypes.c_float),
-                ("fused_reads", ctypes.c_uint64), ("fused_intervals", ctypes.c_uint64)]
+                ("fused_reads", ctypes.c_uint64), ("fused_intervals", ctypes.c_uint64),
+                ("prefiltered_reads", ctypes.c_uint64)]
 
 CLASS_NAMES = "R2,R4,R8,R16,H16,W2,W4,W8,W16,M1,M2,BIG".split(",")
 CLASS_KERNELS = {  # the HIP kernel behind each class, as rocprofv3 prints it

@@ -97,8 +97,10 @@ typedef struct {
     const void *d_read_type;   /* u8[R]   */
 } yacrd_device_result;
 
-/* Wall times of the last run, measured with HIP events on the engine's stream.  The per-phase
- * fields (sweep_*_ms, compact_ms) and class_ms of non-dominant classes need YACRD_F_TIMING_FULL. */
+/* Wall times of the last run, measured with HIP events on the engine's stream.  An event costs
+ * ~3 us of stream time, so by default only the dominant kernel is bracketed (class_ms of the class
+ * with the most intervals, or fused_ms); plan_ms, sweep_*_ms, compact_ms, total_ms and class_ms
+ * of the other classes need YACRD_F_TIMING_FULL and are 0 without it. */
 typedef struct {
     float h2d_ms;
     float plan_ms;          /* size-class binning */

@@ -229,7 +229,7 @@ def test_device_resident_entry_point(engine):
     assert int(out.n_regions) == int(want[0][-1])
     assert_same(got, want, "run_device")
     t = engine.timing()
-    assert t["n_small"] == len(lengths) and t["total_ms"] > 0
+    assert t["n_small"] == len(lengths) and max(t["class_ms"] + [t["fused_ms"]]) > 0
 
 
 def test_read_partitioned_multi_engine(engine):
@@ -251,8 +251,13 @@ def test_class_prediction_is_validated():
     b_sizes = [10] * 300 + [190] * 299 + [60000 - 3000 - 299 * 190]  # same totals, other classes
     assert sum(a_sizes) == sum(b_sizes) == 60000
     c_sizes = [2] * 599 + [60000 - 2 * 599]                # one read beyond the LDS classes
+    # same classes, other proportions: a predicted grid (count + 12.5 % + 64) that is too short
+    d_sizes = [100] * 200 + [36] * 200 + [164] * 200
+    e_sizes = [100] * 400 + [36] * 100 + [164] * 100
+    assert sum(d_sizes) == sum(e_sizes) == 60000
     with yacrd_amd.Engine() as e, yacrd_amd.Engine(flags=yacrd_amd.F_NO_PREDICTION) as ref:
-        for rep, sizes in enumerate([a_sizes, a_sizes, b_sizes, b_sizes, c_sizes, a_sizes, c_sizes]):
+        for rep, sizes in enumerate([a_sizes, a_sizes, b_sizes, b_sizes, c_sizes, a_sizes, c_sizes,
+                                     d_sizes, d_sizes, e_sizes, e_sizes, a_sizes, d_sizes]):
             csr = make_csr(1200 + rep, sizes, REGULAR_MODES + ("degenerate",), len_lo=300000,
                            len_hi=900000)
             want = oracle.run(csr[0], csr[1], csr[2].astype(np.uint64), 3, 0.4, n_threads=4)

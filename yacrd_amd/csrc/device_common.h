@@ -69,6 +69,7 @@ struct SweepArgs {
     const u32 *len;      // [R]
     const u32 *list;     // read ids of this class
     const u32 *list_n;   // device-side count
+    u32 first;           // first list entry this launch covers (remainder launches after a short grid)
     u32 cov;
     u32 prefilter;       // 1: drop events in bins deeper than cov before the sort (sweep_wave.h); 2: and count
     uint2 *stage;        // per-read slot of n+2 regions at off[r] + 2r

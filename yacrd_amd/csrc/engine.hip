@@ -324,25 +324,34 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     // the real counts at the final sync (a class that was not predicted is launched then and
     // the compaction redone).  Streams of similar batches never pay the mid-pipeline sync.
     HIP_TRY(hipMemsetAsync(ctr, 0, ctrl_bytes, e->stream));
-    HIP_TRY(hipEventRecord(e->ev[EV_START], e->stream));
+    if (full) HIP_TRY(hipEventRecord(e->ev[EV_START], e->stream));
     hipLaunchKernelGGL(yk::plan_kernel, dim3((n_reads + yk::kPlanBlock - 1) / yk::kPlanBlock),
                        dim3(yk::kPlanBlock), 0, e->stream, d_off, n_reads, lists, ctr,
                        (u32)((e->flags & YACRD_F_FORCE_GENERAL) ? 1
                              : (e->flags & (YACRD_F_WAVE_ONLY | YACRD_F_FORCE_LDS_SORT)) ? 2
                              : (e->flags & YACRD_F_NO_HALVES) ? 3 : 0));
-    HIP_TRY(hipEventRecord(e->ev[EV_PLAN], e->stream));
+    if (full) HIP_TRY(hipEventRecord(e->ev[EV_PLAN], e->stream));
 
     const bool predicted = e->pred_valid && e->pred_reads == n_reads64 && e->pred_iv == n_iv &&
                            e->pred.n[yk::CLS_GENERAL] == 0 &&
                            !(e->flags & (YACRD_F_FORCE_GENERAL | YACRD_F_NO_PREDICTION));
     struct LaunchSet {
-        u32 n[12];  // reads used to size the grid; 0 = class not launched
-        u64 iv[12]; // intervals (to pick the dominant class)
+        u32 n[12];     // reads used to size the grid; 0 = class not launched
+        u32 first[12]; // first list entry the launch covers (remainder launches)
+        u64 iv[12];    // intervals (to pick the dominant class)
     } ls{};
     yk::Counters c0{};
+    const bool tight_grids = !(e->flags & YACRD_F_FORCE_LDS_SORT);
     if (predicted) {
+        // Register-sort classes: one workgroup per 4..16 reads, so the grid is sized for the
+        // predicted count plus a margin (idle workgroups are not free: 19 000 of them cost ~3 us);
+        // reads beyond the grid are swept by a remainder launch after the validation.  The LDS
+        // classes run grid-stride loops and need no margin.
         for (int cls = 0; cls < yk::CLS_GENERAL; cls++) {
-            ls.n[cls] = e->pred.n[cls] ? n_reads : 0;
+            const u64 p = e->pred.n[cls];
+            const u64 cap = (cls <= yk::CLS_W16 && tight_grids) ? ((p + p / 8 + 64 + 15) & ~(u64)15)
+                                                               : n_reads64;
+            ls.n[cls] = p ? (u32)std::min<u64>(cap, (n_reads64 + 15) & ~(u64)15) : 0;
             ls.iv[cls] = e->pred.iv[cls];
         }
     } else {
@@ -357,6 +366,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     }
 
     yk::SweepArgs sa;
+    sa.first = 0;
     sa.off = d_off;
     sa.iv = d_iv;
     sa.len = d_len;
@@ -412,6 +422,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
                 fa.block_end[fa.n_entries] = blocks;
                 fa.list[fa.n_entries] = list_of(cls);
                 fa.list_n[fa.n_entries] = &ctr->n[cls];
+                fa.first[fa.n_entries] = set.first[cls];
                 fa.n_entries++;
                 has_dom |= cls == dom_cls;
             }
@@ -433,6 +444,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
             HIP_TRY(before_class(cls));
             sa.list = list_of(cls);
             sa.list_n = &ctr->n[cls];
+            sa.first = set.first[cls];
             if (e->flags & YACRD_F_FORCE_LDS_SORT) {
                 const u32 grid = (u32)std::min<uint64_t>(set.n[cls], (uint64_t)e->num_cu * 32);
                 hipLaunchKernelGGL((yk::sweep_lds_kernel<64, (int)yk::kSmallEvents>), dim3(grid),
@@ -452,6 +464,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
             }
             HIP_TRY(mark_class(cls));
         }
+        sa.first = 0;
         if (full && timing_on) HIP_TRY(hipEventRecord(e->ev[EV_SMALL], e->stream));
 
         if (set.n[yk::CLS_MED1]) { // one read per workgroup, LDS resident
@@ -512,7 +525,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
 
     for (int cls = 0; cls < yk::CLS_GENERAL; cls++)
         if (ls.n[cls] && (dom_cls < 0 || ls.iv[cls] > ls.iv[dom_cls])) dom_cls = cls;
-    HIP_TRY(hipEventRecord(e->ev[EV_S0], e->stream));
+    if (full) HIP_TRY(hipEventRecord(e->ev[EV_S0], e->stream));
     int rc = launch_sweeps(ls);
     if (rc) return rc;
     u64 gen_iv = 0;
@@ -525,7 +538,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     // ---- follow-on kernel: scan + compact + classify
     rc = launch_compact(e, d_off, d_len, n_reads, not_cov);
     if (rc) return rc;
-    HIP_TRY(hipEventRecord(e->ev[EV_COMPACT], e->stream));
+    if (full) HIP_TRY(hipEventRecord(e->ev[EV_COMPACT], e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipGetLastError());
     timing_on = false;
@@ -550,8 +563,9 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         LaunchSet missing{};
         bool any_missing = false;
         for (int cls = 0; cls < yk::CLS_GENERAL; cls++)
-            if (c0.n[cls] && !ls.n[cls]) {
-                missing.n[cls] = c0.n[cls];
+            if (c0.n[cls] > ls.n[cls]) { // class not predicted, or larger than its grid
+                missing.first[cls] = (cls <= yk::CLS_W16 && tight_grids) ? ls.n[cls] : 0;
+                missing.n[cls] = c0.n[cls] - missing.first[cls];
                 any_missing = true;
             }
         if (any_missing || c0.n[yk::CLS_GENERAL]) {
@@ -602,15 +616,19 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     e->pred_valid = true;
 
     yacrd_timing &t = e->timing;
-    t.plan_ms = ev_ms(e->ev[EV_START], e->ev[EV_PLAN]);
+    // An event costs ~3 us of stream time: by default only the dominant kernel is bracketed
+    // (class_ms / fused_ms); phases and the whole-pipeline time need YACRD_F_TIMING_FULL.
+    t.plan_ms = t.sweep_small_ms = t.sweep_medium_ms = t.sweep_general_ms = t.compact_ms = 0.f;
+    t.total_ms = 0.f;
     if (full) {
+        t.plan_ms = ev_ms(e->ev[EV_START], e->ev[EV_PLAN]);
         t.sweep_small_ms = ev_ms(e->ev[EV_S0], e->ev[EV_SMALL]);
         t.sweep_medium_ms = ev_ms(e->ev[EV_SMALL], e->ev[EV_MED]);
         t.sweep_general_ms = ev_ms(e->ev[EV_MED], e->ev[EV_GEN]);
         t.compact_ms = ev_ms(e->ev[EV_GEN], e->ev[EV_COMPACT]);
+        t.total_ms = (predicted ? ev_ms(e->ev[EV_START], e->ev[EV_COMPACT])
+                                : t.plan_ms + ev_ms(e->ev[EV_S0], e->ev[EV_COMPACT])) + extra_ms;
     }
-    t.total_ms = (predicted ? ev_ms(e->ev[EV_START], e->ev[EV_COMPACT])
-                            : t.plan_ms + ev_ms(e->ev[EV_S0], e->ev[EV_COMPACT])) + extra_ms;
     t.n_small = 0;
     t.iv_small = 0;
     for (int cls = yk::CLS_R2; cls <= yk::CLS_W16; cls++) {

@@ -516,8 +516,8 @@ __device__ __forceinline__ void sweep_group_block(const SweepArgs &a, u32 block)
     constexpr u32 GROUPS = 64 / LANES; // reads per wavefront
     const u32 list_n = *a.list_n;
     const u32 wave = block * 4u + (threadIdx.x >> 6);
-    if (wave * GROUPS >= list_n) return; // grids may be sized for more reads than the class holds
-    const u32 idx = wave * GROUPS + lane / (u32)LANES;
+    if (a.first + wave * GROUPS >= list_n) return; // grids may be sized for more reads than the class holds
+    const u32 idx = a.first + wave * GROUPS + lane / (u32)LANES;
     const bool active = idx < list_n;
     u32 r = 0, n = 0, len = 0;
     u64 o = 0;
@@ -560,6 +560,7 @@ struct FusedArgs {
     u32 n_entries;
     u32 cls[5];               // CLS_R2 .. CLS_H16
     u32 block_end[5];         // running end of the per-class grids
+    u32 first[5];             // SweepArgs.first per class
     const u32 *list[5];
     const u32 *list_n[5];
 };
@@ -574,6 +575,7 @@ __global__ __launch_bounds__(256, 5) void sweep_small_fused_kernel(FusedArgs f)
     SweepArgs a = f.base;
     a.list = f.list[e];
     a.list_n = f.list_n[e];
+    a.first = f.first[e];
     const u32 b = blockIdx.x - first;
     switch (f.cls[e]) { // the one-read-per-wavefront classes stay separate kernels (registers)
     case CLS_R2: sweep_group_block<16, 2, 0>(a, b); break;

@@ -81,9 +81,9 @@ def make_read(rng, n, length, mode="regular"):
     return iv.astype(np.uint32)
 
 
-def make_csr(seed, sizes, modes=("regular",), len_lo=500, len_hi=60000, lengths=None):
-    """sizes: iterable of interval counts per read.  Returns offsets u64, intervals u32[I,2],
-    lengths u32."""
+def make_csr(seed, sizes, modes=("regular",), len_lo=500, len_hi=60000, lengths=None, mode_block=1):
+    """sizes: iterable of interval counts per read; read r is of mode modes[(r // mode_block) %
+    len(modes)].  Returns offsets u64, intervals u32[I,2], lengths u32."""
     rng = np.random.default_rng(seed)
     sizes = list(sizes)
     R = len(sizes)
@@ -93,7 +93,7 @@ def make_csr(seed, sizes, modes=("regular",), len_lo=500, len_hi=60000, lengths=
     offsets = np.zeros(R + 1, dtype=np.uint64)
     parts = []
     for r, n in enumerate(sizes):
-        mode = modes[r % len(modes)]
+        mode = modes[(r // mode_block) % len(modes)]
         parts.append(make_read(rng, int(n), int(lengths[r]), mode))
         offsets[r + 1] = offsets[r] + np.uint64(n)
     intervals = (np.concatenate(parts, axis=0) if parts else np.zeros((0, 2), np.uint32))

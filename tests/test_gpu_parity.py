@@ -80,7 +80,9 @@ def test_prefilter_on_deep_pileups(cov):
     rng = np.random.default_rng(5)
     sizes = np.concatenate([rng.integers(65, 257, size=3000), [65, 128, 129, 256, 96, 200]])
     lengths = np.concatenate([rng.integers(1, 200, size=300), rng.integers(200, 150000, size=2706)])
-    csr = make_csr(900 + cov, sizes, REGULAR_MODES, lengths=lengths)
+    # the filter is only used by wavefronts whose intervals are all plain (start < end <= len):
+    # modes come in blocks of 256 reads, so some wavefronts qualify and some do not
+    csr = make_csr(900 + cov, sizes, REGULAR_MODES, lengths=lengths, mode_block=256)
     with yacrd_amd.Engine(flags=yacrd_amd.F_COUNT_PREFILTERED) as e:
         got = check(e, csr, cov, 0.4, "prefilter c=%d" % cov)
         fired = e.timing()["prefiltered_reads"]
@@ -89,7 +91,7 @@ def test_prefilter_on_deep_pileups(cov):
         assert e.timing()["prefiltered_reads"] == 0
     assert_same(got, (ref.bad_offsets, ref.bad_regions, ref.read_type), "prefilter on/off")
     if cov <= 9:
-        assert fired > 1000, fired
+        assert fired > 500, fired
     if cov == 40:   # depth never exceeds c on most of these reads: nothing is safe, nothing dropped
         assert fired < 3006
 

@@ -336,7 +336,8 @@ __device__ __forceinline__ void sweep_group_keys(u32 (&x)[K], u32 m, u32 len, i3
 // the LDS pipe is otherwise idle here) and one packed row scan.  Survivors are compacted through
 // LDS; if every group of the wavefront keeps <= LANES*K/2 keys the caller sorts K/2 keys per lane.
 // Exactness does not depend on the bins (any under-estimate of "safe" is fine); reference
-// semantics: src/stack.rs:61-139 via the event formulation above.
+// semantics: src/stack.rs:61-139 via the event formulation above.  Only called for wavefronts
+// whose intervals all end at or before their read's length (bin index < NB without a clip).
 __device__ __forceinline__ void wave_lds_sync()
 {
     // LDS operations of one wavefront execute in order; this only stops the compiler from moving
@@ -387,7 +388,7 @@ __device__ __forceinline__ bool prefilter(const u32 (&x)[K], u32 n, u32 len, i32
 #pragma unroll
     for (int q = 0; q < K; q++) {
         const bool real = lig + (u32)LANES * (q / 2) < n;
-        u32 *p = cell0 + min(x[q] >> ksh, (u32)(NB - 1)) * 4u;
+        u32 *p = cell0 + (x[q] >> ksh) * 4u; // positions <= len: the bin is inside the table
         cell[q] = real ? p : pad_cell;
         atomicAdd(cell[q], (q & 1) ? 0x10000u : 1u);
     }
@@ -455,25 +456,42 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
     // ---- coalesced interval loads (8 B/lane), keys straight into registers
     u32 x[K];
     u32 bad = 0, nz = 0;
+    bool plain;
     {
-        // issue every load before the first use: one memory latency per read, not K/2 of them
+        // Every load is issued before the first use (one memory latency per read, not K/2), from
+        // one base pointer with the index clamped to the read's last interval: no per-load
+        // branches or address arithmetic; the duplicates are turned into pads below.  A group
+        // without intervals reads the first offsets instead (always mapped).
+        const uint2 *src = n ? iv : reinterpret_cast<const uint2 *>(a.off);
+        const u32 last = n ? n - 1u : 0u;
         uint2 v[K / 2];
 #pragma unroll
-        for (int j = 0; j < K / 2; j++) {
-            const u32 i = lig + (u32)LANES * j;
-            v[j] = make_uint2(1u, 2u);
-            if (i < n) v[j] = iv[i];
-        }
+        for (int j = 0; j < K / 2; j++) v[j] = src[min(lig + (u32)LANES * j, last)];
+        // Plain intervals (start < end <= min(len, kMaxKeyPos)) need two instructions per key;
+        // a wavefront that holds anything else (zero-length, start > end, an end beyond the read,
+        // huge positions: ~0.1 % of them) re-derives its keys with the class and rejection logic
+        // of make_event_keys and sorts everything (the pre-filter relies on positions <= len).
+        const u32 len_c = min(len, kMaxKeyPos);
+        u32 irregular = 0;
 #pragma unroll
         for (int j = 0; j < K / 2; j++) {
-            const u32 i = lig + (u32)LANES * j;
-            u32 ks, ke, b = 0, z = 0;
-            make_event_keys(v[j], ks, ke, b, z);
-            const bool real = i < n;
-            x[2 * j] = real ? ks : kPadKey;
-            x[2 * j + 1] = real ? ke : kPadKey;
-            bad |= real ? b : 0u;
-            nz += real ? z : 0u;
+            const bool real = lig + (u32)LANES * j < n;
+            irregular |= (real && (v[j].x >= v[j].y || v[j].y > len_c)) ? 1u : 0u;
+            x[2 * j] = real ? ((v[j].x << kKeyShift) | 3u) : kPadKey;
+            x[2 * j + 1] = real ? (v[j].y << kKeyShift) : kPadKey;
+        }
+        plain = __builtin_amdgcn_ballot_w64(irregular != 0) == 0; // wave-uniform
+        if (!plain) {
+#pragma unroll
+            for (int j = 0; j < K / 2; j++) {
+                u32 ks, ke, b = 0, z = 0;
+                make_event_keys(v[j], ks, ke, b, z);
+                const bool real = lig + (u32)LANES * j < n;
+                x[2 * j] = real ? ks : kPadKey;
+                x[2 * j + 1] = real ? ke : kPadKey;
+                bad |= real ? b : 0u;
+                nz += real ? z : 0u;
+            }
         }
     }
     const u64 badmask = __builtin_amdgcn_ballot_w64(bad != 0);
@@ -489,7 +507,7 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
     const bool zl_check = (zmask & (zmask - 1)) != 0 || __builtin_amdgcn_ballot_w64(nz > 2) != 0;
 
     if constexpr (K == 16 && LANES < 64) {
-        if (a.prefilter) { // uniform
+        if (a.prefilter && plain) { // uniform
             u32 y[K / 2], mf;
             if (prefilter<LANES, K>(x, n, len, c, y, mf)) {
                 if (a.prefilter == 2 && lig == 0 && active) atomicAdd(&a.ctr->prefiltered, 1u);

@@ -1,7 +1,8 @@
 // engine.hip — C ABI of include/yacrd_engine.h: buffer management, launch sequence, timing.
 //
 // Launch sequence per run (one HIP stream per engine):
-//   memset(ctrl) -> plan -> [sync: class counts] -> sweeps of the non-empty classes
+//   plan (also zeroes the other control block for the next run) -> [sync: class counts, unless predicted]
+//   -> sweeps of the non-empty classes
 //   -> exact general path (LDS scratch for rejected reads; global scratch for huge reads)
 //   -> compact_classify (single-pass scan) -> sync.
 //   Rare redo: degenerate reads too large for LDS, or bad_regions too small.
@@ -89,7 +90,11 @@ struct yacrd_engine {
     // inputs staged by yacrd_engine_run
     DevBuf in_off, in_iv, in_len;
     // work buffers
-    DevBuf lists, ctrl, stage, counts, gen_sizes, gen_scratch_off, gen_scratch, big_tab, big_keys, big_redo;
+    DevBuf lists, ctrl2[2], stage, counts, gen_sizes, gen_scratch_off, gen_scratch, big_tab, big_keys, big_redo;
+    // two control blocks (counters + scan state), used alternately: the plan kernel of a run zeroes
+    // the other one for the next run.  ctrl_clean[i] = leading bytes of block i known to be zero.
+    size_t ctrl_clean[2] = {0, 0};
+    int ctrl_cur = 0;
     // results
     DevBuf bad_offsets, bad_regions, read_type;
     yk::Counters *h_ctr = nullptr; // pinned
@@ -132,7 +137,7 @@ float ev_ms(hipEvent_t a, hipEvent_t b)
 int launch_compact(yacrd_engine *e, const u64 *d_off, const u32 *d_len, u32 n_reads, double not_cov)
 {
     const u32 nb = (n_reads + yk::kScanBlock - 1) / yk::kScanBlock;
-    yk::Counters *ctr = e->ctrl.as<yk::Counters>();
+    yk::Counters *ctr = e->ctrl2[e->ctrl_cur].as<yk::Counters>();
     u64 *scan_state = reinterpret_cast<u64 *>(ctr + 1);
     hipLaunchKernelGGL(yk::compact_classify_kernel, dim3(nb), dim3(yk::kScanBlock), 0, e->stream,
                        d_off, d_len, e->stage.as<uint2>(), e->counts.as<u32>(), scan_state, n_reads,
@@ -300,8 +305,14 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     const u32 nb = (n_reads + yk::kScanBlock - 1) / yk::kScanBlock;
     constexpr int kLists = yk::CLS_COUNT + 3; // class lists + three rejection lists
     HIP_TRY(e->lists.reserve((size_t)kLists * n_reads * sizeof(u32)));
-    const size_t ctrl_bytes = sizeof(yk::Counters) + (size_t)nb * sizeof(u64);
-    HIP_TRY(e->ctrl.reserve(ctrl_bytes));
+    const size_t ctrl_bytes = (sizeof(yk::Counters) + (size_t)nb * sizeof(u64) + 255) & ~(size_t)255;
+    e->ctrl_cur ^= 1;
+    const int cur = e->ctrl_cur, other = cur ^ 1;
+    for (int i = 0; i < 2; i++) {
+        const void *before = e->ctrl2[i].p;
+        HIP_TRY(e->ctrl2[i].reserve(ctrl_bytes));
+        if (e->ctrl2[i].p != before) e->ctrl_clean[i] = 0; // fresh allocation: nothing zeroed yet
+    }
     HIP_TRY(e->stage.reserve((size_t)(n_iv + 2 * n_reads64) * sizeof(uint2)));
     HIP_TRY(e->counts.reserve((size_t)n_reads * sizeof(u32)));
     HIP_TRY(e->read_type.reserve((size_t)n_reads));
@@ -312,7 +323,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     auto list_of = [&](int i) { return lists + (size_t)i * n_reads; };
     u32 *rej_small = list_of(yk::CLS_COUNT), *rej_med = list_of(yk::CLS_COUNT + 1),
         *rej_big = list_of(yk::CLS_COUNT + 2);
-    yk::Counters *ctr = e->ctrl.as<yk::Counters>();
+    yk::Counters *ctr = e->ctrl2[cur].as<yk::Counters>();
     const bool full = (e->flags & YACRD_F_TIMING_FULL) != 0;
     const int xm = (e->flags & YACRD_F_XLANE_DS) ? 1 : 0;
 
@@ -323,13 +334,20 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     // are launched without waiting, sized for n_reads, and the prediction is validated against
     // the real counts at the final sync (a class that was not predicted is launched then and
     // the compaction redone).  Streams of similar batches never pay the mid-pipeline sync.
-    HIP_TRY(hipMemsetAsync(ctr, 0, ctrl_bytes, e->stream));
+    // The control block (counters + scan state) must start out zero.  The engine alternates
+    // between two blocks and the plan kernel of a run zeroes the other one, so in steady state no
+    // run starts with a fill (hipMemsetAsync = two fill kernels + their launch gaps).
+    if (e->ctrl_clean[cur] < ctrl_bytes) HIP_TRY(hipMemsetAsync(ctr, 0, ctrl_bytes, e->stream));
+    e->ctrl_clean[cur] = 0;
+    const size_t other_bytes = std::min<size_t>(e->ctrl2[other].cap, (size_t)1 << 30) & ~(size_t)3;
     if (full) HIP_TRY(hipEventRecord(e->ev[EV_START], e->stream));
     hipLaunchKernelGGL(yk::plan_kernel, dim3((n_reads + yk::kPlanBlock - 1) / yk::kPlanBlock),
                        dim3(yk::kPlanBlock), 0, e->stream, d_off, n_reads, lists, ctr,
                        (u32)((e->flags & YACRD_F_FORCE_GENERAL) ? 1
                              : (e->flags & (YACRD_F_WAVE_ONLY | YACRD_F_FORCE_LDS_SORT)) ? 2
-                             : (e->flags & YACRD_F_NO_HALVES) ? 3 : 0));
+                             : (e->flags & YACRD_F_NO_HALVES) ? 3 : 0),
+                       e->ctrl2[other].as<u32>(), (u32)(other_bytes / 4));
+    e->ctrl_clean[other] = other_bytes;
     if (full) HIP_TRY(hipEventRecord(e->ev[EV_PLAN], e->stream));
 
     const bool predicted = e->pred_valid && e->pred_reads == n_reads64 && e->pred_iv == n_iv &&
@@ -756,7 +774,7 @@ void yacrd_engine_destroy(yacrd_engine *e)
     if (!e) return;
     DeviceGuard guard(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    DevBuf *bufs[] = {&e->in_off, &e->in_iv, &e->in_len, &e->lists, &e->ctrl, &e->stage,
+    DevBuf *bufs[] = {&e->in_off, &e->in_iv, &e->in_len, &e->lists, &e->ctrl2[0], &e->ctrl2[1], &e->stage,
                       &e->counts, &e->gen_sizes, &e->gen_scratch_off,
                       &e->gen_scratch, &e->big_tab, &e->big_keys, &e->big_redo,
                       &e->bad_offsets, &e->bad_regions, &e->read_type};

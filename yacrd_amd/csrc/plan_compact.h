@@ -10,9 +10,14 @@ namespace yk {
 // per workgroup.  (One LDS atomic per read serialised 1024 lanes on one address: 8 us -> 3 us.)
 constexpr int kPlanBlock = 1024;
 
+// `zero` / `zero_words`: the control block of the NEXT run (the engine alternates between two), left
+// zeroed here so that no run starts with a fill on its critical path.
 __global__ __launch_bounds__(kPlanBlock) void plan_kernel(const u64 *off, u32 n_reads, u32 *lists,
-                                                          Counters *ctr, u32 mode)
+                                                          Counters *ctr, u32 mode, u32 *zero,
+                                                          u32 zero_words)
 {
+    for (u32 i = blockIdx.x * kPlanBlock + threadIdx.x; i < zero_words; i += gridDim.x * kPlanBlock)
+        zero[i] = 0;
     __shared__ u32 s_cnt[CLS_COUNT];
     __shared__ u32 s_base[CLS_COUNT];
     __shared__ unsigned long long s_iv[CLS_COUNT];

@@ -106,27 +106,40 @@ __global__ __launch_bounds__(kScanBlock) void compact_classify_kernel(
     const u32 g = (r < n_reads) ? counts[r] : 0u;
     u32 tot;
     const u32 local = block_excl_add<kScanBlock>(g, sc, tot);
-    if (threadIdx.x == 0) {
+    if (threadIdx.x < 64) { // decoupled look-back, 64 predecessors per round trip
         constexpr u64 kAgg = 1ull << 62, kPre = 2ull << 62, kVal = (1ull << 62) - 1;
+        const u32 lane = threadIdx.x;
         u64 base = 0;
         if (bid > 0) {
-            __hip_atomic_store(&scan_state[bid], kAgg | tot, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            for (u32 i = bid; i-- > 0;) {
-                u64 v;
-                do {
-                    v = __hip_atomic_load(&scan_state[i], __ATOMIC_RELAXED,
-                                          __HIP_MEMORY_SCOPE_AGENT);
-                    if (!(v >> 62)) __builtin_amdgcn_s_sleep(1);
-                } while (!(v >> 62));
-                base += v & kVal;
-                if ((v >> 62) == 2) break;
+            if (lane == 0)
+                __hip_atomic_store(&scan_state[bid], kAgg | tot, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            for (i32 hi = (i32)bid - 1;; hi -= 64) {
+                const i32 idx = hi - (i32)lane; // lane 0 looks at the nearest predecessor
+                u64 v, pre;
+                for (;;) { // until the window holds no empty entry before its nearest prefix
+                    v = idx >= 0 ? __hip_atomic_load(&scan_state[idx], __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT)
+                                 : kPre; // before the first workgroup: prefix 0
+                    pre = __builtin_amdgcn_ballot_w64((v >> 62) == 2);
+                    const u64 before = pre ? ((pre & (0 - pre)) - 1ull) : ~0ull; // lanes nearer than it
+                    if ((__builtin_amdgcn_ballot_w64((v >> 62) == 0) & before) == 0) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                const u32 first_pre = pre ? (u32)__builtin_ctzll(pre) : 64u;
+                u64 part = lane <= first_pre ? (v & kVal) : 0;
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
+                base += part;
+                if (pre) break;
             }
         }
-        __hip_atomic_store(&scan_state[bid], kPre | (base + tot), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-        s_base = base;
-        if ((u64)(bid + 1) * kScanBlock >= n_reads) ctr->total_regions = base + tot;
+        if (lane == 0) {
+            __hip_atomic_store(&scan_state[bid], kPre | (base + tot), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+            s_base = base;
+            if ((u64)(bid + 1) * kScanBlock >= n_reads) ctr->total_regions = base + tot;
+        }
     }
     __syncthreads();
     if (r < n_reads) {

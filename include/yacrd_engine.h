@@ -158,6 +158,12 @@ int yacrd_engine_last_timing(const yacrd_engine *e, yacrd_timing *t);
  * last run), and how many runs: lets a caller time K runs without K round trips. */
 int yacrd_engine_timing_total(yacrd_engine *e, yacrd_timing *sum, uint64_t *n_runs, int reset);
 
+/* Elapsed time of an EMPTY event bracket on the engine's stream (mean of 32): what the two
+ * hipEventRecord calls add to a class_ms / fused_ms value.  Lets a caller report the kernel's own
+ * duration (bracket - overhead) next to the raw bracket; rocprofv3 --kernel-trace gives the same
+ * figure from the dispatch timestamps. */
+int yacrd_engine_event_overhead(yacrd_engine *e, float *ms);
+
 /* Read-id partitioning for multi-GPU: cuts[n_parts+1], contiguous read
  * ranges balanced by interval count; reads are independent so there is no exchange step. */
 int yacrd_partition_reads(const uint64_t *offsets, uint64_t n_reads, uint32_t n_parts,

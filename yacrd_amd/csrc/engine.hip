@@ -882,6 +882,23 @@ int yacrd_engine_timing_total(yacrd_engine *e, yacrd_timing *sum, uint64_t *n_ru
     return YACRD_OK;
 }
 
+int yacrd_engine_event_overhead(yacrd_engine *e, float *ms)
+{
+    if (!e || !ms) return fail(YACRD_EINVAL, "null argument");
+    DeviceGuard guard(e->device);
+    // an empty bracket: what two event records add to the span they enclose
+    constexpr int kPairs = 32;
+    double sum = 0;
+    for (int i = 0; i < kPairs + 4; i++) {
+        HIP_TRY(hipEventRecord(e->ev_cls[22], e->stream));
+        HIP_TRY(hipEventRecord(e->ev_cls[23], e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (i >= 4) sum += ev_ms(e->ev_cls[22], e->ev_cls[23]); // the first few warm the path up
+    }
+    *ms = (float)(sum / kPairs);
+    return YACRD_OK;
+}
+
 int yacrd_partition_reads(const uint64_t *offsets, uint64_t n_reads, uint32_t n_parts,
                           uint64_t *cuts)
 {

@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "yacrd_abi_version", "yacrd_last_error", "yacrd_engine_create", "yacrd_engine_destroy",
     "yacrd_engine_run", "yacrd_result_free", "yacrd_engine_run_device", "yacrd_engine_fetch",
     "yacrd_engine_last_timing", "yacrd_partition_reads", "yacrd_engine_classify",
-    "yacrd_engines_run_partitioned", "yacrd_engine_timing_total",
+    "yacrd_engines_run_partitioned", "yacrd_engine_timing_total", "yacrd_engine_event_overhead",
 ]
 
 
@@ -150,6 +150,8 @@ def load_library():
     lib.yacrd_partition_reads.argtypes = [u64p, ctypes.c_uint64, ctypes.c_uint32, u64p]
     lib.yacrd_engine_classify.argtypes = [ctypes.c_void_p, u64p, u32p, u32p, ctypes.c_uint64,
                                           ctypes.c_double, u8p]
+    lib.yacrd_engine_event_overhead.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+    lib.yacrd_engine_event_overhead.restype = ctypes.c_int
     lib.yacrd_engine_timing_total.argtypes = [ctypes.c_void_p, ctypes.POINTER(_Timing),
                                               ctypes.POINTER(ctypes.c_uint64), ctypes.c_int]
     lib.yacrd_engines_run_partitioned.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32,
@@ -272,6 +274,12 @@ class Engine:
             v = getattr(t, n)
             out[n] = list(v) if n.startswith("class_") else v
         return out
+
+    def event_overhead_ms(self):
+        """Elapsed time of an empty HIP-event bracket on the engine's stream."""
+        ms = ctypes.c_float()
+        _check(self._lib, self._lib.yacrd_engine_event_overhead(self._h, ctypes.byref(ms)))
+        return float(ms.value)
 
     def timing_total(self, reset=False):
         """(sums over the runs since the last reset, number of runs)."""

@@ -192,6 +192,35 @@ def main():
                                               % (R, I, ncores, rs, rs / cpu_1),
                                     "value_1thread": rs / cpu_1}
             line["parity"] = "bit-exact vs oracle on all %d reads" % R if parity else "MISMATCH vs oracle"
+            # the other half of BASELINE.json's metric: overlaps/s ingested (PAF text -> CSR on the
+            # host, the stage in front of the GPU path), on a bounded sample of the same profile
+            try:
+                import ctypes
+                import tempfile
+                s_reads, s_ovl = max(R // 5, 2), max(args.overlaps // 5, 2)
+                with tempfile.TemporaryDirectory() as td:
+                    paf = os.path.join(td, "sample.paf")
+                    host.synth_paf(prof, s_reads, s_ovl, 20241110, paf)
+                    size = os.path.getsize(paf)
+                    hl = host.load_library()
+                    rates = {}
+                    for th in (1, min(64, ncores)):
+                        best = None
+                        for _ in range(2):
+                            h = ctypes.c_void_p()
+                            t1 = time.perf_counter()
+                            rc = hl.yacrd_csr_from_file(paf.encode(), 0, th, ctypes.byref(h))
+                            dt = time.perf_counter() - t1
+                            if rc != 0:
+                                raise RuntimeError("ingest failed")
+                            hl.yacrd_csr_free(h)
+                            best = dt if best is None else min(best, dt)
+                        rates[th] = s_ovl / best
+                line["ingest"] = {"overlaps_per_sec": max(rates.values()), "unit": "PAF overlaps/s, text -> CSR, host",
+                                  "threads": max(rates, key=rates.get), "overlaps_per_sec_1thread": rates[1],
+                                  "sample": "%d reads / %d overlaps, %.0f MB of PAF text" % (s_reads, s_ovl, size / 1e6)}
+            except Exception as ex:  # the host library is optional for the GPU metric
+                line["ingest"] = {"error": str(ex)}
         print(json.dumps(line), flush=True)
     eng.close()
     if dist is not None:

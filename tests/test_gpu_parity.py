@@ -75,10 +75,10 @@ def test_small_class(engine, cov):
 # ---- coverage pre-filter (sweep_wave.h `prefilter`) -------------------------------------------
 @pytest.mark.parametrize("cov", [0, 1, 4, 9, 40])
 def test_prefilter_on_deep_pileups(cov):
-    """Reads of 65..256 intervals (classes R16 / H16) piled deep: most bins are safe at small c.
+    """Reads of 65..512 intervals (classes R16 / H16 / W16) piled deep: most bins are safe at small c.
     Same results with the filter (default), without it, and from the oracle; the filter fires."""
     rng = np.random.default_rng(5)
-    sizes = np.concatenate([rng.integers(65, 257, size=3000), [65, 128, 129, 256, 96, 200]])
+    sizes = np.concatenate([rng.integers(65, 513, size=3000), [65, 128, 129, 256, 257, 512]])
     lengths = np.concatenate([rng.integers(1, 200, size=300), rng.integers(200, 150000, size=2706)])
     # the filter is only used by wavefronts whose intervals are all plain (start < end <= len):
     # modes come in blocks of 256 reads, so some wavefronts qualify and some do not

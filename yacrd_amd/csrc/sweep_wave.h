@@ -361,7 +361,6 @@ template <int LANES, int K>
 __device__ __forceinline__ bool prefilter(const u32 (&x)[K], u32 n, u32 len, i32 c, u32 (&y)[K / 2],
                                           u32 &m_out)
 {
-    static_assert(LANES == 16 || LANES == 32, "one bin per lane, bin mask in 32 bits");
     static_assert(K == 16, "a lane reads its K/2 = 8 compacted keys as two 16-byte vectors");
     constexpr int NB = LANES, CAP = LANES * K / 2, GROUPS = 64 / LANES;
     static_assert(GROUPS * (NB + 1) * 4 <= kFilterTabWords && GROUPS * CAP <= kFilterKeyWords, "scratch");
@@ -402,9 +401,11 @@ __device__ __forceinline__ bool prefilter(const u32 (&x)[K], u32 n, u32 len, i32
     const bool safe = (cs - S) - ce > c && lig < (len >> sh);
     const u64 sball = __builtin_amdgcn_ballot_w64(safe);
     if (sball == 0) return false; // wave-uniform: nothing to drop
-    const u32 smask = (u32)(sball >> (lane & (u32)(64 - LANES))) & (LANES == 16 ? 0xFFFFu : 0xFFFFFFFFu);
-    const bool head = safe && (((smask << 1) >> lig) & 1u) == 0;
-    const bool tail = safe && (((smask >> 1) >> lig) & 1u) == 0;
+    // the group's safe bits, bit b = bin b (zeros beyond the group)
+    const u64 smask = LANES == 64 ? sball
+                                  : (sball >> (lane & (u32)(64 - LANES))) & ((1ull << (LANES & 63)) - 1ull);
+    const bool head = safe && (((smask << 1) >> lig) & 1ull) == 0;
+    const bool tail = safe && (((smask >> 1) >> lig) & 1ull) == 0;
     const u32 hv = gscan_max<LANES>(head ? (((lig + 1u) << 16) | (u32)depth_at) : 0u);
     const i32 net = tail ? depth_after - (i32)(hv & 0xFFFFu) : 0;
     const u32 nsyn = min((u32)(net < 0 ? -net : net), (u32)CAP + 1u);
@@ -506,7 +507,7 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
     // two zero-length intervals at one position: only looked for when the wavefront saw >= 2
     const bool zl_check = (zmask & (zmask - 1)) != 0 || __builtin_amdgcn_ballot_w64(nz > 2) != 0;
 
-    if constexpr (K == 16 && LANES < 64) {
+    if constexpr (K == 16) {
         if (a.prefilter && plain) { // uniform
             u32 y[K / 2], mf;
             if (prefilter<LANES, K>(x, n, len, c, y, mf)) {

@@ -121,6 +121,24 @@ def test_medium_classes(engine, cov):
           0.4, "medium c=%d" % cov)
 
 
+@pytest.mark.parametrize("cov", [0, 4, 60])
+def test_medium_classes_prefilter(cov):
+    """Workgroup-LDS classes (513..16384 intervals) on deep pile-ups with tiny, short and long
+    reads: with the pre-filter, without it, and the oracle agree."""
+    rng = np.random.default_rng(31)
+    sizes = np.concatenate([rng.integers(513, 4097, size=40), rng.integers(4097, 16385, size=14),
+                            [513, 4096, 4097, 16384]])
+    lengths = np.concatenate([rng.integers(1, 300, size=6), rng.integers(300, 5000, size=10),
+                              rng.integers(5000, 900000, size=42)])
+    csr = make_csr(260 + cov, sizes, ("regular", "abutting", "dups", "sparse", "beyond", "zero_len"),
+                   lengths=lengths)
+    with yacrd_amd.Engine() as e:
+        got = check(e, csr, cov, 0.4, "medium prefilter c=%d" % cov)
+    with yacrd_amd.Engine(flags=yacrd_amd.F_NO_PREFILTER) as e:
+        ref = e.run(*csr, cov, 0.4)
+    assert_same(got, (ref.bad_offsets, ref.bad_regions, ref.read_type), "medium prefilter on/off")
+
+
 @pytest.mark.parametrize("cov", [0, 4])
 def test_general_class_large_reads(engine, cov):
     sizes = [16385, 20000, 40000, 70001, 5, 300]

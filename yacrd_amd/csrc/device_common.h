@@ -183,6 +183,19 @@ __device__ __forceinline__ u32 block_min(u32 v, u32 *sc)
     return r;
 }
 template <int T>
+__device__ __forceinline__ u32 block_or(u32 v, u32 *sc)
+{
+    v = wave_or(v);
+    if (T == 64) return v;
+    if (lane_id() == 0) sc[threadIdx.x >> 6] = v;
+    __syncthreads();
+    u32 r = 0;
+#pragma unroll
+    for (u32 w = 0; w < T / 64; w++) r |= sc[w];
+    __syncthreads();
+    return r;
+}
+template <int T>
 __device__ __forceinline__ u32 block_max(u32 v, u32 *sc)
 {
     v = wave_max(v);

@@ -131,6 +131,83 @@ __device__ __forceinline__ void bitonic_sort_lds(u32 *keys, u32 P)
     }
 }
 
+// ---- coverage pre-filter for the workgroup classes (same rule as sweep_wave.h) --
+// NB = T bins, one per thread.  The staging loop histograms the read's events into the last
+// 4 * T words of the (still empty) key array while it looks for degenerate intervals;
+// lds_filter_plan() turns the counters into slot counters, writes the stand-in keys of the safe
+// runs and says how many keys survive; a second pass over the intervals (L2-resident) then writes
+// each surviving key to the slot it is handed.  Used when the read is plain (no zero-length
+// interval, every end <= len) and keeps at most CAP / 2 keys.
+template <int T, int CAP>
+struct LdsFilter {
+    static constexpr int NB = T;
+    static constexpr u32 kNowhere = 0x80000000u;
+    static_assert(CAP / 2 <= CAP - 5 * NB, "survivors and counters must not overlap");
+    static __device__ __forceinline__ u32 shift_of(u32 len)
+    {
+        const i32 bits = 32 - (i32)__builtin_clz(len | 1u) - ilog2c(NB) + (len != 0 ? 0 : -1);
+        return (u32)max(bits, 0) + kKeyShift;
+    }
+    static __device__ __forceinline__ u32 *hist(u32 *keys) { return keys + (CAP - 4 * NB); }
+    // Add `val` to this thread's counter of the bin that holds `key` (four counters per bin, one
+    // per lane & 3: dovetail overlaps pile thousands of starts into bin 0 and as many ends into
+    // the bin of `len`) and return the counter's previous value.  (One wave-aggregated atomic
+    // for the lanes that hit those two bins was tried: no measurable change.)
+    static __device__ __forceinline__ u32 add(u32 *keys, u32 key, u32 ksh, u32 val)
+    {
+        return atomicAdd(hist(keys) + min(key >> ksh, (u32)(NB - 1)) * 4u + (threadIdx.x & 3u), val);
+    }
+};
+
+// Returns the number of keys that survive (0 = do not filter).  syn_start = largest stand-in
+// start key this thread wrote (for the tail rule's max_start), else 0.
+template <int T, int CAP>
+__device__ __forceinline__ u32 lds_filter_plan(u32 *keys, u32 len, u32 cov, u32 *sc, u32 &syn_start)
+{
+    using F = LdsFilter<T, CAP>;
+    constexpr int NB = T;
+    const u32 tid = threadIdx.x;
+    const i32 c = (i32)min(cov, 0x7FFFFFFFu);
+    const u32 ksh = F::shift_of(len), sh = ksh - kKeyShift;
+    u32 *flags = keys + (CAP - 5 * NB); // [NB]: safe bits, for the neighbours
+    uint4 *my_bin = reinterpret_cast<uint4 *>(F::hist(keys)) + tid;
+    syn_start = 0;
+
+    const uint4 w4 = *my_bin;
+    const u32 w = w4.x + w4.y + w4.z + w4.w; // starts in the low half, ends in the high half
+    u32 w_tot;
+    const u32 incl = block_excl_add<T>(w, sc, w_tot) + w;
+    const i32 S = (i32)(w & 0xFFFFu), E = (i32)(w >> 16);
+    const i32 cs = (i32)(incl & 0xFFFFu), ce = (i32)(incl >> 16);
+    const i32 depth_after = cs - ce, depth_at = depth_after - (S - E);
+    const bool safe = (cs - S) - ce > c && tid < (len >> sh);
+    flags[tid] = safe ? 1u : 0u;
+    if (block_max<T>(safe ? 1u : 0u, sc) == 0) return 0; // nothing to drop (ends with a barrier)
+    const bool head = safe && !(tid > 0 && flags[tid - 1]);
+    const bool tail = safe && !(tid + 1 < (u32)NB && flags[tid + 1]);
+    const u32 hv_own = head ? (((tid + 1u) << 16) | (u32)depth_at) : 0u;
+    u32 hv_tot;
+    const u32 hv = max(block_excl_max<T>(hv_own, sc, hv_tot), hv_own);
+    const i32 net = tail ? depth_after - (i32)(hv & 0xFFFFu) : 0;
+    const u32 nsyn = (u32)(net < 0 ? -net : net);
+    const u32 synkey = (((hv >> 16) - 1u) << ksh) | (net > 0 ? 3u : 0u);
+    const u32 mine = safe ? nsyn : (u32)(S + E);
+    u32 m_new;
+    const u32 base = block_excl_add<T>(mine, sc, m_new);
+    if (m_new > (u32)(CAP / 2)) return 0; // would not shrink the sort
+    uint4 b4;
+    b4.x = base;
+    b4.y = b4.x + (w4.x & 0xFFFFu) + (w4.x >> 16);
+    b4.z = b4.y + (w4.y & 0xFFFFu) + (w4.y >> 16);
+    b4.w = b4.z + (w4.z & 0xFFFFu) + (w4.z >> 16);
+    *my_bin = safe ? make_uint4(F::kNowhere, F::kNowhere, F::kNowhere, F::kNowhere) : b4;
+#pragma unroll 1
+    for (u32 t = 0; t < nsyn; t++) keys[base + t] = synkey;
+    if (tail && net > 0) syn_start = synkey;
+    __syncthreads();
+    return m_new;
+}
+
 // T threads per read, CAP = max events (power of two, CAP % T == 0).
 template <int T, int CAP>
 __global__ __launch_bounds__(T) void sweep_lds_kernel(SweepArgs a)
@@ -166,18 +243,31 @@ __global__ __launch_bounds__(T) void sweep_lds_kernel(SweepArgs a)
         u32 P = 2;
         while (P < m) P <<= 1;
 
-        // ---- stage the read's intervals into LDS as event keys (coalesced 8 B/lane loads)
-        u32 bad = 0, max_start = 0, nz = 0;
+        // ---- first pass over the intervals (coalesced 8 B/lane loads): degenerate ones, the
+        // largest start key, and the pre-filter's histogram (into the tail of the empty key array)
+        using F = LdsFilter<T, CAP>;
+        const bool try_filter = T >= 256 && a.prefilter != 0;
+        const u32 ksh = F::shift_of(len);
+        if (try_filter) {
+            reinterpret_cast<uint4 *>(F::hist(keys))[tid] = make_uint4(0u, 0u, 0u, 0u);
+            __syncthreads();
+        }
+        u32 bad = 0, max_start = 0, nz = 0; // bad bit 1: an end beyond the read (no pre-filter)
         const uint2 *iv = a.iv + o;
         for (u32 i = tid; i < n; i += T) {
             u32 ks, ke;
-            make_event_keys(iv[i], ks, ke, bad, nz);
-            keys[2 * i] = ks;
-            keys[2 * i + 1] = ke;
+            const uint2 v = iv[i];
+            make_event_keys(v, ks, ke, bad, nz);
+            bad |= v.y > len ? 2u : 0u;
             max_start = max(max_start, ks);
+            if (try_filter) {
+                F::add(keys, ks, ksh, 1u);
+                F::add(keys, ke, ksh, 0x10000u);
+            }
         }
-        for (u32 i = m + tid; i < P; i += T) keys[i] = kNoKey;
-        bad = block_max<T>(bad, sc);
+        bad = block_or<T>(bad, sc);
+        const bool beyond = (bad & 2u) != 0;
+        bad &= 1u;
         u32 nz_total;
         block_excl_add<T>(nz, sc, nz_total);
         if (bad) { // degenerate interval: exact general path takes the read
@@ -189,6 +279,39 @@ __global__ __launch_bounds__(T) void sweep_lds_kernel(SweepArgs a)
             continue;
         }
         max_start = block_max<T>(max_start, sc);
+
+        // ---- second pass: the event keys go to LDS — the survivors of the pre-filter to the
+        // slots they are handed, or all of them
+        u32 m_sort = 0, syn_start = 0; // events to sort and sweep
+        if (try_filter && nz_total == 0 && !beyond)
+            m_sort = lds_filter_plan<T, CAP>(keys, len, a.cov, sc, syn_start);
+        if (m_sort) {
+            u32 ms = syn_start;
+            for (u32 i = tid; i < n; i += T) {
+                const uint2 v = iv[i];
+                const u32 ks = (v.x << kKeyShift) | 3u, ke = v.y << kKeyShift;
+                const u32 ps = F::add(keys, ks, ksh, 1u);
+                const u32 pe = F::add(keys, ke, ksh, 1u);
+                if (ps < F::kNowhere) {
+                    keys[ps] = ks;
+                    ms = max(ms, ks);
+                }
+                if (pe < F::kNowhere) keys[pe] = ke;
+            }
+            max_start = block_max<T>(ms, sc);
+        } else {
+            m_sort = m;
+            __syncthreads(); // the counters are dead, the keys may overwrite them
+            for (u32 i = tid; i < n; i += T) {
+                u32 ks, ke, b2 = 0, z2 = 0;
+                make_event_keys(iv[i], ks, ke, b2, z2);
+                keys[2 * i] = ks;
+                keys[2 * i + 1] = ke;
+            }
+        }
+        P = 2;
+        while (P < m_sort) P <<= 1;
+        for (u32 i = m_sort + tid; i < P; i += T) keys[i] = kNoKey;
         __syncthreads();
 
         if (T >= 256 && P >= 1024) hybrid_sort_lds<T>(keys, P, lc);
@@ -196,7 +319,7 @@ __global__ __launch_bounds__(T) void sweep_lds_kernel(SweepArgs a)
 
         if (nz_total > 2) { // two zero-length intervals at one position > 0: exact path (see keys)
             u32 dup = 0;
-            for (u32 i = tid; i + 1 < m; i += T)
+            for (u32 i = tid; i + 1 < m_sort; i += T)
                 dup |= (keys[i] == keys[i + 1] && (keys[i] & 3u) == 1u && keys[i] != 1u);
             if (block_max<T>(dup, sc)) {
                 if (tid == 0) {
@@ -210,7 +333,7 @@ __global__ __launch_bounds__(T) void sweep_lds_kernel(SweepArgs a)
 
         // ---- blocked chunks: thread t owns events [t*K, t*K+K) of the sorted sequence
         const u32 K = (P >= (u32)T) ? P / T : 1;
-        const u32 q0 = min(tid * K, m), q1 = min(q0 + K, m);
+        const u32 q0 = min(tid * K, m_sort), q1 = min(q0 + K, m_sort);
 
         // pass A: depth carried into each chunk
         u32 delta = 0;

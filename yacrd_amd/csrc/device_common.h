@@ -81,27 +81,30 @@ struct SweepArgs {
 
 __device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
 
-// ---- wave64 inclusive scans (shuffle based; used by the workgroup-wide paths) --------------
+// ---- wave64 inclusive scans on DPP (row_shr 1/2/4/8, row_bcast 15/31; identity 0): six VALU
+// instructions instead of six ds_bpermute round trips --------------------------------------
+#define YK_DPP_ZERO(v, ctrl, rm) (u32) __builtin_amdgcn_update_dpp(0, (int)(v), ctrl, rm, 0xF, true)
 __device__ __forceinline__ u32 wave_incl_add(u32 v)
 {
-    const u32 lane = lane_id();
-#pragma unroll
-    for (u32 d = 1; d < 64; d <<= 1) {
-        u32 t = __shfl_up(v, d, 64);
-        if (lane >= d) v += t;
-    }
+    v += YK_DPP_ZERO(v, 0x111, 0xF); // row_shr:1
+    v += YK_DPP_ZERO(v, 0x112, 0xF); // row_shr:2
+    v += YK_DPP_ZERO(v, 0x114, 0xF); // row_shr:4
+    v += YK_DPP_ZERO(v, 0x118, 0xF); // row_shr:8
+    v += YK_DPP_ZERO(v, 0x142, 0xA); // row_bcast:15 -> rows 1, 3
+    v += YK_DPP_ZERO(v, 0x143, 0xC); // row_bcast:31 -> rows 2, 3
     return v;
 }
 __device__ __forceinline__ u32 wave_incl_max(u32 v)
 {
-    const u32 lane = lane_id();
-#pragma unroll
-    for (u32 d = 1; d < 64; d <<= 1) {
-        u32 t = __shfl_up(v, d, 64);
-        if (lane >= d) v = max(v, t);
-    }
+    v = max(v, YK_DPP_ZERO(v, 0x111, 0xF));
+    v = max(v, YK_DPP_ZERO(v, 0x112, 0xF));
+    v = max(v, YK_DPP_ZERO(v, 0x114, 0xF));
+    v = max(v, YK_DPP_ZERO(v, 0x118, 0xF));
+    v = max(v, YK_DPP_ZERO(v, 0x142, 0xA));
+    v = max(v, YK_DPP_ZERO(v, 0x143, 0xC));
     return v;
 }
+__device__ __forceinline__ u32 wave_shift_up1(u32 v) { return YK_DPP_ZERO(v, 0x138, 0xF); } // wave_shr:1
 __device__ __forceinline__ u32 wave_min(u32 v)
 {
 #pragma unroll
@@ -149,8 +152,7 @@ template <int T>
 __device__ __forceinline__ u32 block_excl_max(u32 v, u32 *sc, u32 &total)
 {
     u32 incl = wave_incl_max(v);
-    u32 prev = __shfl_up(incl, 1, 64);
-    if (lane_id() == 0) prev = 0;
+    const u32 prev = wave_shift_up1(incl); // lane 0 gets 0
     if (T == 64) {
         total = __shfl(incl, 63, 64);
         return prev;

@@ -557,6 +557,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     rc = launch_compact(e, d_off, d_len, n_reads, not_cov);
     if (rc) return rc;
     if (full) HIP_TRY(hipEventRecord(e->ev[EV_COMPACT], e->stream));
+    // (spinning on the pinned counter block instead of this call was tried: 0.0816 vs 0.078 ms/step)
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipGetLastError());
     timing_on = false;

@@ -24,6 +24,18 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s measured-copy ceiling
 
 
+def usable_cpus():
+    """CPUs this process may use: os.cpu_count() capped by the cgroup quota (cpu.max)."""
+    n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max" and int(period) > 0:
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -172,7 +184,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             import oracle
-            ncores = os.cpu_count() or 1
+            ncores = usable_cpus()
             l64 = lengths.astype(np.uint64)
             oracle.run(offsets[:1001], intervals[: int(offsets[1000])], l64[:1000], cov, args.not_coverage, 1)
             t1 = time.perf_counter()
@@ -204,7 +216,7 @@ def main():
                     size = os.path.getsize(paf)
                     hl = host.load_library()
                     rates = {}
-                    for th in (1, min(64, ncores)):
+                    for th in (1, min(64, ncores)) if ncores > 1 else (1,):
                         best = None
                         for _ in range(2):
                             h = ctypes.c_void_p()

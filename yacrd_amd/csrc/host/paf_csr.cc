@@ -6,9 +6,9 @@
 //   * a read's length is the FIRST length seen for its id (fullmemory.rs:82-90)
 //   * records may carry extra columns (csv `flexible(true)`), empty lines are skipped
 //   * a short or non-numeric record is an error (the reference bails, mod.rs:93-97)
-// Reads are numbered in first-appearance order.  Parsing is chunk-parallel: each thread interns
-// ids locally, the local tables are merged in file order so numbering and the first-length rule
-// do not depend on the thread count.  csv-crate quoting ("...") is not interpreted (unpinned by
+// Reads are numbered in first-appearance order.  Parsing is chunk-parallel over one shared id
+// table whose entries remember where in the file their id came first, so numbering and the
+// first-length rule do not depend on the thread count.  csv-crate quoting ("...") is not interpreted (unpinned by
 // the reference's tests): a '"' is an ordinary byte here.
 #include "../../../include/yacrd_host.h"
 #include "host_common.h"
@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <memory>
 #include <mutex>
+#include <new>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -56,72 +57,259 @@ namespace {
 
 enum { FMT_AUTO = 0, FMT_PAF = 1, FMT_M4 = 2 };
 
+// Allocator of the ingest's big arrays: anonymous mappings with MADV_HUGEPAGE from 1 MiB up.
+// First-touch page faults on 4 KiB pages top out at ~12 GB/s on this class of host however many
+// threads fault (tools/io_probe.cc: 120 ms for 1.45 GB at 16 and at 64 threads, 11 ms with 2 MiB
+// pages), and the parse touches ~1 GB of fresh memory per 20 M overlaps.
+template <class T>
+struct HugeAlloc {
+    using value_type = T;
+    HugeAlloc() = default;
+    template <class U>
+    HugeAlloc(const HugeAlloc<U> &) {}
+    static constexpr size_t kBig = 1u << 20, kHuge = 2u << 20;
+    static size_t rounded(size_t bytes) { return (bytes + kHuge - 1) & ~(kHuge - 1); }
+    T *allocate(size_t n)
+    {
+        const size_t bytes = n * sizeof(T);
+        if (bytes < kBig) {
+            void *p = std::malloc(bytes ? bytes : 1);
+            if (!p) throw std::bad_alloc();
+            return static_cast<T *>(p);
+        }
+        void *p = mmap(nullptr, rounded(bytes), PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (p == MAP_FAILED) throw std::bad_alloc();
+        (void)madvise(p, rounded(bytes), MADV_HUGEPAGE);
+        return static_cast<T *>(p);
+    }
+    void deallocate(T *p, size_t n)
+    {
+        const size_t bytes = n * sizeof(T);
+        if (bytes < kBig) std::free(p);
+        else munmap(p, rounded(bytes));
+    }
+    template <class U>
+    bool operator==(const HugeAlloc<U> &) const { return true; }
+    template <class U>
+    bool operator!=(const HugeAlloc<U> &) const { return false; }
+};
+template <class T>
+using big_vector = std::vector<T, HugeAlloc<T>>;
+
 struct Rec {
     uint32_t a, b, sa, ea, sb, eb;
 };
 
-// Interning table local to one chunk.  A slot carries the hash next to the id, so a probe
-// touches one cache line of the table and (on a hash match) one of the arena.
-struct Names {
-    struct Slot {
-        uint64_t hash;
-        uint32_t id1; // id + 1, 0 = empty
-        uint32_t nlen;
-    };
-    std::vector<char> arena;
-    std::vector<uint64_t> off;  // start of each name in arena
-    std::vector<uint32_t> nlen; // name length
-    std::vector<uint64_t> hash;
-    std::vector<uint64_t> rlen; // first length seen
-    std::vector<Slot> table;
-    uint64_t mask = 0;
-
-    void init(size_t cap_pow2)
+// Zero-filled memory for the id table, carved out of 64 MiB anonymous regions with MADV_HUGEPAGE:
+// the table is probed at random, and on 4 KiB pages every probe also misses the TLB.
+struct HugePool {
+    std::mutex mu;
+    char *cur = nullptr;
+    size_t left = 0;
+    std::vector<std::pair<void *, size_t>> regions;
+    void *alloc(size_t bytes)
     {
-        table.assign(cap_pow2, Slot{0, 0, 0});
-        mask = cap_pow2 - 1;
-    }
-    void grow()
-    {
-        std::vector<Slot> nt(table.size() * 2, Slot{0, 0, 0});
-        const uint64_t nm = nt.size() - 1;
-        for (const Slot &sl : table) {
-            if (!sl.id1) continue;
-            uint64_t s = sl.hash & nm;
-            while (nt[s].id1) s = (s + 1) & nm;
-            nt[s] = sl;
+        bytes = (bytes + 63) & ~(size_t)63;
+        std::lock_guard<std::mutex> g(mu);
+        if (bytes > left) {
+            const size_t sz = std::max<size_t>((size_t)64 << 20, (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1));
+            void *p = mmap(nullptr, sz, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (p == MAP_FAILED) throw std::bad_alloc();
+            (void)madvise(p, sz, MADV_HUGEPAGE);
+            regions.emplace_back(p, sz);
+            cur = (char *)p;
+            left = sz;
         }
-        table.swap(nt);
-        mask = nm;
+        void *r = cur;
+        cur += bytes;
+        left -= bytes;
+        return r;
     }
-    uint32_t intern(const char *p, size_t n, uint64_t h, uint64_t length)
+    ~HugePool()
     {
-        uint64_t s = h & mask;
-        for (;;) {
-            const Slot &sl = table[s];
-            if (!sl.id1) break;
-            if (sl.hash == h && sl.nlen == n &&
-                std::memcmp(arena.data() + off[sl.id1 - 1], p, n) == 0)
-                return sl.id1 - 1;
-            s = (s + 1) & mask;
-        }
-        const uint32_t id = (uint32_t)off.size();
-        table[s] = Slot{h, id + 1, (uint32_t)n};
-        off.push_back(arena.size());
-        nlen.push_back((uint32_t)n);
-        hash.push_back(h);
-        rlen.push_back(length);
-        arena.insert(arena.end(), p, p + n);
-        if ((off.size() + 1) * 2 > table.size()) grow();
-        return id;
+        for (auto &r : regions) munmap(r.first, r.second);
     }
 };
 
-struct Chunk {
+// Read ids are interned into ONE table shared by the parse threads (per-chunk tables made every
+// chunk re-intern nearly every id: the parse stopped scaling at 16 threads).  The table is
+// sharded by the top hash bits.  Lookups — 99 % of the calls — take no lock and write nothing
+// shared: a shard publishes an immutable open-addressing index (slot = hash, name length, entry
+// number; the entry number is release-stored last) over entries and name bytes that never move
+// (geometrically growing blocks).  A miss, or a hit at an earlier file position than the entry
+// knows, takes the shard's spin lock: inserts re-probe the current index, a full index is replaced
+// by one twice the size (the old one stays allocated until the end: readers may still walk it,
+// and fall back to the locked path when it misses).  An entry remembers the smallest position
+// (byte offset of the line * 2 + 0/1 for the first / second id) at which its id was seen and the
+// length given there: global numbering = order of those positions (first appearance in the
+// file) and a read's length = the first length seen (fullmemory.rs:82-90), whatever the timing.
+struct IdTable {
+    static constexpr uint32_t kIdxBits = 22, kBlock0 = 64, kBlocks = 17; // 64 * (2^17 - 1) > 2^22
+    // What a lookup touches is kept small (16 B per id + the name bytes + a 16 B slot: for 400 k ids
+    // 27 MB, an L3 slice; with hash, length and name length in the same record it was 37 MB and
+    // a single thread parsed 1.6x slower).
+    struct Hot {
+        const char *name;
+        std::atomic<uint64_t> first_pos; // smallest position at which the id was seen
+    };
+    struct Cold {
+        uint64_t hash;
+        uint64_t first_len; // length given at first_pos (written under the lock)
+        uint32_t nlen;
+    };
+    struct Slot {
+        uint64_t hash;
+        uint32_t nlen;
+        std::atomic<uint32_t> idx1; // entry number + 1, 0 = empty; stored last (release)
+    };
+    struct Index {
+        uint32_t mask;
+        Slot *slots;
+    };
+    struct alignas(64) Shard {
+        alignas(64) std::atomic<bool> lock{false};
+        alignas(64) std::atomic<Index *> index{nullptr};
+        Hot *hot[kBlocks] = {};
+        Cold *cold[kBlocks] = {};
+        uint32_t n_entries = 0;
+        char *name_cur = nullptr;
+        size_t name_left = 0;
+    };
+    size_t n_shards = 1;
+    int shard_shift = 63; // shard = (hash >> shard_shift) & (n_shards - 1)
+    std::unique_ptr<Shard[]> shards;
+    HugePool pool; // indexes, entries and name bytes; released as a whole
+    std::atomic<bool> overflow{false};
+
+    explicit IdTable(size_t want_shards)
+    {
+        while (n_shards < want_shards) n_shards <<= 1;
+        shard_shift = n_shards == 1 ? 63 : 64 - __builtin_ctzll((unsigned long long)n_shards);
+        shards.reset(new Shard[n_shards]);
+    }
+    IdTable(const IdTable &) = delete;
+    IdTable &operator=(const IdTable &) = delete;
+
+    static void locate(uint32_t idx, uint32_t &block, uint32_t &at)
+    {
+        const uint32_t v = idx + kBlock0;
+        block = 31u - (uint32_t)__builtin_clz(v) - 6u;
+        at = v - (kBlock0 << block);
+    }
+    static Hot &hot(const Shard &sh, uint32_t idx)
+    {
+        uint32_t k, at;
+        locate(idx, k, at);
+        return sh.hot[k][at];
+    }
+    static Cold &cold(const Shard &sh, uint32_t idx)
+    {
+        uint32_t k, at;
+        locate(idx, k, at);
+        return sh.cold[k][at];
+    }
+    Index *new_index(uint32_t cap)
+    {
+        Index *ix = (Index *)pool.alloc(sizeof(Index));
+        Slot *sl = (Slot *)pool.alloc((size_t)cap * sizeof(Slot)); // all-zero = empty slots
+        ix->mask = cap - 1;
+        ix->slots = sl;
+        return ix;
+    }
+    // lock held.  Puts entry idx into ix (no duplicates possible).
+    static void place(Index *ix, uint64_t hash, uint32_t nlen, uint32_t idx)
+    {
+        uint32_t s2 = (uint32_t)hash & ix->mask;
+        while (ix->slots[s2].idx1.load(std::memory_order_relaxed)) s2 = (s2 + 1) & ix->mask;
+        ix->slots[s2].hash = hash;
+        ix->slots[s2].nlen = nlen;
+        ix->slots[s2].idx1.store(idx + 1, std::memory_order_release);
+    }
+    // returns the entry number, or ~0u when absent
+    static uint32_t probe(const Shard &sh, const Index *ix, const char *p, size_t n, uint64_t h)
+    {
+        uint32_t s2 = (uint32_t)h & ix->mask;
+        for (;;) {
+            const Slot &sl = ix->slots[s2];
+            const uint32_t v = sl.idx1.load(std::memory_order_acquire);
+            if (!v) return ~0u;
+            if (sl.hash == h && sl.nlen == n && std::memcmp(hot(sh, v - 1).name, p, n) == 0) return v - 1;
+            s2 = (s2 + 1) & ix->mask;
+        }
+    }
+    // returns shard << kIdxBits | entry number
+    uint32_t intern(const char *p, size_t n, uint64_t h, uint64_t length, uint64_t pos)
+    {
+        const uint32_t si = (uint32_t)((h >> shard_shift) & (n_shards - 1));
+        Shard &sh = shards[si];
+        const Index *ix = sh.index.load(std::memory_order_acquire);
+        uint32_t idx = ix ? probe(sh, ix, p, n, h) : ~0u;
+        if (idx != ~0u && pos >= hot(sh, idx).first_pos.load(std::memory_order_relaxed))
+            return (si << kIdxBits) | idx; // the common case: nothing shared is written
+
+        while (sh.lock.exchange(true, std::memory_order_acquire))
+            while (sh.lock.load(std::memory_order_relaxed)) __builtin_ia32_pause();
+        Index *cur = sh.index.load(std::memory_order_relaxed);
+        if (!cur) {
+            cur = new_index(64);
+            sh.index.store(cur, std::memory_order_release);
+        }
+        if (idx == ~0u) idx = probe(sh, cur, p, n, h); // somebody else may have inserted it
+        if (idx == ~0u) {
+            idx = sh.n_entries;
+            if (idx >= (1u << kIdxBits)) {
+                overflow.store(true, std::memory_order_relaxed);
+                sh.lock.store(false, std::memory_order_release);
+                return si << kIdxBits;
+            }
+            uint32_t k, at;
+            locate(idx, k, at);
+            if (!sh.hot[k]) {
+                sh.hot[k] = (Hot *)pool.alloc(sizeof(Hot) * ((size_t)kBlock0 << k));
+                sh.cold[k] = (Cold *)pool.alloc(sizeof(Cold) * ((size_t)kBlock0 << k));
+            }
+            if (sh.name_left < n) {
+                const size_t sz = std::max<size_t>(n, 4u << 10);
+                sh.name_cur = (char *)pool.alloc(sz);
+                sh.name_left = sz;
+            }
+            std::memcpy(sh.name_cur, p, n);
+            Hot *e = new (&sh.hot[k][at]) Hot();
+            e->name = sh.name_cur;
+            e->first_pos.store(pos, std::memory_order_relaxed);
+            sh.cold[k][at] = Cold{h, length, (uint32_t)n};
+            sh.name_cur += n;
+            sh.name_left -= n;
+            sh.n_entries = idx + 1;
+            if ((uint64_t)(idx + 2) * 2 > (uint64_t)cur->mask + 1) { // keep the load below 1/2
+                Index *bigger = new_index((cur->mask + 1) * 2);
+                for (uint32_t k2 = 0; k2 <= idx; k2++) {
+                    const Cold &c2 = cold(sh, k2);
+                    place(bigger, c2.hash, c2.nlen, k2);
+                }
+                sh.index.store(bigger, std::memory_order_release);
+            } else {
+                place(cur, h, (uint32_t)n, idx);
+            }
+        } else {
+            Hot &e = hot(sh, idx);
+            if (pos < e.first_pos.load(std::memory_order_relaxed)) {
+                cold(sh, idx).first_len = length;
+                e.first_pos.store(pos, std::memory_order_relaxed);
+            }
+        }
+        sh.lock.store(false, std::memory_order_release);
+        return (si << kIdxBits) | idx;
+    }
+};
+
+// One per parse thread.  Aligned and padded to its own cache lines: the threads update their
+// chunk's counters and vector ends on every line, and neighbours sharing a line cost 10x.
+struct alignas(256) Chunk {
     const char *begin = nullptr, *end = nullptr;
-    Names names;
-    std::vector<Rec> recs;
-    std::vector<uint32_t> l2g;
+    IdTable *ids = nullptr;
+    const char *text = nullptr; // start of the whole input (positions are relative to it)
+    big_vector<Rec> recs; // a / b hold IdTable handles until the global numbering exists
     std::string error;
     uint64_t error_line = 0; // 1-based within chunk
     uint64_t lines = 0;
@@ -201,8 +389,7 @@ inline bool scan_uint(const char *&p, const char *le, uint64_t limit, uint64_t &
 
 void parse_chunk_paf(Chunk &c)
 {
-    c.names.init(1 << 12);
-    c.recs.reserve((size_t)(c.end - c.begin) / 96 + 16);
+    c.recs.reserve((size_t)(c.end - c.begin) / 48 + 16); // untouched pages cost nothing
     const char *p = c.begin;
     while (p < c.end) {
         const char *eol = (const char *)std::memchr(p, '\n', (size_t)(c.end - p));
@@ -242,8 +429,9 @@ void parse_chunk_paf(Chunk &c)
         r.ea = (uint32_t)ea;
         r.sb = (uint32_t)sb;
         r.eb = (uint32_t)eb;
-        r.a = c.names.intern(ida, na, ha, la);
-        r.b = c.names.intern(idb, nb, hb, lb);
+        const uint64_t pos = (uint64_t)(p - c.text) * 2;
+        r.a = c.ids->intern(ida, na, ha, la, pos);
+        r.b = c.ids->intern(idb, nb, hb, lb, pos + 1);
         c.recs.push_back(r);
         p = eol + 1;
     }
@@ -253,8 +441,7 @@ void parse_chunk(Chunk &c, int format)
 {
     const char delim = format == FMT_PAF ? '\t' : ' ';
     const int need = format == FMT_PAF ? 9 : 12;
-    c.names.init(1 << 12);
-    c.recs.reserve((size_t)(c.end - c.begin) / 96 + 16);
+    c.recs.reserve((size_t)(c.end - c.begin) / 48 + 16); // untouched pages cost nothing
     const char *p = c.begin;
     const char *fb[12], *fe[12];
     while (p < c.end) {
@@ -314,8 +501,9 @@ void parse_chunk(Chunk &c, int format)
             return;
         }
         const size_t na = (size_t)(fe[ia] - fb[ia]), nb = (size_t)(fe[ib] - fb[ib]);
-        r.a = c.names.intern(fb[ia], na, yh::hash_bytes(fb[ia], na), la);
-        r.b = c.names.intern(fb[ib], nb, yh::hash_bytes(fb[ib], nb), lb);
+        const uint64_t pos = (uint64_t)(p - c.text) * 2;
+        r.a = c.ids->intern(fb[ia], na, yh::hash_bytes(fb[ia], na), la, pos);
+        r.b = c.ids->intern(fb[ib], nb, yh::hash_bytes(fb[ib], nb), lb, pos + 1);
         c.recs.push_back(r);
         p = eol + 1;
     }
@@ -341,6 +529,24 @@ void parallel_for(size_t n_tasks, size_t n_threads, F fn)
     for (auto &x : th) x.join();
 }
 
+// CPUs this process may actually use: hardware threads, capped by the cgroup CPU quota (a
+// container with cpu.max = "1600000 100000" gets 16 however many the machine has; threads beyond
+// the quota only get throttled).
+unsigned usable_cpus()
+{
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32] = {0};
+        unsigned long long period = 0;
+        if (std::fscanf(f, "%31s %llu", quota, &period) == 2 && period > 0 && std::strcmp(quota, "max") != 0) {
+            const unsigned long long q = std::strtoull(quota, nullptr, 10);
+            if (q > 0) n = std::min<unsigned>(n, (unsigned)std::max<unsigned long long>(1, (q + period - 1) / period));
+        }
+        std::fclose(f);
+    }
+    return n;
+}
+
 struct Phase {
     const bool on = std::getenv("YACRD_INGEST_TIMING") != nullptr;
     std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
@@ -357,19 +563,21 @@ struct Phase {
 int build(const char *text, size_t len, int format, int n_threads, yacrd_csr **out)
 {
     if (format != FMT_PAF && format != FMT_M4) return yh::fail("unknown overlap format");
-    // auto: all cores up to 64 — beyond that the per-chunk id tables (each chunk re-interns most
-    // ids) make the merge grow faster than the parse shrinks (profiles/r01_ingest*.json)
-    if (n_threads <= 0) n_threads = (int)std::min(64u, std::thread::hardware_concurrency());
+    // auto: every usable CPU up to 64
+    if (n_threads <= 0) n_threads = (int)std::min(64u, usable_cpus());
     if (n_threads <= 0) n_threads = 1;
     const size_t NT = (size_t)n_threads;
     // one chunk per thread, >= 2 MiB of text each
     const size_t T = std::max<size_t>(1, std::min<size_t>(NT, len / (2u << 20) + 1));
     Phase ph;
 
+    IdTable ids(T == 1 ? 1 : 1024);
     std::vector<Chunk> chunks(T);
     {
         const char *p = text, *end = text + len;
         for (size_t t = 0; t < T; t++) {
+            chunks[t].ids = &ids;
+            chunks[t].text = text;
             chunks[t].begin = p;
             const char *q = (t + 1 == T) ? end : text + len / T * (t + 1);
             if (q < p) q = p;
@@ -392,115 +600,92 @@ int build(const char *text, size_t len, int format, int n_threads, yacrd_csr **o
                             std::to_string(line0 + chunks[t].error_line) + ")");
         line0 += chunks[t].lines;
     }
+    if (ids.overflow.load()) return yh::fail("more than 2^32 - 2 reads");
     ph.mark("parse");
 
-    // ---- merge the per-chunk id tables.  Global numbering = first appearance in the file, and a
-    // read's length = the first length seen (fullmemory.rs:82-90): both are decided by the FIRST
-    // chunk (file order) that holds the id.  The id space is sharded by hash so shards merge in
-    // parallel; inside a shard, chunks are visited in file order.
-    size_t S = 1;
-    while (S < NT * 2 && S < 1024) S <<= 1;
-    if (T == 1) S = 1;
-    const int sshift = 64 - __builtin_ctzll((unsigned long long)S); // shard = hash >> sshift (S > 1)
-    auto shard_of = [&](uint64_t h) { return S == 1 ? (size_t)0 : (size_t)(h >> sshift); };
-
-    struct ChunkMerge {
-        std::vector<uint32_t> by_shard;  // local ids grouped by shard, local order inside a shard
-        std::vector<uint32_t> shard_off; // S + 1
-        std::vector<uint64_t> owner;     // per local id: owner (chunk << 32 | local id); self if first
+    // ---- global numbering = first appearance in the file = ascending first_pos.  Entries are
+    // bucketed by the chunk their first_pos lies in, buckets sorted in parallel.
+    const size_t S = ids.n_shards;
+    std::vector<uint64_t> shard_base(S + 1, 0);
+    for (size_t i = 0; i < S; i++) shard_base[i + 1] = shard_base[i] + ids.shards[i].n_entries;
+    const uint64_t R = shard_base[S];
+    if (R >= 0xFFFFFFFFull) return yh::fail("more than 2^32 - 2 reads");
+    struct Ord {
+        uint64_t pos;
+        uint32_t flat; // shard_base[shard] + index
     };
-    std::vector<ChunkMerge> cm(T);
-    parallel_for(T, NT, [&](size_t t) {
-        const Names &ln = chunks[t].names;
-        ChunkMerge &m = cm[t];
-        const size_t n = ln.off.size();
-        m.shard_off.assign(S + 1, 0);
-        for (size_t i = 0; i < n; i++) m.shard_off[shard_of(ln.hash[i]) + 1]++;
-        for (size_t sidx = 0; sidx < S; sidx++) m.shard_off[sidx + 1] += m.shard_off[sidx];
-        m.by_shard.resize(n);
-        std::vector<uint32_t> cur(m.shard_off.begin(), m.shard_off.end() - 1);
-        for (size_t i = 0; i < n; i++) m.by_shard[cur[shard_of(ln.hash[i])]++] = (uint32_t)i;
-        m.owner.resize(n);
+    std::vector<uint64_t> chunk_pos(T); // first position of each chunk
+    for (size_t t = 0; t < T; t++) chunk_pos[t] = (uint64_t)(chunks[t].begin - text) * 2;
+    auto bucket_of = [&](uint64_t pos) {
+        return (size_t)(std::upper_bound(chunk_pos.begin(), chunk_pos.end(), pos) - chunk_pos.begin()) - 1;
+    };
+    // per (shard, bucket) counts -> bucket-major offsets, then scatter
+    std::vector<uint32_t> cnt((size_t)S * T, 0);
+    parallel_for(S, NT, [&](size_t i) {
+        const IdTable::Shard &sh = ids.shards[i];
+        for (uint32_t k = 0; k < sh.n_entries; k++)
+            cnt[i * T + bucket_of(IdTable::hot(sh, k).first_pos.load(std::memory_order_relaxed))]++;
     });
-    parallel_for(S, NT, [&](size_t sidx) {
-        size_t total = 0;
-        for (size_t t = 0; t < T; t++) total += cm[t].shard_off[sidx + 1] - cm[t].shard_off[sidx];
-        size_t cap = 16;
-        while (cap < total * 2) cap <<= 1;
-        std::vector<uint64_t> tab(cap, ~0ull); // owner reference or empty
-        const size_t mask = cap - 1;
+    std::vector<uint64_t> bucket_off(T + 1, 0);
+    std::vector<uint64_t> cell_off((size_t)S * T);
+    {
+        uint64_t acc = 0;
         for (size_t t = 0; t < T; t++) {
-            const Names &ln = chunks[t].names;
-            ChunkMerge &m = cm[t];
-            for (uint32_t k = m.shard_off[sidx]; k < m.shard_off[sidx + 1]; k++) {
-                const uint32_t i = m.by_shard[k];
-                const uint64_t h = ln.hash[i];
-                size_t slot = (size_t)(h * 0x9E3779B97F4A7C15ull >> 20) & mask;
-                for (;;) {
-                    const uint64_t ref = tab[slot];
-                    if (ref == ~0ull) {
-                        tab[slot] = ((uint64_t)t << 32) | i;
-                        m.owner[i] = ((uint64_t)t << 32) | i;
-                        break;
-                    }
-                    const Names &on = chunks[ref >> 32].names;
-                    const uint32_t oi = (uint32_t)ref;
-                    if (on.hash[oi] == h && on.nlen[oi] == ln.nlen[i] &&
-                        std::memcmp(on.arena.data() + on.off[oi], ln.arena.data() + ln.off[i],
-                                    ln.nlen[i]) == 0) {
-                        m.owner[i] = ref;
-                        break;
-                    }
-                    slot = (slot + 1) & mask;
-                }
+            bucket_off[t] = acc;
+            for (size_t i = 0; i < S; i++) {
+                cell_off[i * T + t] = acc;
+                acc += cnt[i * T + t];
             }
         }
-    });
-    // owners of chunk t get consecutive global ids in local (= first appearance) order
-    std::vector<uint64_t> base(T + 1, 0);
-    for (size_t t = 0; t < T; t++) {
-        uint64_t own = 0;
-        const ChunkMerge &m = cm[t];
-        for (size_t i = 0; i < m.owner.size(); i++) own += m.owner[i] == (((uint64_t)t << 32) | i);
-        base[t + 1] = base[t] + own;
+        bucket_off[T] = acc;
     }
-    const uint64_t R = base[T];
-    if (R >= 0xFFFFFFFFull) return yh::fail("more than 2^32 - 2 reads");
+    big_vector<Ord> order(R);
+    parallel_for(S, NT, [&](size_t i) {
+        std::vector<uint64_t> cur(cell_off.begin() + i * T, cell_off.begin() + (i + 1) * T);
+        const IdTable::Shard &sh = ids.shards[i];
+        for (uint32_t k = 0; k < sh.n_entries; k++) {
+            const uint64_t fp = IdTable::hot(sh, k).first_pos.load(std::memory_order_relaxed);
+            order[cur[bucket_of(fp)]++] = Ord{fp, (uint32_t)(shard_base[i] + k)};
+        }
+    });
+    parallel_for(T, NT, [&](size_t t) {
+        std::sort(order.begin() + bucket_off[t], order.begin() + bucket_off[t + 1],
+                  [](const Ord &x, const Ord &y) { return x.pos < y.pos; });
+    });
+    // flat entry index -> (shard, index) needs the shard: walk the shards' flat ranges
+    big_vector<uint32_t> dense(R); // flat entry index -> global read id
     yacrd_csr *c = new yacrd_csr();
     c->lengths.resize(R);
     c->name_off.assign(R + 1, 0);
-    parallel_for(T, NT, [&](size_t t) {
-        Chunk &ch = chunks[t];
-        const ChunkMerge &m = cm[t];
-        ch.l2g.resize(m.owner.size());
-        uint32_t g = (uint32_t)base[t];
-        for (size_t i = 0; i < m.owner.size(); i++)
-            if (m.owner[i] == (((uint64_t)t << 32) | i)) {
-                ch.l2g[i] = g;
-                c->lengths[g] = (uint32_t)ch.names.rlen[i]; // first length seen
-                c->name_off[g + 1] = ch.names.nlen[i];
-                g++;
-            }
-    });
-    parallel_for(T, NT, [&](size_t t) {
-        Chunk &ch = chunks[t];
-        const ChunkMerge &m = cm[t];
-        for (size_t i = 0; i < m.owner.size(); i++) {
-            const uint64_t ref = m.owner[i];
-            if (ref != (((uint64_t)t << 32) | i)) ch.l2g[i] = chunks[ref >> 32].l2g[(uint32_t)ref];
+    auto shard_of_flat = [&](uint32_t flat) {
+        return (size_t)(std::upper_bound(shard_base.begin(), shard_base.end(), (uint64_t)flat) -
+                        shard_base.begin()) - 1;
+    };
+    parallel_for(NT, NT, [&](size_t w) {
+        for (uint64_t g = R * w / NT; g < R * (w + 1) / NT; g++) {
+            const uint32_t flat = order[g].flat;
+            const size_t i = shard_of_flat(flat);
+            const IdTable::Cold &e = IdTable::cold(ids.shards[i], (uint32_t)(flat - shard_base[i]));
+            dense[flat] = (uint32_t)g;
+            c->lengths[g] = (uint32_t)e.first_len; // first length seen
+            c->name_off[g + 1] = e.nlen;
         }
     });
     for (uint64_t g = 0; g < R; g++) c->name_off[g + 1] += c->name_off[g];
     c->names.resize(c->name_off[R]);
-    parallel_for(T, NT, [&](size_t t) {
-        const Chunk &ch = chunks[t];
-        const ChunkMerge &m = cm[t];
-        for (size_t i = 0; i < m.owner.size(); i++)
-            if (m.owner[i] == (((uint64_t)t << 32) | i))
-                std::memcpy(c->names.data() + c->name_off[ch.l2g[i]],
-                            ch.names.arena.data() + ch.names.off[i], ch.names.nlen[i]);
+    parallel_for(NT, NT, [&](size_t w) {
+        for (uint64_t g = R * w / NT; g < R * (w + 1) / NT; g++) {
+            const uint32_t flat = order[g].flat;
+            const size_t i = shard_of_flat(flat);
+            const uint32_t k = (uint32_t)(flat - shard_base[i]);
+            std::memcpy(c->names.data() + c->name_off[g], IdTable::hot(ids.shards[i], k).name,
+                        IdTable::cold(ids.shards[i], k).nlen);
+        }
     });
-    ph.mark("merge ids");
+    auto global_id = [&](uint32_t handle) {
+        return dense[shard_base[handle >> IdTable::kIdxBits] + (handle & ((1u << IdTable::kIdxBits) - 1))];
+    };
+    ph.mark("number ids");
 
     // ---- counts -> offsets -> fill ------------------------------------------------------------
     std::vector<std::atomic<uint64_t>> cur(R + 1);
@@ -510,8 +695,8 @@ int build(const char *text, size_t len, int format, int n_threads, yacrd_csr **o
     parallel_for(T, NT, [&](size_t t) {
         Chunk &ch = chunks[t];
         for (Rec &r : ch.recs) {
-            r.a = ch.l2g[r.a];
-            r.b = ch.l2g[r.b];
+            r.a = global_id(r.a);
+            r.b = global_id(r.b);
             cur[r.a].fetch_add(1, std::memory_order_relaxed);
             cur[r.b].fetch_add(1, std::memory_order_relaxed);
         }
@@ -543,6 +728,9 @@ int build(const char *text, size_t len, int format, int n_threads, yacrd_csr **o
     });
     for (auto &ch : chunks) c->n_records += ch.recs.size();
     ph.mark("csr fill");
+    // give the per-chunk arrays back in parallel (hundreds of MB of mappings)
+    parallel_for(T, NT, [&](size_t t) { big_vector<Rec>().swap(chunks[t].recs); });
+    ph.mark("teardown");
     *out = c;
     return 0;
 }

@@ -198,8 +198,10 @@ def main():
             got = eng.fetch()
             parity = bool(np.array_equal(got.bad_offsets, want[0]) and np.array_equal(got.bad_regions, want[1])
                           and np.array_equal(got.read_type, want[2]))
-            line["cpu_baseline"] = {"value": R / cpu_all, "unit": "reads/s", "cores": ncores, "kind": "port",
-                                    "sample": "the whole batch (%d reads, %d intervals) once on %d threads; "
+            line["cpu_baseline"] = {"value": R / cpu_all, "unit": "reads/s", "cores": ncores,
+                                    "hardware_threads": os.cpu_count(), "kind": "port",
+                                    "sample": "the whole batch (%d reads, %d intervals) once on %d threads (= usable CPUs: "
+                                              "hardware threads capped by the cgroup cpu.max quota); "
                                               "single-thread (reference default -t 1) on the first %d reads: %.0f reads/s"
                                               % (R, I, ncores, rs, rs / cpu_1),
                                     "value_1thread": rs / cpu_1}

@@ -78,6 +78,8 @@ typedef struct {
 /* count the reads the pre-filter thinned (yacrd_timing.prefiltered_reads); one global atomic per
  * read, so only for tests */
 #define YACRD_F_COUNT_PREFILTERED 512u
+/* record no HIP events at all (yacrd_timing stays 0): what a caller that only wants results uses */
+#define YACRD_F_NO_TIMING 1024u
 
 /* Host-side result, allocated by the engine, released with yacrd_result_free(). */
 typedef struct {

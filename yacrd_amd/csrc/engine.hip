@@ -400,7 +400,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     int cls_b[12], cls_e[12]; // event indices bracketing each class, -1 = not recorded
     for (int i = 0; i < 12; i++) cls_b[i] = cls_e[i] = -1;
     int n_cls_ev = 0, dom_cls = -1;
-    bool timing_on = true;
+    bool timing_on = !(e->flags & YACRD_F_NO_TIMING);
     auto before_class = [&](int cls) -> hipError_t {
         if (!timing_on || !(full || cls == dom_cls)) return hipSuccess;
         if (n_cls_ev > 0 && full) { // the previous class's end mark is this one's begin mark

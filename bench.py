@@ -39,8 +39,8 @@ def usable_cpus():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--reads", type=int, default=100_000)
     ap.add_argument("--overlaps", type=int, default=5_000_000)
     ap.add_argument("--profile", default="ont", choices=["ont", "sequel", "skewed"])

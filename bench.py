@@ -14,6 +14,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -49,6 +50,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lds-sort", action="store_true", help="A/B: LDS-sort kernel for the small class")
     ap.add_argument("--flags", type=int, default=0, help="extra YACRD_F_* engine flags (A/B)")
+    ap.add_argument("--engines", type=int, default=3,
+                    help="engines (host threads, HIP streams) the batches are pipelined over on each GPU")
     ap.add_argument("--full-timing", action="store_true",
                     help="HIP events around every phase and class kernel (slower steps)")
     args = ap.parse_args()
@@ -86,32 +89,70 @@ def main():
     flags = (yacrd_amd.F_FORCE_LDS_SORT if args.lds_sort else 0) | args.flags
     if args.full_timing:
         flags |= yacrd_amd.F_TIMING_FULL
-    eng = yacrd_amd.Engine(device_id=dev_index, flags=flags)
+    # Batches are pipelined over `--engines` engines on this GPU, one host thread each: the plan /
+    # compaction kernels, the counter copy and the launch gaps of one batch hide behind the sweep
+    # of another (the engines take turns with that launch, so its event bracket times the kernel,
+    # not the queue).  With more than one engine the final wait of a run sleeps instead of
+    # spinning (1.5 CPUs for three engines: eight ranks fit a 16-CPU quota).
+    NE = max(1, min(args.engines, args.steps))
+    if NE > 1:
+        flags |= yacrd_amd.F_BLOCKING_WAIT
+    engs = [yacrd_amd.Engine(device_id=dev_index, flags=flags) for _ in range(NE)]
+    eng = engs[0]
 
-    def step():
-        return eng.run_device(d_off.data_ptr(), d_iv.data_ptr(), d_len.data_ptr(), R, I, cov,
-                              args.not_coverage)
+    def step(e=eng):
+        return e.run_device(d_off.data_ptr(), d_iv.data_ptr(), d_len.data_ptr(), R, I, cov,
+                            args.not_coverage)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for e in engs:
+        for _ in range(args.warmup):
+            step(e)
     keys = ("plan_ms", "sweep_small_ms", "sweep_medium_ms", "sweep_general_ms", "compact_ms", "total_ms")
     acc = dict.fromkeys(keys, 0.0)
     cls_ms = [0.0] * 12
-    eng.timing_total(reset=True)
+    for e in engs:
+        e.timing_total(reset=True)
+    share = [args.steps // NE + (1 if i < args.steps % NE else 0) for i in range(NE)]  # sums to K
+    outs = [None] * NE
+    go = threading.Barrier(NE + 1)
+
+    def worker(i):
+        go.wait()
+        for _ in range(share[i]):
+            outs[i] = step(engs[i])
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(NE)] if NE > 1 else []
+    for th in threads:
+        th.start()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
+    if NE > 1:
+        go.wait()
+        for th in threads:
+            th.join()
+    else:
+        for _ in range(args.steps):
+            outs[0] = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    # HIP events recorded on the engine's stream inside every run_device of the timed region,
-    # summed by the engine (one read-back instead of one per step)
-    t, n_timed = eng.timing_total()
+    out = outs[0]
+    # HIP events recorded on the engines' streams inside every run_device of the timed region,
+    # summed by the engines (one read-back each instead of one per step)
+    t, n_timed = None, 0
+    for e in engs:
+        te, ne = e.timing_total()
+        n_timed += ne
+        if t is None:
+            t = te
+        else:
+            for k2, v in te.items():
+                if k2.endswith("_ms"):
+                    t[k2] = [a + b for a, b in zip(t[k2], v)] if isinstance(v, list) else t[k2] + v
     assert n_timed == args.steps
     ev_overhead_ms = eng.event_overhead_ms()
     for k in keys:
@@ -171,7 +212,7 @@ def main():
             "config": {"workload": "configs[1]: synthetic %s pile-up, %d reads / %d PAF overlaps per GPU, -c %d -n %g, inputs resident in HBM"
                                    % (args.profile.upper(), R, args.overlaps, cov, args.not_coverage),
                        "reads_per_gpu": R, "overlaps_per_gpu": args.overlaps, "intervals_per_gpu": I,
-                       "regions_per_gpu": G, "parallelism": "read-partition x%d, no collective" % world},
+                       "regions_per_gpu": G, "parallelism": "read-partition x%d, no collective; %d batches in flight per GPU (one engine each)" % (world, NE)},
             "overlaps_per_sec": world * args.overlaps * K / elapsed,
             "kernel_ms": avg,
             "path_gbps": b_alg / (avg["total_ms"] * 1e-3) / 1e9 if avg.get("total_ms") else None,
@@ -236,7 +277,8 @@ def main():
             except Exception as ex:  # the host library is optional for the GPU metric
                 line["ingest"] = {"error": str(ex)}
         print(json.dumps(line), flush=True)
-    eng.close()
+    for e in engs:
+        e.close()
     if dist is not None:
         dist.destroy_process_group()
 

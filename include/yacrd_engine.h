@@ -80,6 +80,9 @@ typedef struct {
 #define YACRD_F_COUNT_PREFILTERED 512u
 /* record no HIP events at all (yacrd_timing stays 0): what a caller that only wants results uses */
 #define YACRD_F_NO_TIMING 1024u
+/* the run's final wait sleeps on a blocking-sync event instead of spinning in
+ * hipStreamSynchronize: for several engines per CPU core (pipelined batches, many GPUs) */
+#define YACRD_F_BLOCKING_WAIT 2048u
 
 /* Host-side result, allocated by the engine, released with yacrd_result_free(). */
 typedef struct {

@@ -283,3 +283,30 @@ def test_class_prediction_is_validated():
             want = oracle.run(csr[0], csr[1], csr[2].astype(np.uint64), 3, 0.4, n_threads=4)
             assert_same(e.run(*csr, 3, 0.4), want, "predicted run %d" % rep)
             assert_same(ref.run(*csr, 3, 0.4), want, "unpredicted run %d" % rep)
+
+
+def test_pipelined_engines_on_one_device():
+    """Several engines on one GPU driven by one host thread each (bench.py's pipeline): the engines
+    take turns with the dominant sweep, waits sleep (YACRD_F_BLOCKING_WAIT); every run of every
+    engine is bit-exact."""
+    import threading
+    rng = np.random.default_rng(77)
+    batches = [make_csr(4000 + i, rng.integers(0, 300, size=1500), REGULAR_MODES) for i in range(3)]
+    wants = [oracle.run(b[0], b[1], b[2].astype(np.uint64), 3, 0.4, n_threads=4) for b in batches]
+    errors = []
+
+    def work(i):
+        try:
+            with yacrd_amd.Engine(flags=yacrd_amd.F_BLOCKING_WAIT) as e:
+                for rep in range(40):
+                    k = (i + rep) % 3
+                    assert_same(e.run(*batches[k], 3, 0.4), wants[k], "engine %d rep %d" % (i, rep))
+        except Exception as ex:  # surfaced in the main thread
+            errors.append(ex)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[0]

@@ -10,7 +10,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <time.h>
+
 #include <algorithm>
+#include <mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -78,13 +81,24 @@ enum { EV_START = 0, EV_PLAN, EV_S0, EV_SMALL, EV_MED, EV_GEN, EV_COMPACT, EV_X0
 
 } // namespace
 
+// One per device: whose dominant sweep went out last (see launch_sweeps).
+struct BigLane {
+    std::mutex mu;
+    hipEvent_t last = nullptr;
+    struct yacrd_engine *owner = nullptr;
+    int n_engines = 0;
+};
+static BigLane g_big_lane[64];
+
 struct yacrd_engine {
+    bool in_lane = false;
     int device = 0;
     uint32_t flags = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[EV_COUNT] = {};
     hipEvent_t ev_h2d0 = nullptr, ev_h2d1 = nullptr, ev_d2h0 = nullptr, ev_d2h1 = nullptr;
     hipEvent_t ev_cls[24] = {}; // brackets around class kernels
+    hipEvent_t ev_done = nullptr; // hipEventBlockingSync: the final wait of YACRD_F_BLOCKING_WAIT
     int num_cu = 256;
 
     // inputs staged by yacrd_engine_run
@@ -447,13 +461,25 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
             if (fa.n_entries) {
                 any_small = true;
                 const bool mark = timing_on && (full || has_dom);
+                // Engines that share a device (batches pipelined over several engines, one host
+                // thread each) take turns with this launch: it fills the GPU on its own, two of
+                // them side by side would only stretch each other, while the small kernels,
+                // copies and launch gaps of one engine hide behind the sweep of another.  The
+                // turn is a GPU-side wait on the previous engine's end-of-sweep event, taken
+                // before the bracket opens, so the bracket times the kernel and not the queue.
+                BigLane &lane = g_big_lane[e->device & 63];
+                std::lock_guard<std::mutex> turn(lane.mu);
+                const bool shared = lane.owner != nullptr && lane.owner != e;
+                if (shared) HIP_TRY(hipStreamWaitEvent(e->stream, lane.last, 0));
                 if (mark) HIP_TRY(hipEventRecord(e->ev_cls[22], e->stream));
                 hipLaunchKernelGGL(yk::sweep_small_fused_kernel, dim3(blocks), dim3(256), 0,
                                    e->stream, fa);
-                if (mark) {
+                if (mark || shared || lane.n_engines > 1) {
                     HIP_TRY(hipEventRecord(e->ev_cls[23], e->stream));
-                    fused_marked = true;
+                    lane.last = e->ev_cls[23];
+                    lane.owner = e;
                 }
+                if (mark) fused_marked = true;
             }
         }
         for (int cls = yk::CLS_R2; cls <= yk::CLS_W16; cls++) { // register sort per lane group
@@ -558,7 +584,18 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     if (rc) return rc;
     if (full) HIP_TRY(hipEventRecord(e->ev[EV_COMPACT], e->stream));
     // (spinning on the pinned counter block instead of this call was tried: 0.0816 vs 0.078 ms/step)
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->flags & YACRD_F_BLOCKING_WAIT) { // sleep instead of spinning: for many engines per core
+        HIP_TRY(hipEventRecord(e->ev_done, e->stream));
+        for (;;) { // (hipEventSynchronize spins as well, blocking-sync flag or not)
+            const hipError_t q = hipEventQuery(e->ev_done);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) HIP_TRY(q);
+            struct timespec ts = {0, 20000};
+            nanosleep(&ts, nullptr);
+        }
+    } else {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
     HIP_TRY(hipGetLastError());
     timing_on = false;
 
@@ -757,6 +794,7 @@ int yacrd_engine_create(const yacrd_engine_cfg *cfg, yacrd_engine **out)
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     for (int i = 0; i < EV_COUNT && err == hipSuccess; i++) err = hipEventCreate(&e->ev[i]);
     for (int i = 0; i < 24 && err == hipSuccess; i++) err = hipEventCreate(&e->ev_cls[i]);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_done, hipEventBlockingSync | hipEventDisableTiming);
     if (err == hipSuccess) err = hipEventCreate(&e->ev_h2d0);
     if (err == hipSuccess) err = hipEventCreate(&e->ev_h2d1);
     if (err == hipSuccess) err = hipEventCreate(&e->ev_d2h0);
@@ -765,6 +803,12 @@ int yacrd_engine_create(const yacrd_engine_cfg *cfg, yacrd_engine **out)
     if (err != hipSuccess) {
         yacrd_engine_destroy(e);
         return fail(YACRD_ENODEV, std::string("engine setup: ") + hipGetErrorString(err));
+    }
+    {
+        BigLane &lane = g_big_lane[dev & 63];
+        std::lock_guard<std::mutex> g(lane.mu);
+        lane.n_engines++;
+        e->in_lane = true;
     }
     *out = e;
     return YACRD_OK;
@@ -775,6 +819,15 @@ void yacrd_engine_destroy(yacrd_engine *e)
     if (!e) return;
     DeviceGuard guard(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->in_lane) {
+        BigLane &lane = g_big_lane[e->device & 63];
+        std::lock_guard<std::mutex> g(lane.mu);
+        lane.n_engines--;
+        if (lane.owner == e) { // its event dies with it (its work is done: synchronized above)
+            lane.owner = nullptr;
+            lane.last = nullptr;
+        }
+    }
     DevBuf *bufs[] = {&e->in_off, &e->in_iv, &e->in_len, &e->lists, &e->ctrl2[0], &e->ctrl2[1], &e->stage,
                       &e->counts, &e->gen_sizes, &e->gen_scratch_off,
                       &e->gen_scratch, &e->big_tab, &e->big_keys, &e->big_redo,

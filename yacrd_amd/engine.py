@@ -22,6 +22,7 @@ F_NO_FUSED_LAUNCH = 128
 F_NO_PREFILTER = 256
 F_COUNT_PREFILTERED = 512
 F_NO_TIMING = 1024
+F_BLOCKING_WAIT = 2048
 
 # every symbol include/yacrd_engine.h declares
 EXPORTED_SYMBOLS = [

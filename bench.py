@@ -181,10 +181,10 @@ def main():
             dom_ms = cls_ms[ci] / K
             c_reads, c_iv = t["class_reads"][ci], t["class_intervals"][ci]
         b_dom = 8 * c_iv + 21 * c_reads + 16 + 8 * (G * c_reads // max(R, 1))
-        # dom_ms is the HIP-event bracket around the launch, event latency included: an EMPTY
-        # bracket on the same stream measures ~4.7 us, rocprofv3 --kernel-trace (dispatch
-        # timestamps) gives ~2-3 us less than the bracket.  The roofline uses the bracket as it is
-        # (the conservative figure); the empty bracket is reported next to it.
+        # dom_ms: HIP start / stop events attached to the launch itself (hipExtLaunchKernelGGL: the
+        # dispatch's own timestamps, the figure rocprofv3 --kernel-trace reports), averaged over
+        # every launch of the timed region.  An EMPTY hipEventRecord pair on the same stream measures
+        # ~5 us, which is why the events are not recorded around the launch.
         achieved = b_dom / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         avg["class_ms"] = {yacrd_amd.CLASS_NAMES[i]: cls_ms[i] / K for i in range(12) if cls_ms[i] > 0}
         if t["fused_ms"] > 0:

@@ -103,8 +103,9 @@ typedef struct {
 } yacrd_device_result;
 
 /* Wall times of the last run, measured with HIP events on the engine's stream.  An event costs
- * ~3 us of stream time, so by default only the dominant kernel is bracketed (class_ms of the class
- * with the most intervals, or fused_ms); plan_ms, sweep_*_ms, compact_ms, total_ms and class_ms
+ * ~3 us of stream time, so by default only the dominant kernel is timed (class_ms of the class
+ * with the most intervals, or fused_ms — the latter with start / stop events attached to the
+ * launch, i.e. the dispatch's own timestamps); plan_ms, sweep_*_ms, compact_ms, total_ms and class_ms
  * of the other classes need YACRD_F_TIMING_FULL and are 0 without it. */
 typedef struct {
     float h2d_ms;

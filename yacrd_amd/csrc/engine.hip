@@ -9,6 +9,7 @@
 #include "../../include/yacrd_engine.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <time.h>
 
@@ -472,11 +473,13 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
                 std::lock_guard<std::mutex> turn(lane.mu);
                 const bool shared = lane.owner != nullptr && lane.owner != e;
                 if (shared) HIP_TRY(hipStreamWaitEvent(e->stream, lane.last, 0));
-                if (mark) HIP_TRY(hipEventRecord(e->ev_cls[22], e->stream));
-                hipLaunchKernelGGL(yk::sweep_small_fused_kernel, dim3(blocks), dim3(256), 0,
-                                   e->stream, fa);
-                if (mark || shared || lane.n_engines > 1) {
-                    HIP_TRY(hipEventRecord(e->ev_cls[23], e->stream));
+                // start / stop events attached to the launch itself (hipExtLaunchKernelGGL): the
+                // kernel's own dispatch timestamps, no event packets before and after it
+                const bool chain = shared || lane.n_engines > 1;
+                hipExtLaunchKernelGGL(yk::sweep_small_fused_kernel, dim3(blocks), dim3(256), 0,
+                                      e->stream, mark ? e->ev_cls[22] : (hipEvent_t) nullptr,
+                                      (mark || chain) ? e->ev_cls[23] : (hipEvent_t) nullptr, 0, fa);
+                if (mark || chain) {
                     lane.last = e->ev_cls[23];
                     lane.owner = e;
                 }

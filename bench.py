@@ -95,7 +95,7 @@ def main():
     # not the queue).  With more than one engine the final wait of a run sleeps instead of
     # spinning (1.5 CPUs for three engines: eight ranks fit a 16-CPU quota).
     NE = max(1, min(args.engines, args.steps))
-    if NE > 1:
+    if NE > 1 and not os.environ.get("YACRD_BENCH_SPIN"):  # (A/B: spinning waits)
         flags |= yacrd_amd.F_BLOCKING_WAIT
     engs = [yacrd_amd.Engine(device_id=dev_index, flags=flags) for _ in range(NE)]
     eng = engs[0]

@@ -67,21 +67,23 @@ typedef struct {
 /* no two-reads-per-wavefront layout for reads of 129..256 intervals; A/B only */
 #define YACRD_F_NO_HALVES 16u
 /* record HIP events around every phase and every class kernel (costs ~3 us of stream time per
- * event); by default only the total and the dominant class kernel are bracketed */
+ * event); by default only the dominant class kernel is timed */
 #define YACRD_F_TIMING_FULL 32u
 /* always wait for the plan's class counts (no prediction from the previous run); A/B only */
 #define YACRD_F_NO_PREDICTION 64u
 /* one launch per register-sort class instead of the fused launch; A/B only */
 #define YACRD_F_NO_FUSED_LAUNCH 128u
-/* sort every event: skip the coverage pre-filter of the register-sort classes (A/B, tests) */
+/* sort every event: skip the coverage pre-filter (register-sort and LDS classes; A/B, tests) */
 #define YACRD_F_NO_PREFILTER 256u
 /* count the reads the pre-filter thinned (yacrd_timing.prefiltered_reads); one global atomic per
  * read, so only for tests */
 #define YACRD_F_COUNT_PREFILTERED 512u
 /* record no HIP events at all (yacrd_timing stays 0): what a caller that only wants results uses */
 #define YACRD_F_NO_TIMING 1024u
-/* the run's final wait sleeps on a blocking-sync event instead of spinning in
- * hipStreamSynchronize: for several engines per CPU core (pipelined batches, many GPUs) */
+/* the run's final wait polls an event and sleeps in between instead of spinning in
+ * hipStreamSynchronize: for several engines per CPU core (pipelined batches, many GPUs).
+ * Engines created on the same device (one host thread each) pipeline their batches: they take
+ * turns with the dominant sweep launch, everything else overlaps. */
 #define YACRD_F_BLOCKING_WAIT 2048u
 
 /* Host-side result, allocated by the engine, released with yacrd_result_free(). */

@@ -160,3 +160,20 @@ def test_partition_reads_balances_intervals():
         assert cuts[0] == 0 and cuts[-1] == 5000 and (np.diff(cuts.astype(np.int64)) >= 0).all()
         work = [int(o[int(cuts[i + 1])] - o[int(cuts[i])]) for i in range(parts)]
         assert max(work) - min(work) <= 0.05 * (200000 / parts) + 200
+
+
+def test_ingest_is_identical_for_every_thread_count(tmp_path):
+    """Shared id table + per-chunk fill cursors: names, lengths, offsets AND the order of the
+    intervals inside every read equal the single-threaded (= line order, = oracle) result."""
+    import oracle
+    paf = str(tmp_path / "t.paf")
+    host.synth_paf(host.SYNTH_ONT, 20000, 300000, 11, paf)
+    with open(paf) as f:
+        names, off, iv, ln = oracle.to_csr(oracle.parse_paf(f))
+    iv = np.asarray(iv).reshape(-1, 2)
+    for th in (1, 3, 8, 32):
+        c = host.csr_from_file(paf, n_threads=th)
+        assert c.names == list(names)
+        assert np.array_equal(c.lengths, np.asarray(ln).astype(np.uint32))
+        assert np.array_equal(c.offsets, off)
+        assert np.array_equal(c.intervals.reshape(-1, 2), iv), th

@@ -688,44 +688,97 @@ int build(const char *text, size_t len, int format, int n_threads, yacrd_csr **o
     ph.mark("number ids");
 
     // ---- counts -> offsets -> fill ------------------------------------------------------------
-    std::vector<std::atomic<uint64_t>> cur(R + 1);
-    parallel_for(NT, NT, [&](size_t w) {
-        for (uint64_t r = R * w / NT; r < R * (w + 1) / NT; r++) cur[r].store(0, std::memory_order_relaxed);
-    });
+    // Each chunk counts the intervals it holds per read in a private array, a pass over the reads
+    // turns the counts into every chunk's first write position inside every read (chunk order =
+    // file order), and the chunks fill their slices: no atomics, and the intervals of a read come
+    // out in line order whatever the thread count.  When T private arrays of R counters would
+    // be too big (> 1 GiB), fall back to shared atomic cursors (order inside a read then depends
+    // on thread timing; results do not: the sweep sorts).
     parallel_for(T, NT, [&](size_t t) {
-        Chunk &ch = chunks[t];
-        for (Rec &r : ch.recs) {
+        for (Rec &r : chunks[t].recs) {
             r.a = global_id(r.a);
             r.b = global_id(r.b);
-            cur[r.a].fetch_add(1, std::memory_order_relaxed);
-            cur[r.b].fetch_add(1, std::memory_order_relaxed);
         }
     });
     c->offsets.resize(R + 1);
-    uint64_t acc = 0;
-    for (uint64_t r = 0; r < R; r++) {
-        c->offsets[r] = acc;
-        const uint64_t n = cur[r].load(std::memory_order_relaxed);
-        cur[r].store(acc, std::memory_order_relaxed);
-        acc += n;
-    }
-    c->offsets[R] = acc;
-    // new[] without () leaves the 8 B/interval buffer untouched: a vector would zero it on one
-    // thread (tens of ms for 10^7 intervals) before the parallel fill overwrites every word
-    c->intervals.reset(new uint32_t[2 * acc + 2]);
-    uint32_t *iv = c->intervals.get();
-    // With one chunk the fill is in line order; with several, the order inside a read depends on
-    // thread timing (results do not: the sweep sorts).
-    parallel_for(T, NT, [&](size_t t) {
-        for (const Rec &r : chunks[t].recs) {
-            uint64_t p = cur[r.a].fetch_add(1, std::memory_order_relaxed);
-            iv[2 * p] = r.sa;
-            iv[2 * p + 1] = r.ea;
-            p = cur[r.b].fetch_add(1, std::memory_order_relaxed);
-            iv[2 * p] = r.sb;
-            iv[2 * p + 1] = r.eb;
+    const bool private_counts = (uint64_t)T * R * sizeof(uint32_t) <= (1ull << 30);
+    if (private_counts) {
+        std::vector<big_vector<uint32_t>> cnt2(T);
+        parallel_for(T, NT, [&](size_t t) {
+            cnt2[t].assign(R, 0u);
+            uint32_t *k = cnt2[t].data();
+            for (const Rec &r : chunks[t].recs) {
+                k[r.a]++;
+                k[r.b]++;
+            }
+        });
+        // per read: total, and the exclusive prefix over chunks (in place)
+        big_vector<uint64_t> tot(R);
+        parallel_for(NT, NT, [&](size_t w) {
+            for (uint64_t r = R * w / NT; r < R * (w + 1) / NT; r++) {
+                uint64_t acc2 = 0;
+                for (size_t t = 0; t < T; t++) {
+                    const uint32_t n = cnt2[t][r];
+                    cnt2[t][r] = (uint32_t)acc2;
+                    acc2 += n;
+                }
+                tot[r] = acc2;
+            }
+        });
+        uint64_t acc = 0;
+        for (uint64_t r = 0; r < R; r++) {
+            c->offsets[r] = acc;
+            acc += tot[r];
         }
-    });
+        c->offsets[R] = acc;
+        // new[] without () leaves the 8 B/interval buffer untouched: a vector would zero it on
+        // one thread (tens of ms for 10^7 intervals) before the parallel fill overwrites every word
+        c->intervals.reset(new uint32_t[2 * acc + 2]);
+        uint32_t *iv = c->intervals.get();
+        parallel_for(T, NT, [&](size_t t) {
+            uint32_t *k = cnt2[t].data(); // this chunk's next slot inside each read
+            const uint64_t *off = c->offsets.data();
+            for (const Rec &r : chunks[t].recs) {
+                uint64_t p = off[r.a] + k[r.a]++;
+                iv[2 * p] = r.sa;
+                iv[2 * p + 1] = r.ea;
+                p = off[r.b] + k[r.b]++;
+                iv[2 * p] = r.sb;
+                iv[2 * p + 1] = r.eb;
+            }
+        });
+    } else {
+        std::vector<std::atomic<uint64_t>> cur(R + 1);
+        parallel_for(NT, NT, [&](size_t w) {
+            for (uint64_t r = R * w / NT; r < R * (w + 1) / NT; r++) cur[r].store(0, std::memory_order_relaxed);
+        });
+        parallel_for(T, NT, [&](size_t t) {
+            for (const Rec &r : chunks[t].recs) {
+                cur[r.a].fetch_add(1, std::memory_order_relaxed);
+                cur[r.b].fetch_add(1, std::memory_order_relaxed);
+            }
+        });
+        uint64_t acc = 0;
+        for (uint64_t r = 0; r < R; r++) {
+            c->offsets[r] = acc;
+            const uint64_t n = cur[r].load(std::memory_order_relaxed);
+            cur[r].store(acc, std::memory_order_relaxed);
+            acc += n;
+        }
+        c->offsets[R] = acc;
+        c->intervals.reset(new uint32_t[2 * acc + 2]);
+        uint32_t *iv = c->intervals.get();
+        parallel_for(T, NT, [&](size_t t) {
+            for (const Rec &r : chunks[t].recs) {
+                uint64_t p = cur[r.a].fetch_add(1, std::memory_order_relaxed);
+                iv[2 * p] = r.sa;
+                iv[2 * p + 1] = r.ea;
+                p = cur[r.b].fetch_add(1, std::memory_order_relaxed);
+                iv[2 * p] = r.sb;
+                iv[2 * p + 1] = r.eb;
+            }
+        });
+    }
     for (auto &ch : chunks) c->n_records += ch.recs.size();
     ph.mark("csr fill");
     // give the per-chunk arrays back in parallel (hundreds of MB of mappings)

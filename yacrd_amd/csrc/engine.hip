@@ -6,6 +6,8 @@
 //   -> exact general path (LDS scratch for rejected reads; global scratch for huge reads)
 //   -> compact_classify (single-pass scan) -> sync.
 //   Rare redo: degenerate reads too large for LDS, or bad_regions too small.
+// Several engines may share a device (one host thread each): their batches pipeline, the engines
+// take turns with the dominant sweep launch (BigLane).
 #include "../../include/yacrd_engine.h"
 
 #include <hip/hip_runtime.h>

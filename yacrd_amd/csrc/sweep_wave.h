@@ -1,4 +1,5 @@
-// sweep_wave.h — small class (<= 1024 events): one read per wavefront, everything in registers.
+// sweep_wave.h — small classes (<= 1024 events): one, two or four reads per wavefront, sorted in
+// registers; a coverage pre-filter in front of the sort for the 16-keys-per-lane classes.
 //
 // Same event formulation as sweep_lds.h (reference src/stack.rs:61-139 for regular reads), but
 // the dominant cost — sorting the 2n event keys — runs as a bitonic network over VGPRs:
@@ -9,7 +10,8 @@
 //     no LDS memory is touched), each followed by ONE v_med3_u32: med3(x, partner, 0) = min,
 //     med3(x, partner, ~0) = max, the third operand being a per-lane constant that encodes
 //     "upper lane of the pair" xor "descending block".
-// No LDS allocation, no barriers: a 256-thread workgroup is four independent wavefronts.
+// The sort touches no LDS memory and no barrier: a 256-thread workgroup is four independent
+// wavefronts (the pre-filter keeps a small histogram and its survivors in LDS, per wavefront).
 // Pads are end-like keys (0xFFFFFFFE) and depth compares are signed, so nothing after the sort
 // needs a validity mask (a read without intervals falls out as [(0,len)] on its own).
 // Reads of <= 128 intervals use 16-lane groups: four reads per wavefront (see sweep_group_read).

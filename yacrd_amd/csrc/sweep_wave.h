@@ -586,7 +586,7 @@ struct FusedArgs {
     const u32 *list_n[5];
 };
 
-__global__ __launch_bounds__(256, 5) void sweep_small_fused_kernel(FusedArgs f)
+__global__ __launch_bounds__(256, 6) void sweep_small_fused_kernel(FusedArgs f)
 {
     u32 e = 0, first = 0;
     while (e + 1 < f.n_entries && blockIdx.x >= f.block_end[e]) {

@@ -244,18 +244,21 @@ __device__ __forceinline__ void sweep_group_keys(u32 (&x)[K], u32 m, u32 len, i3
     const u32 len_key = len > kMaxKeyPos ? 0xFFFFFFFFu : (len << kKeyShift);
     u32 mf_incl, ml_incl, mf_in, ml_in;
     u32 cnt = 0, fb = 0, fe = 0, cand = kNoKey;
+    // The loops carry dd = depth + (index inside the lane): one instruction per key (dd += 2 *
+    // start bit) instead of a select and an add; "depth > c" becomes dd > c + q with c + q a
+    // scalar, and the tail test (starts before == all starts) dd == tail_base.
     auto passes = [&](auto zl_tag) {
         constexpr bool ZL = decltype(zl_tag)::value;
         u32 mf = 0, ml = 0;
-        i32 d = depth_in;
+        i32 dd = depth_in;
 #pragma unroll
         for (int q = 0; q < K; q++) {
-            const u32 key = x[q];
-            const bool is_s = (key & 1u) != 0, gt = d > c;
+            const u32 key = x[q], bit = key & 1u;
+            const bool is_s = bit != 0, gt = dd > c + q;
             ml = (is_s && !gt) ? key : ml;
             if (ZL) mf = (!is_s && gt) ? max(mf, key ^ 2u) : mf;
             else mf = (!is_s && gt) ? key : mf;
-            d += is_s ? 1 : -1;
+            dd += (i32)(bit << 1);
         }
         if (!ZL) mf = mf ? (mf ^ 2u) : 0u;
         mf_incl = gscan_max<LANES>(mf);
@@ -265,11 +268,11 @@ __device__ __forceinline__ void sweep_group_keys(u32 (&x)[K], u32 m, u32 len, i3
 
         u32 tc = ZL ? mf_in : (mf_in ^ 2u); // ZL: flipped domain; else true key, "none" = 3
         u32 cml = ml_in;
-        d = depth_in;
+        dd = depth_in;
 #pragma unroll
         for (int q = 0; q < K; q++) {
-            const u32 key = x[q];
-            const bool is_s = (key & 1u) != 0, gt = d > c;
+            const u32 key = x[q], bit = key & 1u;
+            const bool is_s = bit != 0, gt = dd > c + q;
             const bool fl = !is_s && gt, low = is_s && !gt;
             const bool eff = ZL ? (fl && (key ^ 2u) > tc) : fl;
             const u32 begin = ZL ? (tc ^ 2u) : tc;
@@ -277,11 +280,11 @@ __device__ __forceinline__ void sweep_group_keys(u32 (&x)[K], u32 m, u32 len, i3
             cnt += close ? 1u : 0u;
             fb = close ? begin : fb;
             fe = close ? cml : fe;
-            const bool tail = fl && ((u32)d + (u32)q == tail_base) && key >= len_key;
+            const bool tail = fl && ((u32)dd == tail_base) && key >= len_key;
             cand = min(cand, tail ? (key >> kKeyShift) : kNoKey);
             tc = eff ? (ZL ? (key ^ 2u) : key) : tc;
             cml = low ? key : cml;
-            d += is_s ? 1 : -1;
+            dd += (i32)(bit << 1);
         }
     };
     if (zmask == 0) passes(std::false_type{}); // wave-uniform
@@ -454,7 +457,7 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
                                                  const SweepArgs &a, const LaneConst &lc)
 {
     const u32 lane = lane_id(), lig = lane & (u32)(LANES - 1);
-    const i32 c = (i32)min(cov, 0x7FFFFFFFu);
+    const i32 c = (i32)min(cov, 0x3FFFFFFFu); // depths are <= 1024: every larger c behaves the same, and c + q cannot overflow
 
     // ---- coalesced interval loads (8 B/lane), keys straight into registers
     u32 x[K];

@@ -200,12 +200,19 @@ __device__ __forceinline__ u32 gscan_min(u32 v)
 // m = number of real keys of the group (the rest are pads); zl_check = the wavefront holds >= 2
 // zero-length intervals (duplicates must be looked for after the sort).
 template <int LANES, int K, int XM>
-__device__ __forceinline__ void sweep_group_keys(u32 (&x)[K], u32 m, u32 len, i32 c, uint2 *slot,
+__device__ __forceinline__ void sweep_group_keys(u32 (&x)[K], u32 m, u32 len, i32 c,
                                                  bool active, u32 r, u64 badmask, u64 zmask,
                                                  bool zl_check, const SweepArgs &a,
                                                  const LaneConst &lc)
 {
     const u32 lane = lane_id(), lig = lane & (u32)(LANES - 1);
+    // the read's region slot, looked up again where it is needed (rarely, and by few lanes):
+    // kept as a pointer it costs two registers from the loads to the last line
+    auto slot_of = [&]() {
+        u32 rr = r;
+        asm volatile("" : "+v"(rr)); // keeps the address arithmetic here instead of hoisted and spilled
+        return a.stage + (a.off[rr] + 2 * (u64)rr);
+    };
 
     bitonic_sort<LANES, K, 2, XM>(x, lc);
 
@@ -298,8 +305,9 @@ __device__ __forceinline__ void sweep_group_keys(u32 (&x)[K], u32 m, u32 len, i3
         g_closed = cincl; // meaningful on the group's last lane
         u32 pos = cincl - cnt;
         if (live && cnt == 1) {
-            slot[pos] = make_uint2(fb >> kKeyShift, fe >> kKeyShift);
+            slot_of()[pos] = make_uint2(fb >> kKeyShift, fe >> kKeyShift);
         } else if (live && cnt > 1) { // several regions close inside one lane: replay it
+            uint2 *slot = slot_of();
             u32 tc = mf_in, cml = ml_in;
             d = depth_in;
 #pragma unroll
@@ -323,7 +331,7 @@ __device__ __forceinline__ void sweep_group_keys(u32 (&x)[K], u32 m, u32 len, i3
             a.rej_list[atomicAdd(a.rej_count, 1u)] = r;
             a.counts[r] = 0;
         } else {
-            a.counts[r] = finish_read(slot, g_closed, mf_incl ? (mf_incl ^ 2u) : 0u, ml_incl, min_ge, len);
+            a.counts[r] = finish_read(slot_of(), g_closed, mf_incl ? (mf_incl ^ 2u) : 0u, ml_incl, min_ge, len);
         }
     }
 }
@@ -435,12 +443,17 @@ __device__ __forceinline__ bool prefilter(const u32 (&x)[K], u32 n, u32 len, i32
 #pragma unroll 1
     for (u32 t = 0; t < nsyn; t++) keys[base + t] = synkey;
     wave_lds_sync();
-    u32 pos[K]; // every slot request in flight before the first store needs its answer
+    // slot requests go out in batches of 8, all in flight before the first store needs its answer
+    // (16 at once cost eight more registers than the rest of the kernel needs)
 #pragma unroll
-    for (int q = 0; q < K; q++) pos[q] = atomicAdd(cell[q], 1u);
+    for (int q0 = 0; q0 < K; q0 += 8) {
+        u32 pos[8];
 #pragma unroll
-    for (int q = 0; q < K; q++) {
-        if (pos[q] < (u32)CAP) keys[pos[q]] = x[q];
+        for (int q = 0; q < 8; q++) pos[q] = atomicAdd(cell[q0 + q], 1u);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            if (pos[q] < (u32)CAP) keys[pos[q]] = x[q0 + q];
+        }
     }
     wave_lds_sync();
     const uint4 lo = my_keys[0], hi = my_keys[1];
@@ -453,7 +466,7 @@ __device__ __forceinline__ bool prefilter(const u32 (&x)[K], u32 n, u32 len, i32
 // ---- one read per group of LANES lanes: loads, keys, (pre-filter,) sweep ------------------------
 template <int LANES, int K, int XM>
 __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u32 n, u32 len,
-                                                 u32 cov, uint2 *slot, bool active, u32 r,
+                                                 u32 cov, bool active, u32 r,
                                                  const SweepArgs &a, const LaneConst &lc)
 {
     const u32 lane = lane_id(), lig = lane & (u32)(LANES - 1);
@@ -517,13 +530,13 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
             u32 y[K / 2], mf;
             if (prefilter<LANES, K>(x, n, len, c, y, mf)) {
                 if (a.prefilter == 2 && lig == 0 && active) atomicAdd(&a.ctr->prefiltered, 1u);
-                sweep_group_keys<LANES, K / 2, XM>(y, mf, len, c, slot, active, r, badmask, zmask,
+                sweep_group_keys<LANES, K / 2, XM>(y, mf, len, c, active, r, badmask, zmask,
                                                    zl_check, a, lc);
                 return;
             }
         }
     }
-    sweep_group_keys<LANES, K, XM>(x, 2 * n, len, c, slot, active, r, badmask, zmask, zl_check, a, lc);
+    sweep_group_keys<LANES, K, XM>(x, 2 * n, len, c, active, r, badmask, zmask, zl_check, a, lc);
 }
 
 // Body of one workgroup (four wavefronts, 4 * 64/LANES reads) of class (LANES, K).
@@ -551,8 +564,7 @@ __device__ __forceinline__ void sweep_group_block(const SweepArgs &a, u32 block)
         n = (u32)(a.off[r + 1] - o);
         len = a.len[r];
     }
-    sweep_group_read<LANES, K, XM>(a.iv + o, n, len, a.cov, a.stage + (o + 2 * (u64)r), active, r,
-                                   a, lc);
+    sweep_group_read<LANES, K, XM>(a.iv + o, n, len, a.cov, active, r, a, lc);
 }
 
 // One kernel per (LANES, K): small K keep small register footprints.
@@ -589,7 +601,7 @@ struct FusedArgs {
     const u32 *list_n[5];
 };
 
-__global__ __launch_bounds__(256, 6) void sweep_small_fused_kernel(FusedArgs f)
+__global__ __launch_bounds__(256, 5) void sweep_small_fused_kernel(FusedArgs f)
 {
     u32 e = 0, first = 0;
     while (e + 1 < f.n_entries && blockIdx.x >= f.block_end[e]) {

@@ -14,7 +14,6 @@ import argparse
 import json
 import os
 import sys
-import threading
 import time
 
 import numpy as np
@@ -50,8 +49,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lds-sort", action="store_true", help="A/B: LDS-sort kernel for the small class")
     ap.add_argument("--flags", type=int, default=0, help="extra YACRD_F_* engine flags (A/B)")
-    ap.add_argument("--engines", type=int, default=3,
-                    help="engines (host threads, HIP streams) the batches are pipelined over on each GPU")
+    ap.add_argument("--engines", type=int, default=2,
+                    help="engines (HIP streams) the batches are pipelined over on each GPU")
     ap.add_argument("--full-timing", action="store_true",
                     help="HIP events around every phase and class kernel (slower steps)")
     args = ap.parse_args()
@@ -89,55 +88,49 @@ def main():
     flags = (yacrd_amd.F_FORCE_LDS_SORT if args.lds_sort else 0) | args.flags
     if args.full_timing:
         flags |= yacrd_amd.F_TIMING_FULL
-    # Batches are pipelined over `--engines` engines on this GPU, one host thread each: the plan /
-    # compaction kernels, the counter copy and the launch gaps of one batch hide behind the sweep
-    # of another (the engines take turns with that launch, so its event bracket times the kernel,
-    # not the queue).  With more than one engine the final wait of a run sleeps instead of
-    # spinning (1.5 CPUs for three engines: eight ranks fit a 16-CPU quota).
+    # Batches are pipelined over `--engines` engines on this GPU from this one host thread
+    # (yacrd_engine_submit_device / yacrd_engine_wait): the plan / compaction kernels, the counter
+    # copy and the launch gaps of one batch hide behind the sweep of another (the engines take
+    # turns with that launch, so its start / stop events time the kernel, not the queue).
     NE = max(1, min(args.engines, args.steps))
-    if NE > 1 and not os.environ.get("YACRD_BENCH_SPIN"):  # (A/B: spinning waits)
-        flags |= yacrd_amd.F_BLOCKING_WAIT
     engs = [yacrd_amd.Engine(device_id=dev_index, flags=flags) for _ in range(NE)]
     eng = engs[0]
-
-    def step(e=eng):
-        return e.run_device(d_off.data_ptr(), d_iv.data_ptr(), d_len.data_ptr(), R, I, cov,
-                            args.not_coverage)
+    ptrs = (d_off.data_ptr(), d_iv.data_ptr(), d_len.data_ptr(), R, I, cov, args.not_coverage)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for e in engs:
-        for _ in range(args.warmup):
-            step(e)
+    def run_steps(k):
+        """k passes over the batch, NE of them in flight; returns the last result."""
+        if NE == 1:
+            res = None
+            for _ in range(k):
+                res = eng.run_device(*ptrs)
+            return res
+        inflight = [False] * NE
+        res = None
+        for i in range(k):
+            j = i % NE
+            if inflight[j]:
+                res = engs[j].wait()
+            engs[j].submit_device(*ptrs)
+            inflight[j] = True
+        for j in range(NE):
+            if inflight[j]:
+                res = engs[j].wait()
+        return res
+
+    run_steps(max(args.warmup, 2 * NE))  # (a submit only pipelines once the engine has a prediction)
     keys = ("plan_ms", "sweep_small_ms", "sweep_medium_ms", "sweep_general_ms", "compact_ms", "total_ms")
     acc = dict.fromkeys(keys, 0.0)
     cls_ms = [0.0] * 12
     for e in engs:
         e.timing_total(reset=True)
-    share = [args.steps // NE + (1 if i < args.steps % NE else 0) for i in range(NE)]  # sums to K
-    outs = [None] * NE
-    go = threading.Barrier(NE + 1)
-
-    def worker(i):
-        go.wait()
-        for _ in range(share[i]):
-            outs[i] = step(engs[i])
-
-    threads = [threading.Thread(target=worker, args=(i,)) for i in range(NE)] if NE > 1 else []
-    for th in threads:
-        th.start()
     barrier()
     t0 = time.perf_counter()
-    if NE > 1:
-        go.wait()
-        for th in threads:
-            th.join()
-    else:
-        for _ in range(args.steps):
-            outs[0] = step()
+    outs = [run_steps(args.steps)]
     barrier()
     elapsed = time.perf_counter() - t0
     out = outs[0]

@@ -158,6 +158,19 @@ int yacrd_engine_run_device(yacrd_engine *e, const void *d_offsets, const void *
                             const void *d_lengths, uint64_t n_reads, uint64_t n_intervals,
                             uint32_t coverage, double not_coverage, yacrd_device_result *out);
 
+/* yacrd_engine_run_device in two halves, so that one host thread can keep batches in flight on
+ * several engines of a device (submit on engine A, submit on engine B, wait on A, submit on A ...):
+ * the plan / compaction kernels, the counter copy and the launch gaps of one batch hide behind the
+ * sweep of another; the engines take turns with the dominant sweep launch.  submit enqueues the
+ * whole run when the previous run on this engine had the same shape (its class counts size the
+ * launches; wait validates them and, in the rare case they do not hold, runs the batch again the
+ * synchronous way) and otherwise simply runs it to the end.  The inputs must stay valid until
+ * wait returns; between submit and wait the engine accepts no other call. */
+int yacrd_engine_submit_device(yacrd_engine *e, const void *d_offsets, const void *d_intervals,
+                               const void *d_lengths, uint64_t n_reads, uint64_t n_intervals,
+                               uint32_t coverage, double not_coverage);
+int yacrd_engine_wait(yacrd_engine *e, yacrd_device_result *out);
+
 /* Copy the last device result to host (allocates like yacrd_engine_run). */
 int yacrd_engine_fetch(yacrd_engine *e, yacrd_result *out);
 

@@ -310,3 +310,52 @@ def test_pipelined_engines_on_one_device():
     for t in threads:
         t.join()
     assert not errors, errors[0]
+
+
+def test_submit_wait_pipeline_and_misprediction():
+    """yacrd_engine_submit_device / _wait on two engines from one thread: batches of the same
+    shape pipeline; a batch whose classes do not fit the previous run's prediction (same reads and
+    intervals, other proportions; reads for the device-wide path; degenerate reads) comes out
+    bit-exact through wait's fallback."""
+    import torch
+    R = 600
+    a_sizes = [100] * R
+    d_sizes = [100] * 200 + [36] * 200 + [164] * 200
+    e_sizes = [100] * 400 + [36] * 100 + [164] * 100
+    c_sizes = [2] * 599 + [60000 - 2 * 599]
+    seq = [a_sizes, a_sizes, a_sizes, d_sizes, d_sizes, e_sizes, e_sizes, c_sizes, a_sizes, a_sizes]
+    batches, wants, dev = [], [], []
+    for rep, sizes in enumerate(seq):
+        csr = make_csr(5200 + rep, sizes, REGULAR_MODES + ("degenerate",), len_lo=300000, len_hi=900000)
+        batches.append(csr)
+        wants.append(oracle.run(csr[0], csr[1], csr[2].astype(np.uint64), 3, 0.4, n_threads=4))
+        dev.append((torch.from_numpy(csr[0].view(np.int64)).cuda(),
+                    torch.from_numpy(np.ascontiguousarray(csr[1]).view(np.int32)).cuda(),
+                    torch.from_numpy(csr[2].view(np.int32)).cuda()))
+    torch.cuda.synchronize()
+    with yacrd_amd.Engine() as e0, yacrd_amd.Engine() as e1:
+        engs, inflight = (e0, e1), [None, None]
+        for k in range(len(seq) + 2):
+            j = k % 2
+            if inflight[j] is not None:
+                out = engs[j].wait()
+                want = wants[inflight[j]]
+                assert int(out.n_regions) == int(want[0][-1])
+                assert_same(engs[j].fetch(), want, "submit/wait batch %d" % inflight[j])
+                inflight[j] = None
+            if k < len(seq):
+                d = dev[k]
+                engs[j].submit_device(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), R,
+                                      int(batches[k][0][-1]), 3, 0.4)
+                inflight[j] = k
+        # between submit and wait the engine takes no other call
+        d = dev[0]
+        args = (d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), R, int(batches[0][0][-1]), 3, 0.4)
+        e0.run_device(*args)
+        e0.submit_device(*args)
+        with pytest.raises(yacrd_amd.EngineError):
+            e0.run_device(*args)
+        with pytest.raises(yacrd_amd.EngineError):
+            e0.fetch()
+        e0.wait()
+        assert_same(e0.fetch(), wants[0], "after wait")

@@ -93,7 +93,22 @@ struct BigLane {
 };
 static BigLane g_big_lane[64];
 
+// A batch that was submitted without waiting for it (yacrd_engine_submit_device).
+struct Pending {
+    bool active = false;
+    const u64 *d_off = nullptr;
+    const uint2 *d_iv = nullptr;
+    const u32 *d_len = nullptr;
+    uint64_t n_reads = 0, n_iv = 0;
+    uint32_t cov = 0;
+    double not_cov = 0;
+    u32 grid_n[12] = {};      // reads each class's grid covers
+    bool skipped_small = false, fused_marked = false;
+    int cls_b[12] = {}, cls_e[12] = {};
+};
+
 struct yacrd_engine {
+    Pending pending;
     bool in_lane = false;
     int device = 0;
     uint32_t flags = 0;
@@ -301,11 +316,35 @@ int run_big(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u32 *d_l
     return YACRD_OK;
 }
 
+// The run's final wait: spinning (hipStreamSynchronize) or, with YACRD_F_BLOCKING_WAIT, polling
+// an event and sleeping in between (hipEventSynchronize spins as well, blocking-sync flag or not).
+int wait_for_stream(yacrd_engine *e)
+{
+    if (e->flags & YACRD_F_BLOCKING_WAIT) {
+        HIP_TRY(hipEventRecord(e->ev_done, e->stream));
+        for (;;) {
+            const hipError_t q = hipEventQuery(e->ev_done);
+            if (q == hipSuccess) break;
+            if (q != hipErrorNotReady) HIP_TRY(q);
+            struct timespec ts = {0, 20000};
+            nanosleep(&ts, nullptr);
+        }
+    } else {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    HIP_TRY(hipGetLastError());
+    return YACRD_OK;
+}
+
+int conclude_run(yacrd_engine *e, yk::Counters c0, bool predicted, uint64_t n_reads64, uint64_t n_iv,
+                 const int *cls_b, const int *cls_e, bool fused_marked, float extra_ms);
+
 int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u32 *d_len,
-                  uint64_t n_reads64, uint64_t n_iv, uint32_t cov, double not_cov)
+                  uint64_t n_reads64, uint64_t n_iv, uint32_t cov, double not_cov, bool defer = false)
 {
     if (n_reads64 >= 0xFFFFFFFFull) return fail(YACRD_EINVAL, "n_reads must be < 2^32 - 1");
     const u32 n_reads = (u32)n_reads64;
+    if (e->pending.active) return fail(YACRD_EINVAL, "a submitted batch is pending: yacrd_engine_wait first");
     e->has_result = false;
     e->timing = yacrd_timing{};
 
@@ -589,20 +628,28 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     rc = launch_compact(e, d_off, d_len, n_reads, not_cov);
     if (rc) return rc;
     if (full) HIP_TRY(hipEventRecord(e->ev[EV_COMPACT], e->stream));
-    // (spinning on the pinned counter block instead of this call was tried: 0.0816 vs 0.078 ms/step)
-    if (e->flags & YACRD_F_BLOCKING_WAIT) { // sleep instead of spinning: for many engines per core
-        HIP_TRY(hipEventRecord(e->ev_done, e->stream));
-        for (;;) { // (hipEventSynchronize spins as well, blocking-sync flag or not)
-            const hipError_t q = hipEventQuery(e->ev_done);
-            if (q == hipSuccess) break;
-            if (q != hipErrorNotReady) HIP_TRY(q);
-            struct timespec ts = {0, 20000};
-            nanosleep(&ts, nullptr);
+    if (defer && predicted) { // yacrd_engine_submit_device: the caller waits later (finish_pending)
+        Pending &p = e->pending;
+        p.active = true;
+        p.d_off = d_off;
+        p.d_iv = d_iv;
+        p.d_len = d_len;
+        p.n_reads = n_reads64;
+        p.n_iv = n_iv;
+        p.cov = cov;
+        p.not_cov = not_cov;
+        for (int cls = 0; cls < 12; cls++) {
+            p.grid_n[cls] = cls < yk::CLS_GENERAL ? ls.n[cls] : 0;
+            p.cls_b[cls] = cls_b[cls];
+            p.cls_e[cls] = cls_e[cls];
         }
-    } else {
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        p.skipped_small = skipped_small;
+        p.fused_marked = fused_marked;
+        return YACRD_OK;
     }
-    HIP_TRY(hipGetLastError());
+    // (spinning on the pinned counter block instead of this call was tried: 0.0816 vs 0.078 ms/step)
+    rc = wait_for_stream(e);
+    if (rc) return rc;
     timing_on = false;
 
     // ---- rare slow paths: a class the prediction missed; degenerate reads too large for the
@@ -667,6 +714,15 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     }
     if (e->h_ctr->region_overflow) return fail(YACRD_EINTERNAL, "bad_regions overflow persisted");
 
+    return conclude_run(e, c0, predicted, n_reads64, n_iv, cls_b, cls_e, fused_marked, extra_ms);
+}
+
+// Bookkeeping after a run's last sync: result sizes, the next run's prediction, timing.
+int conclude_run(yacrd_engine *e, yk::Counters c0, bool predicted, uint64_t n_reads64, uint64_t n_iv,
+                 const int *cls_b, const int *cls_e, bool fused_marked, float extra_ms)
+{
+    const bool full = (e->flags & YACRD_F_TIMING_FULL) != 0;
+    const u32 n_reads = (u32)n_reads64;
     const yk::Counters c1 = *e->h_ctr;
     if (predicted) c0 = c1; // class counts are final either way
     e->last_reads = n_reads;
@@ -738,10 +794,33 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     return YACRD_OK;
 }
 
+// Second half of yacrd_engine_submit_device: wait, check the prediction the launches were sized
+// with, conclude.  Anything the prediction did not cover (a class beyond its grid, reads for the
+// device-wide or the exact path, a region overflow) sends the batch through the synchronous,
+// unpredicted path once more: rare, and that path has every redo.
+int finish_pending(yacrd_engine *e)
+{
+    Pending &p = e->pending;
+    if (!p.active) return YACRD_OK;
+    p.active = false;
+    int rc = wait_for_stream(e);
+    if (rc) return rc;
+    const yk::Counters c = *e->h_ctr;
+    bool ok = !(p.skipped_small && c.rej_small) && !c.n[yk::CLS_GENERAL] && !c.rej_big &&
+              !c.region_overflow;
+    for (int cls = 0; cls < yk::CLS_GENERAL; cls++) ok = ok && c.n[cls] <= p.grid_n[cls];
+    if (!ok) {
+        e->pred_valid = false;
+        return run_on_device(e, p.d_off, p.d_iv, p.d_len, p.n_reads, p.n_iv, p.cov, p.not_cov);
+    }
+    return conclude_run(e, c, true, p.n_reads, p.n_iv, p.cls_b, p.cls_e, p.fused_marked, 0.f);
+}
+
 int fetch_result(yacrd_engine *e, yacrd_result *out)
 {
     if (!out) return fail(YACRD_EINVAL, "out is null");
     std::memset(out, 0, sizeof(*out));
+    if (e->pending.active) return fail(YACRD_EINVAL, "a submitted batch is pending: yacrd_engine_wait first");
     if (!e->has_result) return fail(YACRD_EINVAL, "no result to fetch");
     const uint64_t R = e->last_reads, G = e->last_regions;
     out->bad_offsets = (uint64_t *)std::malloc((size_t)(R + 1) * sizeof(uint64_t));
@@ -824,6 +903,7 @@ void yacrd_engine_destroy(yacrd_engine *e)
 {
     if (!e) return;
     DeviceGuard guard(e->device);
+    e->pending.active = false;
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->in_lane) {
         BigLane &lane = g_big_lane[e->device & 63];
@@ -862,6 +942,35 @@ int yacrd_engine_run_device(yacrd_engine *e, const void *d_offsets, const void *
     int rc = run_on_device(e, (const u64 *)d_offsets, (const uint2 *)d_intervals,
                            (const u32 *)d_lengths, n_reads, n_intervals, coverage, not_coverage);
     if (rc) return rc;
+    if (out) {
+        out->n_reads = e->last_reads;
+        out->n_regions = e->last_regions;
+        out->d_bad_offsets = e->bad_offsets.p;
+        out->d_bad_regions = e->bad_regions.p;
+        out->d_read_type = e->read_type.p;
+    }
+    return YACRD_OK;
+}
+
+int yacrd_engine_submit_device(yacrd_engine *e, const void *d_offsets, const void *d_intervals,
+                               const void *d_lengths, uint64_t n_reads, uint64_t n_intervals,
+                               uint32_t coverage, double not_coverage)
+{
+    if (!e) return fail(YACRD_EINVAL, "engine is null");
+    if (n_reads && (!d_offsets || !d_lengths)) return fail(YACRD_EINVAL, "null device input");
+    if (n_intervals && !d_intervals) return fail(YACRD_EINVAL, "null device intervals");
+    DeviceGuard guard(e->device);
+    return run_on_device(e, (const u64 *)d_offsets, (const uint2 *)d_intervals,
+                         (const u32 *)d_lengths, n_reads, n_intervals, coverage, not_coverage, true);
+}
+
+int yacrd_engine_wait(yacrd_engine *e, yacrd_device_result *out)
+{
+    if (!e) return fail(YACRD_EINVAL, "engine is null");
+    DeviceGuard guard(e->device);
+    int rc = finish_pending(e);
+    if (rc) return rc;
+    if (!e->has_result) return fail(YACRD_EINVAL, "nothing was submitted");
     if (out) {
         out->n_reads = e->last_reads;
         out->n_regions = e->last_regions;

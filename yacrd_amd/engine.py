@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = [
     "yacrd_abi_version", "yacrd_last_error", "yacrd_engine_create", "yacrd_engine_destroy",
     "yacrd_engine_run", "yacrd_result_free", "yacrd_engine_run_device", "yacrd_engine_fetch",
     "yacrd_engine_last_timing", "yacrd_partition_reads", "yacrd_engine_classify",
-    "yacrd_engines_run_partitioned", "yacrd_engine_timing_total", "yacrd_engine_event_overhead",
+    "yacrd_engines_run_partitioned", "yacrd_engine_timing_total", "yacrd_engine_event_overhead", "yacrd_engine_submit_device", "yacrd_engine_wait",
 ]
 
 
@@ -147,6 +147,10 @@ def load_library():
                                             ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64,
                                             ctypes.c_uint32, ctypes.c_double,
                                             ctypes.POINTER(_DevResult)]
+    lib.yacrd_engine_submit_device.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                               ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64,
+                                               ctypes.c_uint32, ctypes.c_double]
+    lib.yacrd_engine_wait.argtypes = [ctypes.c_void_p, ctypes.POINTER(_DevResult)]
     lib.yacrd_engine_fetch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_Result)]
     lib.yacrd_engine_last_timing.argtypes = [ctypes.c_void_p, ctypes.POINTER(_Timing)]
     lib.yacrd_partition_reads.argtypes = [u64p, ctypes.c_uint64, ctypes.c_uint32, u64p]
@@ -261,6 +265,18 @@ class Engine:
         _check(self._lib, self._lib.yacrd_engine_run_device(
             self._h, d_offsets, d_intervals, d_lengths, n_reads, n_intervals,
             min(int(coverage), 0xFFFFFFFF), float(not_coverage), ctypes.byref(out)))
+        return out
+
+    def submit_device(self, d_offsets, d_intervals, d_lengths, n_reads, n_intervals, coverage,
+                      not_coverage):
+        """run_device without the final wait (see yacrd_engine_submit_device); pair with wait()."""
+        _check(self._lib, self._lib.yacrd_engine_submit_device(
+            self._h, d_offsets, d_intervals, d_lengths, n_reads, n_intervals,
+            min(int(coverage), 0xFFFFFFFF), float(not_coverage)))
+
+    def wait(self):
+        out = _DevResult()
+        _check(self._lib, self._lib.yacrd_engine_wait(self._h, ctypes.byref(out)))
         return out
 
     def fetch(self):

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define YACRD_ABI_VERSION 1
+#define YACRD_ABI_VERSION 2
 
 /* src/editor/mod.rs:42-59 ReadType; numeric encoding is ours, names are the reference's. */
 enum { YACRD_NOT_BAD = 0, YACRD_CHIMERIC = 1, YACRD_NOT_COVERED = 2 };
@@ -170,6 +170,77 @@ int yacrd_engine_submit_device(yacrd_engine *e, const void *d_offsets, const voi
                                const void *d_lengths, uint64_t n_reads, uint64_t n_intervals,
                                uint32_t coverage, double not_coverage);
 int yacrd_engine_wait(yacrd_engine *e, yacrd_device_result *out);
+
+/* yacrd_engine_run in two halves for HOST inputs: submit validates the CSR, enqueues H2D + the whole
+ * run on the engine's stream and returns; collect waits and brings the result home.  With two
+ * engines per GPU a caller keeps PCIe and the kernels busy at the same time (batch k+1 crosses PCIe
+ * while batch k is swept) — the batch loop of FromOverlap::compute_all_bad_part
+ * (src/stack.rs:143-162) as a pipeline.  Inputs should come from yacrd_pinned_alloc (direct DMA,
+ * ~55 GB/s; they must then stay valid until collect returns); pageable inputs are staged through
+ * the engine's pinned bounce buffers before submit returns.  Like submit_device, the run is only
+ * left in flight when the previous run on this engine had the same shape; otherwise submit runs it
+ * to the end and collect just fetches. */
+int yacrd_engine_submit(yacrd_engine *e, const uint64_t *offsets, const uint32_t *intervals,
+                        const uint32_t *lengths, uint64_t n_reads, uint32_t coverage,
+                        double not_coverage);
+int yacrd_engine_collect(yacrd_engine *e, yacrd_result *out);
+
+/* Page-locked host memory (hipHostMalloc) for inputs: the engine recognises it and moves it over
+ * PCIe by direct DMA instead of staging.  NULL on failure. */
+void *yacrd_pinned_alloc(size_t bytes);
+void yacrd_pinned_free(void *p);
+
+/* ---- streaming ingest: overlap records cross PCIe while the parser is still running -------------
+ * The north star's "streams it to HBM via pinned hipMemcpyAsync".  The reference hands the engine
+ * whole reads (MapReads2Ovl, src/reads2ovl/mod.rs:41) only after the last line is parsed
+ * (FullMemory::get_overlaps, src/reads2ovl/fullmemory.rs:46-50); here the parser threads fill
+ * pinned buffers with overlap RECORDS (both reads of a PAF/M4 line, src/reads2ovl/mod.rs:108-109)
+ * and every full buffer goes to HBM on a copy stream at once, double-buffered.  When the parser is
+ * done, yacrd_stream_finish builds the CSR on the GPU (count -> scan -> scatter, the grouping
+ * FullMemory::add_overlap_and_length does per line, src/reads2ovl/fullmemory.rs:82-90) and runs the
+ * engine on it: parse || H2D, then GPU CSR build + kernels + D2H (all sub-millisecond per 10 M
+ * intervals).  Reads are named by 32-bit handles the caller chooses while parsing; `handle_map`
+ * translates them to final read ids at finish (NULL = handles are read ids). */
+#ifndef YACRD_OVL_REC_DEFINED
+#define YACRD_OVL_REC_DEFINED
+typedef struct {
+    uint32_t a, b;   /* handles of the two reads of an overlap line */
+    uint32_t sa, ea; /* interval on read a (PAF cols 3-4, src/io.rs:23-34) */
+    uint32_t sb, eb; /* interval on read b (PAF cols 8-9) */
+} yacrd_ovl_rec;
+/* Where a parser puts its records (implemented by yacrd_stream; consumed by
+ * yacrd_ingest_stream in yacrd_host.h).  Both calls may come from several threads at once. */
+typedef struct {
+    void *ctx;
+    /* a buffer of *capacity records to fill; blocks while all buffers are in flight */
+    int (*acquire)(void *ctx, yacrd_ovl_rec **buf, uint64_t *capacity);
+    /* hand a buffer back with n_records filled (0 allowed): its copy to HBM starts now */
+    int (*commit)(void *ctx, yacrd_ovl_rec *buf, uint64_t n_records);
+} yacrd_rec_sink;
+#endif
+
+typedef struct yacrd_stream yacrd_stream;
+/* chunk_records: records per pinned buffer (0 = 131072, 3 MiB); n_buffers: 0 = 2 per usable CPU + 2 */
+int yacrd_stream_open(yacrd_engine *e, uint64_t chunk_records, uint32_t n_buffers, yacrd_stream **out);
+int yacrd_stream_sink(yacrd_stream *s, yacrd_rec_sink *sink);
+int yacrd_stream_acquire(yacrd_stream *s, yacrd_ovl_rec **buf, uint64_t *capacity);
+int yacrd_stream_commit(yacrd_stream *s, yacrd_ovl_rec *buf, uint64_t n_records);
+/* All records are in.  handle_map[n_handles] (or NULL), lengths[n_reads]: builds the CSR in HBM,
+ * runs the engine (blocking) and returns the host result like yacrd_engine_run.  The stream is
+ * empty again afterwards and can take the next file. */
+int yacrd_stream_finish(yacrd_stream *s, const uint32_t *handle_map, uint64_t n_handles,
+                        const uint32_t *lengths, uint64_t n_reads, uint32_t coverage,
+                        double not_coverage, yacrd_result *out);
+typedef struct {
+    uint64_t n_records;  /* overlap records of the last finished stream */
+    uint64_t h2d_bytes;  /* bytes the copy stream moved */
+    float h2d_busy_ms;   /* sum of the DMA durations (HIP events around each buffer's copy) */
+    float build_ms;      /* CSR build on the GPU: count + scan + scatter */
+    float run_ms;        /* engine run on the built CSR, wall clock incl. its sync */
+    float d2h_ms;
+} yacrd_stream_stats;
+int yacrd_stream_last_stats(const yacrd_stream *s, yacrd_stream_stats *st);
+void yacrd_stream_close(yacrd_stream *s);
 
 /* Copy the last device result to host (allocates like yacrd_engine_run). */
 int yacrd_engine_fetch(yacrd_engine *e, yacrd_result *out);

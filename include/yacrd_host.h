@@ -28,8 +28,8 @@ typedef struct {
     uint64_t n_reads;
     uint64_t n_intervals;
     uint64_t n_records;        /* overlap lines ingested */
-    const uint64_t *offsets;   /* R+1 */
-    const uint32_t *intervals; /* 2*I */
+    const uint64_t *offsets;   /* R+1; NULL after yacrd_ingest_stream (the CSR lives in HBM) */
+    const uint32_t *intervals; /* 2*I; NULL after yacrd_ingest_stream */
     const uint32_t *lengths;   /* R (first length seen) */
     const uint64_t *name_off;  /* R+1 offsets into names */
     const char *names;         /* concatenated read ids, first-appearance order */
@@ -41,6 +41,37 @@ int yacrd_csr_from_file(const char *path, int format, int n_threads, yacrd_csr *
 int yacrd_csr_from_memory(const char *text, size_t len, int format, int n_threads,
                           yacrd_csr **out);
 int yacrd_csr_get(const yacrd_csr *c, yacrd_csr_view *v);
+
+/* ---- streaming ingest ----------------------------------------------------------------------------
+ * Same parse, same numbering, but the overlap records leave for a sink buffer by buffer while the
+ * parse is still running instead of being grouped on the host: with the engine's yacrd_stream as
+ * the sink (include/yacrd_engine.h) they cross PCIe from pinned memory during the parse and the CSR
+ * is built in HBM.  Records name reads by HANDLES (32-bit numbers unique per id, dense enough to
+ * index an array) because the first-appearance numbering only exists once the last line is read
+ * (the reference has the same barrier: FullMemory::get_overlaps hands the map over at the end,
+ * src/reads2ovl/fullmemory.rs:46-50); yacrd_csr_handle_map gives handle -> read id.
+ * The returned yacrd_csr holds names and lengths; its view has offsets == intervals == NULL. */
+#ifndef YACRD_OVL_REC_DEFINED
+#define YACRD_OVL_REC_DEFINED
+typedef struct {
+    uint32_t a, b;   /* handles of the two reads of an overlap line */
+    uint32_t sa, ea; /* interval on read a (PAF cols 3-4, src/io.rs:23-34) */
+    uint32_t sb, eb; /* interval on read b (PAF cols 8-9) */
+} yacrd_ovl_rec;
+typedef struct {
+    void *ctx;
+    /* a buffer of *capacity records to fill; may block; called from several threads */
+    int (*acquire)(void *ctx, yacrd_ovl_rec **buf, uint64_t *capacity);
+    /* hand a buffer back with n_records filled (0 allowed) */
+    int (*commit)(void *ctx, yacrd_ovl_rec *buf, uint64_t n_records);
+} yacrd_rec_sink;
+#endif
+int yacrd_ingest_stream(const char *path, int format, int n_threads, const yacrd_rec_sink *sink,
+                        yacrd_csr **out);
+int yacrd_ingest_stream_memory(const char *text, size_t len, int format, int n_threads,
+                               const yacrd_rec_sink *sink, yacrd_csr **out);
+/* handle -> read id (0xFFFFFFFF for handles no record uses); valid while the csr lives */
+int yacrd_csr_handle_map(const yacrd_csr *c, const uint32_t **map, uint64_t *n_handles);
 /* index of a read id, or -1 (BadPart::get_bad_part answers unknown ids with an empty list,
  * src/stack.rs:164-169) */
 int64_t yacrd_csr_find(const yacrd_csr *c, const char *name, size_t name_len);

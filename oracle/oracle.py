@@ -110,8 +110,81 @@ def run(offsets, intervals, lengths, coverage, not_covered, n_threads=1):
 
 # --------------------------------------------------------------------------------------
 # Ingest: src/reads2ovl/mod.rs:83-145 + src/io.rs:23-50 + src/reads2ovl/fullmemory.rs:82-90.
-# Pure Python, small inputs only.  Plain split on the delimiter: csv-crate quoting is not
-# restated (exotic-input parity is unpinned by the reference's own tests).
+# Pure Python, small inputs only.  Record syntax restates the csv crate the reference reads with
+# (csv 1.3.0 / csv-core 0.1.11, Cargo.lock:241; builder settings mod.rs:84-88: delimiter, no
+# headers, flexible, everything else default => quote '"', double_quote on, no escape, terminator
+# "CRLF" = any of \r, \n, \r\n) as its published DFA: StartRecord skips terminators; a field that
+# STARTS with the quote is quoted (delimiters and terminators inside are data, "" is one quote, and
+# text after the closing quote is appended as is); a quote inside an unquoted field is data.
+# Integer fields: `0x` + hex via from_str_radix, else FromStr (optional leading '+').
+# The crate is not vendored in /root/reference, so this part is "restated from published
+# behaviour", pinned only by the reference's 2-line vectors (mod.rs:173-237) and tests/reads.paf.
+
+def csv_records(text, delim):
+    """Yield lists of fields (str) like csv::Reader::read_record with the settings above."""
+    rec, field, i, n = [], [], 0, len(text)
+    START_RECORD, START_FIELD, IN_FIELD, IN_QUOTED, AFTER_QUOTE = range(5)
+    st = START_RECORD
+    while i < n:
+        c = text[i]
+        i += 1
+        term = c in "\r\n"
+        if st == START_RECORD:
+            if term:
+                continue
+            st = START_FIELD
+        if st == START_FIELD:
+            if c == '"':
+                st = IN_QUOTED
+            elif c == delim:
+                rec.append("")
+            elif term:
+                rec.append("")
+                yield rec
+                rec, st = [], START_RECORD
+            else:
+                field.append(c)
+                st = IN_FIELD
+        elif st == IN_FIELD or st == AFTER_QUOTE:
+            if st == AFTER_QUOTE and c == '"':
+                field.append('"')
+                st = IN_QUOTED
+            elif c == delim:
+                rec.append("".join(field))
+                field, st = [], START_FIELD
+            elif term:
+                rec.append("".join(field))
+                yield rec
+                rec, field, st = [], [], START_RECORD
+            else:
+                field.append(c)
+                st = IN_FIELD
+        elif st == IN_QUOTED:
+            if c == '"':
+                st = AFTER_QUOTE
+            else:
+                field.append(c)
+    if st in (IN_FIELD, IN_QUOTED, AFTER_QUOTE) or (st == START_FIELD and rec):
+        rec.append("".join(field))
+    if rec:
+        yield rec
+
+
+def csv_int(f, bits):
+    """The csv crate's integer deserialisation: 0x-prefixed hex or decimal, optional '+'."""
+    if f.startswith("0x"):
+        body, base = f[2:], 16
+    else:
+        body, base = f, 10
+    digits = body[1:] if body.startswith("+") else body
+    ok = "0123456789abcdefABCDEF" if base == 16 else "0123456789"
+    if not digits or any(ch not in ok for ch in digits):
+        raise ValueError("not an integer: %r" % f)
+    v = int(digits, base)
+    if v >= 1 << bits:
+        raise ValueError("integer out of range: %r" % f)
+    return v
+
 
 def _ingest(lines, delim, cols):
     ia, la, ba, ea, ib, lb, bb, eb = cols
@@ -124,13 +197,11 @@ def _ingest(lines, delim, cols):
         else:
             ent[0].append(ovl)
 
-    for line in lines:
-        line = line.rstrip("\r\n")
-        if not line:
-            continue
-        f = line.split(delim)
-        add(f[ia], (int(f[ba]), int(f[ea])), int(f[la]))  # mod.rs:108 / :140
-        add(f[ib], (int(f[bb]), int(f[eb])), int(f[lb]))  # mod.rs:109 / :141
+    text = lines if isinstance(lines, str) else "".join(
+        l if l.endswith(("\n", "\r")) else l + "\n" for l in lines)
+    for f in csv_records(text, delim):
+        add(f[ia], (csv_int(f[ba], 32), csv_int(f[ea], 32)), csv_int(f[la], 64))  # mod.rs:108 / :140
+        add(f[ib], (csv_int(f[bb], 32), csv_int(f[eb], 32)), csv_int(f[lb], 64))  # mod.rs:109 / :141
     return reads
 
 

@@ -72,6 +72,52 @@ def test_thresholds_match_secondary_vectors(work):
         "0b207320f179e75a93862fded411651225dfc94e982b1afa2f3e8ea3c113dce2"
 
 
+def test_m4_mhap_and_compressed_inputs(work, golden_dir, tmp_path):
+    """N3: .m4 / .mhap overlaps (src/reads2ovl/mod.rs:115-145) and bzip2 / xz / gzip inputs sniffed
+    from magic bytes (src/util.rs:57-70), for the overlaps and for the sequences; editor output in
+    the input's compression (src/util.rs:72-87)."""
+    import bz2
+    import lzma
+    truth = set(lines(os.path.join(golden_dir, "truth.yacrd")))
+    # PAF -> M4 columns (src/io.rs:36-50): a b err shared strand_a ba ea la strand_b bb eb lb
+    m4 = []
+    for l in lines(work / "reads.paf"):
+        f = l.split("\t")
+        m4.append(" ".join([f[0], f[5], "0.1", "2", "0", f[2], f[3], f[1], "0", f[7], f[8], f[6]]))
+    for name in ("reads.m4", "reads.mhap"):
+        with open(tmp_path / name, "w") as o:
+            o.write("\n".join(m4) + "\n")
+        run("-i", str(tmp_path / name), "-o", str(tmp_path / (name + ".yacrd")), "-t", "2")
+        assert set(lines(tmp_path / (name + ".yacrd"))) == truth
+    paf = open(work / "reads.paf", "rb").read()
+    fq = open(work / "reads.fastq", "rb").read()
+    with gzip.open(os.path.join(golden_dir, "truth.scrubb.fastq.gz"), "rb") as f:
+        want = f.read()
+    for ext, mod in (("bz2", bz2), ("xz", lzma), ("gz", gzip)):
+        with mod.open(tmp_path / ("x.paf." + ext), "wb") as o:
+            o.write(paf)
+        with mod.open(tmp_path / ("r.fastq." + ext), "wb") as o:
+            o.write(fq)
+        out = tmp_path / ("scrubbed.fastq." + ext)
+        run("-i", str(tmp_path / ("x.paf." + ext)), "-o", str(tmp_path / (ext + ".yacrd")), "-t", "0",
+            "scrubb", "-i", str(tmp_path / ("r.fastq." + ext)), "-o", str(out))
+        assert set(lines(tmp_path / (ext + ".yacrd"))) == truth, ext
+        assert mod.open(out, "rb").read() == want, ext
+    blob = open(tmp_path / "x.paf.xz", "rb").read()
+    open(tmp_path / "cut.paf.xz", "wb").write(blob[:len(blob) // 2])
+    p = subprocess.run([BIN, "-i", str(tmp_path / "cut.paf.xz"), "-o", str(tmp_path / "cut.yacrd")],
+                       capture_output=True, text=True)
+    assert p.returncode != 0 and "xz" in p.stderr
+
+
+def test_two_engines_partitioned_path(work, golden_dir):
+    """--gpus 2 needs two devices; on a 1-GPU box the host-CSR + partition path is covered through
+    the library (tests/test_gpu_parity.py::test_partitioned...); here: the CLI refuses loudly."""
+    p = subprocess.run([BIN, "-i", str(work / "reads.paf"), "-o", str(work / "g2.yacrd"), "--gpus", "64"],
+                       capture_output=True, text=True)
+    assert p.returncode != 0 and "device" in p.stderr
+
+
 def test_bad_usage_is_loud(work):
     p = subprocess.run([BIN, "-i", str(work / "reads.paf")], capture_output=True, text=True)
     assert p.returncode != 0

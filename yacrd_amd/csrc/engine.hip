@@ -8,10 +8,7 @@
 //   Rare redo: degenerate reads too large for LDS, or bad_regions too small.
 // Several engines may share a device (one host thread each): their batches pipeline, the engines
 // take turns with the dominant sweep launch (BigLane).
-#include "../../include/yacrd_engine.h"
-
-#include <hip/hip_runtime.h>
-#include <hip/hip_ext.h>
+#include "engine_internal.h"
 
 #include <time.h>
 
@@ -31,139 +28,17 @@
 #include "sweep_lds.h"
 #include "sweep_wave.h"
 
-namespace {
+using namespace yke;
 
-thread_local std::string g_err;
-
-int fail(int code, const std::string &msg)
+namespace yke {
+std::string &err_slot()
 {
-    g_err = msg;
-    return code;
+    thread_local std::string s;
+    return s;
 }
-
-#define HIP_TRY(expr)                                                                          \
-    do {                                                                                       \
-        hipError_t _e = (expr);                                                                \
-        if (_e != hipSuccess)                                                                  \
-            return fail(_e == hipErrorOutOfMemory ? YACRD_ENOMEM : YACRD_ENODEV,               \
-                        std::string(#expr) + ": " + hipGetErrorString(_e));                   \
-    } while (0)
-
-struct DevBuf {
-    void *p = nullptr;
-    size_t cap = 0;
-    hipError_t reserve(size_t bytes)
-    {
-        if (bytes <= cap) return hipSuccess;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        size_t want = bytes + bytes / 8 + 256;
-        hipError_t e = hipMalloc(&p, want);
-        if (e != hipSuccess) {
-            e = hipMalloc(&p, bytes);
-            want = bytes;
-        }
-        if (e == hipSuccess) cap = want;
-        return e;
-    }
-    void release()
-    {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-    template <class T>
-    T *as() const
-    {
-        return reinterpret_cast<T *>(p);
-    }
-};
-
-enum { EV_START = 0, EV_PLAN, EV_S0, EV_SMALL, EV_MED, EV_GEN, EV_COMPACT, EV_X0, EV_X1, EV_COUNT };
-
-} // namespace
-
-// One per device: whose dominant sweep went out last (see launch_sweeps).
-struct BigLane {
-    std::mutex mu;
-    hipEvent_t last = nullptr;
-    struct yacrd_engine *owner = nullptr;
-    int n_engines = 0;
-};
-static BigLane g_big_lane[64];
-
-// A batch that was submitted without waiting for it (yacrd_engine_submit_device).
-struct Pending {
-    bool active = false;
-    const u64 *d_off = nullptr;
-    const uint2 *d_iv = nullptr;
-    const u32 *d_len = nullptr;
-    uint64_t n_reads = 0, n_iv = 0;
-    uint32_t cov = 0;
-    double not_cov = 0;
-    u32 grid_n[12] = {};      // reads each class's grid covers
-    bool skipped_small = false, fused_marked = false;
-    int cls_b[12] = {}, cls_e[12] = {};
-};
-
-struct yacrd_engine {
-    Pending pending;
-    bool in_lane = false;
-    int device = 0;
-    uint32_t flags = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[EV_COUNT] = {};
-    hipEvent_t ev_h2d0 = nullptr, ev_h2d1 = nullptr, ev_d2h0 = nullptr, ev_d2h1 = nullptr;
-    hipEvent_t ev_cls[24] = {}; // brackets around class kernels
-    hipEvent_t ev_done = nullptr; // hipEventBlockingSync: the final wait of YACRD_F_BLOCKING_WAIT
-    int num_cu = 256;
-
-    // inputs staged by yacrd_engine_run
-    DevBuf in_off, in_iv, in_len;
-    // work buffers
-    DevBuf lists, ctrl2[2], stage, counts, gen_sizes, gen_scratch_off, gen_scratch, big_tab, big_keys, big_redo;
-    // two control blocks (counters + scan state), used alternately: the plan kernel of a run zeroes
-    // the other one for the next run.  ctrl_clean[i] = leading bytes of block i known to be zero.
-    size_t ctrl_clean[2] = {0, 0};
-    int ctrl_cur = 0;
-    // results
-    DevBuf bad_offsets, bad_regions, read_type;
-    yk::Counters *h_ctr = nullptr; // pinned
-
-    uint64_t last_reads = 0, last_regions = 0;
-    bool has_result = false;
-    // class counts of the previous run: the prediction that lets the next one skip the plan sync
-    yk::Counters pred{};
-    uint64_t pred_reads = 0, pred_iv = 0;
-    bool pred_valid = false;
-    yacrd_timing timing = {};
-    yacrd_timing timing_sum = {};
-    uint64_t timing_runs = 0;
-};
+} // namespace yke
 
 namespace {
-
-struct DeviceGuard {
-    int prev = -1;
-    explicit DeviceGuard(int dev)
-    {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        if (prev != dev) (void)hipSetDevice(dev);
-        else prev = -1;
-    }
-    ~DeviceGuard()
-    {
-        if (prev >= 0) (void)hipSetDevice(prev);
-    }
-};
-
-float ev_ms(hipEvent_t a, hipEvent_t b)
-{
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0.f;
-    return ms;
-}
 
 // scan + compact + classify: one kernel (decoupled look-back), then the totals come home.
 int launch_compact(yacrd_engine *e, const u64 *d_off, const u32 *d_len, u32 n_reads, double not_cov)
@@ -339,8 +214,11 @@ int wait_for_stream(yacrd_engine *e)
 int conclude_run(yacrd_engine *e, yk::Counters c0, bool predicted, uint64_t n_reads64, uint64_t n_iv,
                  const int *cls_b, const int *cls_e, bool fused_marked, float extra_ms);
 
+} // namespace
+
+namespace yke {
 int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u32 *d_len,
-                  uint64_t n_reads64, uint64_t n_iv, uint32_t cov, double not_cov, bool defer = false)
+                  uint64_t n_reads64, uint64_t n_iv, uint32_t cov, double not_cov, bool defer)
 {
     if (n_reads64 >= 0xFFFFFFFFull) return fail(YACRD_EINVAL, "n_reads must be < 2^32 - 1");
     const u32 n_reads = (u32)n_reads64;
@@ -716,6 +594,9 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
 
     return conclude_run(e, c0, predicted, n_reads64, n_iv, cls_b, cls_e, fused_marked, extra_ms);
 }
+} // namespace yke
+
+namespace {
 
 // Bookkeeping after a run's last sync: result sizes, the next run's prediction, timing.
 int conclude_run(yacrd_engine *e, yk::Counters c0, bool predicted, uint64_t n_reads64, uint64_t n_iv,
@@ -816,6 +697,63 @@ int finish_pending(yacrd_engine *e)
     return conclude_run(e, c, true, p.n_reads, p.n_iv, p.cls_b, p.cls_e, p.fused_marked, 0.f);
 }
 
+} // namespace
+
+namespace yke {
+// host -> HBM at PCIe rate.  A pinned source (yacrd_pinned_alloc, hipHostMalloc, hipHostRegister)
+// is one direct DMA, asynchronous on the engine's stream.  A pageable source would make the runtime
+// stage it through its own pinned buffers from ONE thread (9.6 GB/s measured for configs[1]'s 80 MB):
+// here a few threads copy 4 MiB pieces into the engine's pinned bounce buffers and enqueue their
+// DMAs, so memcpy and PCIe overlap.  On return the source is no longer needed in either case.
+int h2d(yacrd_engine *e, void *dst, const void *src, size_t bytes)
+{
+    if (!bytes) return YACRD_OK;
+    hipPointerAttribute_t at;
+    const bool pinned = hipPointerGetAttributes(&at, src) == hipSuccess && at.type == hipMemoryTypeHost;
+    if (!pinned) (void)hipGetLastError(); // an unregistered pointer is reported as an error: not one
+    if (pinned || bytes < ((size_t)1 << 20)) {
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, e->stream));
+        return YACRD_OK;
+    }
+    constexpr size_t kPiece = yacrd_engine::kBounceBytes;
+    for (int b = 0; b < yacrd_engine::kBounce; b++) {
+        if (e->bounce[b]) continue;
+        HIP_TRY(hipHostMalloc(&e->bounce[b], kPiece));
+        HIP_TRY(hipEventCreateWithFlags(&e->bounce_ev[b], hipEventDisableTiming));
+    }
+    const size_t n_pieces = (bytes + kPiece - 1) / kPiece;
+    const int T = (int)std::min<size_t>(yacrd_engine::kBounce / 2, n_pieces);
+    std::vector<hipError_t> errs((size_t)T, hipSuccess);
+    auto work = [&](int t) {
+        if (hipSetDevice(e->device) != hipSuccess) {
+            errs[t] = hipErrorInvalidDevice;
+            return;
+        }
+        int turn = 0;
+        for (size_t piece = (size_t)t; piece < n_pieces; piece += (size_t)T, turn ^= 1) {
+            const int b = 2 * t + turn; // two buffers per thread: one fills while the other flies
+            if (e->bounce_busy[b]) {
+                const hipError_t w = hipEventSynchronize(e->bounce_ev[b]);
+                if (w != hipSuccess) errs[t] = w;
+            }
+            const size_t at2 = piece * kPiece, n = std::min(kPiece, bytes - at2);
+            std::memcpy(e->bounce[b], (const char *)src + at2, n);
+            hipError_t c = hipMemcpyAsync((char *)dst + at2, e->bounce[b], n, hipMemcpyHostToDevice, e->stream);
+            if (c == hipSuccess) c = hipEventRecord(e->bounce_ev[b], e->stream);
+            if (c != hipSuccess) errs[t] = c;
+            e->bounce_busy[b] = true;
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (int t = 1; t < T; t++) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+    }
+    for (hipError_t er : errs) HIP_TRY(er);
+    return YACRD_OK;
+}
+
 int fetch_result(yacrd_engine *e, yacrd_result *out)
 {
     if (!out) return fail(YACRD_EINVAL, "out is null");
@@ -830,30 +768,53 @@ int fetch_result(yacrd_engine *e, yacrd_result *out)
         yacrd_result_free(out);
         return fail(YACRD_ENOMEM, "host allocation failed");
     }
+    // D2H lands in the engine's pinned staging block (direct DMA; into the pageable result arrays
+    // the runtime stages at ~10 GB/s) and is copied out from there; results beyond 1 GiB go direct.
+    const size_t b_off = (size_t)(R + 1) * sizeof(uint64_t), b_reg = (size_t)G * sizeof(uint2), b_typ = (size_t)R;
+    const size_t o_reg = (b_off + 63) & ~(size_t)63, o_typ = (o_reg + b_reg + 63) & ~(size_t)63;
+    const size_t need = o_typ + b_typ + 64;
+    bool staged = need <= ((size_t)1 << 30);
+    if (staged && need > e->h_out_cap) {
+        if (e->h_out) (void)hipHostFree(e->h_out);
+        e->h_out = nullptr;
+        e->h_out_cap = 0;
+        const size_t want = need + need / 4;
+        if (hipHostMalloc(&e->h_out, want) == hipSuccess) e->h_out_cap = want;
+        else {
+            (void)hipGetLastError();
+            staged = false;
+        }
+    }
+    char *h = (char *)e->h_out;
+    void *t_off = staged ? (void *)h : (void *)out->bad_offsets;
+    void *t_reg = staged ? (void *)(h + o_reg) : (void *)out->bad_regions;
+    void *t_typ = staged ? (void *)(h + o_typ) : (void *)out->read_type;
     HIP_TRY(hipEventRecord(e->ev_d2h0, e->stream));
-    HIP_TRY(hipMemcpyAsync(out->bad_offsets, e->bad_offsets.p, (size_t)(R + 1) * sizeof(uint64_t),
-                           hipMemcpyDeviceToHost, e->stream));
-    if (G)
-        HIP_TRY(hipMemcpyAsync(out->bad_regions, e->bad_regions.p, (size_t)G * sizeof(uint2),
-                               hipMemcpyDeviceToHost, e->stream));
-    if (R)
-        HIP_TRY(hipMemcpyAsync(out->read_type, e->read_type.p, (size_t)R, hipMemcpyDeviceToHost,
-                               e->stream));
+    HIP_TRY(hipMemcpyAsync(t_off, e->bad_offsets.p, b_off, hipMemcpyDeviceToHost, e->stream));
+    if (G) HIP_TRY(hipMemcpyAsync(t_reg, e->bad_regions.p, b_reg, hipMemcpyDeviceToHost, e->stream));
+    if (R) HIP_TRY(hipMemcpyAsync(t_typ, e->read_type.p, b_typ, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipEventRecord(e->ev_d2h1, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
+    if (staged) {
+        std::memcpy(out->bad_offsets, t_off, b_off);
+        if (G) std::memcpy(out->bad_regions, t_reg, b_reg);
+        if (R) std::memcpy(out->read_type, t_typ, b_typ);
+    }
     e->timing.d2h_ms = ev_ms(e->ev_d2h0, e->ev_d2h1);
     out->n_reads = R;
     out->n_regions = G;
     return YACRD_OK;
 }
+} // namespace yke
 
+namespace {
 } // namespace
 
 extern "C" {
 
 int yacrd_abi_version(void) { return YACRD_ABI_VERSION; }
 
-const char *yacrd_last_error(void) { return g_err.c_str(); }
+const char *yacrd_last_error(void) { return yke::err_slot().c_str(); }
 
 int yacrd_engine_create(const yacrd_engine_cfg *cfg, yacrd_engine **out)
 {
@@ -920,6 +881,11 @@ void yacrd_engine_destroy(yacrd_engine *e)
                       &e->bad_offsets, &e->bad_regions, &e->read_type};
     for (DevBuf *b : bufs) b->release();
     if (e->h_ctr) (void)hipHostFree(e->h_ctr);
+    if (e->h_out) (void)hipHostFree(e->h_out);
+    for (int b = 0; b < yacrd_engine::kBounce; b++) {
+        if (e->bounce[b]) (void)hipHostFree(e->bounce[b]);
+        if (e->bounce_ev[b]) (void)hipEventDestroy(e->bounce_ev[b]);
+    }
     for (int i = 0; i < EV_COUNT; i++)
         if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
     for (int i = 0; i < 24; i++)
@@ -981,6 +947,32 @@ int yacrd_engine_wait(yacrd_engine *e, yacrd_device_result *out)
     return YACRD_OK;
 }
 
+// validate a host CSR and enqueue its way to HBM on the engine's stream (shared by run / submit)
+static int stage_host_inputs(yacrd_engine *e, const uint64_t *offsets, const uint32_t *intervals,
+                             const uint32_t *lengths, uint64_t n_reads, uint64_t *n_iv_out)
+{
+    if (n_reads && (!offsets || !lengths)) return fail(YACRD_EINVAL, "null input");
+    const uint64_t n_iv = n_reads ? offsets[n_reads] : 0;
+    if (n_reads && offsets[0] != 0) return fail(YACRD_EINVAL, "offsets[0] must be 0");
+    for (uint64_t r = 0; r < n_reads; r++)
+        if (offsets[r + 1] < offsets[r]) return fail(YACRD_EINVAL, "offsets must be non-decreasing");
+    if (n_iv && !intervals) return fail(YACRD_EINVAL, "null intervals");
+    HIP_TRY(e->in_off.reserve((size_t)(n_reads + 1) * sizeof(uint64_t)));
+    HIP_TRY(e->in_iv.reserve((size_t)(n_iv + 1) * sizeof(uint2)));
+    HIP_TRY(e->in_len.reserve((size_t)(n_reads + 1) * sizeof(uint32_t)));
+    HIP_TRY(hipEventRecord(e->ev_h2d0, e->stream));
+    int rc = YACRD_OK;
+    if (n_reads) {
+        rc = h2d(e, e->in_off.p, offsets, (size_t)(n_reads + 1) * sizeof(uint64_t));
+        if (!rc) rc = h2d(e, e->in_len.p, lengths, (size_t)n_reads * sizeof(uint32_t));
+    }
+    if (!rc && n_iv) rc = h2d(e, e->in_iv.p, intervals, (size_t)n_iv * sizeof(uint2));
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(e->ev_h2d1, e->stream));
+    *n_iv_out = n_iv;
+    return YACRD_OK;
+}
+
 int yacrd_engine_run(yacrd_engine *e, const uint64_t *offsets, const uint32_t *intervals,
                      const uint32_t *lengths, uint64_t n_reads, uint32_t coverage,
                      double not_coverage, yacrd_result *out)
@@ -988,32 +980,70 @@ int yacrd_engine_run(yacrd_engine *e, const uint64_t *offsets, const uint32_t *i
     if (!e) return fail(YACRD_EINVAL, "engine is null");
     if (!out) return fail(YACRD_EINVAL, "out is null");
     std::memset(out, 0, sizeof(*out));
-    if (n_reads && (!offsets || !lengths)) return fail(YACRD_EINVAL, "null input");
-    const uint64_t n_iv = n_reads ? offsets[n_reads] : 0;
-    if (n_reads && offsets[0] != 0) return fail(YACRD_EINVAL, "offsets[0] must be 0");
-    for (uint64_t r = 0; r < n_reads; r++)
-        if (offsets[r + 1] < offsets[r]) return fail(YACRD_EINVAL, "offsets must be non-decreasing");
-    if (n_iv && !intervals) return fail(YACRD_EINVAL, "null intervals");
+    if (e->pending.active) return fail(YACRD_EINVAL, "a submitted batch is pending: yacrd_engine_wait first");
     DeviceGuard guard(e->device);
-    HIP_TRY(e->in_off.reserve((size_t)(n_reads + 1) * sizeof(uint64_t)));
-    HIP_TRY(e->in_iv.reserve((size_t)(n_iv + 1) * sizeof(uint2)));
-    HIP_TRY(e->in_len.reserve((size_t)(n_reads + 1) * sizeof(uint32_t)));
-    HIP_TRY(hipEventRecord(e->ev_h2d0, e->stream));
-    if (n_reads) {
-        HIP_TRY(hipMemcpyAsync(e->in_off.p, offsets, (size_t)(n_reads + 1) * sizeof(uint64_t),
-                               hipMemcpyHostToDevice, e->stream));
-        HIP_TRY(hipMemcpyAsync(e->in_len.p, lengths, (size_t)n_reads * sizeof(uint32_t),
-                               hipMemcpyHostToDevice, e->stream));
-    }
-    if (n_iv)
-        HIP_TRY(hipMemcpyAsync(e->in_iv.p, intervals, (size_t)n_iv * sizeof(uint2),
-                               hipMemcpyHostToDevice, e->stream));
-    HIP_TRY(hipEventRecord(e->ev_h2d1, e->stream));
-    int rc = run_on_device(e, e->in_off.as<u64>(), e->in_iv.as<uint2>(), e->in_len.as<u32>(),
-                           n_reads, n_iv, coverage, not_coverage);
+    uint64_t n_iv = 0;
+    int rc = stage_host_inputs(e, offsets, intervals, lengths, n_reads, &n_iv);
+    if (rc) return rc;
+    rc = run_on_device(e, e->in_off.as<u64>(), e->in_iv.as<uint2>(), e->in_len.as<u32>(), n_reads,
+                       n_iv, coverage, not_coverage);
     if (rc) return rc;
     e->timing.h2d_ms = ev_ms(e->ev_h2d0, e->ev_h2d1);
-    return fetch_result(e, out);
+    e->timing_sum.h2d_ms += e->timing.h2d_ms;
+    rc = fetch_result(e, out);
+    if (!rc) e->timing_sum.d2h_ms += e->timing.d2h_ms;
+    return rc;
+}
+
+int yacrd_engine_submit(yacrd_engine *e, const uint64_t *offsets, const uint32_t *intervals,
+                        const uint32_t *lengths, uint64_t n_reads, uint32_t coverage,
+                        double not_coverage)
+{
+    if (!e) return fail(YACRD_EINVAL, "engine is null");
+    if (e->pending.active || e->host_pending)
+        return fail(YACRD_EINVAL, "a submitted batch is pending: collect it first");
+    DeviceGuard guard(e->device);
+    uint64_t n_iv = 0;
+    int rc = stage_host_inputs(e, offsets, intervals, lengths, n_reads, &n_iv);
+    if (rc) return rc;
+    rc = run_on_device(e, e->in_off.as<u64>(), e->in_iv.as<uint2>(), e->in_len.as<u32>(), n_reads,
+                       n_iv, coverage, not_coverage, true);
+    if (rc) return rc;
+    e->host_pending = true;
+    return YACRD_OK;
+}
+
+int yacrd_engine_collect(yacrd_engine *e, yacrd_result *out)
+{
+    if (!e) return fail(YACRD_EINVAL, "engine is null");
+    if (!out) return fail(YACRD_EINVAL, "out is null");
+    std::memset(out, 0, sizeof(*out));
+    if (!e->host_pending) return fail(YACRD_EINVAL, "nothing was submitted");
+    e->host_pending = false;
+    DeviceGuard guard(e->device);
+    int rc = finish_pending(e);
+    if (rc) return rc;
+    e->timing.h2d_ms = ev_ms(e->ev_h2d0, e->ev_h2d1);
+    e->timing_sum.h2d_ms += e->timing.h2d_ms;
+    rc = fetch_result(e, out);
+    if (!rc) e->timing_sum.d2h_ms += e->timing.d2h_ms;
+    return rc;
+}
+
+void *yacrd_pinned_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+        (void)hipGetLastError();
+        yke::err_slot() = "hipHostMalloc failed";
+        return nullptr;
+    }
+    return p;
+}
+
+void yacrd_pinned_free(void *p)
+{
+    if (p) (void)hipHostFree(p);
 }
 
 int yacrd_engine_fetch(yacrd_engine *e, yacrd_result *out)
@@ -1116,7 +1146,7 @@ int yacrd_engines_run_partitioned(yacrd_engine *const *engines, uint32_t n_engin
         codes[p] = yacrd_engine_run(engines[p], loc.data(), intervals ? intervals + 2 * base : nullptr,
                                     lengths ? lengths + r0 : nullptr, r1 - r0, coverage,
                                     not_coverage, &parts[p]);
-        if (codes[p]) errs[p] = g_err; // thread-local message of this worker
+        if (codes[p]) errs[p] = yke::err_slot(); // thread-local message of this worker
     };
     {
         std::vector<std::thread> th;

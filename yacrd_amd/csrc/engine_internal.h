@@ -1,0 +1,170 @@
+// engine_internal.h — host-side internals shared by the translation units of libyacrd_hip.so
+// (engine.hip: batch runs; stream.hip: streaming ingest + CSR build on the GPU).
+#pragma once
+#include "../../include/yacrd_engine.h"
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+
+#include <mutex>
+#include <string>
+
+#include "device_common.h"
+
+namespace yke {
+
+// message of the last error on the calling thread (yacrd_last_error)
+std::string &err_slot();
+inline int fail(int code, const std::string &msg)
+{
+    err_slot() = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return yke::fail(_e == hipErrorOutOfMemory ? YACRD_ENOMEM : YACRD_ENODEV,          \
+                             std::string(#expr) + ": " + hipGetErrorString(_e));              \
+    } while (0)
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 8 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            e = hipMalloc(&p, bytes);
+            want = bytes;
+        }
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T *as() const
+    {
+        return reinterpret_cast<T *>(p);
+    }
+};
+
+enum { EV_START = 0, EV_PLAN, EV_S0, EV_SMALL, EV_MED, EV_GEN, EV_COMPACT, EV_X0, EV_X1, EV_COUNT };
+
+
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) (void)hipSetDevice(dev);
+        else prev = -1;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+inline float ev_ms(hipEvent_t a, hipEvent_t b)
+{
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, a, b) != hipSuccess) return 0.f;
+    return ms;
+}
+
+} // namespace yke
+
+
+// One per device: whose dominant sweep went out last (see launch_sweeps).
+struct BigLane {
+    std::mutex mu;
+    hipEvent_t last = nullptr;
+    struct yacrd_engine *owner = nullptr;
+    int n_engines = 0;
+};
+static BigLane g_big_lane[64];
+
+// A batch that was submitted without waiting for it (yacrd_engine_submit_device).
+struct Pending {
+    bool active = false;
+    const u64 *d_off = nullptr;
+    const uint2 *d_iv = nullptr;
+    const u32 *d_len = nullptr;
+    uint64_t n_reads = 0, n_iv = 0;
+    uint32_t cov = 0;
+    double not_cov = 0;
+    u32 grid_n[12] = {};      // reads each class's grid covers
+    bool skipped_small = false, fused_marked = false;
+    int cls_b[12] = {}, cls_e[12] = {};
+};
+
+struct yacrd_engine {
+    Pending pending;
+    bool in_lane = false;
+    int device = 0;
+    uint32_t flags = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[yke::EV_COUNT] = {};
+    hipEvent_t ev_h2d0 = nullptr, ev_h2d1 = nullptr, ev_d2h0 = nullptr, ev_d2h1 = nullptr;
+    hipEvent_t ev_cls[24] = {}; // brackets around class kernels
+    hipEvent_t ev_done = nullptr; // hipEventBlockingSync: the final wait of YACRD_F_BLOCKING_WAIT
+    int num_cu = 256;
+
+    // inputs staged by yacrd_engine_run
+    yke::DevBuf in_off, in_iv, in_len;
+    // work buffers
+    yke::DevBuf lists, ctrl2[2], stage, counts, gen_sizes, gen_scratch_off, gen_scratch, big_tab, big_keys, big_redo;
+    // two control blocks (counters + scan state), used alternately: the plan kernel of a run zeroes
+    // the other one for the next run.  ctrl_clean[i] = leading bytes of block i known to be zero.
+    size_t ctrl_clean[2] = {0, 0};
+    int ctrl_cur = 0;
+    // results
+    yke::DevBuf bad_offsets, bad_regions, read_type;
+    yk::Counters *h_ctr = nullptr; // pinned
+
+    uint64_t last_reads = 0, last_regions = 0;
+    bool has_result = false;
+    // class counts of the previous run: the prediction that lets the next one skip the plan sync
+    yk::Counters pred{};
+    uint64_t pred_reads = 0, pred_iv = 0;
+    bool pred_valid = false;
+    yacrd_timing timing = {};
+    yacrd_timing timing_sum = {};
+    uint64_t timing_runs = 0;
+    // pinned bounce buffers for pageable inputs (yke::h2d), allocated on first use; an event per
+    // buffer says when its DMA is done and it may be refilled
+    static constexpr int kBounce = 12;
+    static constexpr size_t kBounceBytes = (size_t)4 << 20;
+    void *bounce[kBounce] = {};
+    hipEvent_t bounce_ev[kBounce] = {};
+    bool bounce_busy[kBounce] = {};
+    // pinned staging for the results on their way home (fetch_result), grow-only
+    void *h_out = nullptr;
+    size_t h_out_cap = 0;
+    // a batch submitted from host buffers (yacrd_engine_submit): collect() fetches the result
+    bool host_pending = false;
+};
+
+
+namespace yke {
+// the whole launch sequence over a CSR resident in HBM (engine.hip)
+int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u32 *d_len,
+                  uint64_t n_reads64, uint64_t n_iv, uint32_t cov, double not_cov, bool defer = false);
+// D2H of the last result into a freshly allocated yacrd_result
+int fetch_result(yacrd_engine *e, yacrd_result *out);
+// host -> HBM at PCIe rate: direct DMA when `src` is pinned, otherwise through the engine's pinned
+// bounce buffers filled by a few copy threads; asynchronous on e->stream only for pinned sources
+int h2d(yacrd_engine *e, void *dst, const void *src, size_t bytes);
+} // namespace yke

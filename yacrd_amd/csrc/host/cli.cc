@@ -36,7 +36,9 @@ void usage(FILE *f)
                  "OPTIONS:\n"
                  "    -i, --input <INPUT>                  overlap file (.paf|.m4|.mhap) or yacrd report (.yacrd)\n"
                  "    -o, --output <OUTPUT>                path output file\n"
-                 "    -t, --thread <THREADS>               host threads (overlap parsing); 0 = all [default: 1]\n"
+                 "    -t, --thread <THREADS>               host threads for the overlap parse [default: 1, like the\n"
+                 "                                         reference's rayon pool]; 0 = every usable CPU, which is what\n"
+                 "                                         you want: the parse is the whole wall clock\n"
                  "    -c, --coverage <COVERAGE>            if coverage reach this value region is marked as bad [default: 0]\n"
                  "    -n, --not-coverage <NOT_COVERAGE>    bad-region ratio above which a read is NotCovered [default: 0.8]\n"
                  "        --read-buffer-size <N>           accepted for compatibility [default: 8192]\n"
@@ -157,12 +159,32 @@ int main(int argc, char **argv)
         view.names = bp.names;
         view.lengths = bp.lengths;
     } else {
-        if (yacrd_csr_from_file(input.c_str(), 0, (int)threads, &csr)) die(yacrd_host_last_error());
-        yacrd_csr_get(csr, &view);
-        if (yacrd_engines_run_partitioned(engines.data(), (uint32_t)engines.size(), view.offsets,
-                                          view.intervals, view.lengths, view.n_reads, cov32,
-                                          not_coverage, &res) != YACRD_OK)
-            die(yacrd_last_error());
+        if (engines.size() == 1) {
+            // one GPU: the parser's records cross PCIe from pinned buffers while it is still
+            // parsing, the CSR is built in HBM (yacrd_stream_*), then the engine runs on it
+            yacrd_stream *st = nullptr;
+            if (yacrd_stream_open(engines[0], 0, 0, &st) != YACRD_OK) die(yacrd_last_error());
+            yacrd_rec_sink sink;
+            yacrd_stream_sink(st, &sink);
+            if (yacrd_ingest_stream(input.c_str(), 0, (int)threads, &sink, &csr)) die(yacrd_host_last_error());
+            yacrd_csr_get(csr, &view);
+            const uint32_t *map = nullptr;
+            uint64_t n_handles = 0;
+            if (yacrd_csr_handle_map(csr, &map, &n_handles)) die(yacrd_host_last_error());
+            if (yacrd_stream_finish(st, map, n_handles, view.lengths, view.n_reads, cov32, not_coverage,
+                                    &res) != YACRD_OK)
+                die(yacrd_last_error());
+            yacrd_stream_close(st);
+        } else {
+            // several GPUs: host CSR, contiguous read ranges balanced by interval count, one
+            // engine per GPU, no collective (reads are independent, src/stack.rs:61)
+            if (yacrd_csr_from_file(input.c_str(), 0, (int)threads, &csr)) die(yacrd_host_last_error());
+            yacrd_csr_get(csr, &view);
+            if (yacrd_engines_run_partitioned(engines.data(), (uint32_t)engines.size(), view.offsets,
+                                              view.intervals, view.lengths, view.n_reads, cov32,
+                                              not_coverage, &res) != YACRD_OK)
+                die(yacrd_last_error());
+        }
         bp.n_reads = view.n_reads;
         bp.name_off = view.name_off;
         bp.names = view.names;

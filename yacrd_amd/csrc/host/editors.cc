@@ -15,7 +15,7 @@
 #include "../../../include/yacrd_host.h"
 #include "host_common.h"
 
-#include <zlib.h>
+#include "codec.h"
 
 #include <cstdio>
 #include <cstring>
@@ -51,42 +51,28 @@ const char *type_name(FileType t)
     }
 }
 
-// ---- input: plain or gzip, sniffed from magic bytes like niffler (src/util.rs:57-70) ---------
+// ---- input: plain, gzip, bzip2 or xz, sniffed from magic bytes like niffler (src/util.rs:57-70) --
 struct Reader {
-    gzFile gz = nullptr; // zlib reads plain files transparently
-    bool compressed = false;
+    yh::InStream in;
     std::vector<char> buf;
     size_t pos = 0, end = 0;
     bool eof = false;
+    bool failed = false; // read / decompression error (message in the error slot): callers check
 
     int open(const char *path)
     {
-        FILE *f = std::fopen(path, "rb");
-        if (!f) return yh::fail(std::string("Can't open file ") + path + " to read");
-        unsigned char m[6] = {0};
-        const size_t got = std::fread(m, 1, sizeof m, f);
-        std::fclose(f);
-        if (got >= 2 && m[0] == 0x1f && m[1] == 0x8b) compressed = true;
-        if ((got >= 3 && m[0] == 'B' && m[1] == 'Z' && m[2] == 'h') ||
-            (got >= 6 && m[0] == 0xFD && std::memcmp(m + 1, "7zXZ", 4) == 0))
-            return yh::fail(std::string(path) + ": bzip2/xz input is not supported in this build "
-                                                "(no bzlib.h / lzma.h in the image)");
-        gz = gzopen(path, "rb");
-        if (!gz) return yh::fail(std::string("Can't open file ") + path + " to read");
-        gzbuffer(gz, 1 << 20);
+        if (in.open(path)) return 1;
         buf.resize(1 << 20);
         return 0;
     }
-    ~Reader()
-    {
-        if (gz) gzclose(gz);
-    }
+    yh::Compression compression() const { return in.format(); }
     bool fill()
     {
         if (eof) return false;
-        const int n = gzread(gz, buf.data(), (unsigned)buf.size());
+        const long n = in.read(buf.data(), buf.size());
         if (n <= 0) {
             eof = true;
+            failed = n < 0; // a truncated or corrupt stream is an error, not the end of the file
             return false;
         }
         pos = 0;
@@ -120,30 +106,21 @@ struct Reader {
     }
 };
 
-// ---- output: same compression as the input, gzip level 1 (src/util.rs:72-87) ------------------
+// ---- output: same compression as the input, level 1 (src/util.rs:72-87) ------------------------
 struct Writer {
-    FILE *f = nullptr;
-    gzFile gz = nullptr;
+    yh::OutStream os;
     std::vector<char> buf;
     bool failed = false;
-    int open(const char *path, bool gzip)
+    int open(const char *path, yh::Compression fmt)
     {
-        if (gzip) {
-            gz = gzopen(path, "wb1");
-            if (!gz) return yh::fail(std::string("Can't open file ") + path + " to write");
-            gzbuffer(gz, 1 << 20);
-        } else {
-            f = std::fopen(path, "wb");
-            if (!f) return yh::fail(std::string("Can't open file ") + path + " to write");
-        }
+        if (os.open(path, fmt)) return 1;
         buf.reserve(1 << 20);
         return 0;
     }
     void flush()
     {
         if (buf.empty()) return;
-        if (gz) failed |= gzwrite(gz, buf.data(), (unsigned)buf.size()) != (int)buf.size();
-        else failed |= std::fwrite(buf.data(), 1, buf.size(), f) != buf.size();
+        failed |= !os.write(buf.data(), buf.size());
         buf.clear();
     }
     void put(const char *p, size_t n)
@@ -156,16 +133,8 @@ struct Writer {
     int close()
     {
         flush();
-        if (gz) failed |= gzclose(gz) != Z_OK;
-        if (f) failed |= std::fclose(f) != 0;
-        gz = nullptr;
-        f = nullptr;
-        return failed ? yh::fail("Error during writing of the output file") : 0;
-    }
-    ~Writer()
-    {
-        if (gz) gzclose(gz);
-        if (f) std::fclose(f);
+        const int rc = os.close();
+        return (failed || rc) ? yh::fail("Error during writing of the output file") : 0;
     }
 };
 
@@ -337,6 +306,7 @@ int edit_sequences(int op, bool fastq, Reader &in, Writer &out, const BadParts &
     for (;;) {
         const bool ok = fastq ? next_fastq(in, rec, err) : next_fasta(in, rec, err);
         if (!ok) {
+            if (in.failed) return 1; // message set by the decoder
             if (!err.empty()) return yh::fail(err);
             break;
         }
@@ -429,6 +399,7 @@ int edit_overlaps(int op, bool paf, Reader &in, Writer &out, const BadParts &bp)
             out.put('\n');
         }
     }
+    if (in.failed) return 1; // message set by the decoder
     return 0;
 }
 
@@ -458,7 +429,7 @@ int yacrd_report_read(const char *path, yacrd_report **out)
     auto corrupt = [&](const std::string &why) {
         delete rep;
         return yh::fail("Your yacrd file " + std::string(path) + " seems corrupt at line " +
-                        std::to_string(line_no) + " (" + why + ")");
+                        std::to_string(line_no) + " (1-based; " + why + ")");
     };
     struct Row {
         std::string id;
@@ -467,6 +438,7 @@ int yacrd_report_read(const char *path, yacrd_report **out)
     };
     std::vector<Row> rows;
     while (in.line(l)) {
+        line_no++; // physical lines, 1-based, blank ones included
         if (!l.empty() && l.back() == '\r') l.pop_back();
         if (l.empty()) continue;
         // type \t id \t len \t regions
@@ -517,13 +489,16 @@ int yacrd_report_read(const char *path, yacrd_report **out)
                 if (e == body.size()) break;
             }
         }
-        line_no++;
         auto it = seen.find(row.id);
         if (it != seen.end()) rows[it->second] = std::move(row);
         else {
             seen.emplace(row.id, (uint32_t)rows.size());
             rows.push_back(std::move(row));
         }
+    }
+    if (in.failed) {
+        delete rep;
+        return 1; // message set by the decoder
     }
     for (const Row &row : rows) {
         rep->names.insert(rep->names.end(), row.id.begin(), row.id.end());
@@ -566,7 +541,7 @@ int yacrd_edit_file(int op, const char *in_path, const char *out_path, const yac
     Reader in;
     if (in.open(in_path)) return 1;
     Writer out;
-    if (out.open(out_path, in.compressed)) return 1;
+    if (out.open(out_path, in.compression())) return 1;
     const BadParts table(bp);
     const int rc = seq ? edit_sequences(op, ft == FT_FASTQ, in, out, table)
                        : edit_overlaps(op, ft == FT_PAF, in, out, table);

@@ -1,4 +1,4 @@
-// paf_csr.cc — overlap ingest: PAF / M4 text -> the CSR the engine consumes.
+// paf_csr.cc — overlap ingest: PAF / M4 text -> overlap records -> the CSR the engine consumes.
 //
 // Replaces reference Reads2Ovl::init_paf / init_m4 (src/reads2ovl/mod.rs:83-145; column contract
 // src/io.rs:23-50) and FullMemory::add_overlap_and_length (src/reads2ovl/fullmemory.rs:82-90):
@@ -6,29 +6,40 @@
 //   * a read's length is the FIRST length seen for its id (fullmemory.rs:82-90)
 //   * records may carry extra columns (csv `flexible(true)`), empty lines are skipped
 //   * a short or non-numeric record is an error (the reference bails, mod.rs:93-97)
-// Reads are numbered in first-appearance order.  Parsing is chunk-parallel over one shared id
-// table whose entries remember where in the file their id came first, so numbering and the
-// first-length rule do not depend on the thread count.  csv-crate quoting ("...") is not interpreted (unpinned by
-// the reference's tests): a '"' is an ordinary byte here.
+// Reads are numbered in first-appearance order.  The input is cut into blocks of whole lines that
+// a pool of parse threads takes in turn (a mapped file is sliced in place; a gzip / bzip2 / xz
+// stream is decoded by a reader thread that feeds the pool).  All threads intern read ids into one
+// shared table whose entries remember where in the file their id came first, so numbering and the
+// first-length rule do not depend on the thread count or on timing.
+// Two destinations for the parsed records:
+//   * yacrd_csr_from_file / _from_memory: kept on the host, grouped into the CSR by the host;
+//   * yacrd_ingest_stream: handed to a yacrd_rec_sink buffer by buffer while the parse goes on
+//     (the engine's yacrd_stream moves them over PCIe from pinned memory and builds the CSR in HBM).
+// Record syntax follows the csv crate the reference reads with (csv 1.3 / csv-core 0.1.11,
+// Cargo.lock:241; unpinned by the reference's tests): `"`-quoted fields with `""`
+// escapes, records ended by \n, \r\n or \r, integers with an optional `+` or a `0x` prefix.  One
+// deviation, loud: a quoted field may not contain a line break.
 #include "../../../include/yacrd_host.h"
+#include "codec.h"
 #include "host_common.h"
 
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
-#include <zlib.h>
 
 #include <algorithm>
 #include <atomic>
 #include <cerrno>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
 #include <memory>
 #include <mutex>
 #include <new>
-#include <cstdlib>
-#include <cstring>
 #include <string>
 #include <thread>
 #include <vector>
@@ -48,6 +59,8 @@ struct yacrd_csr {
     std::vector<uint64_t> name_off;
     std::vector<char> names;
     uint64_t n_records = 0;
+    bool streamed = false;             // records went to a sink: no offsets / intervals on the host
+    std::vector<uint32_t> handle_map;  // streamed: record handle -> read id (~0u = unused handle)
     std::vector<uint32_t> table; // open addressing over read ids (value = id + 1), lazy
     uint64_t mask = 0;
     std::once_flag table_once;
@@ -96,9 +109,7 @@ struct HugeAlloc {
 template <class T>
 using big_vector = std::vector<T, HugeAlloc<T>>;
 
-struct Rec {
-    uint32_t a, b, sa, ea, sb, eb;
-};
+using Rec = yacrd_ovl_rec; // a / b hold IdTable handles until the global numbering exists
 
 // Zero-filled memory for the id table, carved out of 64 MiB anonymous regions with MADV_HUGEPAGE:
 // the table is probed at random, and on 4 KiB pages every probe also misses the TLB.
@@ -140,11 +151,16 @@ struct HugePool {
 // knows, takes the shard's spin lock: inserts re-probe the current index, a full index is replaced
 // by one twice the size (the old one stays allocated until the end: readers may still walk it,
 // and fall back to the locked path when it misses).  An entry remembers the smallest position
-// (byte offset of the line * 2 + 0/1 for the first / second id) at which its id was seen and the
+// (byte offset of the record * 2 + 0/1 for the first / second id) at which its id was seen and the
 // length given there: global numbering = order of those positions (first appearance in the
 // file) and a read's length = the first length seen (fullmemory.rs:82-90), whatever the timing.
+// What intern() returns is a HANDLE: a 32-bit number unique to the id, dense enough to index an
+// array (entry blocks draw their handle ranges from one global counter; at most the last block of
+// a shard is partly unused), valid before the numbering exists — records carry handles to the GPU
+// while the parse is still running, and a handle -> read id map follows at the end.
 struct IdTable {
     static constexpr uint32_t kIdxBits = 22, kBlock0 = 64, kBlocks = 17; // 64 * (2^17 - 1) > 2^22
+    static constexpr size_t kShards = 1024; // capacity: kShards * 2^22 ids, far beyond the 2^32 - 2 cap
     // What a lookup touches is kept small (16 B per id + the name bytes + a 16 B slot: for 400 k ids
     // 27 MB, an L3 slice; with hash, length and name length in the same record it was 37 MB and
     // a single thread parsed 1.6x slower).
@@ -171,22 +187,18 @@ struct IdTable {
         alignas(64) std::atomic<Index *> index{nullptr};
         Hot *hot[kBlocks] = {};
         Cold *cold[kBlocks] = {};
+        uint32_t handle_base[kBlocks] = {}; // handle of the block's first entry
         uint32_t n_entries = 0;
         char *name_cur = nullptr;
         size_t name_left = 0;
     };
-    size_t n_shards = 1;
-    int shard_shift = 63; // shard = (hash >> shard_shift) & (n_shards - 1)
+    static constexpr int shard_shift = 64 - 10; // shard = hash >> shard_shift
     std::unique_ptr<Shard[]> shards;
     HugePool pool; // indexes, entries and name bytes; released as a whole
     std::atomic<bool> overflow{false};
+    std::atomic<uint64_t> next_handle{0};
 
-    explicit IdTable(size_t want_shards)
-    {
-        while (n_shards < want_shards) n_shards <<= 1;
-        shard_shift = n_shards == 1 ? 63 : 64 - __builtin_ctzll((unsigned long long)n_shards);
-        shards.reset(new Shard[n_shards]);
-    }
+    IdTable() { shards.reset(new Shard[kShards]); }
     IdTable(const IdTable &) = delete;
     IdTable &operator=(const IdTable &) = delete;
 
@@ -207,6 +219,12 @@ struct IdTable {
         uint32_t k, at;
         locate(idx, k, at);
         return sh.cold[k][at];
+    }
+    static uint32_t handle_of(const Shard &sh, uint32_t idx)
+    {
+        uint32_t k, at;
+        locate(idx, k, at);
+        return sh.handle_base[k] + at;
     }
     Index *new_index(uint32_t cap)
     {
@@ -237,15 +255,18 @@ struct IdTable {
             s2 = (s2 + 1) & ix->mask;
         }
     }
-    // returns shard << kIdxBits | entry number
+    // returns the id's handle
     uint32_t intern(const char *p, size_t n, uint64_t h, uint64_t length, uint64_t pos)
     {
-        const uint32_t si = (uint32_t)((h >> shard_shift) & (n_shards - 1));
-        Shard &sh = shards[si];
+        Shard &sh = shards[(size_t)(h >> shard_shift)];
         const Index *ix = sh.index.load(std::memory_order_acquire);
         uint32_t idx = ix ? probe(sh, ix, p, n, h) : ~0u;
-        if (idx != ~0u && pos >= hot(sh, idx).first_pos.load(std::memory_order_relaxed))
-            return (si << kIdxBits) | idx; // the common case: nothing shared is written
+        if (idx != ~0u) {
+            uint32_t k, at;
+            locate(idx, k, at);
+            if (pos >= sh.hot[k][at].first_pos.load(std::memory_order_relaxed))
+                return sh.handle_base[k] + at; // the common case: nothing shared is written
+        }
 
         while (sh.lock.exchange(true, std::memory_order_acquire))
             while (sh.lock.load(std::memory_order_relaxed)) __builtin_ia32_pause();
@@ -255,18 +276,25 @@ struct IdTable {
             sh.index.store(cur, std::memory_order_release);
         }
         if (idx == ~0u) idx = probe(sh, cur, p, n, h); // somebody else may have inserted it
+        uint32_t k, at;
         if (idx == ~0u) {
             idx = sh.n_entries;
             if (idx >= (1u << kIdxBits)) {
                 overflow.store(true, std::memory_order_relaxed);
                 sh.lock.store(false, std::memory_order_release);
-                return si << kIdxBits;
+                return 0;
             }
-            uint32_t k, at;
             locate(idx, k, at);
             if (!sh.hot[k]) {
-                sh.hot[k] = (Hot *)pool.alloc(sizeof(Hot) * ((size_t)kBlock0 << k));
+                const uint64_t base = next_handle.fetch_add((uint64_t)kBlock0 << k, std::memory_order_relaxed);
+                if (base + ((uint64_t)kBlock0 << k) >= 0xFFFFFFF0ull) {
+                    overflow.store(true, std::memory_order_relaxed);
+                    sh.lock.store(false, std::memory_order_release);
+                    return 0;
+                }
+                sh.handle_base[k] = (uint32_t)base;
                 sh.cold[k] = (Cold *)pool.alloc(sizeof(Cold) * ((size_t)kBlock0 << k));
+                sh.hot[k] = (Hot *)pool.alloc(sizeof(Hot) * ((size_t)kBlock0 << k));
             }
             if (sh.name_left < n) {
                 const size_t sz = std::max<size_t>(n, 4u << 10);
@@ -292,29 +320,91 @@ struct IdTable {
                 place(cur, h, (uint32_t)n, idx);
             }
         } else {
-            Hot &e = hot(sh, idx);
+            locate(idx, k, at);
+            Hot &e = sh.hot[k][at];
             if (pos < e.first_pos.load(std::memory_order_relaxed)) {
-                cold(sh, idx).first_len = length;
+                sh.cold[k][at].first_len = length;
                 e.first_pos.store(pos, std::memory_order_relaxed);
             }
         }
+        const uint32_t handle = sh.handle_base[k] + at;
         sh.lock.store(false, std::memory_order_release);
-        return (si << kIdxBits) | idx;
+        return handle;
     }
 };
 
-// One per parse thread.  Aligned and padded to its own cache lines: the threads update their
-// chunk's counters and vector ends on every line, and neighbours sharing a line cost 10x.
-struct alignas(256) Chunk {
-    const char *begin = nullptr, *end = nullptr;
-    IdTable *ids = nullptr;
-    const char *text = nullptr; // start of the whole input (positions are relative to it)
-    big_vector<Rec> recs; // a / b hold IdTable handles until the global numbering exists
+// ---- where a parse thread puts its records ----------------------------------------------------
+struct RecOut {
+    Rec *cur = nullptr, *lim = nullptr;
     std::string error;
-    uint64_t error_line = 0; // 1-based within chunk
-    uint64_t lines = 0;
+    virtual ~RecOut() {}
+    virtual bool more() = 0; // cur == lim: make room (false: `error` says why)
 };
 
+// host destination: 4 MiB segments of records that stay where they are
+struct SegOut final : RecOut {
+    struct Seg {
+        Rec *p;
+        size_t n;
+    };
+    static constexpr size_t kSegRecs = ((size_t)4 << 20) / sizeof(Rec); // 4 MiB: two huge pages
+    std::vector<Seg> segs;
+    bool more() override
+    {
+        close_segment();
+        Rec *p = HugeAlloc<Rec>().allocate(kSegRecs);
+        segs.push_back(Seg{p, 0});
+        cur = p;
+        lim = p + kSegRecs;
+        return true;
+    }
+    void close_segment()
+    {
+        if (!segs.empty() && cur) segs.back().n = (size_t)(cur - segs.back().p);
+    }
+    void release()
+    {
+        for (Seg &s : segs) HugeAlloc<Rec>().deallocate(s.p, kSegRecs);
+        segs.clear();
+        cur = lim = nullptr;
+    }
+    ~SegOut() override { release(); }
+};
+
+// streaming destination: buffers borrowed from the sink (pinned memory on its way over PCIe)
+struct SinkOut final : RecOut {
+    const yacrd_rec_sink *sink = nullptr;
+    Rec *base = nullptr;
+    uint64_t committed = 0;
+    bool more() override
+    {
+        if (!flush()) return false;
+        uint64_t cap = 0;
+        Rec *p = nullptr;
+        if (sink->acquire(sink->ctx, &p, &cap) != 0 || !p || cap == 0) {
+            error = "the record sink refused to hand out a buffer";
+            return false;
+        }
+        base = cur = p;
+        lim = p + cap;
+        return true;
+    }
+    bool flush()
+    {
+        if (!base) return true;
+        const uint64_t n = (uint64_t)(cur - base);
+        Rec *b = base;
+        base = cur = lim = nullptr;
+        if (sink->commit(sink->ctx, b, n) != 0) {
+            error = "the record sink failed to take a buffer";
+            return false;
+        }
+        committed += n;
+        return true;
+    }
+};
+
+// ---- field syntax --------------------------------------------------------------------------------
 inline bool parse_u64(const char *p, const char *e, uint64_t &out)
 {
     if (p < e && *p == '+') p++;
@@ -329,10 +419,33 @@ inline bool parse_u64(const char *p, const char *e, uint64_t &out)
     out = v;
     return true;
 }
-inline bool parse_u32(const char *p, const char *e, uint32_t &out)
+// the csv crate's integer fields: `0x` + hex digits (from_str_radix) or FromStr (decimal, optional +)
+inline bool parse_csv_u64(const char *p, const char *e, uint64_t &out)
+{
+    if (e - p >= 2 && p[0] == '0' && p[1] == 'x') {
+        p += 2;
+        if (p < e && *p == '+') p++;
+        if (p == e) return false;
+        uint64_t v = 0;
+        for (; p < e; p++) {
+            const unsigned char c = (unsigned char)*p;
+            unsigned d;
+            if (c >= '0' && c <= '9') d = c - '0';
+            else if (c >= 'a' && c <= 'f') d = c - 'a' + 10;
+            else if (c >= 'A' && c <= 'F') d = c - 'A' + 10;
+            else return false;
+            if (v >> 60) return false;
+            v = (v << 4) | d;
+        }
+        out = v;
+        return true;
+    }
+    return parse_u64(p, e, out);
+}
+inline bool parse_csv_u32(const char *p, const char *e, uint32_t &out)
 {
     uint64_t v;
-    if (!parse_u64(p, e, v) || v > 0xFFFFFFFFull) return false;
+    if (!parse_csv_u64(p, e, v) || v > 0xFFFFFFFFull) return false;
     out = (uint32_t)v;
     return true;
 }
@@ -343,27 +456,62 @@ inline bool is_one_char(const char *p, const char *e)
     const int n = c < 0x80 ? 1 : (c >> 5) == 6 ? 2 : (c >> 4) == 14 ? 3 : (c >> 3) == 30 ? 4 : 0;
     return n != 0 && e - p == n;
 }
-
-// ---- PAF fast path: one forward scan per line; ids are hashed while they are scanned ----------
-// Same acceptance as the generic path below (src/io.rs:23-34): 9 leading tab-separated fields,
-// u64 lengths, u32 positions (optional '+'), one-character strand, anything after ignored.
-inline bool scan_id(const char *&p, const char *le, uint64_t &h, const char *&b, size_t &n)
+// Rust's f64::from_str: decimal digits with optional sign, point and exponent, or inf / infinity /
+// nan in any case.  strtod also takes hex floats, nan(...) and leading blanks: excluded here.
+inline bool is_rust_f64(const char *p, const char *e)
 {
-    b = p;
-    uint64_t x = 0xcbf29ce484222325ull;
-    while (p < le && *p != '\t') {
-        x ^= (unsigned char)*p++;
-        x *= 0x100000001b3ull;
-    }
-    if (p >= le) return false; // an id must be followed by more fields
-    n = (size_t)(p - b);
+    if (p == e) return false;
+    for (const char *q = p; q < e; q++)
+        if (*q == 'x' || *q == 'X' || *q == '(' || *q == ' ' || *q == '\t' || *q == 'p' || *q == 'P') return false;
+    const std::string s(p, e);
+    char *endp = nullptr;
+    errno = 0;
+    (void)std::strtod(s.c_str(), &endp);
+    return endp && *endp == '\0';
+}
+
+// 64-bit hash of an id, eight bytes at a time (the byte-at-a-time FNV chain cost ~40 cycles per
+// id: two per line).  Must agree with hash_id_scan below.
+inline uint64_t mix64(uint64_t x)
+{
     x ^= x >> 32;
     x *= 0xd6e8feb86659fd93ull;
     x ^= x >> 32;
-    h = x;
-    p++;
-    return true;
+    x *= 0xd6e8feb86659fd93ull;
+    x ^= x >> 32;
+    return x;
 }
+inline uint64_t hash_id(const char *p, size_t n)
+{
+    uint64_t h = 0x9e3779b97f4a7c15ull ^ (uint64_t)n;
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t w;
+        std::memcpy(&w, p + i, 8);
+        h = (h ^ w) * 0xff51afd7ed558ccdull;
+        h ^= h >> 29;
+    }
+    if (i < n) {
+        uint64_t w = 0;
+        std::memcpy(&w, p + i, n - i);
+        h = (h ^ w) * 0xff51afd7ed558ccdull;
+        h ^= h >> 29;
+    }
+    return mix64(h);
+}
+
+struct Fields { // one overlap record, syntax checked
+    const char *ida, *idb;
+    size_t na, nb;
+    uint64_t la, lb;
+    uint32_t sa, ea, sb, eb;
+};
+
+// ---- PAF fast path: one forward scan per line ----------------------------------------------------
+// Accepts the plain form of a record (src/io.rs:23-34): 9 leading tab-separated fields, decimal
+// u64 lengths and u32 positions with an optional '+', one-character strand, anything after
+// ignored, no quote at the start of a field.  Whatever it does not accept gets a second look by
+// parse_record_general (quotes, 0x integers, \r inside the line).
 inline bool scan_uint(const char *&p, const char *le, uint64_t limit, uint64_t &out, bool last)
 {
     if (p < le && *p == '+') p++;
@@ -386,125 +534,197 @@ inline bool scan_uint(const char *&p, const char *le, uint64_t limit, uint64_t &
     out = v;
     return true;
 }
-
-void parse_chunk_paf(Chunk &c)
+inline bool scan_id(const char *&p, const char *le, const char *&b, size_t &n)
 {
-    c.recs.reserve((size_t)(c.end - c.begin) / 48 + 16); // untouched pages cost nothing
-    const char *p = c.begin;
-    while (p < c.end) {
-        const char *eol = (const char *)std::memchr(p, '\n', (size_t)(c.end - p));
-        if (!eol) eol = c.end;
-        const char *le = eol;
-        if (le > p && le[-1] == '\r') le--;
-        c.lines++;
-        if (le == p) {
-            p = eol + 1;
-            continue;
-        }
-        const char *q = p, *ida, *idb;
-        size_t na, nb;
-        uint64_t ha, hb, la, lb, sa, ea, sb, eb;
-        bool ok = scan_id(q, le, ha, ida, na) && scan_uint(q, le, ~0ull, la, false) &&
-                  scan_uint(q, le, 0xFFFFFFFFull, sa, false) &&
-                  scan_uint(q, le, 0xFFFFFFFFull, ea, false);
-        if (ok) { // strand: exactly one UTF-8 scalar, then a tab
-            const char *t = (const char *)std::memchr(q, '\t', (size_t)(le - q));
-            ok = t && is_one_char(q, t);
-            q = t ? t + 1 : le;
-        }
-        ok = ok && scan_id(q, le, hb, idb, nb) && scan_uint(q, le, ~0ull, lb, false) &&
-             scan_uint(q, le, 0xFFFFFFFFull, sb, false) && scan_uint(q, le, 0xFFFFFFFFull, eb, true);
-        if (ok && (la > 0xFFFFFFFFull || lb > 0xFFFFFFFFull)) {
-            c.error = "read length >= 2^32 is not supported by the engine";
-            c.error_line = c.lines;
-            return;
-        }
-        if (!ok) {
-            c.error = "Reading of the file in paf format failed";
-            c.error_line = c.lines;
-            return;
-        }
-        Rec r;
-        r.sa = (uint32_t)sa;
-        r.ea = (uint32_t)ea;
-        r.sb = (uint32_t)sb;
-        r.eb = (uint32_t)eb;
-        const uint64_t pos = (uint64_t)(p - c.text) * 2;
-        r.a = c.ids->intern(ida, na, ha, la, pos);
-        r.b = c.ids->intern(idb, nb, hb, lb, pos + 1);
-        c.recs.push_back(r);
-        p = eol + 1;
+    b = p;
+    if (p < le && *p == '"') return false; // quoted field: the general parser's business
+    const char *t = (const char *)std::memchr(p, '\t', (size_t)(le - p));
+    if (!t) return false; // an id must be followed by more fields
+    n = (size_t)(t - p);
+    p = t + 1;
+    return true;
+}
+inline bool parse_paf_fast(const char *p, const char *le, Fields &f)
+{
+    const char *q = p;
+    uint64_t sa, ea, sb, eb;
+    if (!(scan_id(q, le, f.ida, f.na) && scan_uint(q, le, ~0ull, f.la, false) &&
+          scan_uint(q, le, 0xFFFFFFFFull, sa, false) && scan_uint(q, le, 0xFFFFFFFFull, ea, false)))
+        return false;
+    { // strand: exactly one UTF-8 scalar, then a tab
+        const char *t = (const char *)std::memchr(q, '\t', (size_t)(le - q));
+        if (!t || !is_one_char(q, t) || *q == '"') return false;
+        q = t + 1;
     }
+    if (!(scan_id(q, le, f.idb, f.nb) && scan_uint(q, le, ~0ull, f.lb, false) &&
+          scan_uint(q, le, 0xFFFFFFFFull, sb, false) && scan_uint(q, le, 0xFFFFFFFFull, eb, true)))
+        return false;
+    f.sa = (uint32_t)sa;
+    f.ea = (uint32_t)ea;
+    f.sb = (uint32_t)sb;
+    f.eb = (uint32_t)eb;
+    return true;
 }
 
-void parse_chunk(Chunk &c, int format)
+// ---- general record parser: csv-crate field syntax, PAF and M4 --------------------------------
+// Scans ONE record from p: fields are split at `delim`, the record ends at an unquoted '\r' (csv's
+// default terminator takes \r, \n and \r\n alike; \n never gets here) or at le; `rec_end` is where
+// it stopped.  A field that starts with '"' is quoted: it runs to the closing quote, `""` inside
+// stands for one quote, delimiters and \r inside are data, and whatever follows the closing quote
+// up to the delimiter is appended as is (csv-core's DFA: StartField / InField / InQuotedField /
+// InDoubleEscapedQuote).  A quote inside an unquoted field is data.  The first `need` fields are
+// returned: unquoted ones point into the line, quoted ones into `scratch` (reserved up front, so
+// it never reallocates under them).
+bool split_fields(const char *p, const char *le, char delim, int need, const char **fb, const char **fe,
+                  std::string &scratch, const char *&rec_end)
 {
-    const char delim = format == FMT_PAF ? '\t' : ' ';
-    const int need = format == FMT_PAF ? 9 : 12;
-    c.recs.reserve((size_t)(c.end - c.begin) / 48 + 16); // untouched pages cost nothing
-    const char *p = c.begin;
+    scratch.clear();
+    scratch.reserve((size_t)(le - p) + 1);
+    int nf = 0;
+    const char *q = p;
+    for (;;) {
+        if (q < le && *q == '"') {
+            const size_t s0 = scratch.size();
+            q++;
+            bool closed = false;
+            while (q < le) {
+                if (*q == '"') {
+                    if (q + 1 < le && q[1] == '"') {
+                        scratch.push_back('"');
+                        q += 2;
+                        continue;
+                    }
+                    q++;
+                    closed = true;
+                    break;
+                }
+                scratch.push_back(*q++);
+            }
+            if (!closed) return false; // the quote never closes on this line
+            while (q < le && *q != delim && *q != '\r') scratch.push_back(*q++);
+            if (nf < need) {
+                fb[nf] = scratch.data() + s0;
+                fe[nf] = scratch.data() + scratch.size();
+            }
+        } else {
+            const char *d = q;
+            while (d < le && *d != delim && *d != '\r') d++;
+            if (nf < need) {
+                fb[nf] = q;
+                fe[nf] = d;
+            }
+            q = d;
+        }
+        nf++;
+        if (q >= le || *q == '\r') break;
+        q++; // the delimiter
+    }
+    rec_end = q;
+    return nf >= need;
+}
+bool parse_record_general(const char *p, const char *le, int format, Fields &f, std::string &scratch,
+                          const char *&rec_end)
+{
     const char *fb[12], *fe[12];
-    while (p < c.end) {
-        const char *eol = (const char *)std::memchr(p, '\n', (size_t)(c.end - p));
-        if (!eol) eol = c.end;
+    rec_end = le;
+    if (format == FMT_PAF) { // src/io.rs:23-34
+        if (!split_fields(p, le, '\t', 9, fb, fe, scratch, rec_end)) return false;
+        f.ida = fb[0], f.na = (size_t)(fe[0] - fb[0]);
+        f.idb = fb[5], f.nb = (size_t)(fe[5] - fb[5]);
+        return parse_csv_u64(fb[1], fe[1], f.la) && parse_csv_u32(fb[2], fe[2], f.sa) &&
+               parse_csv_u32(fb[3], fe[3], f.ea) && is_one_char(fb[4], fe[4]) &&
+               parse_csv_u64(fb[6], fe[6], f.lb) && parse_csv_u32(fb[7], fe[7], f.sb) &&
+               parse_csv_u32(fb[8], fe[8], f.eb);
+    }
+    // src/io.rs:36-50: a b err shared strand_a begin_a end_a len_a strand_b begin_b end_b len_b
+    if (!split_fields(p, le, ' ', 12, fb, fe, scratch, rec_end)) return false;
+    uint64_t shared;
+    f.ida = fb[0], f.na = (size_t)(fe[0] - fb[0]);
+    f.idb = fb[1], f.nb = (size_t)(fe[1] - fb[1]);
+    return is_rust_f64(fb[2], fe[2]) && parse_csv_u64(fb[3], fe[3], shared) && is_one_char(fb[4], fe[4]) &&
+           parse_csv_u32(fb[5], fe[5], f.sa) && parse_csv_u32(fb[6], fe[6], f.ea) &&
+           parse_csv_u64(fb[7], fe[7], f.la) && is_one_char(fb[8], fe[8]) &&
+           parse_csv_u32(fb[9], fe[9], f.sb) && parse_csv_u32(fb[10], fe[10], f.eb) &&
+           parse_csv_u64(fb[11], fe[11], f.lb);
+}
+
+// ---- one block of whole lines --------------------------------------------------------------------
+struct BlockResult {
+    uint64_t lines = 0;      // '\n'-terminated lines seen (for error messages)
+    uint64_t records = 0;
+    std::string error;
+    uint64_t error_line = 0; // 1-based within the block
+};
+
+void parse_block(const char *begin, const char *end, uint64_t pos0, int format, IdTable &ids,
+                 RecOut &out, BlockResult &res)
+{
+    std::string scratch;
+    const char *p = begin;
+    auto emit = [&](const Fields &f, const char *rec_start) -> bool {
+        if (f.la > 0xFFFFFFFFull || f.lb > 0xFFFFFFFFull) {
+            res.error = "read length >= 2^32 is not supported by the engine";
+            return false;
+        }
+        if (out.cur == out.lim && !out.more()) {
+            res.error = out.error;
+            return false;
+        }
+        const uint64_t pos = (pos0 + (uint64_t)(rec_start - begin)) * 2;
+        Rec &r = *out.cur++;
+        r.sa = f.sa;
+        r.ea = f.ea;
+        r.sb = f.sb;
+        r.eb = f.eb;
+        // (ids that live in `scratch` are copied by the table before the next record reuses it)
+        r.a = ids.intern(f.ida, f.na, hash_id(f.ida, f.na), f.la, pos);
+        r.b = ids.intern(f.idb, f.nb, hash_id(f.idb, f.nb), f.lb, pos + 1);
+        res.records++;
+        return true;
+    };
+    const char *what = format == FMT_PAF ? "Reading of the file in paf format failed"
+                                         : "Reading of the file in m4 format failed";
+    while (p < end) {
+        const char *eol = (const char *)std::memchr(p, '\n', (size_t)(end - p));
+        if (!eol) eol = end;
         const char *le = eol;
         if (le > p && le[-1] == '\r') le--;
-        c.lines++;
+        res.lines++;
         if (le == p) { // csv skips empty lines
             p = eol + 1;
             continue;
         }
-        int nf = 0;
-        const char *q = p;
-        while (nf < need) {
-            const char *d = (const char *)std::memchr(q, delim, (size_t)(le - q));
-            fb[nf] = q;
-            fe[nf] = d ? d : le;
-            nf++;
-            if (!d) break;
-            q = d + 1;
+        Fields f;
+        if (format == FMT_PAF && parse_paf_fast(p, le, f)) {
+            if (!emit(f, p)) {
+                res.error_line = res.lines;
+                return;
+            }
+            p = eol + 1;
+            continue;
         }
-        bool ok = nf == need;
-        Rec r{};
-        uint64_t la = 0, lb = 0;
-        int ia = 0, ib = 0;
-        if (ok && format == FMT_PAF) { // src/io.rs:23-34
-            ia = 0;
-            ib = 5;
-            ok = parse_u64(fb[1], fe[1], la) && parse_u32(fb[2], fe[2], r.sa) &&
-                 parse_u32(fb[3], fe[3], r.ea) && is_one_char(fb[4], fe[4]) &&
-                 parse_u64(fb[6], fe[6], lb) && parse_u32(fb[7], fe[7], r.sb) &&
-                 parse_u32(fb[8], fe[8], r.eb);
-        } else if (ok) { // src/io.rs:36-50: a b err shared sa ba ea la sb bb eb lb
-            ia = 0;
-            ib = 1;
-            uint64_t shared;
-            char *endp = nullptr;
-            std::string errf(fb[2], fe[2]);
-            errno = 0;
-            (void)std::strtod(errf.c_str(), &endp);
-            ok = !errf.empty() && endp && *endp == '\0' && parse_u64(fb[3], fe[3], shared) &&
-                 is_one_char(fb[4], fe[4]) && parse_u32(fb[5], fe[5], r.sa) &&
-                 parse_u32(fb[6], fe[6], r.ea) && parse_u64(fb[7], fe[7], la) &&
-                 is_one_char(fb[8], fe[8]) && parse_u32(fb[9], fe[9], r.sb) &&
-                 parse_u32(fb[10], fe[10], r.eb) && parse_u64(fb[11], fe[11], lb);
+        // the general parser; a lone \r also ends a record (csv's default terminator)
+        const char *s = p;
+        while (s < le) {
+            if (*s == '\r') { // a run of terminators: no record
+                s++;
+                continue;
+            }
+            const char *rec_end = le;
+            if (!parse_record_general(s, le, format, f, scratch, rec_end)) {
+                res.error = what;
+                if (std::memchr(s, '"', (size_t)(le - s)))
+                    res.error += " (the record holds a '\"': quoted fields follow the csv crate's rules and "
+                                 "may not span lines)";
+                res.error_line = res.lines;
+                return;
+            }
+            if (!emit(f, s)) {
+                res.error_line = res.lines;
+                return;
+            }
+            s = rec_end;
         }
-        if (ok && (la > 0xFFFFFFFFull || lb > 0xFFFFFFFFull)) {
-            c.error = "read length >= 2^32 is not supported by the engine";
-            c.error_line = c.lines;
-            return;
-        }
-        if (!ok) {
-            c.error = format == FMT_PAF ? "Reading of the file in paf format failed"
-                                        : "Reading of the file in m4 format failed";
-            c.error_line = c.lines;
-            return;
-        }
-        const size_t na = (size_t)(fe[ia] - fb[ia]), nb = (size_t)(fe[ib] - fb[ib]);
-        const uint64_t pos = (uint64_t)(p - c.text) * 2;
-        r.a = c.ids->intern(fb[ia], na, yh::hash_bytes(fb[ia], na), la, pos);
-        r.b = c.ids->intern(fb[ib], nb, yh::hash_bytes(fb[ib], nb), lb, pos + 1);
-        c.recs.push_back(r);
         p = eol + 1;
     }
 }
@@ -560,113 +780,297 @@ struct Phase {
     }
 };
 
-int build(const char *text, size_t len, int format, int n_threads, yacrd_csr **out)
-{
-    if (format != FMT_PAF && format != FMT_M4) return yh::fail("unknown overlap format");
-    // auto: every usable CPU up to 64
-    if (n_threads <= 0) n_threads = (int)std::min(64u, usable_cpus());
-    if (n_threads <= 0) n_threads = 1;
-    const size_t NT = (size_t)n_threads;
-    // one chunk per thread, >= 2 MiB of text each
-    const size_t T = std::max<size_t>(1, std::min<size_t>(NT, len / (2u << 20) + 1));
-    Phase ph;
+// ---- where the text comes from -----------------------------------------------------------------
+struct TextBlock {
+    const char *b = nullptr, *e = nullptr;
+    uint64_t pos0 = 0;  // byte offset of b in the whole (decoded) input
+    size_t index = 0;   // file order
+    std::unique_ptr<char[]> owner; // decoded blocks own their bytes
+};
+struct BlockSource {
+    virtual ~BlockSource() {}
+    virtual bool next(TextBlock &blk) = 0; // thread-safe; false at the end or after an error
+    virtual void abort() {}                // a consumer failed: stop producing, wake everybody
+    std::string error;                     // set before next() returns false for good
+};
 
-    IdTable ids(T == 1 ? 1 : 1024);
-    std::vector<Chunk> chunks(T);
+// text already in memory (a mapped file): blocks are slices, cut at line starts
+struct MemSource final : BlockSource {
+    const char *text;
+    size_t len, block;
+    std::atomic<size_t> turn{0};
+    MemSource(const char *t, size_t n, size_t b) : text(t), len(n), block(std::max<size_t>(b, 1)) {}
+    size_t line_start_at_or_after(size_t x) const
     {
-        const char *p = text, *end = text + len;
-        for (size_t t = 0; t < T; t++) {
-            chunks[t].ids = &ids;
-            chunks[t].text = text;
-            chunks[t].begin = p;
-            const char *q = (t + 1 == T) ? end : text + len / T * (t + 1);
-            if (q < p) q = p;
-            if (t + 1 != T) {
-                const char *nl = (const char *)std::memchr(q, '\n', (size_t)(end - q));
-                q = nl ? nl + 1 : end;
-            }
-            chunks[t].end = q;
-            p = q;
+        if (x == 0) return 0;
+        if (x >= len) return len;
+        const char *nl = (const char *)std::memchr(text + x - 1, '\n', len - (x - 1));
+        return nl ? (size_t)(nl - text) + 1 : len;
+    }
+    bool next(TextBlock &blk) override
+    {
+        for (;;) {
+            const size_t i = turn.fetch_add(1, std::memory_order_relaxed);
+            if (i > len / block) return false; // (i * block cannot overflow below this bound)
+            const size_t b = line_start_at_or_after(i * block), e = line_start_at_or_after((i + 1) * block);
+            if (b >= len) return false;
+            if (b == e) continue; // a line longer than a block swallowed this slot
+            blk.b = text + b;
+            blk.e = text + e;
+            blk.pos0 = b;
+            blk.index = i;
+            blk.owner.reset();
+            return true;
         }
     }
-    parallel_for(T, NT, [&](size_t t) {
-        if (format == FMT_PAF) parse_chunk_paf(chunks[t]);
-        else parse_chunk(chunks[t], format);
-    });
-    uint64_t line0 = 0;
-    for (size_t t = 0; t < T; t++) {
-        if (!chunks[t].error.empty())
-            return yh::fail(chunks[t].error + " (line " +
-                            std::to_string(line0 + chunks[t].error_line) + ")");
-        line0 += chunks[t].lines;
-    }
-    if (ids.overflow.load()) return yh::fail("more than 2^32 - 2 reads");
-    ph.mark("parse");
+};
 
-    // ---- global numbering = first appearance in the file = ascending first_pos.  Entries are
-    // bucketed by the chunk their first_pos lies in, buckets sorted in parallel.
-    const size_t S = ids.n_shards;
+// a compressed (or otherwise sequential) stream: one reader thread decodes blocks of whole lines
+// into a bounded queue
+struct DecodeSource final : BlockSource {
+    yh::InStream &in;
+    const size_t block, depth;
+    std::mutex mu;
+    std::condition_variable cv_full, cv_empty;
+    std::deque<TextBlock> q;
+    bool done = false, stop = false;
+    std::thread reader;
+    DecodeSource(yh::InStream &s, size_t block_bytes, size_t queue_depth)
+        : in(s), block(block_bytes), depth(std::max<size_t>(2, queue_depth))
+    {
+        reader = std::thread([this] { produce(); });
+    }
+    ~DecodeSource() override
+    {
+        abort();
+        if (reader.joinable()) reader.join();
+    }
+    void abort() override
+    {
+        std::lock_guard<std::mutex> g(mu);
+        stop = true;
+        cv_full.notify_all();
+        cv_empty.notify_all();
+    }
+    void produce()
+    {
+        std::string carry; // the partial last line of the previous block
+        uint64_t pos = 0;
+        size_t index = 0;
+        bool eof = false;
+        std::string fail_msg;
+        while (!eof) {
+            size_t cap = block + carry.size() + 1;
+            std::unique_ptr<char[]> buf(new (std::nothrow) char[cap]);
+            if (!buf) {
+                fail_msg = "out of memory while decoding the input";
+                break;
+            }
+            size_t n = carry.size();
+            std::memcpy(buf.get(), carry.data(), n);
+            carry.clear();
+            size_t cut = 0; // one past the last '\n'
+            for (;;) {
+                while (n < cap - 1) {
+                    const long got = in.read(buf.get() + n, cap - 1 - n);
+                    if (got < 0) {
+                        fail_msg = yh::err_slot();
+                        break;
+                    }
+                    if (got == 0) {
+                        eof = true;
+                        break;
+                    }
+                    n += (size_t)got;
+                }
+                if (!fail_msg.empty()) break;
+                if (eof) {
+                    cut = n;
+                    break;
+                }
+                const char *base = buf.get();
+                const void *nl = memrchr(base, '\n', n);
+                if (nl) {
+                    cut = (size_t)((const char *)nl - base) + 1;
+                    break;
+                }
+                // a line longer than the block: keep reading into a bigger buffer
+                const size_t bigger = cap * 2;
+                std::unique_ptr<char[]> nb(new (std::nothrow) char[bigger]);
+                if (!nb) {
+                    fail_msg = "out of memory while decoding the input";
+                    break;
+                }
+                std::memcpy(nb.get(), buf.get(), n);
+                buf.swap(nb);
+                cap = bigger;
+            }
+            if (!fail_msg.empty()) break;
+            carry.assign(buf.get() + cut, n - cut);
+            if (cut == 0) continue;
+            TextBlock blk;
+            blk.b = buf.get();
+            blk.e = buf.get() + cut;
+            blk.pos0 = pos;
+            blk.index = index++;
+            blk.owner = std::move(buf);
+            pos += cut;
+            std::unique_lock<std::mutex> g(mu);
+            cv_full.wait(g, [&] { return stop || q.size() < depth; });
+            if (stop) return;
+            q.push_back(std::move(blk));
+            cv_empty.notify_one();
+        }
+        std::lock_guard<std::mutex> g(mu);
+        if (!fail_msg.empty()) error = fail_msg;
+        done = true;
+        cv_empty.notify_all();
+    }
+    bool next(TextBlock &blk) override
+    {
+        std::unique_lock<std::mutex> g(mu);
+        cv_empty.wait(g, [&] { return stop || done || !q.empty(); });
+        if (stop || q.empty()) return false;
+        blk = std::move(q.front());
+        q.pop_front();
+        cv_full.notify_one();
+        return true;
+    }
+};
+
+// ---- parse every block of a source on NT threads -------------------------------------------------
+struct Parsed {
+    struct Block {
+        size_t index;
+        uint64_t lines, records;
+        std::unique_ptr<SegOut> recs; // host destination only
+    };
+    std::vector<Block> blocks; // sorted by index on return
+    uint64_t n_records = 0, text_bytes = 0;
+};
+
+int parse_all(BlockSource &src, int format, size_t NT, const yacrd_rec_sink *sink, IdTable &ids,
+              Parsed &out)
+{
+    std::mutex mu;
+    std::string first_error;
+    size_t error_index = ~(size_t)0;
+    uint64_t error_line = 0;
+    std::atomic<bool> failed{false};
+    auto worker = [&]() {
+        SinkOut so;
+        so.sink = sink;
+        TextBlock blk;
+        while (!failed.load(std::memory_order_relaxed) && src.next(blk)) {
+            BlockResult res;
+            std::unique_ptr<SegOut> seg;
+            if (sink) parse_block(blk.b, blk.e, blk.pos0, format, ids, so, res);
+            else {
+                seg.reset(new SegOut());
+                parse_block(blk.b, blk.e, blk.pos0, format, ids, *seg, res);
+                seg->close_segment();
+            }
+            std::lock_guard<std::mutex> g(mu);
+            out.text_bytes = std::max<uint64_t>(out.text_bytes, blk.pos0 + (uint64_t)(blk.e - blk.b));
+            if (!res.error.empty()) {
+                if (blk.index < error_index) { // report the earliest failing block
+                    error_index = blk.index;
+                    first_error = res.error;
+                    error_line = res.error_line;
+                }
+                failed.store(true, std::memory_order_relaxed);
+                src.abort();
+            }
+            out.blocks.push_back(Parsed::Block{blk.index, res.lines, res.records, std::move(seg)});
+            blk.owner.reset();
+        }
+        if (sink && !so.flush()) {
+            std::lock_guard<std::mutex> g(mu);
+            if (first_error.empty()) first_error = so.error;
+            failed.store(true, std::memory_order_relaxed);
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (size_t i = 1; i < NT; i++) th.emplace_back(worker);
+        worker();
+        for (auto &x : th) x.join();
+    }
+    std::sort(out.blocks.begin(), out.blocks.end(),
+              [](const Parsed::Block &a, const Parsed::Block &b) { return a.index < b.index; });
+    if (!src.error.empty() && first_error.empty()) return yh::fail(src.error);
+    if (!first_error.empty()) {
+        uint64_t line0 = 0; // lines of the blocks in front of the failing one (all of them were parsed
+                            // unless they failed too, in which case the earliest one is reported)
+        for (const auto &b : out.blocks)
+            if (b.index < error_index) line0 += b.lines;
+        if (error_index == ~(size_t)0) return yh::fail(first_error);
+        return yh::fail(first_error + " (line " + std::to_string(line0 + error_line) + ")");
+    }
+    if (ids.overflow.load())
+        return yh::fail("too many reads: the id table holds at most 2^32 - 2 of them (2^22 per shard of 1024)");
+    for (const auto &b : out.blocks) out.n_records += b.records;
+    return 0;
+}
+
+// ---- global numbering = first appearance in the file = ascending first_pos -------------------------
+// Fills lengths / names of `c` and `dense` (handle -> read id, ~0u for unused handles).
+int number_ids(IdTable &ids, uint64_t text_bytes, size_t NT, yacrd_csr *c, big_vector<uint32_t> &dense)
+{
+    const size_t S = IdTable::kShards;
     std::vector<uint64_t> shard_base(S + 1, 0);
     for (size_t i = 0; i < S; i++) shard_base[i + 1] = shard_base[i] + ids.shards[i].n_entries;
     const uint64_t R = shard_base[S];
-    if (R >= 0xFFFFFFFFull) return yh::fail("more than 2^32 - 2 reads");
+    if (R >= 0xFFFFFFFFull) return yh::fail("too many reads: at most 2^32 - 2");
     struct Ord {
         uint64_t pos;
-        uint32_t flat; // shard_base[shard] + index
+        uint32_t shard, idx;
     };
-    std::vector<uint64_t> chunk_pos(T); // first position of each chunk
-    for (size_t t = 0; t < T; t++) chunk_pos[t] = (uint64_t)(chunks[t].begin - text) * 2;
-    auto bucket_of = [&](uint64_t pos) {
-        return (size_t)(std::upper_bound(chunk_pos.begin(), chunk_pos.end(), pos) - chunk_pos.begin()) - 1;
-    };
-    // per (shard, bucket) counts -> bucket-major offsets, then scatter
-    std::vector<uint32_t> cnt((size_t)S * T, 0);
+    // entries are bucketed by the slice of the text their first position lies in; buckets are
+    // sorted in parallel
+    const size_t NB = std::max<size_t>(1, std::min<size_t>(NT * 4, (size_t)(R / 4096 + 1)));
+    const uint64_t span = 2 * text_bytes + 2;
+    auto bucket_of = [&](uint64_t pos) { return (size_t)((unsigned __int128)pos * NB / span); };
+    std::vector<uint32_t> cnt(S * NB, 0);
     parallel_for(S, NT, [&](size_t i) {
         const IdTable::Shard &sh = ids.shards[i];
         for (uint32_t k = 0; k < sh.n_entries; k++)
-            cnt[i * T + bucket_of(IdTable::hot(sh, k).first_pos.load(std::memory_order_relaxed))]++;
+            cnt[i * NB + bucket_of(IdTable::hot(sh, k).first_pos.load(std::memory_order_relaxed))]++;
     });
-    std::vector<uint64_t> bucket_off(T + 1, 0);
-    std::vector<uint64_t> cell_off((size_t)S * T);
+    std::vector<uint64_t> bucket_off(NB + 1, 0), cell_off(S * NB);
     {
         uint64_t acc = 0;
-        for (size_t t = 0; t < T; t++) {
+        for (size_t t = 0; t < NB; t++) {
             bucket_off[t] = acc;
             for (size_t i = 0; i < S; i++) {
-                cell_off[i * T + t] = acc;
-                acc += cnt[i * T + t];
+                cell_off[i * NB + t] = acc;
+                acc += cnt[i * NB + t];
             }
         }
-        bucket_off[T] = acc;
+        bucket_off[NB] = acc;
     }
     big_vector<Ord> order(R);
     parallel_for(S, NT, [&](size_t i) {
-        std::vector<uint64_t> cur(cell_off.begin() + i * T, cell_off.begin() + (i + 1) * T);
+        std::vector<uint64_t> cur(cell_off.begin() + i * NB, cell_off.begin() + (i + 1) * NB);
         const IdTable::Shard &sh = ids.shards[i];
         for (uint32_t k = 0; k < sh.n_entries; k++) {
             const uint64_t fp = IdTable::hot(sh, k).first_pos.load(std::memory_order_relaxed);
-            order[cur[bucket_of(fp)]++] = Ord{fp, (uint32_t)(shard_base[i] + k)};
+            order[cur[bucket_of(fp)]++] = Ord{fp, (uint32_t)i, k};
         }
     });
-    parallel_for(T, NT, [&](size_t t) {
+    parallel_for(NB, NT, [&](size_t t) {
         std::sort(order.begin() + bucket_off[t], order.begin() + bucket_off[t + 1],
                   [](const Ord &x, const Ord &y) { return x.pos < y.pos; });
     });
-    // flat entry index -> (shard, index) needs the shard: walk the shards' flat ranges
-    big_vector<uint32_t> dense(R); // flat entry index -> global read id
-    yacrd_csr *c = new yacrd_csr();
+    const uint64_t n_handles = ids.next_handle.load();
+    dense.assign(n_handles, ~0u);
     c->lengths.resize(R);
     c->name_off.assign(R + 1, 0);
-    auto shard_of_flat = [&](uint32_t flat) {
-        return (size_t)(std::upper_bound(shard_base.begin(), shard_base.end(), (uint64_t)flat) -
-                        shard_base.begin()) - 1;
-    };
     parallel_for(NT, NT, [&](size_t w) {
         for (uint64_t g = R * w / NT; g < R * (w + 1) / NT; g++) {
-            const uint32_t flat = order[g].flat;
-            const size_t i = shard_of_flat(flat);
-            const IdTable::Cold &e = IdTable::cold(ids.shards[i], (uint32_t)(flat - shard_base[i]));
-            dense[flat] = (uint32_t)g;
+            const IdTable::Shard &sh = ids.shards[order[g].shard];
+            const IdTable::Cold &e = IdTable::cold(sh, order[g].idx);
+            dense[IdTable::handle_of(sh, order[g].idx)] = (uint32_t)g;
             c->lengths[g] = (uint32_t)e.first_len; // first length seen
             c->name_off[g + 1] = e.nlen;
         }
@@ -675,51 +1079,57 @@ int build(const char *text, size_t len, int format, int n_threads, yacrd_csr **o
     c->names.resize(c->name_off[R]);
     parallel_for(NT, NT, [&](size_t w) {
         for (uint64_t g = R * w / NT; g < R * (w + 1) / NT; g++) {
-            const uint32_t flat = order[g].flat;
-            const size_t i = shard_of_flat(flat);
-            const uint32_t k = (uint32_t)(flat - shard_base[i]);
-            std::memcpy(c->names.data() + c->name_off[g], IdTable::hot(ids.shards[i], k).name,
-                        IdTable::cold(ids.shards[i], k).nlen);
+            const IdTable::Shard &sh = ids.shards[order[g].shard];
+            std::memcpy(c->names.data() + c->name_off[g], IdTable::hot(sh, order[g].idx).name,
+                        IdTable::cold(sh, order[g].idx).nlen);
         }
     });
-    auto global_id = [&](uint32_t handle) {
-        return dense[shard_base[handle >> IdTable::kIdxBits] + (handle & ((1u << IdTable::kIdxBits) - 1))];
-    };
-    ph.mark("number ids");
+    return 0;
+}
 
-    // ---- counts -> offsets -> fill ------------------------------------------------------------
-    // Each chunk counts the intervals it holds per read in a private array, a pass over the reads
-    // turns the counts into every chunk's first write position inside every read (chunk order =
-    // file order), and the chunks fill their slices: no atomics, and the intervals of a read come
-    // out in line order whatever the thread count.  When T private arrays of R counters would
-    // be too big (> 1 GiB), fall back to shared atomic cursors (order inside a read then depends
-    // on thread timing; results do not: the sweep sorts).
-    parallel_for(T, NT, [&](size_t t) {
-        for (Rec &r : chunks[t].recs) {
-            r.a = global_id(r.a);
-            r.b = global_id(r.b);
-        }
+// ---- host destination: records -> CSR -----------------------------------------------------------
+// Blocks are grouped into G runs of consecutive blocks (file order).  Each group counts the
+// intervals it holds per read in a private array, a pass over the reads turns the counts into
+// every group's first write position inside every read, and the groups fill their slices: no
+// atomics, and the intervals of a read come out in line order whatever the thread count.  When G
+// private arrays of R counters would be too big (> 1 GiB), fall back to shared atomic cursors
+// (order inside a read then depends on thread timing; results do not: the sweep sorts).
+void fill_csr(Parsed &ps, const big_vector<uint32_t> &dense, size_t NT, yacrd_csr *c)
+{
+    const uint64_t R = c->lengths.size();
+    const size_t nb = ps.blocks.size();
+    const size_t G = std::max<size_t>(1, std::min(NT, nb));
+    auto for_group = [&](size_t g, auto fn) {
+        for (size_t b = nb * g / G; b < nb * (g + 1) / G; b++)
+            for (const SegOut::Seg &s : ps.blocks[b].recs->segs)
+                for (size_t i = 0; i < s.n; i++) fn(s.p[i]);
+    };
+    parallel_for(nb, NT, [&](size_t b) { // handles -> read ids, in place
+        for (const SegOut::Seg &s : ps.blocks[b].recs->segs)
+            for (size_t i = 0; i < s.n; i++) {
+                s.p[i].a = dense[s.p[i].a];
+                s.p[i].b = dense[s.p[i].b];
+            }
     });
     c->offsets.resize(R + 1);
-    const bool private_counts = (uint64_t)T * R * sizeof(uint32_t) <= (1ull << 30);
+    const bool private_counts = (uint64_t)G * R * sizeof(uint32_t) <= (1ull << 30);
     if (private_counts) {
-        std::vector<big_vector<uint32_t>> cnt2(T);
-        parallel_for(T, NT, [&](size_t t) {
-            cnt2[t].assign(R, 0u);
-            uint32_t *k = cnt2[t].data();
-            for (const Rec &r : chunks[t].recs) {
+        std::vector<big_vector<uint32_t>> cnt2(G);
+        parallel_for(G, NT, [&](size_t g) {
+            cnt2[g].assign(R, 0u);
+            uint32_t *k = cnt2[g].data();
+            for_group(g, [&](const Rec &r) {
                 k[r.a]++;
                 k[r.b]++;
-            }
+            });
         });
-        // per read: total, and the exclusive prefix over chunks (in place)
         big_vector<uint64_t> tot(R);
-        parallel_for(NT, NT, [&](size_t w) {
+        parallel_for(NT, NT, [&](size_t w) { // per read: total, and the exclusive prefix over groups
             for (uint64_t r = R * w / NT; r < R * (w + 1) / NT; r++) {
                 uint64_t acc2 = 0;
-                for (size_t t = 0; t < T; t++) {
-                    const uint32_t n = cnt2[t][r];
-                    cnt2[t][r] = (uint32_t)acc2;
+                for (size_t g = 0; g < G; g++) {
+                    const uint32_t n = cnt2[g][r];
+                    cnt2[g][r] = (uint32_t)acc2;
                     acc2 += n;
                 }
                 tot[r] = acc2;
@@ -735,28 +1145,28 @@ int build(const char *text, size_t len, int format, int n_threads, yacrd_csr **o
         // one thread (tens of ms for 10^7 intervals) before the parallel fill overwrites every word
         c->intervals.reset(new uint32_t[2 * acc + 2]);
         uint32_t *iv = c->intervals.get();
-        parallel_for(T, NT, [&](size_t t) {
-            uint32_t *k = cnt2[t].data(); // this chunk's next slot inside each read
-            const uint64_t *off = c->offsets.data();
-            for (const Rec &r : chunks[t].recs) {
+        const uint64_t *off = c->offsets.data();
+        parallel_for(G, NT, [&](size_t g) {
+            uint32_t *k = cnt2[g].data(); // this group's next slot inside each read
+            for_group(g, [&](const Rec &r) {
                 uint64_t p = off[r.a] + k[r.a]++;
                 iv[2 * p] = r.sa;
                 iv[2 * p + 1] = r.ea;
                 p = off[r.b] + k[r.b]++;
                 iv[2 * p] = r.sb;
                 iv[2 * p + 1] = r.eb;
-            }
+            });
         });
     } else {
         std::vector<std::atomic<uint64_t>> cur(R + 1);
         parallel_for(NT, NT, [&](size_t w) {
             for (uint64_t r = R * w / NT; r < R * (w + 1) / NT; r++) cur[r].store(0, std::memory_order_relaxed);
         });
-        parallel_for(T, NT, [&](size_t t) {
-            for (const Rec &r : chunks[t].recs) {
+        parallel_for(G, NT, [&](size_t g) {
+            for_group(g, [&](const Rec &r) {
                 cur[r.a].fetch_add(1, std::memory_order_relaxed);
                 cur[r.b].fetch_add(1, std::memory_order_relaxed);
-            }
+            });
         });
         uint64_t acc = 0;
         for (uint64_t r = 0; r < R; r++) {
@@ -768,24 +1178,60 @@ int build(const char *text, size_t len, int format, int n_threads, yacrd_csr **o
         c->offsets[R] = acc;
         c->intervals.reset(new uint32_t[2 * acc + 2]);
         uint32_t *iv = c->intervals.get();
-        parallel_for(T, NT, [&](size_t t) {
-            for (const Rec &r : chunks[t].recs) {
+        parallel_for(G, NT, [&](size_t g) {
+            for_group(g, [&](const Rec &r) {
                 uint64_t p = cur[r.a].fetch_add(1, std::memory_order_relaxed);
                 iv[2 * p] = r.sa;
                 iv[2 * p + 1] = r.ea;
                 p = cur[r.b].fetch_add(1, std::memory_order_relaxed);
                 iv[2 * p] = r.sb;
                 iv[2 * p + 1] = r.eb;
-            }
+            });
         });
     }
-    for (auto &ch : chunks) c->n_records += ch.recs.size();
-    ph.mark("csr fill");
-    // give the per-chunk arrays back in parallel (hundreds of MB of mappings)
-    parallel_for(T, NT, [&](size_t t) { big_vector<Rec>().swap(chunks[t].recs); });
-    ph.mark("teardown");
-    *out = c;
+}
+
+size_t thread_count(int n_threads)
+{
+    if (n_threads <= 0) n_threads = (int)std::min(64u, usable_cpus()); // auto: every usable CPU up to 64
+    return (size_t)std::max(1, n_threads);
+}
+
+// the whole ingest over one source; sink == nullptr keeps the records and builds the host CSR
+int ingest(BlockSource &src, int format, int n_threads, const yacrd_rec_sink *sink, yacrd_csr **out)
+{
+    if (format != FMT_PAF && format != FMT_M4) return yh::fail("unknown overlap format");
+    const size_t NT = thread_count(n_threads);
+    Phase ph;
+    IdTable ids;
+    Parsed ps;
+    if (parse_all(src, format, NT, sink, ids, ps)) return 1;
+    ph.mark("parse");
+    std::unique_ptr<yacrd_csr> c(new yacrd_csr());
+    big_vector<uint32_t> dense;
+    if (number_ids(ids, ps.text_bytes, NT, c.get(), dense)) return 1;
+    ph.mark("number ids");
+    c->n_records = ps.n_records;
+    if (sink) {
+        c->streamed = true;
+        c->handle_map.assign(dense.begin(), dense.end());
+    } else {
+        fill_csr(ps, dense, NT, c.get());
+        ph.mark("csr fill");
+        // give the record segments back in parallel (hundreds of MB of mappings)
+        parallel_for(ps.blocks.size(), NT, [&](size_t b) { ps.blocks[b].recs.reset(); });
+        ph.mark("teardown");
+    }
+    *out = c.release();
     return 0;
+}
+
+// block size of the parse: big enough that a block's bookkeeping vanishes, small enough that the
+// last blocks balance the threads and a streamed buffer goes out every few milliseconds
+size_t block_bytes_for(size_t len, size_t NT)
+{
+    const size_t target = len / (NT * 8) + 1;
+    return std::min<size_t>((size_t)8 << 20, std::max<size_t>((size_t)1 << 20, target));
 }
 
 // name -> id index for yacrd_csr_find, built on first use
@@ -814,26 +1260,14 @@ int sniff_format(const std::string &name)
     return FMT_AUTO;
 }
 
-} // namespace
-
-extern "C" {
-
-const char *yacrd_host_last_error(void) { return yh::err_slot().c_str(); }
-
-int yacrd_csr_from_memory(const char *text, size_t len, int format, int n_threads, yacrd_csr **out)
-{
-    if (!out || (!text && len)) return yh::fail("null argument");
-    *out = nullptr;
-    return build(text, len, format, n_threads, out);
-}
-
-int yacrd_csr_from_file(const char *path, int format, int n_threads, yacrd_csr **out)
+int ingest_file(const char *path, int format, int n_threads, const yacrd_rec_sink *sink, yacrd_csr **out)
 {
     if (!out || !path) return yh::fail("null argument");
     *out = nullptr;
     if (format == FMT_AUTO) format = sniff_format(path);
     if (format == FMT_AUTO)
         return yh::fail(std::string("Format detection of file ") + path + " failed");
+    const size_t NT = thread_count(n_threads);
     const int fd = ::open(path, O_RDONLY);
     if (fd < 0) return yh::fail(std::string("Can't open file ") + path + " to read");
     struct stat st;
@@ -844,53 +1278,87 @@ int yacrd_csr_from_file(const char *path, int format, int n_threads, yacrd_csr *
     unsigned char magic[6] = {0};
     const ssize_t got = ::pread(fd, magic, sizeof magic, 0);
     // compression is sniffed from magic bytes like niffler (src/util.rs:57-70)
-    if (got >= 2 && magic[0] == 0x1f && magic[1] == 0x8b) {
+    const bool regular = S_ISREG(st.st_mode);
+    if (!regular || yh::sniff_compression(magic, got > 0 ? (size_t)got : 0) != yh::COMP_NONE) {
         ::close(fd);
-        gzFile gz = gzopen(path, "rb");
-        if (!gz) return yh::fail(std::string("Can't open gzip file ") + path);
-        gzbuffer(gz, 1 << 20);
-        std::vector<char> buf;
-        size_t used = 0;
-        for (;;) {
-            if (buf.size() - used < (1u << 20)) buf.resize(buf.size() * 2 + (4u << 20));
-            const int n = gzread(gz, buf.data() + used, 1u << 20);
-            if (n < 0) {
-                gzclose(gz);
-                return yh::fail(std::string("gzip read error in ") + path);
-            }
-            if (n == 0) break;
-            used += (size_t)n;
-        }
-        gzclose(gz);
-        return build(buf.data(), used, format, n_threads, out);
-    }
-    if ((got >= 3 && magic[0] == 'B' && magic[1] == 'Z' && magic[2] == 'h') ||
-        (got >= 6 && magic[0] == 0xFD && std::memcmp(magic + 1, "7zXZ", 4) == 0)) {
-        ::close(fd);
-        return yh::fail(std::string(path) + ": bzip2/xz input is not supported in this build "
-                                             "(no bzlib.h / lzma.h in the image); decompress first");
+        yh::InStream in; // gzip / bzip2 / xz (or a pipe): decoded by a reader thread while the pool parses
+        if (in.open(path)) return 1;
+        DecodeSource src(in, (size_t)4 << 20, NT * 2 + 2);
+        return ingest(src, format, (int)NT, sink, out);
     }
     if (st.st_size == 0) {
         ::close(fd);
-        return build("", 0, format, n_threads, out);
+        MemSource src("", 0, 1);
+        return ingest(src, format, (int)NT, sink, out);
     }
     void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
     ::close(fd);
     if (m == MAP_FAILED) return yh::fail(std::string("mmap failed for ") + path);
     madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
-    const int rc = build((const char *)m, (size_t)st.st_size, format, n_threads, out);
+    int rc;
+    {
+        MemSource src((const char *)m, (size_t)st.st_size, block_bytes_for((size_t)st.st_size, NT));
+        rc = ingest(src, format, (int)NT, sink, out);
+    }
     munmap(m, (size_t)st.st_size);
     return rc;
+}
+
+} // namespace
+
+extern "C" {
+
+const char *yacrd_host_last_error(void) { return yh::err_slot().c_str(); }
+
+int yacrd_csr_from_memory(const char *text, size_t len, int format, int n_threads, yacrd_csr **out)
+{
+    if (!out || (!text && len)) return yh::fail("null argument");
+    *out = nullptr;
+    const size_t NT = thread_count(n_threads);
+    MemSource src(text ? text : "", len, block_bytes_for(len, NT));
+    return ingest(src, format, (int)NT, nullptr, out);
+}
+
+int yacrd_csr_from_file(const char *path, int format, int n_threads, yacrd_csr **out)
+{
+    return ingest_file(path, format, n_threads, nullptr, out);
+}
+
+int yacrd_ingest_stream(const char *path, int format, int n_threads, const yacrd_rec_sink *sink,
+                        yacrd_csr **out)
+{
+    if (!sink || !sink->acquire || !sink->commit) return yh::fail("null sink");
+    return ingest_file(path, format, n_threads, sink, out);
+}
+
+int yacrd_ingest_stream_memory(const char *text, size_t len, int format, int n_threads,
+                               const yacrd_rec_sink *sink, yacrd_csr **out)
+{
+    if (!out || (!text && len)) return yh::fail("null argument");
+    if (!sink || !sink->acquire || !sink->commit) return yh::fail("null sink");
+    *out = nullptr;
+    const size_t NT = thread_count(n_threads);
+    MemSource src(text ? text : "", len, block_bytes_for(len, NT));
+    return ingest(src, format, (int)NT, sink, out);
+}
+
+int yacrd_csr_handle_map(const yacrd_csr *c, const uint32_t **map, uint64_t *n_handles)
+{
+    if (!c || !map || !n_handles) return yh::fail("null argument");
+    if (!c->streamed) return yh::fail("this CSR was not built by yacrd_ingest_stream");
+    *map = c->handle_map.data();
+    *n_handles = c->handle_map.size();
+    return 0;
 }
 
 int yacrd_csr_get(const yacrd_csr *c, yacrd_csr_view *v)
 {
     if (!c || !v) return yh::fail("null argument");
     v->n_reads = c->lengths.size();
-    v->n_intervals = c->offsets.empty() ? 0 : c->offsets.back();
+    v->n_intervals = c->streamed ? 2 * c->n_records : (c->offsets.empty() ? 0 : c->offsets.back());
     v->n_records = c->n_records;
-    v->offsets = c->offsets.data();
-    v->intervals = c->intervals.get();
+    v->offsets = c->streamed ? nullptr : c->offsets.data();
+    v->intervals = c->streamed ? nullptr : c->intervals.get();
     v->lengths = c->lengths.data();
     v->name_off = c->name_off.data();
     v->names = c->names.data();

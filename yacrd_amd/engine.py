@@ -30,6 +30,9 @@ EXPORTED_SYMBOLS = [
     "yacrd_engine_run", "yacrd_result_free", "yacrd_engine_run_device", "yacrd_engine_fetch",
     "yacrd_engine_last_timing", "yacrd_partition_reads", "yacrd_engine_classify",
     "yacrd_engines_run_partitioned", "yacrd_engine_timing_total", "yacrd_engine_event_overhead", "yacrd_engine_submit_device", "yacrd_engine_wait",
+    "yacrd_engine_submit", "yacrd_engine_collect", "yacrd_pinned_alloc", "yacrd_pinned_free",
+    "yacrd_stream_open", "yacrd_stream_sink", "yacrd_stream_acquire", "yacrd_stream_commit",
+    "yacrd_stream_finish", "yacrd_stream_last_stats", "yacrd_stream_close",
 ]
 
 
@@ -75,6 +78,29 @@ CLASS_KERNELS = {  # the HIP kernel behind each class, as rocprofv3 prints it
     "M2": "sweep_lds_kernel<1024, 32768>", "BIG": "big_* kernels (sweep_big.h)",
 }
 
+
+class _StreamStats(ctypes.Structure):
+    _fields_ = [("n_records", ctypes.c_uint64), ("h2d_bytes", ctypes.c_uint64),
+                ("h2d_busy_ms", ctypes.c_float), ("build_ms", ctypes.c_float),
+                ("run_ms", ctypes.c_float), ("d2h_ms", ctypes.c_float)]
+
+
+class OvlRec(ctypes.Structure):
+    """yacrd_ovl_rec: one overlap line, both reads (handles) and their intervals."""
+    _fields_ = [(n, ctypes.c_uint32) for n in ("a", "b", "sa", "ea", "sb", "eb")]
+
+
+_ACQUIRE = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.POINTER(OvlRec)),
+                            ctypes.POINTER(ctypes.c_uint64))
+_COMMIT = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(OvlRec), ctypes.c_uint64)
+
+
+class RecSink(ctypes.Structure):
+    """yacrd_rec_sink"""
+    _fields_ = [("ctx", ctypes.c_void_p), ("acquire", _ACQUIRE), ("commit", _COMMIT)]
+
+
+OVL_REC_DTYPE = np.dtype([(n, np.uint32) for n in ("a", "b", "sa", "ea", "sb", "eb")])
 
 Result = namedtuple("Result", "bad_offsets bad_regions read_type")
 
@@ -164,6 +190,24 @@ def load_library():
                                                   u64p, u32p, u32p, ctypes.c_uint64,
                                                   ctypes.c_uint32, ctypes.c_double,
                                                   ctypes.POINTER(_Result)]
+    lib.yacrd_engine_submit.argtypes = [ctypes.c_void_p, u64p, u32p, u32p, ctypes.c_uint64,
+                                        ctypes.c_uint32, ctypes.c_double]
+    lib.yacrd_engine_collect.argtypes = [ctypes.c_void_p, ctypes.POINTER(_Result)]
+    lib.yacrd_pinned_alloc.argtypes = [ctypes.c_size_t]
+    lib.yacrd_pinned_alloc.restype = ctypes.c_void_p
+    lib.yacrd_pinned_free.argtypes = [ctypes.c_void_p]
+    lib.yacrd_pinned_free.restype = None
+    lib.yacrd_stream_open.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32,
+                                      ctypes.POINTER(ctypes.c_void_p)]
+    lib.yacrd_stream_sink.argtypes = [ctypes.c_void_p, ctypes.POINTER(RecSink)]
+    lib.yacrd_stream_acquire.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.POINTER(OvlRec)),
+                                         ctypes.POINTER(ctypes.c_uint64)]
+    lib.yacrd_stream_commit.argtypes = [ctypes.c_void_p, ctypes.POINTER(OvlRec), ctypes.c_uint64]
+    lib.yacrd_stream_finish.argtypes = [ctypes.c_void_p, u32p, ctypes.c_uint64, u32p, ctypes.c_uint64,
+                                        ctypes.c_uint32, ctypes.c_double, ctypes.POINTER(_Result)]
+    lib.yacrd_stream_last_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(_StreamStats)]
+    lib.yacrd_stream_close.argtypes = [ctypes.c_void_p]
+    lib.yacrd_stream_close.restype = None
     _lib = lib
     return lib
 
@@ -311,6 +355,22 @@ class Engine:
             out[name] = list(v) if name.startswith("class_") else v
         return out, int(n.value)
 
+    def submit(self, offsets, intervals, lengths, coverage, not_coverage):
+        """run() without the final wait (yacrd_engine_submit); the arrays must stay alive and
+        unchanged until collect().  Pass PinnedArray.array views for direct DMA."""
+        n_reads = offsets.shape[0] - 1
+        self._keep = (offsets, intervals, lengths)
+        _check(self._lib, self._lib.yacrd_engine_submit(
+            self._h, _ptr(offsets, ctypes.c_uint64), _ptr(intervals.reshape(-1), ctypes.c_uint32),
+            _ptr(lengths, ctypes.c_uint32), n_reads, min(int(coverage), 0xFFFFFFFF),
+            float(not_coverage)))
+
+    def collect(self):
+        res = _Result()
+        _check(self._lib, self._lib.yacrd_engine_collect(self._h, ctypes.byref(res)))
+        self._keep = None
+        return _take(self._lib, res)
+
     def classify(self, bad_offsets, bad_regions, lengths, not_coverage):
         bad_offsets = np.ascontiguousarray(bad_offsets, dtype=np.uint64)
         bad_regions = np.ascontiguousarray(bad_regions, dtype=np.uint32).reshape(-1)
@@ -324,3 +384,102 @@ class Engine:
             _ptr(lengths, ctypes.c_uint32), n_reads, float(not_coverage),
             _ptr(out, ctypes.c_uint8)))
         return out[:n_reads]
+
+
+class PinnedArray:
+    """A numpy array over page-locked host memory (yacrd_pinned_alloc): the engine moves it over
+    PCIe by direct DMA.  Keep the object alive while `array` is in use."""
+
+    def __init__(self, shape, dtype):
+        self._lib = load_library()
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        self._p = self._lib.yacrd_pinned_alloc(max(n, 1))
+        if not self._p:
+            raise EngineError("yacrd_pinned_alloc(%d) failed" % n)
+        buf = (ctypes.c_char * max(n, 1)).from_address(self._p)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    @classmethod
+    def copy_of(cls, a):
+        a = np.ascontiguousarray(a)
+        p = cls(a.shape, a.dtype)
+        p.array[...] = a
+        return p
+
+    def close(self):
+        if self._p:
+            self.array = None
+            self._lib.yacrd_pinned_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Stream:
+    """yacrd_stream: overlap records go to HBM from pinned buffers while they are produced; finish()
+    builds the CSR on the GPU and runs the engine on it."""
+
+    def __init__(self, engine, chunk_records=0, n_buffers=0):
+        self._lib = load_library()
+        self._engine = engine
+        self._h = ctypes.c_void_p()
+        _check(self._lib, self._lib.yacrd_stream_open(engine._h, chunk_records, n_buffers,
+                                                      ctypes.byref(self._h)))
+
+    def sink(self):
+        """A RecSink for host.ingest_stream (keep this Stream alive while it is in use)."""
+        s = RecSink()
+        _check(self._lib, self._lib.yacrd_stream_sink(self._h, ctypes.byref(s)))
+        return s
+
+    def push(self, recs):
+        """Copy an OVL_REC_DTYPE array into stream buffers (tests; the parser fills them in place)."""
+        recs = np.ascontiguousarray(recs, dtype=OVL_REC_DTYPE)
+        at = 0
+        while at < len(recs):
+            buf = ctypes.POINTER(OvlRec)()
+            cap = ctypes.c_uint64()
+            _check(self._lib, self._lib.yacrd_stream_acquire(self._h, ctypes.byref(buf), ctypes.byref(cap)))
+            n = min(int(cap.value), len(recs) - at)
+            ctypes.memmove(buf, recs[at:at + n].ctypes.data, n * OVL_REC_DTYPE.itemsize)
+            _check(self._lib, self._lib.yacrd_stream_commit(self._h, buf, n))
+            at += n
+
+    def finish(self, handle_map, lengths, coverage, not_coverage):
+        lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+        if handle_map is not None:
+            handle_map = np.ascontiguousarray(handle_map, dtype=np.uint32)
+        res = _Result()
+        _check(self._lib, self._lib.yacrd_stream_finish(
+            self._h, _ptr(handle_map, ctypes.c_uint32) if handle_map is not None and handle_map.size else None,
+            0 if handle_map is None else handle_map.shape[0],
+            _ptr(lengths, ctypes.c_uint32) if lengths.size else None, lengths.shape[0],
+            min(int(coverage), 0xFFFFFFFF), float(not_coverage), ctypes.byref(res)))
+        return _take(self._lib, res)
+
+    def stats(self):
+        st = _StreamStats()
+        _check(self._lib, self._lib.yacrd_stream_last_stats(self._h, ctypes.byref(st)))
+        return {n: getattr(st, n) for n, _ in _StreamStats._fields_}
+
+    def close(self):
+        if self._h:
+            self._lib.yacrd_stream_close(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

@@ -15,7 +15,7 @@ EXPORTED_SYMBOLS = [
     "yacrd_host_last_error", "yacrd_csr_from_file", "yacrd_csr_from_memory", "yacrd_csr_get",
     "yacrd_csr_find", "yacrd_csr_free", "yacrd_report_write", "yacrd_synth_csr", "yacrd_synth_paf",
     "yacrd_edit_file", "yacrd_report_read", "yacrd_report_get", "yacrd_report_free",
-    "yacrd_synth_fastq",
+    "yacrd_synth_fastq", "yacrd_ingest_stream", "yacrd_ingest_stream_memory", "yacrd_csr_handle_map",
 ]
 
 OP_SCRUBB, OP_FILTER, OP_EXTRACT, OP_SPLIT = 0, 1, 2, 3
@@ -73,6 +73,13 @@ def load_library():
                                             ctypes.POINTER(ctypes.c_void_p)]
         lib.yacrd_csr_from_memory.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int,
                                               ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        lib.yacrd_ingest_stream.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                            ctypes.POINTER(ctypes.c_void_p)]
+        lib.yacrd_ingest_stream_memory.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_int,
+                                                   ctypes.c_int, ctypes.c_void_p,
+                                                   ctypes.POINTER(ctypes.c_void_p)]
+        lib.yacrd_csr_handle_map.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.POINTER(ctypes.c_uint32)),
+                                             ctypes.POINTER(ctypes.c_uint64)]
         lib.yacrd_csr_get.argtypes = [ctypes.c_void_p, ctypes.POINTER(_View)]
         lib.yacrd_csr_find.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
         lib.yacrd_csr_find.restype = ctypes.c_int64
@@ -113,9 +120,18 @@ class Csr:
         self._view = v
         R, I = int(v.n_reads), int(v.n_intervals)
         self.n_reads, self.n_intervals, self.n_records = R, I, int(v.n_records)
-        self.offsets = np.ctypeslib.as_array(v.offsets, shape=(R + 1,)).copy()
-        self.intervals = (np.ctypeslib.as_array(v.intervals, shape=(2 * I,)).copy().reshape(-1, 2)
-                          if I else np.zeros((0, 2), np.uint32))
+        self.streamed = not bool(v.offsets)  # yacrd_ingest_stream: the CSR lives in HBM
+        if self.streamed:
+            self.offsets = self.intervals = None
+            mp = ctypes.POINTER(ctypes.c_uint32)()
+            nh = ctypes.c_uint64()
+            _check(self._lib, self._lib.yacrd_csr_handle_map(self._h, ctypes.byref(mp), ctypes.byref(nh)))
+            self.handle_map = (np.ctypeslib.as_array(mp, shape=(int(nh.value),)).copy()
+                               if nh.value else np.zeros(0, np.uint32))
+        else:
+            self.offsets = np.ctypeslib.as_array(v.offsets, shape=(R + 1,)).copy()
+            self.intervals = (np.ctypeslib.as_array(v.intervals, shape=(2 * I,)).copy().reshape(-1, 2)
+                              if I else np.zeros((0, 2), np.uint32))
         self.lengths = (np.ctypeslib.as_array(v.lengths, shape=(R,)).copy()
                         if R else np.zeros(0, np.uint32))
         name_off = np.ctypeslib.as_array(v.name_off, shape=(R + 1,)).copy()
@@ -156,6 +172,25 @@ def csr_from_file(path, fmt=FMT_AUTO, n_threads=0):
     lib = load_library()
     h = ctypes.c_void_p()
     _check(lib, lib.yacrd_csr_from_file(path.encode(), fmt, n_threads, ctypes.byref(h)))
+    return Csr(h)
+
+
+def ingest_stream(path, sink, fmt=FMT_AUTO, n_threads=0):
+    """Parse `path`, handing the overlap records to `sink` (a yacrd_rec_sink struct, e.g.
+    yacrd_amd.Stream.sink()) while parsing.  Returns a Csr with names / lengths / handle_map."""
+    lib = load_library()
+    h = ctypes.c_void_p()
+    _check(lib, lib.yacrd_ingest_stream(path.encode(), fmt, n_threads, ctypes.addressof(sink), ctypes.byref(h)))
+    return Csr(h)
+
+
+def ingest_stream_memory(text, sink, fmt, n_threads=0):
+    lib = load_library()
+    if isinstance(text, str):
+        text = text.encode()
+    h = ctypes.c_void_p()
+    _check(lib, lib.yacrd_ingest_stream_memory(text, len(text), fmt, n_threads, ctypes.addressof(sink),
+                                               ctypes.byref(h)))
     return Csr(h)
 
 

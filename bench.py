@@ -8,12 +8,23 @@ data-path collective — torch.distributed is used only for the barrier and the 
 
 Prints ONE JSON line on rank 0 (see the contract in the task statement) carrying `roofline`
 for the dominant kernel (HIP-event time measured inside the engine, on the engine's stream)
-and `cpu_baseline` (the CPU oracle timed on this box's cores; rank 0, N=1 only).
+and `cpu_baseline` (the CPU oracle timed on this box's cores; rank 0, N=1 only), plus, next to
+the kernel-only `value` (SURVEY.md §8d asks for all of them):
+  pcie_inclusive  R / (H2D + kernels + D2H): the same batch sent from pinned host memory every step
+  end_to_end      overlaps/s from PAF TEXT to read types on the full configs[1] file: parse threads
+                  -> pinned buffers -> HBM during the parse -> CSR build on the GPU -> run -> D2H
+  large           configs[2] (2 M reads / 200 M overlaps, 3.3 GB: outside the 256 MiB Infinity
+                  Cache) read-partitioned over the ranks with yacrd_partition_reads — one GPU at
+                  N=1, the north star's strong-scaling workload at N>1 — with oracle parity on a
+                  sampled subset of reads.
+`--strong` makes the large workload the headline (`value`, "scaling": "strong").
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
+import tempfile
 import time
 
 import numpy as np
@@ -36,6 +47,22 @@ def usable_cpus():
     return n
 
 
+def alg_bytes(R, I, G):
+    """16 B per overlap (8 per interval) + 21 B per read + 8 B per region
+    (8(R+1) + 4R read, 8(R+1) + R written; the survey's "29 B per read" shorthand over-counts)."""
+    return 8 * I + 8 * (R + 1) + 4 * R + 8 * (R + 1) + 8 * G + R
+
+
+def dominant(t, K, yacrd_amd):
+    """(kernel name, class name, ms per launch, reads, intervals) of the kernel with the most time."""
+    cls_ms = list(t["class_ms"])
+    ci = max(range(12), key=lambda i: cls_ms[i])
+    if t["fused_ms"] >= cls_ms[ci]:  # the row / half-wavefront classes run as one launch
+        return "sweep_small_fused_kernel", "R2..H16", t["fused_ms"] / K, t["fused_reads"], t["fused_intervals"]
+    cname = yacrd_amd.CLASS_NAMES[ci]
+    return yacrd_amd.CLASS_KERNELS[cname], cname, cls_ms[ci] / K, t["class_reads"][ci], t["class_intervals"][ci]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -53,7 +80,15 @@ def main():
                     help="engines (HIP streams) the batches are pipelined over on each GPU")
     ap.add_argument("--full-timing", action="store_true",
                     help="HIP events around every phase and class kernel (slower steps)")
+    ap.add_argument("--strong", action="store_true",
+                    help="headline = the large fixed input partitioned over the ranks (strong scaling)")
+    ap.add_argument("--no-extras", action="store_true", help="skip pcie_inclusive / end_to_end / large")
+    ap.add_argument("--large-reads", type=int, default=2_000_000)
+    ap.add_argument("--large-overlaps", type=int, default=200_000_000)
+    ap.add_argument("--large-steps", type=int, default=5)
     args = ap.parse_args()
+    if os.environ.get("YACRD_BENCH_STRONG"):
+        args.strong = True
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -124,18 +159,15 @@ def main():
 
     run_steps(max(args.warmup, 2 * NE))  # (a submit only pipelines once the engine has a prediction)
     keys = ("plan_ms", "sweep_small_ms", "sweep_medium_ms", "sweep_general_ms", "compact_ms", "total_ms")
-    acc = dict.fromkeys(keys, 0.0)
-    cls_ms = [0.0] * 12
     for e in engs:
         e.timing_total(reset=True)
     barrier()
     t0 = time.perf_counter()
-    outs = [run_steps(args.steps)]
+    out = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    out = outs[0]
-    # HIP events recorded on the engines' streams inside every run_device of the timed region,
-    # summed by the engines (one read-back each instead of one per step)
+    # HIP events recorded on the engines' streams inside every run of the timed region, summed by
+    # the engines (one read-back each instead of one per step)
     t, n_timed = None, 0
     for e in engs:
         te, ne = e.timing_total()
@@ -148,38 +180,22 @@ def main():
                     t[k2] = [a + b for a, b in zip(t[k2], v)] if isinstance(v, list) else t[k2] + v
     assert n_timed == args.steps
     ev_overhead_ms = eng.event_overhead_ms()
-    for k in keys:
-        acc[k] = t[k]
-    cls_ms = list(t["class_ms"])
-
     G = int(out.n_regions)
     elapsed = ydist.max_over_ranks(dist, elapsed, dev)
 
+    line = None
     if rank == 0:
         K = args.steps
-        avg = {k: acc[k] / K for k in keys if acc[k] > 0}  # per-phase fields need --full-timing
-        # algorithmic bytes per pass, SURVEY.md §8(d): 16 B per overlap + 21 B per read + 8 B per region
-        # (8(R+1) + 4R read, 8(R+1) + R written; the survey's "29 B per read" shorthand over-counts)
-        b_alg = 8 * I + 8 * (R + 1) + 4 * R + 8 * (R + 1) + 8 * G + R
-        # dominant kernel = the size class with the largest own kernel time (HIP events around that
-        # launch on the engine's stream); its algorithmic bytes are those of the reads it processed
-        ci = max(range(12), key=lambda i: cls_ms[i])
-        if t["fused_ms"] >= cls_ms[ci]:  # the row / half-wavefront classes run as one launch
-            cname, dom = "R2..H16", "sweep_small_fused_kernel"
-            dom_ms = t["fused_ms"] / K
-            c_reads, c_iv = t["fused_reads"], t["fused_intervals"]
-        else:
-            cname = yacrd_amd.CLASS_NAMES[ci]
-            dom = yacrd_amd.CLASS_KERNELS[cname]
-            dom_ms = cls_ms[ci] / K
-            c_reads, c_iv = t["class_reads"][ci], t["class_intervals"][ci]
+        avg = {k: t[k] / K for k in keys if t[k] > 0}  # per-phase fields need --full-timing
+        b_alg = alg_bytes(R, I, G)
+        # dominant kernel = the size class with the largest own kernel time; its algorithmic bytes
+        # are those of the reads it processed.  dom_ms: HIP start / stop events attached to the
+        # launch itself (hipExtLaunchKernelGGL: the dispatch's own timestamps, the figure rocprofv3
+        # --kernel-trace reports), averaged over every launch of the timed region.
+        dom, cname, dom_ms, c_reads, c_iv = dominant(t, K, yacrd_amd)
         b_dom = 8 * c_iv + 21 * c_reads + 16 + 8 * (G * c_reads // max(R, 1))
-        # dom_ms: HIP start / stop events attached to the launch itself (hipExtLaunchKernelGGL: the
-        # dispatch's own timestamps, the figure rocprofv3 --kernel-trace reports), averaged over
-        # every launch of the timed region.  An EMPTY hipEventRecord pair on the same stream measures
-        # ~5 us, which is why the events are not recorded around the launch.
         achieved = b_dom / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        avg["class_ms"] = {yacrd_amd.CLASS_NAMES[i]: cls_ms[i] / K for i in range(12) if cls_ms[i] > 0}
+        avg["class_ms"] = {yacrd_amd.CLASS_NAMES[i]: t["class_ms"][i] / K for i in range(12) if t["class_ms"][i] > 0}
         if t["fused_ms"] > 0:
             avg["class_ms"]["R2..H16 (one launch)"] = t["fused_ms"] / K
         traffic = None
@@ -202,11 +218,16 @@ def main():
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": "configs[1]: synthetic %s pile-up, %d reads / %d PAF overlaps per GPU, -c %d -n %g, inputs resident in HBM"
-                                   % (args.profile.upper(), R, args.overlaps, cov, args.not_coverage),
+            "config": {"workload": "configs[1]: synthetic %s pile-up, %d reads / %d PAF overlaps per GPU, -c %d -n %g; "
+                                   "KERNELS ONLY: inputs resident in HBM, the same batch every step, %d batches in "
+                                   "flight per GPU, launch grids sized from the previous identical batch's class "
+                                   "counts (validated at the final sync); see pcie_inclusive / end_to_end for the "
+                                   "rates that include PCIe and the parse"
+                                   % (args.profile.upper(), R, args.overlaps, cov, args.not_coverage, NE),
                        "reads_per_gpu": R, "overlaps_per_gpu": args.overlaps, "intervals_per_gpu": I,
-                       "regions_per_gpu": G, "parallelism": "read-partition x%d, no collective; %d batches in flight per GPU (one engine each)" % (world, NE)},
-            "overlaps_per_sec": world * args.overlaps * K / elapsed,
+                       "regions_per_gpu": G,
+                       "parallelism": "read-partition x%d, no collective; %d batches in flight per GPU (one engine each)" % (world, NE)},
+            "kernel_overlaps_per_sec": world * args.overlaps * K / elapsed,
             "kernel_ms": avg,
             "path_gbps": b_alg / (avg["total_ms"] * 1e-3) / 1e9 if avg.get("total_ms") else None,
             "roofline": {"bound": "hbm", "kernel": dom, "size_class": cname, "achieved": achieved,
@@ -214,66 +235,291 @@ def main():
                          "traffic": traffic, "algorithmic_bytes": b_dom, "kernel_ms": dom_ms,
                          "empty_event_bracket_ms": ev_overhead_ms,
                          "kernel_reads": c_reads, "kernel_intervals": c_iv,
-                         "whole_path_algorithmic_bytes": b_alg},
+                         "whole_path_algorithmic_bytes": b_alg,
+                         "note": "batch (82 MB + scratch) fits the 256 MiB Infinity Cache: see large.roofline for the "
+                                 "same kernel on a 3.3 GB input"},
         }
         if world == 1 and not args.no_cpu_baseline:
-            import oracle
-            ncores = usable_cpus()
-            l64 = lengths.astype(np.uint64)
-            oracle.run(offsets[:1001], intervals[: int(offsets[1000])], l64[:1000], cov, args.not_coverage, 1)
-            t1 = time.perf_counter()
-            want = oracle.run(offsets, intervals, l64, cov, args.not_coverage, n_threads=ncores)
-            cpu_all = time.perf_counter() - t1
-            # reference default is -t 1 (src/main.rs:75-77): time a bounded single-thread sample too
-            rs = min(R, 20000)
-            t1 = time.perf_counter()
-            oracle.run(offsets[: rs + 1], intervals[: int(offsets[rs])], l64[:rs], cov, args.not_coverage, 1)
-            cpu_1 = time.perf_counter() - t1
-            got = eng.fetch()
-            parity = bool(np.array_equal(got.bad_offsets, want[0]) and np.array_equal(got.bad_regions, want[1])
-                          and np.array_equal(got.read_type, want[2]))
-            line["cpu_baseline"] = {"value": R / cpu_all, "unit": "reads/s", "cores": ncores,
-                                    "hardware_threads": os.cpu_count(), "kind": "port",
-                                    "sample": "the whole batch (%d reads, %d intervals) once on %d threads (= usable CPUs: "
-                                              "hardware threads capped by the cgroup cpu.max quota); "
-                                              "single-thread (reference default -t 1) on the first %d reads: %.0f reads/s"
-                                              % (R, I, ncores, rs, rs / cpu_1),
-                                    "value_1thread": rs / cpu_1}
-            line["parity"] = "bit-exact vs oracle on all %d reads" % R if parity else "MISMATCH vs oracle"
-            # the other half of BASELINE.json's metric: overlaps/s ingested (PAF text -> CSR on the
-            # host, the stage in front of the GPU path), on a bounded sample of the same profile
+            cpu_baseline(line, eng, offsets, intervals, lengths, R, I, cov, args)
+        if world == 1 and not args.no_extras:
             try:
-                import ctypes
-                import tempfile
-                s_reads, s_ovl = max(R // 5, 2), max(args.overlaps // 5, 2)
-                with tempfile.TemporaryDirectory() as td:
-                    paf = os.path.join(td, "sample.paf")
-                    host.synth_paf(prof, s_reads, s_ovl, 20241110, paf)
-                    size = os.path.getsize(paf)
-                    hl = host.load_library()
-                    rates = {}
-                    for th in (1, min(64, ncores)) if ncores > 1 else (1,):
-                        best = None
-                        for _ in range(2):
-                            h = ctypes.c_void_p()
-                            t1 = time.perf_counter()
-                            rc = hl.yacrd_csr_from_file(paf.encode(), 0, th, ctypes.byref(h))
-                            dt = time.perf_counter() - t1
-                            if rc != 0:
-                                raise RuntimeError("ingest failed")
-                            hl.yacrd_csr_free(h)
-                            best = dt if best is None else min(best, dt)
-                        rates[th] = s_ovl / best
-                line["ingest"] = {"overlaps_per_sec": max(rates.values()), "unit": "PAF overlaps/s, text -> CSR, host",
-                                  "threads": max(rates, key=rates.get), "overlaps_per_sec_1thread": rates[1],
-                                  "sample": "%d reads / %d overlaps, %.0f MB of PAF text" % (s_reads, s_ovl, size / 1e6)}
-            except Exception as ex:  # the host library is optional for the GPU metric
-                line["ingest"] = {"error": str(ex)}
-        print(json.dumps(line), flush=True)
-    for e in engs:
+                line["pcie_inclusive"] = pcie_inclusive(yacrd_amd, engs, offsets, intervals, lengths, cov, args, G)
+            except Exception as ex:
+                line["pcie_inclusive"] = {"error": repr(ex)}
+            try:
+                line["end_to_end"] = end_to_end(yacrd_amd, host, eng, prof, R, args.overlaps, cov, args)
+            except Exception as ex:
+                line["end_to_end"] = {"error": repr(ex)}
+    for e in engs[1:]:
         e.close()
+    del d_off, d_iv, d_len
+    torch.cuda.empty_cache()
+
+    if not args.no_extras or args.strong:
+        try:
+            large = large_block(yacrd_amd, host, ydist, dist, dev, torch, eng, rank, world, args)
+        except Exception as ex:  # the headline must survive a failure here
+            large = {"error": repr(ex)}
+        if rank == 0:
+            line["large"] = large
+            if args.strong and "error" not in large:
+                line.update({"value": large["reads_per_sec"], "scaling": "strong", "steps": large["steps"],
+                             "warmup": large["warmup"], "ms_per_step": large["ms_per_step"]})
+                line["config"]["workload"] = large["workload"]
+                line["roofline"] = large["roofline"]
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    eng.close()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def cpu_baseline(line, eng, offsets, intervals, lengths, R, I, cov, args):
+    """The oracle on this box's cores (kind "port"): the whole batch once on every usable CPU, and
+    a bounded single-thread sample (the reference's default is -t 1, src/main.rs:75-77)."""
+    import oracle
+    ncores = usable_cpus()
+    l64 = lengths.astype(np.uint64)
+    oracle.run(offsets[:1001], intervals[: int(offsets[1000])], l64[:1000], cov, args.not_coverage, 1)
+    t1 = time.perf_counter()
+    want = oracle.run(offsets, intervals, l64, cov, args.not_coverage, n_threads=ncores)
+    cpu_all = time.perf_counter() - t1
+    rs = min(R, 20000)
+    t1 = time.perf_counter()
+    oracle.run(offsets[: rs + 1], intervals[: int(offsets[rs])], l64[:rs], cov, args.not_coverage, 1)
+    cpu_1 = time.perf_counter() - t1
+    got = eng.fetch()
+    parity = bool(np.array_equal(got.bad_offsets, want[0]) and np.array_equal(got.bad_regions, want[1])
+                  and np.array_equal(got.read_type, want[2]))
+    line["cpu_baseline"] = {"value": R / cpu_all, "unit": "reads/s", "cores": ncores,
+                            "hardware_threads": os.cpu_count(), "kind": "port",
+                            "sample": "the whole batch (%d reads, %d intervals) once on %d threads (= usable CPUs: "
+                                      "hardware threads capped by the cgroup cpu.max quota); "
+                                      "single-thread (reference default -t 1) on the first %d reads: %.0f reads/s"
+                                      % (R, I, ncores, rs, rs / cpu_1),
+                            "value_1thread": rs / cpu_1}
+    line["parity"] = "bit-exact vs oracle on all %d reads" % R if parity else "MISMATCH vs oracle"
+
+
+def pcie_inclusive(yacrd_amd, engs, offsets, intervals, lengths, cov, args, G):
+    """R / (H2D + kernels + D2H): the batch leaves pinned host memory every step
+    (yacrd_engine_submit / _collect, two engines: the H2D of one batch overlaps the kernels and the
+    D2H of the other), plus one blocking yacrd_engine_run for the unpipelined latency, and the same
+    from PAGEABLE memory (threaded bounce-buffer staging)."""
+    R, I = len(lengths), int(offsets[-1])
+    pins = [yacrd_amd.PinnedArray.copy_of(x) for x in (offsets, intervals, lengths)]
+    arrs = tuple(p.array for p in pins)
+    e0 = engs[0]
+    h2d_bytes = offsets.nbytes + intervals.nbytes + lengths.nbytes
+    d2h_bytes = 8 * (R + 1) + 8 * G + R
+    # blocking, one engine
+    for _ in range(2):
+        e0.run(*arrs, cov, args.not_coverage)
+    K1 = 10
+    e0.timing_total(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(K1):
+        e0.run(*arrs, cov, args.not_coverage)
+    blocking = (time.perf_counter() - t0) / K1
+    tt, _ = e0.timing_total(reset=True)
+    h2d_ms, d2h_ms = tt["h2d_ms"] / K1, tt["d2h_ms"] / K1
+    # pipelined over the engines
+    NE = len(engs)
+    K2 = 40
+
+    def steps(k):
+        inflight = [False] * NE
+        for i in range(k):
+            j = i % NE
+            if inflight[j]:
+                engs[j].collect()
+            engs[j].submit(*arrs, cov, args.not_coverage)
+            inflight[j] = True
+        for j in range(NE):
+            if inflight[j]:
+                engs[j].collect()
+    steps(2 * NE)
+    t0 = time.perf_counter()
+    steps(K2)
+    piped = (time.perf_counter() - t0) / K2
+    # pageable source
+    for _ in range(2):
+        e0.run(offsets, intervals, lengths, cov, args.not_coverage)
+    e0.timing_total(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(5):
+        e0.run(offsets, intervals, lengths, cov, args.not_coverage)
+    pageable = (time.perf_counter() - t0) / 5
+    tp, _ = e0.timing_total(reset=True)
+    for p in pins:
+        p.close()
+    return {"reads_per_sec": R / piped, "ms_per_batch": piped * 1e3, "engines": NE, "batches": K2,
+            "overlaps_per_sec": (I // 2) / piped,
+            "blocking_ms_per_batch": blocking * 1e3, "blocking_reads_per_sec": R / blocking,
+            "h2d_ms": h2d_ms, "h2d_GBps": h2d_bytes / (h2d_ms * 1e-3) / 1e9 if h2d_ms else None,
+            "d2h_ms": d2h_ms, "h2d_bytes": h2d_bytes, "d2h_bytes": d2h_bytes,
+            "pageable_ms_per_batch": pageable * 1e3,
+            "pageable_h2d_GBps": h2d_bytes / (tp["h2d_ms"] / 5 * 1e-3) / 1e9 if tp["h2d_ms"] else None,
+            "source": "pinned host memory (yacrd_pinned_alloc), the same batch every step; PCIe Gen5 x16 spec 63 GB/s"}
+
+
+def end_to_end(yacrd_amd, host, eng, prof, R, O, cov, args):
+    """BASELINE's "overlaps/sec ingested -> reads/sec classified" as ONE number: the full
+    configs[1] PAF text (not a sample) to read types.  Parse threads fill pinned buffers, every
+    full buffer crosses PCIe at once (yacrd_stream_*), the CSR is built on the GPU, the engine
+    runs, results come home.  Also: the parse alone into a host CSR, by thread count."""
+    ncores = usable_cpus()
+    d = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    paf = os.path.join(d, "yacrd_bench_%d_%d_%d.paf" % (os.getpid(), R, O))
+    hl = host.load_library()
+    el = yacrd_amd.load_library()
+    try:
+        t0 = time.perf_counter()
+        host.synth_paf(prof, R, O, 20241110, paf)
+        gen_s = time.perf_counter() - t0
+        size = os.path.getsize(paf)
+        out = {"paf_bytes": size, "overlaps": O, "reads": R, "generate_s": gen_s, "file_on": d}
+        best = None
+        with yacrd_amd.Stream(eng) as st:
+            for th in sorted(set([ncores, min(2 * ncores, 64)])):
+                for rep in range(3):
+                    sink = st.sink()
+                    h = ctypes.c_void_p()
+                    t0 = time.perf_counter()
+                    rc = hl.yacrd_ingest_stream(paf.encode(), 0, th, ctypes.addressof(sink), ctypes.byref(h))
+                    t1 = time.perf_counter()
+                    if rc != 0:
+                        raise RuntimeError(hl.yacrd_host_last_error().decode())
+                    v = host._View()
+                    hl.yacrd_csr_get(h, ctypes.byref(v))
+                    mp, nh = ctypes.POINTER(ctypes.c_uint32)(), ctypes.c_uint64()
+                    hl.yacrd_csr_handle_map(h, ctypes.byref(mp), ctypes.byref(nh))
+                    res = yacrd_amd.engine._Result()
+                    rc = el.yacrd_stream_finish(st._h, mp, nh, v.lengths, v.n_reads, cov, args.not_coverage,
+                                                ctypes.byref(res))
+                    t2 = time.perf_counter()
+                    if rc != 0:
+                        raise RuntimeError(el.yacrd_last_error().decode())
+                    n_reads, n_regions = int(res.n_reads), int(res.n_regions)
+                    el.yacrd_result_free(ctypes.byref(res))
+                    hl.yacrd_csr_free(h)
+                    if best is None or t2 - t0 < best["s"]:
+                        s = st.stats()
+                        best = {"s": t2 - t0, "threads": th, "parse_s": t1 - t0, "finish_ms": (t2 - t1) * 1e3,
+                                "h2d_GBps_while_busy": s["h2d_bytes"] / max(s["h2d_busy_ms"], 1e-6) / 1e6,
+                                "h2d_bytes": s["h2d_bytes"], "csr_build_on_gpu_ms": s["build_ms"],
+                                "engine_run_ms": s["run_ms"], "d2h_ms": s["d2h_ms"],
+                                "reads_found": n_reads, "regions": n_regions}
+        out.update({"overlaps_per_sec": O / best["s"], "reads_per_sec": best["reads_found"] / best["s"],
+                    "text_GBps": size / best["s"] / 1e9, "seconds": best["s"], "stream": best,
+                    "path": "PAF text -> yacrd_ingest_stream (pread blocks, shared id table) -> pinned buffers -> "
+                            "hipMemcpyAsync during the parse -> CSR build on the GPU -> engine -> D2H"})
+        rates = {}
+        for th in sorted(set([1, ncores])):
+            bt = None
+            for _ in range(2 if th > 1 else 1):
+                h = ctypes.c_void_p()
+                t0 = time.perf_counter()
+                if hl.yacrd_csr_from_file(paf.encode(), 0, th, ctypes.byref(h)) != 0:
+                    raise RuntimeError(hl.yacrd_host_last_error().decode())
+                dt = time.perf_counter() - t0
+                hl.yacrd_csr_free(h)
+                bt = dt if bt is None else min(bt, dt)
+            rates[str(th)] = O / bt
+        out["host_csr_ingest_overlaps_per_sec_by_threads"] = rates
+        return out
+    finally:
+        if os.path.exists(paf):
+            os.remove(paf)
+
+
+def large_block(yacrd_amd, host, ydist, dist, dev, torch, eng, rank, world, args):
+    """configs[2] shape, one fixed input for every N: 2 M reads / 200 M overlaps (Sequel-like,
+    -c 3 -n 0.4).  yacrd_partition_reads cuts contiguous read ranges balanced by interval count,
+    rank r takes range r (its own GPU, no collective), time = max over ranks."""
+    R, O, cov, nc = args.large_reads, args.large_overlaps, 3, 0.4
+    t0 = time.perf_counter()
+    offsets, intervals, lengths = host.synth_csr(host.SYNTH_SEQUEL, R, O, 20241108 + 3)
+    gen_s = time.perf_counter() - t0
+    cuts = yacrd_amd.partition_reads(offsets, world)
+    r0, r1 = int(cuts[rank]), int(cuts[rank + 1])
+    off, iv, ln = ydist.local_csr(offsets, intervals, lengths, r0, r1)
+    Rl, Il = r1 - r0, int(off[-1])
+    t0 = time.perf_counter()
+    d_off = torch.from_numpy(np.ascontiguousarray(off).view(np.int64)).to(dev)
+    d_iv = torch.from_numpy(np.ascontiguousarray(iv).view(np.int32)).to(dev)
+    d_len = torch.from_numpy(np.ascontiguousarray(ln).view(np.int32)).to(dev)
+    torch.cuda.synchronize()
+    upload_s = time.perf_counter() - t0
+    ptrs = (d_off.data_ptr(), d_iv.data_ptr(), d_len.data_ptr(), Rl, Il, cov, nc)
+    W, K = 2, max(1, args.large_steps)
+    for _ in range(W):
+        res = eng.run_device(*ptrs)
+    eng.timing_total(reset=True)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        res = eng.run_device(*ptrs)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    mine = time.perf_counter() - t0
+    elapsed = ydist.max_over_ranks(dist, mine, dev)
+    t, _ = eng.timing_total()
+    G = int(res.n_regions)
+    # oracle parity on a sample of this rank's reads (every ~100th read, at most 20 000)
+    import oracle
+    got = eng.fetch()
+    step = max(1, Rl // 20000)
+    pick = np.arange(0, Rl, step)
+    n = np.diff(off.astype(np.int64))[pick]
+    s_off = np.zeros(len(pick) + 1, np.uint64)
+    s_off[1:] = np.cumsum(n)
+    idx = np.concatenate([np.arange(int(off[p]), int(off[p + 1])) for p in pick]) if len(pick) else np.zeros(0, np.int64)
+    s_iv = np.asarray(iv)[idx]
+    want = oracle.run(s_off, s_iv, np.asarray(ln)[pick].astype(np.uint64), cov, nc, n_threads=usable_cpus())
+    ok = True
+    for j, p in enumerate(pick):
+        a, b = int(got.bad_offsets[p]), int(got.bad_offsets[p + 1])
+        wa, wb = int(want[0][j]), int(want[0][j + 1])
+        if b - a != wb - wa or not np.array_equal(got.bad_regions[a:b], want[1][wa:wb]) or got.read_type[p] != want[2][j]:
+            ok = False
+            break
+    per_rank = {"rank": rank, "reads": Rl, "intervals": Il, "ms_per_step": mine / K * 1e3,
+                "parity_sample_ok": ok, "sampled_reads": int(len(pick))}
+    if dist is not None:
+        allr = [None] * world
+        dist.all_gather_object(allr, per_rank)
+    else:
+        allr = [per_rank]
+    if rank != 0:
+        del d_off, d_iv, d_len
+        return None
+    dom, cname, dom_ms, c_reads, c_iv = dominant(t, K, yacrd_amd)
+    Gl = G
+    b_dom = 8 * c_iv + 21 * c_reads + 16 + 8 * (Gl * c_reads // max(Rl, 1))
+    ach = b_dom / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    ivs = [p["intervals"] for p in allr]
+    b_all = alg_bytes(R, int(offsets[-1]), G * world if world > 1 else G)
+    out = {"workload": "configs[2]: synthetic SEQUEL pile-up, %d reads / %d PAF overlaps in total, -c %d -n %g, "
+                       "read-partitioned over %d GPU(s) by yacrd_partition_reads (contiguous ranges balanced by "
+                       "interval count, no collective); KERNELS ONLY, inputs resident in HBM" % (R, O, cov, nc, world),
+           "reads_per_sec": R * K / elapsed, "kernel_overlaps_per_sec": O * K / elapsed,
+           "ms_per_step": elapsed / K * 1e3, "steps": K, "warmup": W, "n_gpus": world,
+           "generate_s": gen_s, "upload_s": upload_s,
+           "interval_imbalance_max_over_min": max(ivs) / max(1, min(ivs)),
+           "per_rank": allr,
+           "whole_path_GBps": b_all / (elapsed / K) / 1e9,
+           "parity": ("bit-exact vs oracle on %d sampled reads per rank" % per_rank["sampled_reads"])
+                     if all(p["parity_sample_ok"] for p in allr) else "MISMATCH vs oracle",
+           "roofline": {"bound": "hbm", "kernel": dom, "size_class": cname, "achieved": ach, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": b_dom,
+                        "kernel_ms": dom_ms, "kernel_reads": c_reads, "kernel_intervals": c_iv,
+                        "note": "rank 0's launch; input %.2f GB per GPU, outside the 256 MiB Infinity Cache" % (8 * Il / 1e9)}}
+    del d_off, d_iv, d_len
+    return out
 
 
 if __name__ == "__main__":

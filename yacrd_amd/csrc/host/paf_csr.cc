@@ -481,21 +481,35 @@ inline uint64_t mix64(uint64_t x)
     x ^= x >> 32;
     return x;
 }
+inline uint64_t load64(const char *p)
+{
+    uint64_t w;
+    std::memcpy(&w, p, 8);
+    return w;
+}
+inline uint64_t load32(const char *p)
+{
+    uint32_t w;
+    std::memcpy(&w, p, 4);
+    return w;
+}
+// whole words, then the LAST eight bytes again (overlapping the previous word when n % 8 != 0);
+// short ids take two overlapping 4-byte loads or three single bytes: no byte loops, no calls
 inline uint64_t hash_id(const char *p, size_t n)
 {
-    uint64_t h = 0x9e3779b97f4a7c15ull ^ (uint64_t)n;
-    size_t i = 0;
-    for (; i + 8 <= n; i += 8) {
-        uint64_t w;
-        std::memcpy(&w, p + i, 8);
-        h = (h ^ w) * 0xff51afd7ed558ccdull;
-        h ^= h >> 29;
-    }
-    if (i < n) {
-        uint64_t w = 0;
-        std::memcpy(&w, p + i, n - i);
-        h = (h ^ w) * 0xff51afd7ed558ccdull;
-        h ^= h >> 29;
+    uint64_t h = 0x9e3779b97f4a7c15ull ^ ((uint64_t)n * 0xff51afd7ed558ccdull);
+    if (n >= 8) {
+        size_t i = 0;
+        for (; i + 8 < n; i += 8) {
+            h = (h ^ load64(p + i)) * 0xff51afd7ed558ccdull;
+            h ^= h >> 29;
+        }
+        h = (h ^ load64(p + n - 8)) * 0xc4ceb9fe1a85ec53ull;
+    } else if (n >= 4) {
+        h = (h ^ (load32(p) | (load32(p + n - 4) << 32))) * 0xc4ceb9fe1a85ec53ull;
+    } else if (n > 0) {
+        h = (h ^ ((uint64_t)(unsigned char)p[0] | ((uint64_t)(unsigned char)p[n >> 1] << 8) |
+                  ((uint64_t)(unsigned char)p[n - 1] << 16))) * 0xc4ceb9fe1a85ec53ull;
     }
     return mix64(h);
 }
@@ -538,8 +552,9 @@ inline bool scan_id(const char *&p, const char *le, const char *&b, size_t &n)
 {
     b = p;
     if (p < le && *p == '"') return false; // quoted field: the general parser's business
-    const char *t = (const char *)std::memchr(p, '\t', (size_t)(le - p));
-    if (!t) return false; // an id must be followed by more fields
+    const char *t = p;
+    while (t < le && *t != '\t') t++; // ids are short: a byte loop beats a memchr call
+    if (t == le) return false; // an id must be followed by more fields
     n = (size_t)(t - p);
     p = t + 1;
     return true;
@@ -551,7 +566,9 @@ inline bool parse_paf_fast(const char *p, const char *le, Fields &f)
     if (!(scan_id(q, le, f.ida, f.na) && scan_uint(q, le, ~0ull, f.la, false) &&
           scan_uint(q, le, 0xFFFFFFFFull, sa, false) && scan_uint(q, le, 0xFFFFFFFFull, ea, false)))
         return false;
-    { // strand: exactly one UTF-8 scalar, then a tab
+    if (le - q >= 2 && (unsigned char)q[0] < 0x80 && q[0] != '"' && q[0] != '\t' && q[1] == '\t') {
+        q += 2; // strand: one ASCII character and a tab, the usual case
+    } else { // exactly one UTF-8 scalar, then a tab
         const char *t = (const char *)std::memchr(q, '\t', (size_t)(le - q));
         if (!t || !is_one_char(q, t) || *q == '"') return false;
         q = t + 1;
@@ -820,6 +837,91 @@ struct MemSource final : BlockSource {
             blk.pos0 = b;
             blk.index = i;
             blk.owner.reset();
+            return true;
+        }
+    }
+};
+
+// a regular file: every parse thread preads the block it takes into a buffer of its own.  Mapping
+// the file instead costs a minor fault per 4 KiB page, and the threads' faults serialise on the
+// process's mmap lock (the parse stopped scaling at 8-16 threads); pread copies out of the page
+// cache at memcpy speed with no shared lock.  Block i holds the lines that START in
+// [i * block, (i + 1) * block): it reads from one byte earlier (is the first byte a line start?) to
+// the end of the line that straddles its upper edge.
+struct FileSource final : BlockSource {
+    const int fd;
+    const size_t len, block;
+    std::atomic<size_t> turn{0};
+    std::mutex mu;
+    FileSource(int f, size_t n, size_t b) : fd(f), len(n), block(std::max<size_t>(b, 1)) {}
+    bool read_at(char *dst, size_t n, size_t off)
+    {
+        size_t got = 0;
+        while (got < n) {
+            const ssize_t k = ::pread(fd, dst + got, n - got, (off_t)(off + got));
+            if (k < 0 && errno == EINTR) continue;
+            if (k <= 0) return false;
+            got += (size_t)k;
+        }
+        return true;
+    }
+    bool next(TextBlock &blk) override
+    {
+        for (;;) {
+            const size_t i = turn.fetch_add(1, std::memory_order_relaxed);
+            if (i > len / block) return false;
+            const size_t lo = i * block, hi = std::min(len, lo + block);
+            if (lo >= len) return false;
+            const size_t from = lo ? lo - 1 : 0;
+            size_t extra = 64u << 10, have = 0, cap = (hi - from) + extra;
+            std::unique_ptr<char[]> buf(new (std::nothrow) char[cap]);
+            bool ok = buf != nullptr;
+            size_t end_rel = 0; // one past the block's last byte, relative to `from`
+            while (ok) {
+                const size_t want = std::min(len - from, cap);
+                ok = read_at(buf.get() + have, want - have, from + have);
+                if (!ok) break;
+                have = want;
+                if (hi >= len) {
+                    end_rel = have;
+                    break;
+                }
+                // the line that covers byte hi - 1 ends the block
+                const char *nl = (const char *)std::memchr(buf.get() + (hi - 1 - from), '\n', have - (hi - 1 - from));
+                if (nl) {
+                    end_rel = (size_t)(nl - buf.get()) + 1;
+                    break;
+                }
+                if (from + have >= len) {
+                    end_rel = have;
+                    break;
+                }
+                cap = (hi - from) + (extra *= 4); // a very long line: read further
+                std::unique_ptr<char[]> nb(new (std::nothrow) char[cap]);
+                if (!nb) {
+                    ok = false;
+                    break;
+                }
+                std::memcpy(nb.get(), buf.get(), have);
+                buf.swap(nb);
+            }
+            if (!ok) {
+                std::lock_guard<std::mutex> g(mu);
+                if (error.empty()) error = "read error in the overlap file";
+                return false;
+            }
+            size_t begin_rel = 0; // first line start at or after lo
+            if (lo) {
+                const char *nl = (const char *)std::memchr(buf.get(), '\n', end_rel);
+                if (!nl) continue; // a line that started in an earlier block covers this one entirely
+                begin_rel = (size_t)(nl - buf.get()) + 1;
+            }
+            if (begin_rel >= end_rel) continue;
+            blk.b = buf.get() + begin_rel;
+            blk.e = buf.get() + end_rel;
+            blk.pos0 = from + begin_rel;
+            blk.index = i;
+            blk.owner = std::move(buf);
             return true;
         }
     }
@@ -1291,16 +1393,26 @@ int ingest_file(const char *path, int format, int n_threads, const yacrd_rec_sin
         MemSource src("", 0, 1);
         return ingest(src, format, (int)NT, sink, out);
     }
-    void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-    ::close(fd);
-    if (m == MAP_FAILED) return yh::fail(std::string("mmap failed for ") + path);
-    madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+    if (std::getenv("YACRD_INGEST_MMAP")) { // A/B: slices of a mapping instead of pread copies
+        void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        ::close(fd);
+        if (m == MAP_FAILED) return yh::fail(std::string("mmap failed for ") + path);
+        madvise(m, (size_t)st.st_size, MADV_SEQUENTIAL);
+        int rc;
+        {
+            MemSource src((const char *)m, (size_t)st.st_size, block_bytes_for((size_t)st.st_size, NT));
+            rc = ingest(src, format, (int)NT, sink, out);
+        }
+        munmap(m, (size_t)st.st_size);
+        return rc;
+    }
+    (void)posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
     int rc;
     {
-        MemSource src((const char *)m, (size_t)st.st_size, block_bytes_for((size_t)st.st_size, NT));
+        FileSource src(fd, (size_t)st.st_size, block_bytes_for((size_t)st.st_size, NT));
         rc = ingest(src, format, (int)NT, sink, out);
     }
-    munmap(m, (size_t)st.st_size);
+    ::close(fd);
     return rc;
 }
 

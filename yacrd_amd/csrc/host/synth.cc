@@ -6,7 +6,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -51,46 +54,79 @@ struct Line {
     uint32_t sa, ea, sb, eb;
 };
 
+// Every read and every line has its own PRNG stream (seeded from the config's seed and the read /
+// line number), so any range of lines can be generated on any thread: the output is the same for
+// every thread count.  (Round 1 drew everything from ONE stream: 385 s for configs[4].)
+inline Rng stream_rng(uint64_t seed, uint64_t kind, uint64_t id)
+{
+    return Rng(seed ^ (kind * 0xA0761D6478BD642Full) ^ (id * 0xD1342543DE82EF95ull + 0x632BE59BD9B4E019ull));
+}
+
+unsigned synth_threads()
+{
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32] = {0};
+        unsigned long long period = 0;
+        if (std::fscanf(f, "%31s %llu", quota, &period) == 2 && period > 0 && std::strcmp(quota, "max") != 0) {
+            const unsigned long long q = std::strtoull(quota, nullptr, 10);
+            if (q > 0) n = std::min<unsigned>(n, (unsigned)std::max<unsigned long long>(1, (q + period - 1) / period));
+        }
+        std::fclose(f);
+    }
+    return std::min(n, 64u);
+}
+
+template <class F>
+void parallel_ranges(uint64_t n, unsigned T, F fn) // fn(t, begin, end) over T contiguous ranges
+{
+    T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(T, n ? n : 1));
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; t++) th.emplace_back(fn, t, n * t / T, n * (t + 1) / T);
+    fn(0u, (uint64_t)0, n / T);
+    for (auto &x : th) x.join();
+}
+
 struct Gen {
     yacrd_synth_cfg cfg;
-    Rng rng;
     std::vector<uint32_t> len;      // read lengths
     std::vector<uint32_t> junction; // 0 = none (2 % of reads: chimera junction)
     std::vector<uint32_t> win0, win1; // win1 == 0: none (3 % of reads: only a 20 % window is covered)
-    std::vector<uint32_t> last_end; // state for abutting injection
     std::vector<double> zipf_cdf;   // skewed profile
-    uint64_t line_no = 0, n_round_robin = 0;
+    uint64_t n_round_robin = 0;
 
-    explicit Gen(const yacrd_synth_cfg &c) : cfg(c), rng(c.seed)
+    explicit Gen(const yacrd_synth_cfg &c) : cfg(c)
     {
         const uint64_t R = c.n_reads;
         len.resize(R);
         junction.assign(R, 0);
         win0.assign(R, 0);
         win1.assign(R, 0);
-        last_end.assign(R, 0);
-        for (uint64_t r = 0; r < R; r++) {
-            double L;
-            if (c.profile == YACRD_SYNTH_ONT) {
-                L = std::exp(std::log(6000.0) + 0.9 * rng.normal());
-                L = std::min(std::max(L, 500.0), 150000.0);
-            } else if (c.profile == YACRD_SYNTH_SEQUEL) {
-                L = std::exp(std::log(9000.0) + 0.5 * rng.normal());
-                L = std::min(std::max(L, 1000.0), 60000.0);
-            } else {
-                L = 200000.0 + rng.uniform() * 800000.0;
+        parallel_ranges(R, synth_threads(), [&](unsigned, uint64_t r0, uint64_t r1) {
+            for (uint64_t r = r0; r < r1; r++) {
+                Rng rng = stream_rng(c.seed, 1, r);
+                double L;
+                if (c.profile == YACRD_SYNTH_ONT) {
+                    L = std::exp(std::log(6000.0) + 0.9 * rng.normal());
+                    L = std::min(std::max(L, 500.0), 150000.0);
+                } else if (c.profile == YACRD_SYNTH_SEQUEL) {
+                    L = std::exp(std::log(9000.0) + 0.5 * rng.normal());
+                    L = std::min(std::max(L, 1000.0), 60000.0);
+                } else {
+                    L = 200000.0 + rng.uniform() * 800000.0;
+                }
+                len[r] = (uint32_t)L;
+                const double u = rng.uniform();
+                if (u < 0.02) {
+                    junction[r] = (uint32_t)((0.2 + 0.6 * rng.uniform()) * L);
+                    if (junction[r] == 0) junction[r] = 1;
+                } else if (u < 0.05) {
+                    const uint32_t w = std::max<uint32_t>(len[r] / 5, 2);
+                    win0[r] = (uint32_t)rng.below(len[r] - w + 1);
+                    win1[r] = win0[r] + w;
+                }
             }
-            len[r] = (uint32_t)L;
-            const double u = rng.uniform();
-            if (u < 0.02) {
-                junction[r] = (uint32_t)((0.2 + 0.6 * rng.uniform()) * L);
-                if (junction[r] == 0) junction[r] = 1;
-            } else if (u < 0.05) {
-                const uint32_t w = std::max<uint32_t>(len[r] / 5, 2);
-                win0[r] = (uint32_t)rng.below(len[r] - w + 1);
-                win1[r] = win0[r] + w;
-            }
-        }
+        });
         if (c.profile == YACRD_SYNTH_SKEWED) {
             n_round_robin = c.n_overlaps / 6 * 5;
             zipf_cdf.resize(R);
@@ -103,7 +139,7 @@ struct Gen {
         }
     }
 
-    void draw_interval(uint32_t r, uint32_t &s, uint32_t &e)
+    void draw_interval(Rng &rng, uint32_t r, uint32_t &s, uint32_t &e) const
     {
         const uint32_t L = len[r];
         int64_t lo = 0, hi = L;
@@ -130,6 +166,17 @@ struct Gen {
         }
         st = std::min(std::max(st, lo), hi - 1);
         en = std::min(std::max(en, st + 1), hi);
+        const double u = (cfg.flags & 1u) ? 1.0 : rng.uniform();
+        if (u < 2e-3 && !win1[r]) {
+            // abutting intervals without any state: snap both ends to an eighth-of-the-read grid;
+            // two snapped intervals of a read often share a grid point (end of one == start of
+            // the other), which is what the reference's zero-length-gap quirk needs
+            const int64_t g = std::max<int64_t>(1, L / 8);
+            st = (st + g / 2) / g * g;
+            en = std::max(st + g, (en + g / 2) / g * g);
+            st = std::min(st, (int64_t)L - 1);
+            en = std::min<int64_t>(std::max(en, st + 1), L);
+        }
         if (junction[r]) { // chimera: nothing crosses the junction
             const int64_t j = junction[r];
             if (st < j && en > j) {
@@ -138,31 +185,19 @@ struct Gen {
                 else st = std::min(en - 1, j + cut);
             }
         }
-        if (!(cfg.flags & 1u)) {
-            const double u = rng.uniform();
-            if (u < 1e-4) { // abutting: start where the read's previous interval ended
-                const int64_t p = last_end[r];
-                if (p > 0 && p < (int64_t)L) {
-                    const int64_t ell = en - st;
-                    st = p;
-                    en = std::min<int64_t>(p + ell, L);
-                }
-            } else if (u < 1e-4 + 1e-5) { // degenerate: start == end
-                en = st;
-            }
-        }
+        if (u >= 2e-3 && u < 2e-3 + 1e-5) en = st; // degenerate: start == end
         s = (uint32_t)st;
         e = (uint32_t)en;
-        last_end[r] = e;
     }
 
-    void next(Line &ln)
+    void line(uint64_t i, Line &ln) const
     {
         const uint64_t R = cfg.n_reads;
+        Rng rng = stream_rng(cfg.seed, 2, i);
         uint32_t a, b;
-        if (cfg.profile == YACRD_SYNTH_SKEWED && line_no < n_round_robin) {
-            a = (uint32_t)((2 * line_no) % R);
-            b = (uint32_t)((2 * line_no + 1) % R);
+        if (cfg.profile == YACRD_SYNTH_SKEWED && i < n_round_robin) {
+            a = (uint32_t)((2 * i) % R);
+            b = (uint32_t)((2 * i + 1) % R);
         } else if (cfg.profile == YACRD_SYNTH_SKEWED) {
             const double u = rng.uniform();
             a = (uint32_t)(std::lower_bound(zipf_cdf.begin(), zipf_cdf.end(), u) - zipf_cdf.begin());
@@ -176,11 +211,32 @@ struct Gen {
         }
         ln.a = a;
         ln.b = b;
-        draw_interval(a, ln.sa, ln.ea);
-        draw_interval(b, ln.sb, ln.eb);
-        line_no++;
+        draw_interval(rng, a, ln.sa, ln.ea);
+        draw_interval(rng, b, ln.sb, ln.eb);
     }
 };
+
+// decimal digits of v at p, returns the end
+inline char *put_uint(char *p, uint64_t v)
+{
+    char tmp[24];
+    int n = 0;
+    do {
+        tmp[n++] = (char)('0' + v % 10);
+        v /= 10;
+    } while (v);
+    while (n) *p++ = tmp[--n];
+    return p;
+}
+inline char *put_id(char *p, char prefix, uint64_t v) // r%09u
+{
+    *p++ = prefix;
+    for (int k = 8; k >= 0; k--) {
+        p[k] = (char)('0' + v % 10);
+        v /= 10;
+    }
+    return p + 9;
+}
 
 int check_cfg(const yacrd_synth_cfg *cfg)
 {
@@ -199,34 +255,49 @@ int yacrd_synth_csr(const yacrd_synth_cfg *cfg, uint64_t *offsets, uint32_t *int
 {
     if (check_cfg(cfg)) return 1;
     if (!offsets || !intervals || !lengths) return yh::fail("null output");
-    const uint64_t R = cfg->n_reads;
-    Line ln;
-    { // pass 1: intervals per read
-        Gen g(*cfg);
-        std::memset(offsets, 0, (R + 1) * sizeof(uint64_t));
-        for (uint64_t i = 0; i < cfg->n_overlaps; i++) {
-            g.next(ln);
-            offsets[ln.a + 1]++;
-            offsets[ln.b + 1]++;
+    const uint64_t R = cfg->n_reads, N = cfg->n_overlaps;
+    const Gen g(*cfg);
+    // T contiguous line ranges; private per-range counts when they fit (no atomics, and the fill
+    // below lands every interval where a sequential pass in line order would put it)
+    unsigned T = synth_threads();
+    while (T > 1 && (uint64_t)T * R * sizeof(uint32_t) > ((uint64_t)2 << 30)) T /= 2;
+    T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(T, N ? N : 1));
+    std::vector<std::vector<uint32_t>> cnt(T);
+    parallel_ranges(N, T, [&](unsigned t, uint64_t i0, uint64_t i1) {
+        cnt[t].assign(R, 0u);
+        Line ln;
+        for (uint64_t i = i0; i < i1; i++) {
+            g.line(i, ln);
+            cnt[t][ln.a]++;
+            cnt[t][ln.b]++;
         }
-        for (uint64_t r = 0; r < R; r++) {
-            offsets[r + 1] += offsets[r];
-            lengths[r] = g.len[r];
+    });
+    uint64_t acc = 0;
+    for (uint64_t r = 0; r < R; r++) { // offsets, and every range's first slot inside every read
+        offsets[r] = acc;
+        uint64_t in_read = 0;
+        for (unsigned t = 0; t < T; t++) {
+            const uint32_t n = cnt[t][r];
+            cnt[t][r] = (uint32_t)in_read;
+            in_read += n;
         }
+        acc += in_read;
+        lengths[r] = g.len[r];
     }
-    { // pass 2: same stream, fill in line order (the order an ingest of the PAF would produce)
-        Gen g(*cfg);
-        std::vector<uint64_t> cur(offsets, offsets + R);
-        for (uint64_t i = 0; i < cfg->n_overlaps; i++) {
-            g.next(ln);
-            uint64_t p = cur[ln.a]++;
+    offsets[R] = acc;
+    parallel_ranges(N, T, [&](unsigned t, uint64_t i0, uint64_t i1) {
+        Line ln;
+        uint32_t *k = cnt[t].data();
+        for (uint64_t i = i0; i < i1; i++) { // line order inside every read, like an ingest of the PAF
+            g.line(i, ln);
+            uint64_t p = offsets[ln.a] + k[ln.a]++;
             intervals[2 * p] = ln.sa;
             intervals[2 * p + 1] = ln.ea;
-            p = cur[ln.b]++;
+            p = offsets[ln.b] + k[ln.b]++;
             intervals[2 * p] = ln.sb;
             intervals[2 * p + 1] = ln.eb;
         }
-    }
+    });
     return 0;
 }
 
@@ -235,18 +306,52 @@ int yacrd_synth_paf(const yacrd_synth_cfg *cfg, const char *path)
     if (check_cfg(cfg)) return 1;
     FILE *f = std::fopen(path, "wb");
     if (!f) return yh::fail(std::string("cannot open ") + path);
-    std::vector<char> buf(1 << 20);
-    std::setvbuf(f, buf.data(), _IOFBF, buf.size());
-    Gen g(*cfg);
-    Line ln;
-    for (uint64_t i = 0; i < cfg->n_overlaps; i++) {
-        g.next(ln);
-        const uint32_t la = ln.ea - ln.sa, lb = ln.eb - ln.sb;
-        std::fprintf(f, "r%09u\t%u\t%u\t%u\t%c\tr%09u\t%u\t%u\t%u\t%u\t%u\t255\ttp:A:S\n", ln.a,
-                     g.len[ln.a], ln.sa, ln.ea, (i & 1) ? '-' : '+', ln.b, g.len[ln.b], ln.sb, ln.eb,
-                     std::min(la, lb), std::max(la, lb));
+    const Gen g(*cfg);
+    const unsigned T = synth_threads();
+    const uint64_t N = cfg->n_overlaps, kRound = (uint64_t)T * 65536; // lines formatted per round
+    std::vector<std::vector<char>> out(T);
+    bool ok = true;
+    for (uint64_t base = 0; base < N && ok; base += kRound) {
+        const uint64_t n = std::min(kRound, N - base);
+        parallel_ranges(n, T, [&](unsigned t, uint64_t i0, uint64_t i1) {
+            std::vector<char> &o = out[t];
+            o.resize((size_t)(i1 - i0) * 128 + 128);
+            char *p = o.data();
+            Line ln;
+            for (uint64_t i = base + i0; i < base + i1; i++) {
+                g.line(i, ln);
+                const uint32_t la = ln.ea - ln.sa, lb = ln.eb - ln.sb;
+                p = put_id(p, 'r', ln.a);
+                *p++ = '\t';
+                p = put_uint(p, g.len[ln.a]);
+                *p++ = '\t';
+                p = put_uint(p, ln.sa);
+                *p++ = '\t';
+                p = put_uint(p, ln.ea);
+                *p++ = '\t';
+                *p++ = (i & 1) ? '-' : '+';
+                *p++ = '\t';
+                p = put_id(p, 'r', ln.b);
+                *p++ = '\t';
+                p = put_uint(p, g.len[ln.b]);
+                *p++ = '\t';
+                p = put_uint(p, ln.sb);
+                *p++ = '\t';
+                p = put_uint(p, ln.eb);
+                *p++ = '\t';
+                p = put_uint(p, std::min(la, lb));
+                *p++ = '\t';
+                p = put_uint(p, std::max(la, lb));
+                std::memcpy(p, "\t255\ttp:A:S\n", 12);
+                p += 12;
+            }
+            o.resize((size_t)(p - o.data()));
+        });
+        const unsigned used = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(T, n));
+        for (unsigned t = 0; t < used && ok; t++)
+            ok = out[t].empty() || std::fwrite(out[t].data(), 1, out[t].size(), f) == out[t].size();
     }
-    if (std::fclose(f) != 0) return yh::fail("write error");
+    if (std::fclose(f) != 0 || !ok) return yh::fail("write error");
     return 0;
 }
 
@@ -257,7 +362,7 @@ int yacrd_synth_fastq(const yacrd_synth_cfg *cfg, uint64_t extra_reads, const ch
     if (!f) return yh::fail(std::string("cannot open ") + path);
     std::vector<char> buf(1 << 20);
     std::setvbuf(f, buf.data(), _IOFBF, buf.size());
-    Gen g(*cfg); // same lengths as the overlaps
+    const Gen g(*cfg); // same lengths as the overlaps
     Rng rng(cfg->seed ^ 0x5eedf00dull);
     std::string seq, qual;
     const uint64_t total = cfg->n_reads + extra_reads;

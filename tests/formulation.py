@@ -198,3 +198,128 @@ def general_events(intervals, length, cov):
                 e = max(e, lst[t - 1][1])
             out.append((b, e))
     return out
+
+
+# --------------------------------------------------------------------------------------------------
+# Pile trimming: the pre-filter with position-exact bins at both ends of the read.
+#
+# An event is DEEP when the depth is above `cov` on both sides of it (start: depth_before >= cov+1;
+# end: depth_before >= cov+2).  Deep starts are never low; a deep flagged end is always followed by
+# another flagged end before the next low start and before the end of the read (the end that takes
+# the depth from cov+1 to cov is not deep), so it never supplies a region's begin, and if it was
+# the first flagged end after a run of low starts the next kept flagged end closes the same region.
+# Any set of deep events may therefore be dropped as long as the depth of every kept event is
+# unchanged: each maximal run of dropped events (contiguous in key order) is stood in for by |net|
+# keys of one type placed between the kept events on either side of it.
+# Which events are deep is known exactly, without sorting, in two kinds of bins:
+#   * a coarse bin that more than `cov` intervals span completely: all of its events (the old rule);
+#   * a bin holding ONE position p: its keys are E ends followed by S starts, all equal within a
+#     type, so with the depth D at the bin's head the first max(0, D - cov - 1) ends and all but the
+#     first max(0, cov + 1 - (D - E)) starts are deep.  Dovetail overlaps pile hundreds of starts
+#     within a few dozen positions of 0 and as many ends near `length`: the first F and the last F
+#     positions get such bins, and of a pile only its cov + 1 outermost events survive.
+# Only for plain reads (every interval 0 <= start < end <= length).
+
+def trim_keys(intervals, length, cov, nb, F):
+    """Zero-length intervals (start == end) are taken too: in a coarse bin they count as a start and
+    an end of that bin (kept or dropped with it); at a one-position bin their two keys sit between
+    the bin's regular ends and its regular starts, at depth D - E, so the pair is deep — dropped —
+    exactly when the bin's first regular start would be (D - E >= cov + 1), and kept otherwise."""
+    if length < 2 * F + 2:
+        F = 0
+    sh = bin_shift(max(length - 2 * F, 0), nb)
+    hi0 = length - F + 1                      # first position of the right fine zone
+    nbins = F + nb + F
+    S, E, Z = [0] * nbins, [0] * nbins, [0] * nbins
+
+    def bin_of(pos):
+        if pos < F:
+            return pos
+        if F and pos >= hi0:
+            return F + nb + (pos - hi0)
+        return F + ((pos - F) >> sh)
+
+    def first_pos(b):
+        if b < F:
+            return b
+        if b >= F + nb:
+            return hi0 + (b - F - nb)
+        return F + ((b - F) << sh)
+
+    uniform = [b < F or b >= F + nb for b in range(nbins)]
+    keys = []
+    for s, e in intervals:
+        assert 0 <= s <= e <= length
+        if s == e:
+            b = bin_of(s)
+            if uniform[b]:
+                Z[b] += 1
+            else:
+                S[b] += 1
+                E[b] += 1
+            keys += [(s << SH) | 1, (s << SH) | 2]
+        else:
+            S[bin_of(s)] += 1
+            E[bin_of(e)] += 1
+            keys += [(s << SH) | 3, e << SH]
+    # per bin: kept ends / kept starts (uniform), or everything / nothing (coarse)
+    D = 0
+    keep_e, keep_s, keep_z, d_in = [0] * nbins, [0] * nbins, [0] * nbins, [0] * nbins
+    for b in range(nbins):
+        d_in[b] = D
+        if uniform[b]:
+            n_de = min(max(D - cov - 1, 0), E[b])
+            keep_e[b] = E[b] - n_de
+            keep_s[b] = min(max(cov + 1 - (D - E[b]), 0), S[b])
+            keep_z[b] = Z[b] if D - E[b] <= cov else 0
+        elif D - E[b] > cov:                  # spanned by more than cov intervals: all deep
+            keep_e[b] = keep_s[b] = 0
+        else:
+            keep_e[b], keep_s[b] = E[b], S[b]
+        D += S[b] - E[b]
+    assert D == 0
+    out = []
+    took_e, took_s = [0] * nbins, [0] * nbins
+    for k in keys:                            # any keep_x[b] of a uniform bin's equal keys
+        b = bin_of(k >> SH)
+        cls = k & 3
+        if uniform[b] and cls in (1, 2):
+            if keep_z[b]:
+                out.append(k)
+        elif k & 1:
+            if took_s[b] < keep_s[b]:
+                took_s[b] += 1
+                out.append(k)
+        elif took_e[b] < keep_e[b]:
+            took_e[b] += 1
+            out.append(k)
+    # stand-ins: in front of every bin that keeps something, the net of the dropped run before it
+    A = 0                                     # depth after the kept block of the last such bin
+    for b in range(nbins):
+        opaque = keep_e[b] + keep_s[b] + keep_z[b] > 0 or (not uniform[b] and d_in[b] - E[b] <= cov)
+        if not opaque:
+            continue
+        n_de = E[b] - keep_e[b]
+        net = (d_in[b] - n_de) - A
+        fp = first_pos(b)
+        if net > 0:
+            assert fp >= 1
+            out += [(fp << SH) - 1] * net     # starts at fp - 1: after everything before the bin
+        elif net < 0:
+            out += [fp << SH] * (-net)        # ends at fp: before everything else in the bin
+        A = d_in[b] - E[b] + keep_s[b]
+    assert A == 0
+    return out
+
+
+def trimmed_events(intervals, length, cov, nb=16, F=32):
+    """sweep over the keys trim_keys leaves; None unless the read is plain."""
+    if len(intervals) == 0:
+        return [(0, length)] if length != 0 else []
+    if any(not (0 <= s <= e <= length) for s, e in intervals) or length >= 2**30 - 1:
+        return None
+    keys = sorted(trim_keys(intervals, length, cov, nb, F))
+    for a, b in zip(keys, keys[1:]):
+        if a == b and (a & 3) == 1 and a != 1:
+            return None  # two zero-length intervals at one position survive: exact general path
+    return sweep_keys(keys, length, cov)

@@ -73,3 +73,70 @@ def test_prefilter_deep_pileups():
                 total += 2 * len(iv)
                 dropped += 2 * len(iv) - len(prefilter_keys(iv, L, cov, 16))
     assert dropped > total // 4  # the filter really fires in this test
+
+
+def _pile_read(rng, n, L, jitter):
+    """Dovetail-style read: piles of starts near 0 and of ends near L, some internal intervals."""
+    iv = []
+    for _ in range(n):
+        u = rng.random()
+        ell = int(rng.integers(1, max(2, L)))
+        if u < 0.35:
+            s = max(0, int(round(jitter * rng.normal())))
+            e = s + ell
+        elif u < 0.7:
+            e = L + int(round(jitter * rng.normal()))
+            s = e - ell
+        else:
+            s = int(rng.integers(0, max(1, L)))
+            e = s + ell
+        s = min(max(s, 0), L - 1)
+        e = min(max(e, s + 1), L)
+        iv.append((s, e))
+    return iv
+
+
+def test_pile_trimming_matches_oracle():
+    from formulation import trim_keys, trimmed_events
+    rng = np.random.default_rng(2024)
+    kept = total = n_zl_checked = 0
+    for it in range(1500):
+        L = int(rng.integers(2, 200)) if it % 3 == 0 else int(rng.integers(200, 50000))
+        n = int(rng.integers(1, 30)) if it % 4 == 0 else int(rng.integers(30, 400))
+        jitter = (0.0, 1.0, 5.0, 30.0)[it % 4]
+        iv = _pile_read(rng, n, L, jitter)
+        if it % 5 == 1:  # some zero-length intervals, in the piles and elsewhere
+            for _ in range(int(rng.integers(1, 4))):
+                j = int(rng.integers(0, len(iv)))
+                p0 = (iv[j][0], iv[j][1], 0, L, L // 2)[int(rng.integers(0, 5))]
+                iv[j] = (p0, p0)
+        if it % 11 == 0:  # everything on a coarse grid: ties everywhere
+            g = max(1, L // 8)
+            iv = [(min((s // g) * g, L - 1), min(max((e // g) * g, (s // g) * g + 1), L)) for s, e in iv]
+            iv = [(s, max(e, s + 1)) for s, e in iv]
+        has_zl = any(s == e for s, e in iv)
+        for cov in (0, 1, 4, 9, 50):
+            want = oracle.compute_bad_part(iv, L, cov)
+            for nb, F in ((16, 32), (16, 0), (4, 3), (256, 128), (16, 64)):
+                got = trimmed_events(iv, L, cov, nb, F)
+                assert got == want or (got is None and has_zl), (iv, L, cov, nb, F)
+                n_zl_checked += has_zl and got is not None
+            if cov == 4:
+                total += 2 * len(iv)
+                kept += len(trim_keys(iv, L, cov, 16, 32))
+    assert kept < total // 3 and n_zl_checked > 500
+
+
+def test_pile_trimming_tiny_exhaustive():
+    import itertools
+    from formulation import trimmed_events
+    for L in range(1, 6):
+        pairs = [(s, e) for s in range(L + 1) for e in range(s, L + 1)]  # zero-length ones included
+        for k in range(1, 4):
+            for iv in itertools.combinations_with_replacement(pairs, k):
+                for cov in range(0, 3):
+                    want = oracle.compute_bad_part(list(iv), L, cov)
+                    for nb, F in ((2, 1), (2, 2), (4, 0), (4, 2)):
+                        got = trimmed_events(list(iv), L, cov, nb, F)
+                        assert got is None or got == want, (iv, L, cov, nb, F)
+                        assert got is not None or regular_events(list(iv), L, cov) is None

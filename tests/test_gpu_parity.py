@@ -359,3 +359,32 @@ def test_submit_wait_pipeline_and_misprediction():
             e0.fetch()
         e0.wait()
         assert_same(e0.fetch(), wants[0], "after wait")
+
+
+# ---- configs[3]: the skewed profile (ultra-long reads, >= 5 k intervals each, a Zipf tail past the
+# workgroup-LDS cap) at reduced R: M2 through the 256-thread kernel, its overflow list, BIG ----------
+@pytest.mark.parametrize("cov", [4, 0, 40])
+def test_skewed_profile_config4_shape(engine, cov):
+    from yacrd_amd import host
+    offsets, intervals, lengths = host.synth_csr(host.SYNTH_SKEWED, 300, 900000, 20241112)
+    n = np.diff(offsets.astype(np.int64))
+    assert n.min() >= 5000 and (n > 16384).sum() >= 2 and lengths.min() >= 200000
+    check(engine, (offsets, intervals, lengths), cov, 0.4, "skewed c=%d" % cov)
+    t = engine.timing()
+    names = yacrd_amd.CLASS_NAMES
+    assert t["class_reads"][names.index("M2")] > 250 and t["class_reads"][names.index("BIG")] >= 2
+
+
+def test_skewed_profile_without_prefilter_and_with_degenerates():
+    from yacrd_amd import host
+    offsets, intervals, lengths = host.synth_csr(host.SYNTH_SKEWED, 120, 360000, 7)
+    intervals = intervals.copy()
+    rng = np.random.default_rng(3)
+    for r in rng.choice(120, 6, replace=False):  # a zero-length and a reversed interval in some reads
+        a = int(offsets[r])
+        intervals[a + 5] = (intervals[a + 5][0], intervals[a + 5][0])
+        intervals[a + 9] = (intervals[a + 9][1], intervals[a + 9][0])
+    want = oracle.run(offsets, intervals, lengths.astype(np.uint64), 4, 0.4, n_threads=8)
+    for flags in (0, yacrd_amd.F_NO_PREFILTER):
+        with yacrd_amd.Engine(flags=flags) as e:
+            assert_same(e.run(offsets, intervals, lengths, 4, 0.4), want, "flags %d" % flags)

@@ -59,7 +59,7 @@ struct Counters {
     u32 scan_ticket;         // dynamic workgroup id of the single-pass scan
     u32 scan_done;           // workgroups of the scan kernel that finished
     u32 prefiltered;         // reads that took the pre-filtered sort (only counted when asked)
-    u32 pad1;
+    u32 over_med;            // M2 reads whose filtered keys do not fit the 256-thread kernel's LDS
     u64 total_regions;       // G, written by the last scan workgroup
 };
 
@@ -76,6 +76,8 @@ struct SweepArgs {
     u32 *counts;         // [R] regions per read
     u32 *rej_list;       // reads this sweep cannot take (degenerate interval): append here
     u32 *rej_count;
+    u32 *over_list;      // sweep_lds_kernel: reads with more events than its LDS holds even after the
+    u32 *over_count;     // pre-filter: append here (the 1024-thread kernel takes them)
     Counters *ctr;
 };
 

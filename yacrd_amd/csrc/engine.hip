@@ -24,6 +24,7 @@
 #include "device_common.h"
 #include "plan_compact.h"
 #include "sweep_big.h"
+#include "sweep_big_trim.h"
 #include "sweep_general.h"
 #include "sweep_lds.h"
 #include "sweep_wave.h"
@@ -109,15 +110,16 @@ int run_general_global(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, con
 // Reads with more than 16 384 intervals: device-wide segmented sort + chunked sweep
 // (sweep_big.h).  Reads that turn out to hold a degenerate interval are redone by the exact
 // general kernel afterwards.
-int run_big(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u32 *d_len,
-            const u32 *d_list, u32 count, u32 cov, hipStream_t stream, u64 *iv_total)
+// Reads with more than 16 384 intervals that the trimming filter could not thin: device-wide
+// segmented sort + chunked sweep (sweep_big.h).  Reads that turn out to hold a degenerate interval
+// are appended to `redo` for the exact general kernel.
+int run_big_sort(yacrd_engine *e, const uint2 *d_iv, const std::vector<yk::GatherOut> &info, u32 cov,
+                 hipStream_t stream, std::vector<u32> &redo)
 {
-    std::vector<yk::GatherOut> info;
-    int rc = gather_reads(e, d_off, d_len, d_list, count, stream, info);
-    if (rc) return rc;
+    const u32 count = (u32)info.size();
     std::vector<yk::BigSeg> segs(count);
     std::vector<u32> chunk_seg;
-    u64 key_off = 0, gen_iv = 0;
+    u64 key_off = 0;
     u32 max_P = 0;
     for (u32 i = 0; i < count; i++) {
         u64 P = yk::kBigC;
@@ -134,10 +136,8 @@ int run_big(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u32 *d_l
         sg.pad = 0;
         for (u64 c = 0; c < P / yk::kBigC; c++) chunk_seg.push_back(i);
         key_off += P;
-        gen_iv += info[i].n;
         max_P = std::max(max_P, (u32)P);
     }
-    if (iv_total) *iv_total = gen_iv;
     const size_t n_chunks = chunk_seg.size();
     if (n_chunks >= 0x7FFFFFFFull / (yk::kBigC / 2)) return fail(YACRD_EINVAL, "big path: too many keys");
     const size_t tab_bytes = (size_t)count * sizeof(yk::BigSeg) + n_chunks * sizeof(u32) +
@@ -176,9 +176,88 @@ int run_big(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u32 *d_l
                            stream));
     HIP_TRY(hipStreamSynchronize(stream)); // host tables must outlive the copies
     HIP_TRY(hipGetLastError());
-    std::vector<u32> redo;
     for (u32 i = 0; i < count; i++)
         if (bad[i]) redo.push_back(info[i].read);
+    return YACRD_OK;
+}
+
+int run_big(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u32 *d_len,
+            const u32 *d_list, u32 count, u32 cov, hipStream_t stream, u64 *iv_total)
+{
+    std::vector<yk::GatherOut> info;
+    int rc = gather_reads(e, d_off, d_len, d_list, count, stream, info);
+    if (rc) return rc;
+    if (iv_total) {
+        *iv_total = 0;
+        for (const auto &g : info) *iv_total += g.n;
+    }
+    std::vector<u32> redo; // reads for the exact general path (an interval the keys cannot express)
+
+    // ---- first attempt: thin the reads with the device-wide pile-trimming filter (sweep_big_trim.h);
+    // what fits one workgroup's LDS afterwards is swept there, the rest takes the segmented sort below
+    if (!(e->flags & YACRD_F_NO_PREFILTER)) {
+        std::vector<yk::BtSeg> bs(count);
+        std::vector<u32> chunk_seg;
+        for (u32 i = 0; i < count; i++) {
+            yk::BtSeg &b = bs[i];
+            b.iv_off = info[i].iv_off;
+            b.n = (u32)info[i].n;
+            b.len = info[i].len;
+            b.read = info[i].read;
+            b.chunk_off = (u32)chunk_seg.size();
+            b.flags = 0;
+            b.m_new = 0;
+            b.n_zl = 0;
+            b.pad = 0;
+            for (u64 c = 0; c < (info[i].n + yk::kBtChunk - 1) / yk::kBtChunk; c++) chunk_seg.push_back(i);
+        }
+        const size_t n_chunks = chunk_seg.size();
+        const size_t tab_words = (size_t)count * 3 * yk::kBtSeq;
+        HIP_TRY(e->bt_tab.reserve((size_t)count * sizeof(yk::BtSeg) + n_chunks * sizeof(u32) + 64));
+        HIP_TRY(e->bt_hist.reserve(tab_words * sizeof(u32)));
+        HIP_TRY(e->bt_cur.reserve(2 * tab_words * sizeof(u32)));
+        HIP_TRY(e->bt_keys.reserve((size_t)count * yk::kBtCap * sizeof(u32)));
+        yk::BtArgs ba;
+        ba.seg = e->bt_tab.as<yk::BtSeg>();
+        ba.chunk_seg = reinterpret_cast<const u32 *>(e->bt_tab.as<char>() + (size_t)count * sizeof(yk::BtSeg));
+        ba.iv = d_iv;
+        ba.n_chunks = (u32)n_chunks;
+        ba.n_segs = count;
+        ba.cov = cov;
+        ba.hist = e->bt_hist.as<u32>();
+        ba.cur = e->bt_cur.as<u32>();
+        ba.lim = e->bt_cur.as<u32>() + tab_words;
+        ba.tkeys = e->bt_keys.as<u32>();
+        ba.stage = e->stage.as<uint2>();
+        ba.counts = e->counts.as<u32>();
+        HIP_TRY(hipMemcpyAsync((void *)ba.seg, bs.data(), (size_t)count * sizeof(yk::BtSeg),
+                               hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync((void *)ba.chunk_seg, chunk_seg.data(), n_chunks * sizeof(u32),
+                               hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemsetAsync(ba.hist, 0, tab_words * sizeof(u32), stream));
+        yk::Counters *ctr = e->ctrl2[e->ctrl_cur].as<yk::Counters>();
+        u32 *rej = e->lists.as<u32>() + (size_t)(yk::CLS_COUNT + 2) * e->last_list_stride;
+        hipLaunchKernelGGL(yk::bt_hist_kernel, dim3((u32)n_chunks), dim3(yk::kBtT), 0, stream, ba);
+        hipLaunchKernelGGL(yk::bt_plan_kernel, dim3(count), dim3(yk::kBtT), 0, stream, ba);
+        hipLaunchKernelGGL(yk::bt_scatter_kernel, dim3((u32)n_chunks), dim3(yk::kBtT), 0, stream, ba);
+        hipLaunchKernelGGL(yk::bt_sweep_kernel, dim3(count), dim3(1024), 0, stream, ba, rej, &ctr->rej_big);
+        HIP_TRY(hipMemcpyAsync(bs.data(), (void *)ba.seg, (size_t)count * sizeof(yk::BtSeg),
+                               hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream)); // host tables must outlive the copies
+        HIP_TRY(hipGetLastError());
+        std::vector<yk::GatherOut> rest;
+        for (u32 i = 0; i < count; i++) {
+            if (bs[i].flags & yk::BT_TRIMMED) continue;
+            if (bs[i].flags & yk::BT_BAD) redo.push_back(info[i].read);
+            else rest.push_back(info[i]);
+        }
+        info.swap(rest);
+        count = (u32)info.size();
+    }
+    if (count) {
+        rc = run_big_sort(e, d_iv, info, cov, stream, redo);
+        if (rc) return rc;
+    }
     if (!redo.empty()) { // degenerate interval in a huge read: exact path, single workgroup each
         HIP_TRY(e->big_redo.reserve(redo.size() * sizeof(u32)));
         HIP_TRY(hipMemcpyAsync(e->big_redo.p, redo.data(), redo.size() * sizeof(u32),
@@ -190,7 +269,6 @@ int run_big(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u32 *d_l
     }
     return YACRD_OK;
 }
-
 // The run's final wait: spinning (hipStreamSynchronize) or, with YACRD_F_BLOCKING_WAIT, polling
 // an event and sleeping in between (hipEventSynchronize spins as well, blocking-sync flag or not).
 int wait_for_stream(yacrd_engine *e)
@@ -237,7 +315,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     }
 
     const u32 nb = (n_reads + yk::kScanBlock - 1) / yk::kScanBlock;
-    constexpr int kLists = yk::CLS_COUNT + 3; // class lists + three rejection lists
+    constexpr int kLists = yk::CLS_COUNT + 4; // class lists + three rejection lists + M2 overflow
     HIP_TRY(e->lists.reserve((size_t)kLists * n_reads * sizeof(u32)));
     const size_t ctrl_bytes = (sizeof(yk::Counters) + (size_t)nb * sizeof(u64) + 255) & ~(size_t)255;
     e->ctrl_cur ^= 1;
@@ -254,9 +332,10 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         HIP_TRY(e->bad_regions.reserve((size_t)(4 * n_reads64 + 1024) * sizeof(uint2)));
 
     u32 *lists = e->lists.as<u32>();
+    e->last_list_stride = n_reads;
     auto list_of = [&](int i) { return lists + (size_t)i * n_reads; };
     u32 *rej_small = list_of(yk::CLS_COUNT), *rej_med = list_of(yk::CLS_COUNT + 1),
-        *rej_big = list_of(yk::CLS_COUNT + 2);
+        *rej_big = list_of(yk::CLS_COUNT + 2), *over_med = list_of(yk::CLS_COUNT + 3);
     yk::Counters *ctr = e->ctrl2[cur].as<yk::Counters>();
     const bool full = (e->flags & YACRD_F_TIMING_FULL) != 0;
     const int xm = (e->flags & YACRD_F_XLANE_DS) ? 1 : 0;
@@ -327,6 +406,8 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     sa.stage = e->stage.as<uint2>();
     sa.counts = e->counts.as<u32>();
     sa.ctr = ctr;
+    sa.over_list = over_med;
+    sa.over_count = &ctr->over_med;
 
     // Kernel-level timing.  An event costs ~3 us of stream time, so by default only the class
     // with the most intervals (the dominant kernel) is bracketed; YACRD_F_TIMING_FULL brackets
@@ -451,6 +532,17 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
             sa.list_n = &ctr->n[yk::CLS_MED2];
             sa.rej_list = rej_big;
             sa.rej_count = &ctr->rej_big;
+            sa.over_list = over_med;
+            sa.over_count = &ctr->over_med;
+            if (sa.prefilter) {
+                // first through the 256-thread kernel (five workgroups per CU): a read whose
+                // filtered keys fit its 8192-key array is done there, the others land in over_med
+                const u32 g256 = (u32)std::min<uint64_t>(set.n[yk::CLS_MED2], (uint64_t)e->num_cu * 5);
+                hipLaunchKernelGGL((yk::sweep_lds_kernel<256, (int)yk::kMedium1Events>), dim3(g256),
+                                   dim3(256), 0, e->stream, sa);
+                sa.list = over_med;
+                sa.list_n = &ctr->over_med;
+            }
             const u32 grid = (u32)std::min<uint64_t>(set.n[yk::CLS_MED2], (uint64_t)e->num_cu);
             hipLaunchKernelGGL((yk::sweep_lds_kernel<1024, (int)yk::kMedium2Events>), dim3(grid),
                                dim3(1024), 0, e->stream, sa);
@@ -877,7 +969,7 @@ void yacrd_engine_destroy(yacrd_engine *e)
     }
     DevBuf *bufs[] = {&e->in_off, &e->in_iv, &e->in_len, &e->lists, &e->ctrl2[0], &e->ctrl2[1], &e->stage,
                       &e->counts, &e->gen_sizes, &e->gen_scratch_off,
-                      &e->gen_scratch, &e->big_tab, &e->big_keys, &e->big_redo,
+                      &e->gen_scratch, &e->big_tab, &e->big_keys, &e->big_redo, &e->bt_tab, &e->bt_hist, &e->bt_cur, &e->bt_keys,
                       &e->bad_offsets, &e->bad_regions, &e->read_type};
     for (DevBuf *b : bufs) b->release();
     if (e->h_ctr) (void)hipHostFree(e->h_ctr);

@@ -125,7 +125,7 @@ struct yacrd_engine {
     // inputs staged by yacrd_engine_run
     yke::DevBuf in_off, in_iv, in_len;
     // work buffers
-    yke::DevBuf lists, ctrl2[2], stage, counts, gen_sizes, gen_scratch_off, gen_scratch, big_tab, big_keys, big_redo;
+    yke::DevBuf lists, ctrl2[2], stage, counts, gen_sizes, gen_scratch_off, gen_scratch, big_tab, big_keys, big_redo, bt_tab, bt_hist, bt_cur, bt_keys;
     // two control blocks (counters + scan state), used alternately: the plan kernel of a run zeroes
     // the other one for the next run.  ctrl_clean[i] = leading bytes of block i known to be zero.
     size_t ctrl_clean[2] = {0, 0};
@@ -135,6 +135,7 @@ struct yacrd_engine {
     yk::Counters *h_ctr = nullptr; // pinned
 
     uint64_t last_reads = 0, last_regions = 0;
+    size_t last_list_stride = 0; // reads per class list of the current run (lists = [class][read])
     bool has_result = false;
     // class counts of the previous run: the prediction that lets the next one skip the plan sync
     yk::Counters pred{};

@@ -131,81 +131,291 @@ __device__ __forceinline__ void bitonic_sort_lds(u32 *keys, u32 P)
     }
 }
 
-// ---- coverage pre-filter for the workgroup classes (same rule as sweep_wave.h) --
-// NB = T bins, one per thread.  The staging loop histograms the read's events into the last
-// 4 * T words of the (still empty) key array while it looks for degenerate intervals;
-// lds_filter_plan() turns the counters into slot counters, writes the stand-in keys of the safe
-// runs and says how many keys survive; a second pass over the intervals (L2-resident) then writes
-// each surviving key to the slot it is handed.  Used when the read is plain (no zero-length
-// interval, every end <= len) and keeps at most CAP / 2 keys.
-template <int T, int CAP>
-struct LdsFilter {
-    static constexpr int NB = T;
-    static constexpr u32 kNowhere = 0x80000000u;
-    static_assert(CAP / 2 <= CAP - 5 * NB, "survivors and counters must not overlap");
-    static __device__ __forceinline__ u32 shift_of(u32 len)
+// ---- coverage pre-filter with pile trimming for the workgroup classes (DESIGN.md §3.4 / §3.5;
+// emulated and fuzzed in tests/formulation.py::trim_keys) -------------------------------------------
+// An event is DEEP when the depth is above c on both sides of it; deep events never matter (a deep
+// start is never low, a deep flagged end is always superseded by a later flagged end before the
+// next low start), so any of them may be dropped as long as each maximal run of dropped events is
+// stood in for by |net| keys of one type.  Which events are deep is known without sorting in two
+// kinds of bins:
+//   * a coarse bin (2^sh positions) that more than c intervals span completely: all of it;
+//   * a bin that holds ONE position: its keys are E ends then S starts, equal within a type, so with
+//     the depth D at its head the first max(0, D - c - 1) ends and all but the first
+//     max(0, c + 1 - (D - E)) starts are deep.  The first F and the last F positions of the read
+//     get such bins: dovetail overlaps pile their starts within a few dozen positions of 0 and their
+//     ends near `len`, and of a pile only the c + 1 outermost events survive (configs[3]: a read of
+//     5 600 intervals keeps ~10 keys instead of ~3 500).
+// Bin sequence in key order: F fine | M + 1 coarse | F fine, idx(pos) below; 2 T bins at most, two
+// per thread.  Every bin has four counters; pass 1 counts starts (low half) and ends (high half)
+// in the copy of lane & 3; pass 2 re-uses them as packed (quota << 16 | next slot) cursors — the
+// copies of a coarse bin keep everything (quota 0x7FFF) or nothing, a fine bin uses copy 0 for its
+// ends and copy 1 for its starts with the quotas above — so one LDS atomic per key decides whether
+// it is kept and where it goes.  Only for plain reads (every interval start < end <= len).
+// Bin geometry: F fine (one-position) bins | up to NB coarse bins | F fine bins, in key order.
+template <int NB, int F>
+struct TrimGeo {
+    u32 f;      // fine positions on either side (F, or 0 for reads too short for fine zones)
+    u32 hk;     // key of position H = len - f: the last coarse position
+    u32 ksh;    // coarse bin = (key - fk) >> ksh
+    u32 m_last; // coarse index of H
+    static __device__ __forceinline__ TrimGeo make(u32 len)
     {
-        const i32 bits = 32 - (i32)__builtin_clz(len | 1u) - ilog2c(NB) + (len != 0 ? 0 : -1);
-        return (u32)max(bits, 0) + kKeyShift;
+        TrimGeo g;
+        g.f = len >= 2u * F + 2u ? (u32)F : 0u;
+        const u32 span = len - 2u * g.f; // coarse positions f .. len - f
+        const i32 bits = 32 - (i32)__builtin_clz(span | 1u) - ilog2c(NB) + (span != 0 ? 0 : -1);
+        g.ksh = (u32)max(bits, 0) + kKeyShift;
+        g.hk = (len - g.f) << kKeyShift;
+        g.m_last = ((len - g.f - g.f) << kKeyShift) >> g.ksh;
+        return g;
     }
-    static __device__ __forceinline__ u32 *hist(u32 *keys) { return keys + (CAP - 4 * NB); }
-    // Add `val` to this thread's counter of the bin that holds `key` (four counters per bin, one
-    // per lane & 3: dovetail overlaps pile thousands of starts into bin 0 and as many ends into
-    // the bin of `len`) and return the counter's previous value.  (One wave-aggregated atomic
-    // for the lanes that hit those two bins was tried: no measurable change.)
-    static __device__ __forceinline__ u32 add(u32 *keys, u32 key, u32 ksh, u32 val)
+    __device__ __forceinline__ u32 n_seq() const { return 2u * f + m_last + 1u; }
+    // sequence index of the bin that holds `key` (monotone in the key, the class bits do not matter)
+    __device__ __forceinline__ u32 idx(u32 key) const
     {
-        return atomicAdd(hist(keys) + min(key >> ksh, (u32)(NB - 1)) * 4u + (threadIdx.x & 3u), val);
+        const u32 pos = key >> kKeyShift, fk = f << kKeyShift;
+        const u32 lo = min(pos, f);                               // fine zone at the head
+        const u32 mid = (min(max(key, fk), hk) - fk) >> ksh;      // coarse, re-based at f
+        const u32 hi = max(key, hk | 3u) - (hk | 3u);             // > 0 beyond position H
+        return lo + mid + ((hi + 3u) >> kKeyShift);
     }
+    __device__ __forceinline__ u32 first_pos(u32 i) const
+    {
+        if (i < f) return i;
+        if (i <= f + m_last) return f + (((i - f) << ksh) >> kKeyShift);
+        return (hk >> kKeyShift) + (i - f - m_last);
+    }
+    __device__ __forceinline__ bool uniform(u32 i) const { return i < f || i > f + m_last; }
 };
 
-// Returns the number of keys that survive (0 = do not filter).  syn_start = largest stand-in
-// start key this thread wrote (for the tail rule's max_start), else 0.
 template <int T, int CAP>
-__device__ __forceinline__ u32 lds_filter_plan(u32 *keys, u32 len, u32 cov, u32 *sc, u32 &syn_start)
-{
-    using F = LdsFilter<T, CAP>;
-    constexpr int NB = T;
-    const u32 tid = threadIdx.x;
-    const i32 c = (i32)min(cov, 0x7FFFFFFFu);
-    const u32 ksh = F::shift_of(len), sh = ksh - kKeyShift;
-    u32 *flags = keys + (CAP - 5 * NB); // [NB]: safe bits, for the neighbours
-    uint4 *my_bin = reinterpret_cast<uint4 *>(F::hist(keys)) + tid;
-    syn_start = 0;
+struct LdsTrim {
+    static constexpr int NB = T, F = T / 2, NSEQ = 2 * T;
+    static constexpr u32 kTakeOne = 0xFFFF0001u; // quota - 1, slot + 1
+    static_assert(T < 256 || CAP / 2 + 5 * NSEQ + 8 <= CAP, "survivors and counters must not overlap");
+    using Geo = TrimGeo<NB, F>;
+    static __device__ __forceinline__ Geo geo(u32 len) { return Geo::make(len); }
+    static __device__ __forceinline__ u32 idx(const Geo &g, u32 key) { return g.idx(key); }
+    static __device__ __forceinline__ u32 first_pos(const Geo &g, u32 i) { return g.first_pos(i); }
+    static __device__ __forceinline__ bool uniform(const Geo &g, u32 i) { return g.uniform(i); }
+    static __device__ __forceinline__ u32 *tab(u32 *keys) { return keys + (CAP - 4 * NSEQ); }
+    // zero-length intervals per one-position bin (by sequence index; coarse bins count them as a
+    // start and an end of their own)
+    static __device__ __forceinline__ u32 *ztab(u32 *keys) { return keys + (CAP - 5 * NSEQ); }
+};
 
-    const uint4 w4 = *my_bin;
-    const u32 w = w4.x + w4.y + w4.z + w4.w; // starts in the low half, ends in the high half
-    u32 w_tot;
-    const u32 incl = block_excl_add<T>(w, sc, w_tot) + w;
-    const i32 S = (i32)(w & 0xFFFFu), E = (i32)(w >> 16);
-    const i32 cs = (i32)(incl & 0xFFFFu), ce = (i32)(incl >> 16);
-    const i32 depth_after = cs - ce, depth_at = depth_after - (S - E);
-    const bool safe = (cs - S) - ce > c && tid < (len >> sh);
-    flags[tid] = safe ? 1u : 0u;
-    if (block_max<T>(safe ? 1u : 0u, sc) == 0) return 0; // nothing to drop (ends with a barrier)
-    const bool head = safe && !(tid > 0 && flags[tid - 1]);
-    const bool tail = safe && !(tid + 1 < (u32)NB && flags[tid + 1]);
-    const u32 hv_own = head ? (((tid + 1u) << 16) | (u32)depth_at) : 0u;
-    u32 hv_tot;
-    const u32 hv = max(block_excl_max<T>(hv_own, sc, hv_tot), hv_own);
-    const i32 net = tail ? depth_after - (i32)(hv & 0xFFFFu) : 0;
-    const u32 nsyn = (u32)(net < 0 ? -net : net);
-    const u32 synkey = (((hv >> 16) - 1u) << ksh) | (net > 0 ? 3u : 0u);
-    const u32 mine = safe ? nsyn : (u32)(S + E);
+// Turns the pass-1 histogram into the pass-2 cursors, writes the stand-in keys and returns the
+// number of keys that survive (0 = do not filter).  syn_start = largest stand-in start key.
+template <int T, int CAP>
+__device__ __forceinline__ u32 lds_trim_plan(u32 *keys, u32 len, u32 cov, u32 *sc, u32 &syn_start)
+{
+    using F = LdsTrim<T, CAP>;
+    const typename F::Geo g = F::geo(len);
+    const u32 tid = threadIdx.x;
+    const i32 c = (i32)min(cov, 0x3FFFFFFFu);
+    uint4 *bins = reinterpret_cast<uint4 *>(F::tab(keys));
+    const u32 *zt = F::ztab(keys);
+    syn_start = 0;
+    const u32 n_seq = g.n_seq();
+
+    // this thread's two bins: counts, depth at their heads
+    uint4 w4[2];
+    i32 S[2], E[2];
+    u32 delta = 0;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        w4[k] = bins[2 * tid + k];
+        const u32 w = w4[k].x + w4[k].y + w4[k].z + w4[k].w;
+        S[k] = (i32)(w & 0xFFFFu);
+        E[k] = (i32)(w >> 16);
+        delta += (u32)(S[k] - E[k]);
+    }
+    u32 tot;
+    i32 D = (i32)block_excl_add<T>(delta, sc, tot);
+
+    // per bin: what is kept, the depth before / after its kept block
+    i32 keep_e[2], keep_s[2], keep_z[2], B[2], A[2];
+    bool opaque[2];
+    u32 last_own = 0; // (seq index + 1) << 16 | A of this thread's last opaque bin
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const u32 i = 2 * tid + k;
+        if (F::uniform(g, i)) {
+            const i32 n_de = min(max(D - c - 1, 0), E[k]);
+            keep_e[k] = E[k] - n_de;
+            keep_s[k] = min(max(c + 1 - (D - E[k]), 0), S[k]);
+            // a zero-length interval's two keys sit between the bin's ends and its starts, at depth
+            // D - E: deep exactly when the first regular start would be
+            keep_z[k] = (D - E[k] <= c) ? 2 * (i32)zt[i] : 0;
+            opaque[k] = keep_e[k] + keep_s[k] + keep_z[k] > 0;
+        } else {
+            const bool deep = D - E[k] > c; // spanned by more than c intervals
+            keep_e[k] = deep ? 0 : E[k];
+            keep_s[k] = deep ? 0 : S[k];
+            keep_z[k] = 0;
+            opaque[k] = !deep && i < n_seq;
+        }
+        B[k] = D - (E[k] - keep_e[k]);
+        A[k] = D - E[k] + keep_s[k];
+        if (opaque[k]) last_own = ((i + 1u) << 16) | (u32)A[k];
+        D += S[k] - E[k];
+    }
+    u32 any;
+    const u32 prev = block_excl_max<T>(last_own, sc, any);
+    if (any == 0) return 0; // (cannot happen for a non-empty read; keeps the caller's fallback honest)
+
+    // stand-ins in front of every opaque bin: the net of the dropped run before it
+    u32 nsyn[2], synkey[2], mine = 0;
+    i32 a_prev = (i32)(prev & 0xFFFFu);
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        nsyn[k] = 0;
+        synkey[k] = 0;
+        if (opaque[k]) {
+            const i32 net = B[k] - a_prev;
+            const u32 fpk = F::first_pos(g, 2 * tid + k) << kKeyShift;
+            nsyn[k] = (u32)(net < 0 ? -net : net);
+            synkey[k] = net > 0 ? fpk - 1u : fpk; // starts just before the bin, ends at its head
+            a_prev = A[k];
+        }
+        mine += (u32)(keep_e[k] + keep_s[k] + keep_z[k]) + nsyn[k];
+    }
     u32 m_new;
-    const u32 base = block_excl_add<T>(mine, sc, m_new);
-    if (m_new > (u32)(CAP / 2)) return 0; // would not shrink the sort
-    uint4 b4;
-    b4.x = base;
-    b4.y = b4.x + (w4.x & 0xFFFFu) + (w4.x >> 16);
-    b4.z = b4.y + (w4.y & 0xFFFFu) + (w4.y >> 16);
-    b4.w = b4.z + (w4.z & 0xFFFFu) + (w4.z >> 16);
-    *my_bin = safe ? make_uint4(F::kNowhere, F::kNowhere, F::kNowhere, F::kNowhere) : b4;
+    u32 base = block_excl_add<T>(mine, sc, m_new);
+    if (m_new > (u32)(CAP / 2)) return 0; // would not fit / shrink the sort: the caller falls back
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const u32 i = 2 * tid + k;
+        uint4 cur;
+        if (F::uniform(g, i)) { // copy 0: ends, copy 1: starts, copy 2: keys of zero-length intervals
+            cur.x = ((u32)keep_e[k] << 16) | base;
+            cur.y = ((u32)keep_s[k] << 16) | (base + (u32)keep_e[k]);
+            cur.z = ((u32)keep_z[k] << 16) | (base + (u32)(keep_e[k] + keep_s[k]));
+            cur.w = 0;
+        } else {
+            const u32 q = (keep_e[k] + keep_s[k] > 0) ? 0x7FFF0000u : 0u;
+            cur.x = q | base;
+            cur.y = q | (base + (w4[k].x & 0xFFFFu) + (w4[k].x >> 16));
+            cur.z = q | ((cur.y & 0xFFFFu) + (w4[k].y & 0xFFFFu) + (w4[k].y >> 16));
+            cur.w = q | ((cur.z & 0xFFFFu) + (w4[k].z & 0xFFFFu) + (w4[k].z >> 16));
+        }
+        bins[i] = cur;
+        base += (u32)(keep_e[k] + keep_s[k] + keep_z[k]);
 #pragma unroll 1
-    for (u32 t = 0; t < nsyn; t++) keys[base + t] = synkey;
-    if (tail && net > 0) syn_start = synkey;
+        for (u32 t = 0; t < nsyn[k]; t++) keys[base + t] = synkey[k];
+        base += nsyn[k];
+        if (nsyn[k] && (synkey[k] & 1u)) syn_start = max(syn_start, synkey[k]);
+    }
     __syncthreads();
     return m_new;
+}
+
+// ---- everything after the event keys of a read are in LDS: pad, sort, the four sweep passes,
+// finish_read.  Shared by sweep_lds_kernel and the device-wide trimmed path (sweep_big.h).
+template <int T>
+__device__ __forceinline__ void lds_sort_and_sweep(u32 *keys, u32 *sc, u32 m_sort, u32 len, u32 cov,
+                                                   u32 max_start, u32 nz_total, const LaneConst &lc,
+                                                   uint2 *slot, u32 *counts, u32 r, u32 *rej_list,
+                                                   u32 *rej_count)
+{
+    const u32 tid = threadIdx.x;
+    u32 P;
+    P = 2;
+    while (P < m_sort) P <<= 1;
+    for (u32 i = m_sort + tid; i < P; i += T) keys[i] = kNoKey;
+    __syncthreads();
+
+    if (T >= 256 && P >= 1024) hybrid_sort_lds<T>(keys, P, lc);
+    else bitonic_sort_lds<T>(keys, P);
+
+    if (nz_total > 2) { // two zero-length intervals at one position > 0: exact path (see keys)
+        u32 dup = 0;
+        for (u32 i = tid; i + 1 < m_sort; i += T)
+            dup |= (keys[i] == keys[i + 1] && (keys[i] & 3u) == 1u && keys[i] != 1u);
+        if (block_max<T>(dup, sc)) {
+            if (tid == 0) {
+                rej_list[atomicAdd(rej_count, 1u)] = r;
+                counts[r] = 0;
+            }
+            __syncthreads();
+            return;
+        }
+    }
+
+    // ---- blocked chunks: thread t owns events [t*K, t*K+K) of the sorted sequence
+    const u32 K = (P >= (u32)T) ? P / T : 1;
+    const u32 q0 = min(tid * K, m_sort), q1 = min(q0 + K, m_sort);
+
+    // pass A: depth carried into each chunk
+    u32 delta = 0;
+    for (u32 q = q0; q < q1; q++) delta += (keys[q] & 1u) ? 1u : 0xFFFFFFFFu;
+    u32 tot;
+    const u32 depth_in = block_excl_add<T>(delta, sc, tot);
+
+    // pass B: last flagged end (flipped domain, device_common.h) / last low start per chunk
+    u32 d = depth_in, mf = 0, ml = 0;
+    for (u32 q = q0; q < q1; q++) {
+        const u32 key = keys[q];
+        if (key & 1u) {
+            if (d <= cov) ml = key;
+            d++;
+        } else {
+            if (d > cov) mf = max(mf, key ^ 2u);
+            d--;
+        }
+    }
+    u32 mf_t, ml_t;
+    const u32 mf_in = max(block_excl_max<T>(mf, sc, mf_t), kNoFlag);
+    const u32 ml_in = block_excl_max<T>(ml, sc, ml_t);
+
+    // pass C: count the regions this chunk closes; tail rule (stack.rs:93-105)
+    u32 cnt = 0, min_ge = kNoKey;
+    d = depth_in;
+    mf = mf_in;
+    ml = ml_in;
+    for (u32 q = q0; q < q1; q++) {
+        const u32 key = keys[q];
+        if (key & 1u) {
+            if (d <= cov) ml = key;
+            d++;
+        } else {
+            if (d > cov) {
+                if ((key ^ 2u) > mf) {
+                    if (ml > (mf ^ 2u)) cnt++;
+                    mf = key ^ 2u;
+                }
+                if (key > max_start && (key >> kKeyShift) >= len)
+                    min_ge = min(min_ge, key >> kKeyShift);
+            }
+            d--;
+        }
+    }
+    u32 g_closed;
+    u32 pos = block_excl_add<T>(cnt, sc, g_closed);
+    min_ge = block_min<T>(min_ge, sc);
+
+    // pass D: write them, in event order
+    if (cnt) {
+        d = depth_in;
+        mf = mf_in;
+        ml = ml_in;
+        for (u32 q = q0; q < q1; q++) {
+            const u32 key = keys[q];
+            if (key & 1u) {
+                if (d <= cov) ml = key;
+                d++;
+            } else {
+                if (d > cov && (key ^ 2u) > mf) {
+                    if (ml > (mf ^ 2u))
+                        slot[pos++] = make_uint2((mf ^ 2u) >> kKeyShift, ml >> kKeyShift);
+                    mf = key ^ 2u;
+                }
+                d--;
+            }
+        }
+    }
+    if (tid == 0)
+        counts[r] = finish_read(slot, g_closed, mf_t ? (mf_t ^ 2u) : 0u, ml_t, min_ge, len);
 }
 
 // T threads per read, CAP = max events (power of two, CAP % T == 0).
@@ -240,29 +450,51 @@ __global__ __launch_bounds__(T) void sweep_lds_kernel(SweepArgs a)
         }
 
         const u32 m = 2 * n;
-        u32 P = 2;
-        while (P < m) P <<= 1;
+        // A read with more events than the LDS array holds is still taken when the pre-filter
+        // leaves at most CAP / 2 of them (configs[3]'s reads of ~5 600 intervals keep ~30 %: they
+        // fit a 256-thread workgroup, five of which share a CU, instead of owning a whole CU as a
+        // 1024-thread one); otherwise it goes to over_list for the kernel with the larger array.
+        const bool over = m > (u32)CAP;
 
         // ---- first pass over the intervals (coalesced 8 B/lane loads): degenerate ones, the
         // largest start key, and the pre-filter's histogram (into the tail of the empty key array)
-        using F = LdsFilter<T, CAP>;
-        const bool try_filter = T >= 256 && a.prefilter != 0;
-        const u32 ksh = F::shift_of(len);
+        using F = LdsTrim<T, CAP>;
+        const typename F::Geo geo = F::geo(len);
+        u32 *tab = F::tab(keys);
+        const bool try_filter = T >= 256 && a.prefilter != 0 && len <= kMaxKeyPos;
+        if (over && !try_filter) { // uniform
+            if (tid == 0) a.over_list[atomicAdd(a.over_count, 1u)] = r;
+            continue;
+        }
         if (try_filter) {
-            reinterpret_cast<uint4 *>(F::hist(keys))[tid] = make_uint4(0u, 0u, 0u, 0u);
+            reinterpret_cast<uint4 *>(tab)[2 * tid] = make_uint4(0u, 0u, 0u, 0u);
+            reinterpret_cast<uint4 *>(tab)[2 * tid + 1] = make_uint4(0u, 0u, 0u, 0u);
+            reinterpret_cast<uint2 *>(F::ztab(keys))[tid] = make_uint2(0u, 0u);
             __syncthreads();
         }
         u32 bad = 0, max_start = 0, nz = 0; // bad bit 1: an end beyond the read (no pre-filter)
         const uint2 *iv = a.iv + o;
-        for (u32 i = tid; i < n; i += T) {
-            u32 ks, ke;
-            const uint2 v = iv[i];
-            make_event_keys(v, ks, ke, bad, nz);
-            bad |= v.y > len ? 2u : 0u;
-            max_start = max(max_start, ks);
-            if (try_filter) {
-                F::add(keys, ks, ksh, 1u);
-                F::add(keys, ke, ksh, 0x10000u);
+        // (four loads in flight per thread: one memory latency per 4 T intervals instead of per T)
+        for (u32 i0 = tid; i0 < n; i0 += 4 * T) {
+            uint2 v4[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) v4[j] = iv[min(i0 + (u32)j * T, n - 1u)];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (i0 + (u32)j * T >= n) break;
+                u32 ks, ke;
+                const uint2 v = v4[j];
+                make_event_keys(v, ks, ke, bad, nz);
+                bad |= v.y > len ? 2u : 0u;
+                max_start = max(max_start, ks);
+                if (try_filter && v.x <= v.y && v.y <= len) { // (anything else switches the filter off below)
+                    const u32 is = F::idx(geo, ks);
+                    if (v.x == v.y && F::uniform(geo, is)) atomicAdd(F::ztab(keys) + is, 1u);
+                    else {
+                        atomicAdd(tab + is * 4u + (tid & 3u), 1u);
+                        atomicAdd(tab + F::idx(geo, ke) * 4u + (tid & 3u), 0x10000u);
+                    }
+                }
             }
         }
         bad = block_or<T>(bad, sc);
@@ -283,20 +515,40 @@ __global__ __launch_bounds__(T) void sweep_lds_kernel(SweepArgs a)
         // ---- second pass: the event keys go to LDS — the survivors of the pre-filter to the
         // slots they are handed, or all of them
         u32 m_sort = 0, syn_start = 0; // events to sort and sweep
-        if (try_filter && nz_total == 0 && !beyond)
-            m_sort = lds_filter_plan<T, CAP>(keys, len, a.cov, sc, syn_start);
+        if (try_filter && !beyond)
+            m_sort = lds_trim_plan<T, CAP>(keys, len, a.cov, sc, syn_start);
+        if (!m_sort && over) { // uniform: too much survives
+            if (tid == 0) a.over_list[atomicAdd(a.over_count, 1u)] = r;
+            __syncthreads();
+            continue;
+        }
         if (m_sort) {
             u32 ms = syn_start;
-            for (u32 i = tid; i < n; i += T) {
-                const uint2 v = iv[i];
-                const u32 ks = (v.x << kKeyShift) | 3u, ke = v.y << kKeyShift;
-                const u32 ps = F::add(keys, ks, ksh, 1u);
-                const u32 pe = F::add(keys, ke, ksh, 1u);
-                if (ps < F::kNowhere) {
-                    keys[ps] = ks;
-                    ms = max(ms, ks);
+            // A cursor whose quota is used up never gets one back, so it is looked at before it is
+            // asked (a plain read: lanes reading one address are a broadcast): of a pile of hundreds of
+            // equal keys only the first few still do the atomic.
+            auto take = [&](u32 *cur) -> u32 {
+                return (i32)*reinterpret_cast<volatile u32 *>(cur) >= 0x10000 ? atomicAdd(cur, F::kTakeOne) : 0u;
+            };
+            for (u32 i0 = tid; i0 < n; i0 += 4 * T) {
+                uint2 v4[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) v4[j] = iv[min(i0 + (u32)j * T, n - 1u)];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    if (i0 + (u32)j * T >= n) break;
+                    const uint2 v = v4[j];
+                    u32 ks, ke, b2 = 0, z2 = 0;
+                    make_event_keys(v, ks, ke, b2, z2);
+                    const u32 is = F::idx(geo, ks), ie = F::idx(geo, ke);
+                    const u32 ps = take(tab + is * 4u + (F::uniform(geo, is) ? (z2 ? 2u : 1u) : (tid & 3u)));
+                    const u32 pe = take(tab + ie * 4u + (F::uniform(geo, ie) ? (z2 ? 2u : 0u) : (tid & 3u)));
+                    if ((i32)ps >= 0x10000) { // quota left: kept, at the slot in the low half
+                        keys[ps & 0xFFFFu] = ks;
+                        ms = max(ms, ks);
+                    }
+                    if ((i32)pe >= 0x10000) keys[pe & 0xFFFFu] = ke;
                 }
-                if (pe < F::kNowhere) keys[pe] = ke;
             }
             max_start = block_max<T>(ms, sc);
         } else {
@@ -309,102 +561,8 @@ __global__ __launch_bounds__(T) void sweep_lds_kernel(SweepArgs a)
                 keys[2 * i + 1] = ke;
             }
         }
-        P = 2;
-        while (P < m_sort) P <<= 1;
-        for (u32 i = m_sort + tid; i < P; i += T) keys[i] = kNoKey;
-        __syncthreads();
-
-        if (T >= 256 && P >= 1024) hybrid_sort_lds<T>(keys, P, lc);
-        else bitonic_sort_lds<T>(keys, P);
-
-        if (nz_total > 2) { // two zero-length intervals at one position > 0: exact path (see keys)
-            u32 dup = 0;
-            for (u32 i = tid; i + 1 < m_sort; i += T)
-                dup |= (keys[i] == keys[i + 1] && (keys[i] & 3u) == 1u && keys[i] != 1u);
-            if (block_max<T>(dup, sc)) {
-                if (tid == 0) {
-                    a.rej_list[atomicAdd(a.rej_count, 1u)] = r;
-                    a.counts[r] = 0;
-                }
-                __syncthreads();
-                continue;
-            }
-        }
-
-        // ---- blocked chunks: thread t owns events [t*K, t*K+K) of the sorted sequence
-        const u32 K = (P >= (u32)T) ? P / T : 1;
-        const u32 q0 = min(tid * K, m_sort), q1 = min(q0 + K, m_sort);
-
-        // pass A: depth carried into each chunk
-        u32 delta = 0;
-        for (u32 q = q0; q < q1; q++) delta += (keys[q] & 1u) ? 1u : 0xFFFFFFFFu;
-        u32 tot;
-        const u32 depth_in = block_excl_add<T>(delta, sc, tot);
-
-        // pass B: last flagged end (flipped domain, device_common.h) / last low start per chunk
-        u32 d = depth_in, mf = 0, ml = 0;
-        for (u32 q = q0; q < q1; q++) {
-            const u32 key = keys[q];
-            if (key & 1u) {
-                if (d <= a.cov) ml = key;
-                d++;
-            } else {
-                if (d > a.cov) mf = max(mf, key ^ 2u);
-                d--;
-            }
-        }
-        u32 mf_t, ml_t;
-        const u32 mf_in = max(block_excl_max<T>(mf, sc, mf_t), kNoFlag);
-        const u32 ml_in = block_excl_max<T>(ml, sc, ml_t);
-
-        // pass C: count the regions this chunk closes; tail rule (stack.rs:93-105)
-        u32 cnt = 0, min_ge = kNoKey;
-        d = depth_in;
-        mf = mf_in;
-        ml = ml_in;
-        for (u32 q = q0; q < q1; q++) {
-            const u32 key = keys[q];
-            if (key & 1u) {
-                if (d <= a.cov) ml = key;
-                d++;
-            } else {
-                if (d > a.cov) {
-                    if ((key ^ 2u) > mf) {
-                        if (ml > (mf ^ 2u)) cnt++;
-                        mf = key ^ 2u;
-                    }
-                    if (key > max_start && (key >> kKeyShift) >= len)
-                        min_ge = min(min_ge, key >> kKeyShift);
-                }
-                d--;
-            }
-        }
-        u32 g_closed;
-        u32 pos = block_excl_add<T>(cnt, sc, g_closed);
-        min_ge = block_min<T>(min_ge, sc);
-
-        // pass D: write them, in event order
-        if (cnt) {
-            d = depth_in;
-            mf = mf_in;
-            ml = ml_in;
-            for (u32 q = q0; q < q1; q++) {
-                const u32 key = keys[q];
-                if (key & 1u) {
-                    if (d <= a.cov) ml = key;
-                    d++;
-                } else {
-                    if (d > a.cov && (key ^ 2u) > mf) {
-                        if (ml > (mf ^ 2u))
-                            slot[pos++] = make_uint2((mf ^ 2u) >> kKeyShift, ml >> kKeyShift);
-                        mf = key ^ 2u;
-                    }
-                    d--;
-                }
-            }
-        }
-        if (tid == 0)
-            a.counts[r] = finish_read(slot, g_closed, mf_t ? (mf_t ^ 2u) : 0u, ml_t, min_ge, len);
+        lds_sort_and_sweep<T>(keys, sc, m_sort, len, a.cov, max_start, nz_total, lc, slot, a.counts, r,
+                              a.rej_list, a.rej_count);
         __syncthreads(); // keys / sc reused by the next read
     }
 }

@@ -220,33 +220,59 @@ def general_events(intervals, length, cov):
 #     positions get such bins, and of a pile only its cov + 1 outermost events survive.
 # Only for plain reads (every interval 0 <= start < end <= length).
 
-def trim_keys(intervals, length, cov, nb, F):
-    """Zero-length intervals (start == end) are taken too: in a coarse bin they count as a start and
+def trim_keys(intervals, length, cov, nb, F, wave=False):
+    """wave=True: the bin geometry of sweep_wave.h (coarse bins aligned at 0, fine zones only when
+    length >= nb * F, sequence index = min(pos, F) + (pos >> sh) + max(pos - (length - F), 0)).
+    Zero-length intervals (start == end) are taken too: in a coarse bin they count as a start and
     an end of that bin (kept or dropped with it); at a one-position bin their two keys sit between
     the bin's regular ends and its regular starts, at depth D - E, so the pair is deep — dropped —
     exactly when the bin's first regular start would be (D - E >= cov + 1), and kept otherwise."""
-    if length < 2 * F + 2:
-        F = 0
-    sh = bin_shift(max(length - 2 * F, 0), nb)
-    hi0 = length - F + 1                      # first position of the right fine zone
-    nbins = F + nb + F
+    if wave:
+        if length < nb * F:
+            F = 0
+        sh = bin_shift(length, nb)
+        H = length - F
+        nbins = F + nb + F
+        idx_h = F + (H >> sh)
+
+        def bin_of(pos):
+            return min(pos, F) + (pos >> sh) + max(pos - H, 0)
+
+        fp_table = {}
+        for pos in range(0, min(F, length + 1)):
+            fp_table.setdefault(bin_of(pos), pos)
+        for pos in range(H + 1, length + 1):
+            fp_table.setdefault(bin_of(pos), pos)
+
+        def first_pos(b):
+            if b in fp_table:
+                return fp_table[b]
+            return max((b - F) << sh, F)      # a coarse bin
+
+        uniform = [b < F or b > idx_h for b in range(nbins)]
+    else:
+        if length < 2 * F + 2:
+            F = 0
+        sh = bin_shift(max(length - 2 * F, 0), nb)
+        hi0 = length - F + 1                  # first position of the right fine zone
+        nbins = F + nb + F
+
+        def bin_of(pos):
+            if pos < F:
+                return pos
+            if F and pos >= hi0:
+                return F + nb + (pos - hi0)
+            return F + ((pos - F) >> sh)
+
+        def first_pos(b):
+            if b < F:
+                return b
+            if b >= F + nb:
+                return hi0 + (b - F - nb)
+            return F + ((b - F) << sh)
+
+        uniform = [b < F or b >= F + nb for b in range(nbins)]
     S, E, Z = [0] * nbins, [0] * nbins, [0] * nbins
-
-    def bin_of(pos):
-        if pos < F:
-            return pos
-        if F and pos >= hi0:
-            return F + nb + (pos - hi0)
-        return F + ((pos - F) >> sh)
-
-    def first_pos(b):
-        if b < F:
-            return b
-        if b >= F + nb:
-            return hi0 + (b - F - nb)
-        return F + ((b - F) << sh)
-
-    uniform = [b < F or b >= F + nb for b in range(nbins)]
     keys = []
     for s, e in intervals:
         assert 0 <= s <= e <= length
@@ -312,13 +338,13 @@ def trim_keys(intervals, length, cov, nb, F):
     return out
 
 
-def trimmed_events(intervals, length, cov, nb=16, F=32):
+def trimmed_events(intervals, length, cov, nb=16, F=32, wave=False):
     """sweep over the keys trim_keys leaves; None unless the read is plain."""
     if len(intervals) == 0:
         return [(0, length)] if length != 0 else []
     if any(not (0 <= s <= e <= length) for s, e in intervals) or length >= 2**30 - 1:
         return None
-    keys = sorted(trim_keys(intervals, length, cov, nb, F))
+    keys = sorted(trim_keys(intervals, length, cov, nb, F, wave))
     for a, b in zip(keys, keys[1:]):
         if a == b and (a & 3) == 1 and a != 1:
             return None  # two zero-length intervals at one position survive: exact general path

@@ -121,6 +121,8 @@ def test_pile_trimming_matches_oracle():
                 got = trimmed_events(iv, L, cov, nb, F)
                 assert got == want or (got is None and has_zl), (iv, L, cov, nb, F)
                 n_zl_checked += has_zl and got is not None
+                gw = trimmed_events(iv, L, cov, nb, F, wave=True)  # sweep_wave.h's bin geometry
+                assert gw == want or (gw is None and has_zl), (iv, L, cov, nb, F, "wave")
             if cov == 4:
                 total += 2 * len(iv)
                 kept += len(trim_keys(iv, L, cov, 16, 32))
@@ -139,4 +141,6 @@ def test_pile_trimming_tiny_exhaustive():
                     for nb, F in ((2, 1), (2, 2), (4, 0), (4, 2)):
                         got = trimmed_events(list(iv), L, cov, nb, F)
                         assert got is None or got == want, (iv, L, cov, nb, F)
+                        gw = trimmed_events(list(iv), L, cov, nb, min(F, 1), wave=True)
+                        assert gw is None or gw == want, (iv, L, cov, nb, F, "wave")
                         assert got is not None or regular_events(list(iv), L, cov) is None

@@ -194,6 +194,9 @@ __global__ __launch_bounds__(kBtT) void bt_plan_kernel(BtArgs a)
 
 __global__ __launch_bounds__(kBtT) void bt_scatter_kernel(BtArgs a)
 {
+    // which cursors this workgroup has seen at their limit (they stay there): a pile of 10^5 equal keys
+    // then costs one look at global memory per workgroup, not one per key
+    __shared__ unsigned char done[3 * kBtSeq];
     const u32 c = blockIdx.x, si = a.chunk_seg[c];
     const BtSeg s = a.seg[si];
     if (!(s.flags & BT_TRIMMED)) return;
@@ -201,14 +204,18 @@ __global__ __launch_bounds__(kBtT) void bt_scatter_kernel(BtArgs a)
     u32 *cur = a.cur + (size_t)si * 3 * kBtSeq;
     const u32 *lim = a.lim + (size_t)si * 3 * kBtSeq;
     u32 *tk = a.tkeys + (size_t)si * kBtCap;
+    for (u32 b = threadIdx.x; b < 3u * kBtSeq / 4u; b += kBtT) reinterpret_cast<u32 *>(done)[b] = 0;
+    __syncthreads();
     const u32 i0 = (c - s.chunk_off) * kBtChunk, i1 = min(i0 + (u32)kBtChunk, s.n);
     const uint2 *iv = a.iv + s.iv_off;
     auto put = [&](u32 key, u32 at) {
+        if (done[at]) return;
         const u32 l = lim[at];
-        // a cursor at its limit stays there: look before asking (the pile of 10^5 equal keys reads)
         if (__hip_atomic_load(&cur[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < l) {
             const u32 p = atomicAdd(&cur[at], 1u);
             if (p < l) tk[p] = key;
+        } else {
+            done[at] = 1;
         }
     };
     for (u32 i = i0 + threadIdx.x; i < i1; i += 4 * kBtT) {

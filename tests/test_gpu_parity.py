@@ -91,7 +91,7 @@ def test_prefilter_on_deep_pileups(cov):
         assert e.timing()["prefiltered_reads"] == 0
     assert_same(got, (ref.bad_offsets, ref.bad_regions, ref.read_type), "prefilter on/off")
     if cov <= 9:
-        assert fired > 300, fired  # (wavefronts holding an interval shorter than LANES positions sort everything)
+        assert fired > 500, fired
     if cov == 40:   # depth never exceeds c on most of these reads: nothing is safe, nothing dropped
         assert fired < 3006
 

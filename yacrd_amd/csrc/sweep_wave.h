@@ -360,222 +360,107 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// LDS scratch of one wavefront for the trimming filter: per group (2 LANES + 1) bins of four
-// counters (one per lane & 3; the last bin takes the pads), then the compacted keys of every group.
-constexpr int kTrimTabWords = 528, kFilterKeyWords = 512;
+// LDS scratch of one wavefront for the pre-filter: bin counters of every group + compacted keys.
+// A bin has four counters (one per lane & 3): the reads' hot bins (dovetails start at 0 and end at
+// len) would otherwise serialise the LDS atomics of a row.
+constexpr int kFilterTabWords = 272, kFilterKeyWords = 512;
 __device__ __forceinline__ u32 *wave_filter_scratch()
 {
-    __shared__ __attribute__((aligned(16))) u32 s_scratch[4][kTrimTabWords + kFilterKeyWords];
+    __shared__ __attribute__((aligned(16))) u32 s_scratch[4][kFilterTabWords + kFilterKeyWords];
     return s_scratch[threadIdx.x >> 6];
 }
 
-// ---- coverage pre-filter with pile trimming (emulated and fuzzed in
-// tests/formulation.py::trim_keys(wave=True)) ------------------------------------------------------
-// An event is DEEP when the depth is above c on both sides of it: a deep start is never low, a deep
-// flagged end is always superseded by a later flagged end before the next low start, so deep events
-// can be dropped as long as every maximal run of dropped events is stood in for by |net| keys of one
-// type (net = depth after the run - depth before it; 0 for a healthy read).  Which events are deep
-// is known without sorting in two kinds of bins:
-//   * a coarse bin (2^sh positions, NB = LANES of them) that more than c intervals span
-//     completely: all of its events;
-//   * a bin that holds ONE position: its keys are E ends then S starts, equal within a type, so
-//     with the depth D at its head the first max(0, D - c - 1) ends and all but the first
-//     max(0, c + 1 - (D - E)) starts are deep.  The first F = LANES / 2 and the last F positions of the
-//     read get such bins: dovetail overlaps pile their starts at the head of the read and their ends
-//     at its tail — a third of all events each on configs[1] — and of a pile only the c + 1
-//     outermost events survive: a read of 100 intervals keeps 2 (c + 1) = 10 of its 200 keys.
-// Bin sequence index of a position: min(pos, f) + (pos >> sh) + max(pos - (len - f), 0), f = F or 0
-// for reads shorter than NB * F; lane i of a group owns the bins i and LANES + i.
-// Pass 1 counts (one LDS atomic per key; a bin has four counters, one per lane & 3),
-// the lanes work out what every bin keeps and turn the counters into packed cursors (quota << 16 |
-// next slot), pass 2 asks them (one LDS atomic per key: kept or not, and where).  Returns the tier:
-// 0 = sort everything as before (some group keeps more than LANES * K / 2 keys), 1 = every group
-// kept <= LANES keys (y1: one key per lane), 2 = y: K / 2 keys per lane.
-// Only for wavefronts whose intervals all satisfy start + F <= end <= len (so a start never lies in
-// the tail zone nor an end in the head zone, and the class bits of a key never reach the bin index).
 template <int LANES, int K>
-__device__ __forceinline__ int trimfilter(const u32 (&x)[K], u32 n, u32 len, i32 c, u32 (&y1)[1],
-                                          u32 (&y)[K / 2], u32 &m_out)
+__device__ __forceinline__ bool prefilter(const u32 (&x)[K], u32 n, u32 len, i32 c, u32 (&y)[K / 2],
+                                          u32 &m_out)
 {
     static_assert(K == 16, "a lane reads its K/2 = 8 compacted keys as two 16-byte vectors");
-    constexpr int NB = LANES, F = LANES / 2, NBIN = 2 * LANES + 1, CAP = LANES * K / 2, GROUPS = 64 / LANES;
-    constexpr u32 kTakeOne = 0xFFFF0001u; // quota - 1, slot + 1
-    static_assert(GROUPS * NBIN * 4 <= kTrimTabWords && GROUPS * CAP <= kFilterKeyWords, "scratch");
+    constexpr int NB = LANES, CAP = LANES * K / 2, GROUPS = 64 / LANES;
+    static_assert(GROUPS * (NB + 1) * 4 <= kFilterTabWords && GROUPS * CAP <= kFilterKeyWords, "scratch");
     const u32 lane = lane_id(), lig = lane & (u32)(LANES - 1), grp = lane / (u32)LANES;
     u32 *scratch = wave_filter_scratch();
-    u32 *tab = scratch + grp * (u32)(NBIN * 4);
-    u32 *keys = scratch + kTrimTabWords + grp * (u32)CAP;
-    uint4 *bins = reinterpret_cast<uint4 *>(tab);
+    u32 *tab = scratch + grp * (u32)((NB + 1) * 4);        // (NB bins + one for the pads) x 4 copies
+    u32 *keys = scratch + kFilterTabWords + grp * (u32)CAP;
+    uint4 *my_bin = reinterpret_cast<uint4 *>(tab) + lig;
     uint4 *my_keys = reinterpret_cast<uint4 *>(keys) + lig * 2u;
-    char *tb = reinterpret_cast<char *>(tab);
 
-    // geometry (uniform inside a group): coarse bins of 2^sh positions, smallest sh with len >> sh < NB
+    // smallest shift with (len >> sh) < NB: the bin holding `len` and every later one stay unsafe
     const i32 bits = 32 - (i32)__builtin_clz(len | 1u) - ilog2c(NB) + (len != 0 ? 0 : -1);
     const u32 sh = (u32)max(bits, 0), ksh = sh + kKeyShift;
-    const u32 f = len >= (u32)(NB * F) ? (u32)F : 0u; // (then 2^sh > F: at most one coarse edge per zone)
-    const u32 H = len - f, mH = H >> sh, idxH = f + mH;
 
-    bins[lig] = make_uint4(0u, 0u, 0u, 0u);
-    bins[LANES + lig] = make_uint4(0u, 0u, 0u, 0u);
-    if (lig == 0) bins[2 * LANES] = make_uint4(0u, 0u, 0u, 0u);
+    // ---- histogram: starts in the low half of a counter, ends in the high half (LDS atomics).
+    // The compacted-key area starts out as pads.
+    *my_bin = make_uint4(0u, 0u, 0u, 0u);
     my_keys[0] = make_uint4(kPadKey, kPadKey, kPadKey, kPadKey);
     my_keys[1] = make_uint4(kPadKey, kPadKey, kPadKey, kPadKey);
     wave_lds_sync();
-
-    // ---- pass 1: count.  A bin has four counters, one per lane & 3 (the hot bins would otherwise
-    // serialise the LDS atomics of a row); starts count in the low half, ends in the high half
-    const u32 cp = (lig & 3u) * 4u, fk = f << kKeyShift, lenk = len << kKeyShift;
-    const u32 base_e = 32u * f + cp, pad_off = (u32)(2 * LANES * 16) + cp;
-    u32 off[K];
+    u32 *cell0 = tab + (lig & 3u);        // this lane's copy of bin 0
+    u32 *pad_cell = cell0 + NB * 4;
+    u32 *cell[K];
 #pragma unroll
-    for (int j = 0; j < K / 2; j++) {
-        const bool real = lig + (u32)LANES * j < n;
-        const u32 ks = x[2 * j], ke = x[2 * j + 1];
-        // start: bin = min(pos, f) + (pos >> sh); end: bin = 2 f + (pos >> sh) - min(len - pos, f)
-        const u32 os = ((min(ks, fk | 3u) & ~3u) << 2) + ((ks >> ksh) << 4) + cp;
-        const u32 oe = ((ke >> ksh) << 4) - (min(lenk - ke, fk) << 2) + base_e;
-        off[2 * j] = real ? os : pad_off;
-        off[2 * j + 1] = real ? oe : pad_off;
-        atomicAdd(reinterpret_cast<u32 *>(tb + off[2 * j]), 1u);
-        atomicAdd(reinterpret_cast<u32 *>(tb + off[2 * j + 1]), 0x10000u);
+    for (int q = 0; q < K; q++) {
+        const bool real = lig + (u32)LANES * (q / 2) < n;
+        u32 *p = cell0 + (x[q] >> ksh) * 4u; // positions <= len: the bin is inside the table
+        cell[q] = real ? p : pad_cell;
+        atomicAdd(cell[q], (q & 1) ? 0x10000u : 1u);
     }
     wave_lds_sync();
+    const uint4 w4 = *my_bin;
+    const u32 w = w4.x + w4.y + w4.z + w4.w;
+    const u32 incl = gscan_add<LANES>(w); // packed: both halves scanned at once
+    const i32 S = (i32)(w & 0xFFFFu), E = (i32)(w >> 16);
+    const i32 cs = (i32)(incl & 0xFFFFu), ce = (i32)(incl >> 16);
+    const i32 depth_after = cs - ce, depth_at = depth_after - (S - E);
+    const bool safe = (cs - S) - ce > c && lig < (len >> sh);
+    const u64 sball = __builtin_amdgcn_ballot_w64(safe);
+    if (sball == 0) return false; // wave-uniform: nothing to drop
+    // the group's safe bits, bit b = bin b (zeros beyond the group)
+    const u64 smask = LANES == 64 ? sball
+                                  : (sball >> (lane & (u32)(64 - LANES))) & ((1ull << (LANES & 63)) - 1ull);
+    const bool head = safe && (((smask << 1) >> lig) & 1ull) == 0;
+    const bool tail = safe && (((smask >> 1) >> lig) & 1ull) == 0;
+    const u32 hv = gscan_max<LANES>(head ? (((lig + 1u) << 16) | (u32)depth_at) : 0u);
+    const i32 net = tail ? depth_after - (i32)(hv & 0xFFFFu) : 0;
+    const u32 nsyn = min((u32)(net < 0 ? -net : net), (u32)CAP + 1u);
+    const u32 synkey = (((hv >> 16) - 1u) << ksh) | (net > 0 ? 3u : 0u);
 
-    // ---- what the group's bins keep.  Lane i: bins i and LANES + i (sequence order = all first
-    // bins, then all second ones: two row scans with a carry)
-    const int last_addr = (int)((lane | (u32)(LANES - 1)) << 2);
-    auto row_total = [&](u32 v) { return (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)v); };
-    uint4 c4[2];
-    i32 S[2], E[2], D[2];
+    // ---- slots: a bin's survivors go to [base, base + S + E), a run's stand-ins to the tail
+    // lane's range; counters of safe bins (and of the pads) start at CAP = "nowhere"
+    const u32 mine = safe ? nsyn : (u32)(S + E);
+    const u32 rincl = gscan_add<LANES>(mine);
+    const u32 m = (u32)__builtin_amdgcn_ds_bpermute((int)((lane | (u32)(LANES - 1)) << 2), (int)rincl);
+    if (__builtin_amdgcn_ballot_w64(m > (u32)CAP) != 0) return false; // some group keeps too much
+    const u32 base = rincl - mine;
     {
-        u32 w[2], incl[2];
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            c4[k] = bins[k * LANES + lig];
-            w[k] = c4[k].x + c4[k].y + c4[k].z + c4[k].w;
-            S[k] = (i32)(w[k] & 0xFFFFu);
-            E[k] = (i32)(w[k] >> 16);
-            incl[k] = gscan_add<LANES>(w[k]); // packed: both halves scanned at once
-        }
-        const u32 ex0 = incl[0] - w[0], ex1 = row_total(incl[0]) + incl[1] - w[1];
-        D[0] = (i32)(ex0 & 0xFFFFu) - (i32)(ex0 >> 16);
-        D[1] = (i32)(ex1 & 0xFFFFu) - (i32)(ex1 >> 16);
+        uint4 b4;
+        b4.x = base;
+        b4.y = b4.x + (w4.x & 0xFFFFu) + (w4.x >> 16);
+        b4.z = b4.y + (w4.y & 0xFFFFu) + (w4.y >> 16);
+        b4.w = b4.z + (w4.z & 0xFFFFu) + (w4.z >> 16);
+        *my_bin = safe ? make_uint4(CAP, CAP, CAP, CAP) : b4;
+        if (lig < 4u) tab[NB * 4 + lig] = (u32)CAP;
     }
-    i32 keep_e[2], keep_s[2], B[2];
-    bool uni[2];
-    u32 tag[2]; // (sequence index + 1) << 16 | depth after the bin's kept block, 0 = keeps nothing
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const u32 i = (u32)(k * LANES) + lig;
-        uni[k] = i < f || i > idxH;
-        const i32 n_de = min(max(D[k] - c - 1, 0), E[k]);            // deep ends of a one-position bin
-        const i32 ks1 = min(max(c + 1 - (D[k] - E[k]), 0), S[k]);    // its starts that are not deep
-        const bool deep = D[k] - E[k] > c;                           // coarse bin spanned by > c intervals
-        keep_e[k] = uni[k] ? E[k] - n_de : (deep ? 0 : E[k]);
-        keep_s[k] = uni[k] ? ks1 : (deep ? 0 : S[k]);
-        const bool opaque = uni[k] ? (keep_e[k] + keep_s[k] > 0) : !deep;
-        B[k] = D[k] - (E[k] - keep_e[k]);
-        tag[k] = opaque ? (((i + 1u) << 16) | (u32)(D[k] - E[k] + keep_s[k])) : 0u;
-    }
-    // depth after the kept block of the previous bin that keeps something
-    u32 nsyn[2];
-    i32 net[2];
-    {
-        u32 mi[2], ex[2];
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            mi[k] = gscan_max<LANES>(tag[k]);
-            ex[k] = gshift_up1<LANES>(mi[k]);
-            if (LANES == 32 && lig == 0) ex[k] = 0; // (gshift_up1<32> already zeroes lane 32; lane 0 gets 0 from the wave shift)
-        }
-        const u32 prev[2] = {ex[0], max(ex[1], row_total(mi[0]))};
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            net[k] = tag[k] ? B[k] - (i32)(prev[k] & 0xFFFFu) : 0;
-            nsyn[k] = (u32)(net[k] < 0 ? -net[k] : net[k]);
-        }
-    }
-    // slots: a bin's kept keys (copy by copy), then its stand-ins
-    u32 base[2], m;
-    {
-        u32 mine[2], ri[2];
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            mine[k] = (u32)(keep_e[k] + keep_s[k]) + nsyn[k];
-            ri[k] = gscan_add<LANES>(mine[k]);
-        }
-        const u32 t0 = row_total(ri[0]), t1 = row_total(ri[1]);
-        base[0] = ri[0] - mine[0];
-        base[1] = t0 + ri[1] - mine[1];
-        m = t0 + t1;
-    }
-    if (__builtin_amdgcn_ballot_w64(m > (u32)CAP) != 0) return 0; // some group keeps too much
-    // cursors.  A one-position bin holds one type only (starts in the head zone, ends in the tail
-    // zone: start + F <= end), so its quota is dealt out to its four copies in turn; a coarse bin's
-    // copies keep everything (quota 0x7FFF) or nothing.
-#pragma unroll
-    for (int k = 0; k < 2; k++) {
-        const u32 keep = (u32)(keep_e[k] + keep_s[k]);
-        const u32 n0 = (c4[k].x & 0xFFFFu) + (c4[k].x >> 16), n1 = (c4[k].y & 0xFFFFu) + (c4[k].y >> 16),
-                  n2 = (c4[k].z & 0xFFFFu) + (c4[k].z >> 16), n3 = (c4[k].w & 0xFFFFu) + (c4[k].w >> 16);
-        u32 q0, q1, q2, q3;
-        if (uni[k]) {
-            q0 = min(n0, keep);
-            q1 = min(n1, keep - q0);
-            q2 = min(n2, keep - q0 - q1);
-            q3 = keep - q0 - q1 - q2;
-        } else {
-            q0 = n0, q1 = n1, q2 = n2, q3 = n3; // kept whole (keep = all) or not at all (quota 0 below)
-        }
-        const u32 hi = uni[k] ? 0u : (keep ? 0x7FFF0000u : 0u);
-        uint4 cur;
-        cur.x = (uni[k] ? (q0 << 16) : hi) | base[k];
-        cur.y = (uni[k] ? (q1 << 16) : hi) | (base[k] + q0);
-        cur.z = (uni[k] ? (q2 << 16) : hi) | (base[k] + q0 + q1);
-        cur.w = (uni[k] ? (q3 << 16) : hi) | (base[k] + q0 + q1 + q2);
-        bins[k * LANES + lig] = cur;
-    }
-    if (lig == 0) bins[2 * LANES] = make_uint4(0u, 0u, 0u, 0u); // the pads' bin: quota 0
-    if (__builtin_amdgcn_ballot_w64((nsyn[0] | nsyn[1]) != 0) != 0) { // rare: net != 0 somewhere
-        const u32 q_edge = (mH + 1u) << sh;                    // coarse edge inside the tail zone, if <= len
-        const u32 i_edge = f + mH + 1u + (q_edge - H);         // its bin
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const u32 i = (u32)(k * LANES) + lig;
-            u32 pos; // first position of bin i
-            if (i < f) pos = i;
-            else if (i <= idxH) pos = max((i - f) << sh, f);
-            else pos = H + (i - f - mH) - ((q_edge <= len && i >= i_edge) ? 1u : 0u);
-            // starts go right in front of the bin (position - 1, start class), ends to its head
-            const u32 synkey = net[k] > 0 ? (pos << kKeyShift) - 1u : (pos << kKeyShift);
-            const u32 at = base[k] + (u32)(keep_e[k] + keep_s[k]);
 #pragma unroll 1
-            for (u32 t = 0; t < nsyn[k]; t++) keys[at + t] = synkey;
-        }
-    }
+    for (u32 t = 0; t < nsyn; t++) keys[base + t] = synkey;
     wave_lds_sync();
-
-    // ---- pass 2: every key asks the cursor it counted on
+    // slot requests go out in batches of 8, all in flight before the first store needs its answer
+    // (16 at once cost eight more registers than the rest of the kernel needs)
 #pragma unroll
     for (int q0 = 0; q0 < K; q0 += 8) {
-        u32 got[8];
+        u32 pos[8];
 #pragma unroll
-        for (int q = 0; q < 8; q++) got[q] = atomicAdd(reinterpret_cast<u32 *>(tb + off[q0 + q]), kTakeOne);
+        for (int q = 0; q < 8; q++) pos[q] = atomicAdd(cell[q0 + q], 1u);
 #pragma unroll
         for (int q = 0; q < 8; q++) {
-            if ((i32)got[q] >= 0x10000) keys[got[q] & 0xFFFFu] = x[q0 + q];
+            if (pos[q] < (u32)CAP) keys[pos[q]] = x[q0 + q];
         }
     }
     wave_lds_sync();
-    m_out = m;
-    if (__builtin_amdgcn_ballot_w64(m > (u32)LANES) == 0) { // every group fits one key per lane
-        y1[0] = keys[lig];
-        return 1;
-    }
     const uint4 lo = my_keys[0], hi = my_keys[1];
     y[0] = lo.x, y[1] = lo.y, y[2] = lo.z, y[3] = lo.w;
     y[4] = hi.x, y[5] = hi.y, y[6] = hi.z, y[7] = hi.w;
-    return 2;
+    m_out = m;
+    return true;
 }
 
 // ---- one read per group of LANES lanes: loads, keys, (pre-filter,) sweep ------------------------
@@ -610,9 +495,7 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
 #pragma unroll
         for (int j = 0; j < K / 2; j++) {
             const bool real = lig + (u32)LANES * j < n;
-            // (an interval shorter than LANES / 2 positions also counts as irregular: the trimming
-            // filter's bin index relies on start + LANES / 2 <= end; x > y wraps into the same test)
-            irregular |= (real && (v[j].y - v[j].x - (u32)(LANES / 2) >= 0x80000000u || max(v[j].x, v[j].y) > len_c)) ? 1u : 0u;
+            irregular |= (real && (v[j].x >= v[j].y || v[j].y > len_c)) ? 1u : 0u;
             x[2 * j] = real ? ((v[j].x << kKeyShift) | 3u) : kPadKey;
             x[2 * j + 1] = real ? (v[j].y << kKeyShift) : kPadKey;
         }
@@ -644,15 +527,11 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
 
     if constexpr (K == 16) {
         if (a.prefilter && plain) { // uniform
-            u32 y1[1], y[K / 2], mf;
-            const int tier = trimfilter<LANES, K>(x, n, len, c, y1, y, mf);
-            if (tier == 1 && a.prefilter == 2 && lig == 0 && active) atomicAdd(&a.ctr->prefiltered, 1u); // DEBUG tier 1 only
-            if (tier == 1) {
-                sweep_group_keys<LANES, 1, XM>(y1, mf, len, c, active, r, badmask, zmask, zl_check, a, lc);
-                return;
-            }
-            if (tier == 2) {
-                sweep_group_keys<LANES, K / 2, XM>(y, mf, len, c, active, r, badmask, zmask, zl_check, a, lc);
+            u32 y[K / 2], mf;
+            if (prefilter<LANES, K>(x, n, len, c, y, mf)) {
+                if (a.prefilter == 2 && lig == 0 && active) atomicAdd(&a.ctr->prefiltered, 1u);
+                sweep_group_keys<LANES, K / 2, XM>(y, mf, len, c, active, r, badmask, zmask,
+                                                   zl_check, a, lc);
                 return;
             }
         }

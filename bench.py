@@ -433,6 +433,14 @@ def end_to_end(yacrd_amd, host, eng, prof, R, O, cov, args):
             os.remove(paf)
 
 
+def large_traffic(R, O):
+    """PMC traffic of the dominant kernel on this workload, when profiles/traffic.json has it."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("sequel_%d_%d" % (R, O))
+    except Exception:
+        return None
+
+
 def large_block(yacrd_amd, host, ydist, dist, dev, torch, eng, rank, world, args):
     """configs[2] shape, one fixed input for every N: 2 M reads / 200 M overlaps (Sequel-like,
     -c 3 -n 0.4).  yacrd_partition_reads cuts contiguous read ranges balanced by interval count,
@@ -515,7 +523,8 @@ def large_block(yacrd_amd, host, ydist, dist, dev, torch, eng, rank, world, args
            "parity": ("bit-exact vs oracle on %d sampled reads per rank" % per_rank["sampled_reads"])
                      if all(p["parity_sample_ok"] for p in allr) else "MISMATCH vs oracle",
            "roofline": {"bound": "hbm", "kernel": dom, "size_class": cname, "achieved": ach, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None, "algorithmic_bytes": b_dom,
+                        "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                        "traffic": large_traffic(R, O) if world == 1 else None, "algorithmic_bytes": b_dom,
                         "kernel_ms": dom_ms, "kernel_reads": c_reads, "kernel_intervals": c_iv,
                         "note": "rank 0's launch; input %.2f GB per GPU, outside the 256 MiB Infinity Cache" % (8 * Il / 1e9)}}
     del d_off, d_iv, d_len

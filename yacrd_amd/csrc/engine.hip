@@ -215,7 +215,7 @@ int run_big(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u32 *d_l
         const size_t tab_words = (size_t)count * 3 * yk::kBtSeq;
         HIP_TRY(e->bt_tab.reserve((size_t)count * sizeof(yk::BtSeg) + n_chunks * sizeof(u32) + 64));
         HIP_TRY(e->bt_hist.reserve(tab_words * sizeof(u32)));
-        HIP_TRY(e->bt_cur.reserve(2 * tab_words * sizeof(u32)));
+        HIP_TRY(e->bt_cur.reserve((2 * tab_words + (size_t)count * (3 * yk::kBtSeq / 32)) * sizeof(u32)));
         HIP_TRY(e->bt_keys.reserve((size_t)count * yk::kBtCap * sizeof(u32)));
         yk::BtArgs ba;
         ba.seg = e->bt_tab.as<yk::BtSeg>();
@@ -227,6 +227,7 @@ int run_big(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u32 *d_l
         ba.hist = e->bt_hist.as<u32>();
         ba.cur = e->bt_cur.as<u32>();
         ba.lim = e->bt_cur.as<u32>() + tab_words;
+        ba.drop = e->bt_cur.as<u32>() + 2 * tab_words;
         ba.tkeys = e->bt_keys.as<u32>();
         ba.stage = e->stage.as<uint2>();
         ba.counts = e->counts.as<u32>();

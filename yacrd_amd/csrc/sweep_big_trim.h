@@ -23,6 +23,7 @@ constexpr int kBtNB = 1024, kBtF = 512, kBtSeq = 2 * kBtF + kBtNB; // bins per r
 constexpr int kBtT = 256;          // threads of hist / plan / scatter
 constexpr int kBtChunk = 4096;     // intervals per workgroup in hist / scatter
 constexpr u32 kBtCap = 16384;      // event keys a thinned read may keep (half the 1024-thread LDS array)
+constexpr int PER8 = kBtSeq / kBtT; // bins per thread of the plan kernel
 using BtGeo = TrimGeo<kBtNB, kBtF>;
 
 enum { BT_PLAIN_NO = 1u, BT_BAD = 2u, BT_TRIMMED = 4u }; // BtSeg.flags
@@ -48,6 +49,7 @@ struct BtArgs {
     u32 *cur;   // [n_segs][3][kBtSeq]: next slot of (type, bin): 0 ends, 1 starts, 2 zero-length keys
     u32 *lim;   // [n_segs][3][kBtSeq]: one past its last slot
     u32 *tkeys; // [n_segs][kBtCap]
+    u32 *drop;  // [n_segs][3 * kBtSeq / 32]: bit = this (type, bin) keeps nothing
     uint2 *stage;
     u32 *counts;
 };
@@ -186,6 +188,19 @@ __global__ __launch_bounds__(kBtT) void bt_plan_kernel(BtArgs a)
             for (u32 t = 0; t < nsyn[k]; t++) tk[base + t] = synkey[k];
         base += nsyn[k];
     }
+    // which (type, bin) keep nothing: one byte per thread and type (its eight bins), read back by
+    // every scatter workgroup so that the keys of dropped bins never touch the cursors
+    unsigned char *db = reinterpret_cast<unsigned char *>(a.drop + (size_t)si * (3 * kBtSeq / 32));
+    u32 de = 0, ds = 0, dz = 0;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        de |= (keep_e[k] == 0 ? 1u : 0u) << k;
+        ds |= (keep_s[k] == 0 ? 1u : 0u) << k;
+        dz |= (keep_z[k] == 0 ? 1u : 0u) << k;
+    }
+    db[tid] = (unsigned char)de;
+    db[kBtSeq / 8 + tid] = (unsigned char)ds;
+    db[2 * kBtSeq / 8 + tid] = (unsigned char)dz;
     if (tid == 0) {
         sg.m_new = m_new;
         if (fits) sg.flags = s.flags | BT_TRIMMED;
@@ -196,7 +211,7 @@ __global__ __launch_bounds__(kBtT) void bt_scatter_kernel(BtArgs a)
 {
     // which cursors this workgroup has seen at their limit (they stay there): a pile of 10^5 equal keys
     // then costs one look at global memory per workgroup, not one per key
-    __shared__ unsigned char done[3 * kBtSeq];
+    __shared__ u32 done[3 * kBtSeq / 32]; // bit per (type, bin): nothing (more) to take there
     const u32 c = blockIdx.x, si = a.chunk_seg[c];
     const BtSeg s = a.seg[si];
     if (!(s.flags & BT_TRIMMED)) return;
@@ -204,18 +219,19 @@ __global__ __launch_bounds__(kBtT) void bt_scatter_kernel(BtArgs a)
     u32 *cur = a.cur + (size_t)si * 3 * kBtSeq;
     const u32 *lim = a.lim + (size_t)si * 3 * kBtSeq;
     u32 *tk = a.tkeys + (size_t)si * kBtCap;
-    for (u32 b = threadIdx.x; b < 3u * kBtSeq / 4u; b += kBtT) reinterpret_cast<u32 *>(done)[b] = 0;
+    static_assert(PER8 == 8, "the plan kernel writes one byte per thread and type");
+    for (u32 b = threadIdx.x; b < 3u * kBtSeq / 32u; b += kBtT) done[b] = a.drop[(size_t)si * (3 * kBtSeq / 32) + b];
     __syncthreads();
     const u32 i0 = (c - s.chunk_off) * kBtChunk, i1 = min(i0 + (u32)kBtChunk, s.n);
     const uint2 *iv = a.iv + s.iv_off;
     auto put = [&](u32 key, u32 at) {
-        if (done[at]) return;
+        if ((done[at >> 5] >> (at & 31u)) & 1u) return;
         const u32 l = lim[at];
         if (__hip_atomic_load(&cur[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < l) {
             const u32 p = atomicAdd(&cur[at], 1u);
             if (p < l) tk[p] = key;
         } else {
-            done[at] = 1;
+            atomicOr(&done[at >> 5], 1u << (at & 31u));
         }
     };
     for (u32 i = i0 + threadIdx.x; i < i1; i += 4 * kBtT) {

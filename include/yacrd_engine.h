@@ -85,6 +85,10 @@ typedef struct {
  * Engines created on the same device (one host thread each) pipeline their batches: they take
  * turns with the dominant sweep launch, everything else overlaps. */
 #define YACRD_F_BLOCKING_WAIT 2048u
+/* the register-sort classes never defer the reads their filter cannot thin to a launch of their own
+ * (by default they do when the fused launch holds >= 40 M intervals); 8192: always defer; A/B only */
+#define YACRD_F_NO_DEFER 4096u
+#define YACRD_F_ALWAYS_DEFER 8192u
 
 /* Host-side result, allocated by the engine, released with yacrd_result_free(). */
 typedef struct {

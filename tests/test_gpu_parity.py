@@ -388,3 +388,27 @@ def test_skewed_profile_without_prefilter_and_with_degenerates():
     for flags in (0, yacrd_amd.F_NO_PREFILTER):
         with yacrd_amd.Engine(flags=flags) as e:
             assert_same(e.run(offsets, intervals, lengths, 4, 0.4), want, "flags %d" % flags)
+
+
+# ---- the deferring build of the fused register-sort kernel (pile trimming at position 0 / len, reads
+# the filter cannot thin finished by sweep_deferred_kernel) against the oracle and the other build ----
+@pytest.mark.parametrize("cov", [0, 1, 4, 9, 40])
+def test_fused_defer_build(cov):
+    from yacrd_amd import host
+    rng = np.random.default_rng(11)
+    sizes = np.concatenate([rng.integers(65, 257, size=3000), [65, 128, 129, 256], rng.integers(1, 65, size=300)])
+    lengths = np.concatenate([rng.integers(1, 300, size=300), rng.integers(300, 150000, size=3004)])
+    csr = make_csr(1900 + cov, sizes, REGULAR_MODES, lengths=lengths, mode_block=256)
+    want = oracle.run(csr[0], csr[1], csr[2].astype(np.uint64), cov, 0.4, n_threads=4)
+    for prof, R, O in ((host.SYNTH_ONT, 6000, 300000), (host.SYNTH_SEQUEL, 3000, 300000)):
+        o, iv, ln = host.synth_csr(prof, R, O, 5 + cov)
+        w2 = oracle.run(o, iv, ln.astype(np.uint64), cov, 0.4, n_threads=4)
+        for flags in (yacrd_amd.F_ALWAYS_DEFER, yacrd_amd.F_NO_DEFER):
+            with yacrd_amd.Engine(flags=flags | yacrd_amd.F_COUNT_PREFILTERED) as e:
+                assert_same(e.run(o, iv, ln, cov, 0.4), w2, "profile %d flags %d" % (prof, flags))
+                if cov <= 4:
+                    assert e.timing()["prefiltered_reads"] > R // 2
+    for flags in (yacrd_amd.F_ALWAYS_DEFER, yacrd_amd.F_NO_DEFER):
+        with yacrd_amd.Engine(flags=flags) as e:
+            assert_same(e.run(*csr, cov, 0.4), want, "cases flags %d" % flags)
+            assert_same(e.run(*csr, cov, 0.4), want, "cases flags %d, predicted run" % flags)

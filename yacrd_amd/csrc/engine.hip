@@ -291,7 +291,7 @@ int wait_for_stream(yacrd_engine *e)
 }
 
 int conclude_run(yacrd_engine *e, yk::Counters c0, bool predicted, uint64_t n_reads64, uint64_t n_iv,
-                 const int *cls_b, const int *cls_e, bool fused_marked, float extra_ms);
+                 const int *cls_b, const int *cls_e, bool fused_marked, bool deferred_marked, float extra_ms);
 
 } // namespace
 
@@ -316,7 +316,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     }
 
     const u32 nb = (n_reads + yk::kScanBlock - 1) / yk::kScanBlock;
-    constexpr int kLists = yk::CLS_COUNT + 4; // class lists + three rejection lists + M2 overflow
+    constexpr int kLists = yk::CLS_COUNT + 5; // class lists + three rejection lists + M2 overflow + R16 / H16 deferred
     HIP_TRY(e->lists.reserve((size_t)kLists * n_reads * sizeof(u32)));
     const size_t ctrl_bytes = (sizeof(yk::Counters) + (size_t)nb * sizeof(u64) + 255) & ~(size_t)255;
     e->ctrl_cur ^= 1;
@@ -336,8 +336,12 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     e->last_list_stride = n_reads;
     auto list_of = [&](int i) { return lists + (size_t)i * n_reads; };
     u32 *rej_small = list_of(yk::CLS_COUNT), *rej_med = list_of(yk::CLS_COUNT + 1),
-        *rej_big = list_of(yk::CLS_COUNT + 2), *over_med = list_of(yk::CLS_COUNT + 3);
+        *rej_big = list_of(yk::CLS_COUNT + 2), *over_med = list_of(yk::CLS_COUNT + 3),
+        *over_small = list_of(yk::CLS_COUNT + 4);
     yk::Counters *ctr = e->ctrl2[cur].as<yk::Counters>();
+    // reads the fused kernel's filter deferred (it could not thin them): counted in a spare slot of
+    // Counters.n (the plan kernel only fills the class slots)
+    u32 *over_small_n = &ctr->n[12];
     const bool full = (e->flags & YACRD_F_TIMING_FULL) != 0;
     const int xm = (e->flags & YACRD_F_XLANE_DS) ? 1 : 0;
 
@@ -433,7 +437,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     };
 
     bool skip_rejected_small = predicted && e->pred.rej_small == 0, skipped_small = false;
-    bool fused_marked = false;
+    bool fused_marked = false, deferred_marked = false;
     // sweeps of the classes in `set`, then the LDS exact path for what they rejected
     auto launch_sweeps = [&](const LaunchSet &set) -> int {
         bool any_small = false;
@@ -445,6 +449,13 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         if (fuse) {
             yk::FusedArgs fa;
             fa.base = sa;
+            // R16 / H16 reads their filter cannot thin: deferred to a launch of their own when the fused
+            // launch is long enough to pay for it (~6 us)
+            const u64 fused_iv = set.iv[yk::CLS_R16] + set.iv[yk::CLS_H16];
+            const bool defer = sa.prefilter && !(e->flags & YACRD_F_NO_DEFER) &&
+                               ((e->flags & YACRD_F_ALWAYS_DEFER) || fused_iv >= 40000000ull);
+            fa.base.over_list = defer ? over_small : nullptr;
+            fa.base.over_count = defer ? over_small_n : nullptr;
             fa.n_entries = 0;
             u32 blocks = 0;
             bool has_dom = false;
@@ -477,14 +488,33 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
                 // start / stop events attached to the launch itself (hipExtLaunchKernelGGL): the
                 // kernel's own dispatch timestamps, no event packets before and after it
                 const bool chain = shared || lane.n_engines > 1;
-                hipExtLaunchKernelGGL(yk::sweep_small_fused_kernel, dim3(blocks), dim3(256), 0,
-                                      e->stream, mark ? e->ev_cls[22] : (hipEvent_t) nullptr,
-                                      (mark || chain) ? e->ev_cls[23] : (hipEvent_t) nullptr, 0, fa);
+                if (defer)
+                    hipExtLaunchKernelGGL(yk::sweep_small_fused_defer_kernel, dim3(blocks), dim3(256), 0,
+                                          e->stream, mark ? e->ev_cls[22] : (hipEvent_t) nullptr,
+                                          (mark || chain) ? e->ev_cls[23] : (hipEvent_t) nullptr, 0, fa);
+                else
+                    hipExtLaunchKernelGGL(yk::sweep_small_fused_kernel, dim3(blocks), dim3(256), 0,
+                                          e->stream, mark ? e->ev_cls[22] : (hipEvent_t) nullptr,
+                                          (mark || chain) ? e->ev_cls[23] : (hipEvent_t) nullptr, 0, fa);
                 if (mark || chain) {
                     lane.last = e->ev_cls[23];
                     lane.owner = e;
                 }
                 if (mark) fused_marked = true;
+                // the reads the filter deferred, sorted whole in a launch of their own
+                if (defer && (set.n[yk::CLS_R16] || set.n[yk::CLS_H16])) {
+                    yk::SweepArgs da = sa;
+                    da.prefilter = 0;
+                    da.over_list = nullptr;
+                    da.over_count = nullptr;
+                    da.first = 0;
+                    da.list = over_small;
+                    da.list_n = over_small_n;
+                    hipExtLaunchKernelGGL(yk::sweep_deferred_kernel, dim3(e->num_cu * 4), dim3(256), 0, e->stream,
+                                          mark ? e->ev_cls[20] : (hipEvent_t) nullptr,
+                                          mark ? e->ev_cls[21] : (hipEvent_t) nullptr, 0, da);
+                    if (mark) deferred_marked = true;
+                }
             }
         }
         for (int cls = yk::CLS_R2; cls <= yk::CLS_W16; cls++) { // register sort per lane group
@@ -616,6 +646,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         }
         p.skipped_small = skipped_small;
         p.fused_marked = fused_marked;
+        p.deferred_marked = deferred_marked;
         return YACRD_OK;
     }
     // (spinning on the pinned counter block instead of this call was tried: 0.0816 vs 0.078 ms/step)
@@ -685,7 +716,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     }
     if (e->h_ctr->region_overflow) return fail(YACRD_EINTERNAL, "bad_regions overflow persisted");
 
-    return conclude_run(e, c0, predicted, n_reads64, n_iv, cls_b, cls_e, fused_marked, extra_ms);
+    return conclude_run(e, c0, predicted, n_reads64, n_iv, cls_b, cls_e, fused_marked, deferred_marked, extra_ms);
 }
 } // namespace yke
 
@@ -693,7 +724,7 @@ namespace {
 
 // Bookkeeping after a run's last sync: result sizes, the next run's prediction, timing.
 int conclude_run(yacrd_engine *e, yk::Counters c0, bool predicted, uint64_t n_reads64, uint64_t n_iv,
-                 const int *cls_b, const int *cls_e, bool fused_marked, float extra_ms)
+                 const int *cls_b, const int *cls_e, bool fused_marked, bool deferred_marked, float extra_ms)
 {
     const bool full = (e->flags & YACRD_F_TIMING_FULL) != 0;
     const u32 n_reads = (u32)n_reads64;
@@ -745,6 +776,8 @@ int conclude_run(yacrd_engine *e, yk::Counters c0, bool predicted, uint64_t n_re
     t.prefiltered_reads = c1.prefiltered;
     if (fused_marked) {
         t.fused_ms = ev_ms(e->ev_cls[22], e->ev_cls[23]);
+        // (the launch that finishes the reads the fused kernel's filter deferred belongs to it)
+        if (deferred_marked) t.fused_ms += ev_ms(e->ev_cls[20], e->ev_cls[21]);
         for (int cls = yk::CLS_R2; cls <= yk::CLS_H16; cls++) {
             t.fused_reads += c0.n[cls];
             t.fused_intervals += c0.iv[cls];
@@ -787,7 +820,7 @@ int finish_pending(yacrd_engine *e)
         e->pred_valid = false;
         return run_on_device(e, p.d_off, p.d_iv, p.d_len, p.n_reads, p.n_iv, p.cov, p.not_cov);
     }
-    return conclude_run(e, c, true, p.n_reads, p.n_iv, p.cls_b, p.cls_e, p.fused_marked, 0.f);
+    return conclude_run(e, c, true, p.n_reads, p.n_iv, p.cls_b, p.cls_e, p.fused_marked, p.deferred_marked, 0.f);
 }
 
 } // namespace

@@ -106,7 +106,7 @@ struct Pending {
     uint32_t cov = 0;
     double not_cov = 0;
     u32 grid_n[12] = {};      // reads each class's grid covers
-    bool skipped_small = false, fused_marked = false;
+    bool skipped_small = false, fused_marked = false, deferred_marked = false;
     int cls_b[12] = {}, cls_e[12] = {};
 };
 

@@ -360,16 +360,180 @@ __device__ __forceinline__ void wave_lds_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// LDS scratch of one wavefront for the pre-filter: bin counters of every group + compacted keys.
-// A bin has four counters (one per lane & 3): the reads' hot bins (dovetails start at 0 and end at
-// len) would otherwise serialise the LDS atomics of a row.
-constexpr int kFilterTabWords = 272, kFilterKeyWords = 512;
+// LDS scratch of one wavefront for the filter: per group LANES coarse bins + the pads' bin + two
+// one-position bins, four counters each (one per lane & 3: the reads' hot bins would otherwise
+// serialise the LDS atomics of a row), then the compacted keys of every group.
+constexpr int kFilterTabWords = 304, kFilterKeyWords = 512;
 __device__ __forceinline__ u32 *wave_filter_scratch()
 {
     __shared__ __attribute__((aligned(16))) u32 s_scratch[4][kFilterTabWords + kFilterKeyWords];
     return s_scratch[threadIdx.x >> 6];
 }
 
+// ---- coverage pre-filter with pile trimming at the two ends of the read (DESIGN.md §3.4 / §3.5;
+// tests/formulation.py::trim_keys is the emulation, F = 1) ------------------------------------------
+// Bins: NB = LANES coarse bins of 2^sh positions, one per lane, plus one bin for position 0 and
+// one for position `len` — where dovetail overlaps clamp: on configs[1] 15 % of a read's starts sit
+// at exactly 0 and 15 % of its ends at exactly len.  In key order: [starts at 0][coarse 0 .. NB-1]
+// [ends at len] (nothing else can lie at those two positions: an end is > 0, a start < len).
+//   * coarse bin spanned by more than c intervals (depth at its head - its ends > c): every event in
+//     it is deep (depth above c on both sides) and dropped; otherwise the bin is kept whole;
+//   * starts at 0: the j-th one has depth j, so only the first c + 1 are kept; ends at len: the
+//     depth before the j-th of E is E - j, so only the last c + 1 are kept.  Equal keys: which of
+//     them does not matter.
+// Each maximal run of dropped events is stood in for by |net| keys of one type in front of the next
+// bin that keeps something (net = depth after the run - depth before it; 0 for a healthy read), so
+// the depth of every kept event is unchanged.  Pass 1 counts (one LDS atomic per key, starts in
+// the low half of a counter, ends in the high half), the lanes turn the counters into packed cursors
+// quota << 16 | next slot, pass 2 asks them (one LDS atomic per key: kept or not, and where).
+// A group that keeps more than LANES * K / 2 keys (a read with low coverage throughout: nothing
+// can be dropped) is HEAVY: with DEFER it is reported through `heavy` and goes on empty — the
+// caller appends the read to the overflow list, sweep_deferred_kernel sorts it whole — so that one
+// such read does not drag the other reads of its wavefront into the full sort (and the full sort
+// is not even part of that code path: fewer registers, one more wavefront per SIMD).
+// Returns the tier: 0 = sort everything as before, 1 = every group kept <= LANES keys (y1: one
+// key per lane), 2 = y: K / 2 keys per lane.  Only for wavefronts whose intervals are all plain
+// (start < end <= len).
+template <int LANES, int K, bool DEFER>
+__device__ __forceinline__ int trimfilter(const u32 (&x)[K], u32 n, u32 len, i32 c,
+                                          u32 (&y1)[1], u32 (&y)[K / 2], u32 &m_out, bool &heavy)
+{
+    static_assert(K == 16, "a lane reads its K/2 = 8 compacted keys as two 16-byte vectors");
+    constexpr int NB = LANES, NBIN = LANES + 3, CAP = LANES * K / 2, GROUPS = 64 / LANES;
+    constexpr u32 kTakeOne = 0xFFFF0001u; // quota - 1, slot + 1
+    constexpr u32 kPadBin = NB, kHeadBin = NB + 1, kTailBin = NB + 2;
+    static_assert(GROUPS * NBIN * 4 <= kFilterTabWords && GROUPS * CAP <= kFilterKeyWords, "scratch");
+    const u32 lane = lane_id(), lig = lane & (u32)(LANES - 1), grp = lane / (u32)LANES;
+    u32 *scratch = wave_filter_scratch();
+    u32 *tab = scratch + grp * (u32)(NBIN * 4);
+    u32 *keys = scratch + kFilterTabWords + grp * (u32)CAP;
+    uint4 *bins = reinterpret_cast<uint4 *>(tab);
+    uint4 *my_keys = reinterpret_cast<uint4 *>(keys) + lig * 2u;
+    char *tb = reinterpret_cast<char *>(tab);
+    heavy = false;
+
+    // smallest shift with (len >> sh) < NB: the bin holding `len` exists inside the table
+    const i32 bits = 32 - (i32)__builtin_clz(len | 1u) - ilog2c(NB) + (len != 0 ? 0 : -1);
+    const u32 sh = (u32)max(bits, 0), ksh = sh + kKeyShift, lenk = len << kKeyShift;
+
+    bins[lig] = make_uint4(0u, 0u, 0u, 0u);
+    if (lig < 3u) bins[NB + lig] = make_uint4(0u, 0u, 0u, 0u);
+    my_keys[0] = make_uint4(kPadKey, kPadKey, kPadKey, kPadKey);
+    my_keys[1] = make_uint4(kPadKey, kPadKey, kPadKey, kPadKey);
+    wave_lds_sync();
+
+    // ---- pass 1: count.  Byte offset of a key's counter = bin * 16 + (lane & 3) * 4; the pads
+    // (0xFFFFFFFE, in the slots of intervals the read does not have) clamp into the pads' bin
+    const u32 cp = (lig & 3u) * 4u, head_off = kHeadBin * 16u + cp, tail_off = kTailBin * 16u + cp;
+    // (computed again in pass 2 rather than kept: sixteen registers less between the passes buy one
+    // more wavefront per SIMD, and the kernel is bound by how many wavefronts overlap their latencies)
+    auto off_start = [&](u32 ks) { return ks == 3u ? head_off : (min(ks >> ksh, (u32)NB) << 4) + cp; };  // a start at 0
+    auto off_end = [&](u32 ke) { return ke == lenk ? tail_off : (min(ke >> ksh, (u32)NB) << 4) + cp; }; // an end at len
+#pragma unroll
+    for (int j = 0; j < K / 2; j++) {
+        atomicAdd(reinterpret_cast<u32 *>(tb + off_start(x[2 * j])), 1u);
+        atomicAdd(reinterpret_cast<u32 *>(tb + off_end(x[2 * j + 1])), 0x10000u);
+    }
+    wave_lds_sync();
+
+    // ---- what the bins keep
+    const int last_addr = (int)((lane | (u32)(LANES - 1)) << 2);
+    auto row_total = [&](u32 v) { return (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)v); };
+    const uint4 c4 = bins[lig], h4 = bins[kHeadBin], t4 = bins[kTailBin];
+    const u32 w = c4.x + c4.y + c4.z + c4.w;
+    const i32 S = (i32)(w & 0xFFFFu), E = (i32)(w >> 16);
+    const i32 S0 = (i32)((h4.x + h4.y + h4.z + h4.w) & 0xFFFFu);  // starts at 0
+    const i32 E1 = (i32)((t4.x + t4.y + t4.z + t4.w) >> 16);      // ends at len
+    const i32 ks0 = min(S0, c + 1), ke1 = min(E1, c + 1);
+    const u32 incl = gscan_add<LANES>(w); // packed: both halves scanned at once
+    const u32 ex = incl - w;
+    const i32 D = S0 + (i32)(ex & 0xFFFFu) - (i32)(ex >> 16);     // depth at the head of this lane's bin
+    const bool deep = D - E > c;                                   // spanned by more than c intervals
+    // (sequence index + 1) << 16 | depth after the kept block, for bins that keep something
+    const u32 tag = deep ? 0u : (((lig + 2u) << 16) | (u32)(D - E + S));
+    const u32 tag0 = S0 > 0 ? ((1u << 16) | (u32)ks0) : 0u;
+    const u32 mi = gscan_max<LANES>(tag);
+    u32 exm = gshift_up1<LANES>(mi);
+    if (LANES == 16 && lig == 0) exm = 0; // (row_shr pulls nothing in, bound_ctrl zero: explicit for clarity)
+    const u32 prev = max(exm, tag0);
+    const i32 net = deep ? 0 : D - (i32)(prev & 0xFFFFu);
+    const u32 nsyn = (u32)(net < 0 ? -net : net);
+    const i32 a_last = (i32)(max(row_total(mi), tag0) & 0xFFFFu);
+    const i32 net1 = E1 > 0 ? ke1 - a_last : 0;
+    const u32 nsyn1 = (u32)(net1 < 0 ? -net1 : net1);
+    const u32 keep = deep ? 0u : (u32)(S + E);
+    const u32 mine = keep + nsyn;
+    const u32 ri = gscan_add<LANES>(mine);
+    const u32 coarse_total = row_total(ri);
+    const u32 base = (u32)ks0 + ri - mine;
+    const u32 tail_base = (u32)ks0 + coarse_total;
+    u32 m = tail_base + (u32)ke1 + nsyn1;
+    heavy = m > (u32)CAP;
+    if constexpr (DEFER) m = heavy ? 0u : m; // its read goes to the overflow list; the group goes on empty
+    else if (__builtin_amdgcn_ballot_w64(heavy) != 0) return 0; // the wavefront sorts everything
+    {
+        // cursors: a coarse bin's copies keep everything (quota 0x7FFF) or nothing
+        const u32 q = (deep || heavy) ? 0u : 0x7FFF0000u;
+        const u32 n0 = (c4.x & 0xFFFFu) + (c4.x >> 16), n1 = (c4.y & 0xFFFFu) + (c4.y >> 16),
+                  n2 = (c4.z & 0xFFFFu) + (c4.z >> 16);
+        bins[lig] = make_uint4(q | base, q | (base + n0), q | (base + n0 + n1), q | (base + n0 + n1 + n2));
+        // the two one-position bins hold one type each: their quota is dealt out to the four copies
+        if (lig < 2u) {
+            const uint4 s4 = lig ? t4 : h4;
+            const u32 sh2 = lig ? 16u : 0u;
+            const u32 keep2 = heavy ? 0u : (u32)(lig ? ke1 : ks0), b2 = lig ? tail_base : 0u;
+            const u32 k0 = (s4.x >> sh2) & 0xFFFFu, k1 = (s4.y >> sh2) & 0xFFFFu, k2 = (s4.z >> sh2) & 0xFFFFu;
+            const u32 q0 = min(k0, keep2), q1 = min(k1, keep2 - q0), q2 = min(k2, keep2 - q0 - q1),
+                      q3 = keep2 - q0 - q1 - q2;
+            bins[kHeadBin + lig] = make_uint4((q0 << 16) | b2, (q1 << 16) | (b2 + q0), (q2 << 16) | (b2 + q0 + q1),
+                                              (q3 << 16) | (b2 + q0 + q1 + q2));
+        }
+        if (lig == 2u) bins[kPadBin] = make_uint4(0u, 0u, 0u, 0u); // the pads: quota 0
+    }
+    if (__builtin_amdgcn_ballot_w64(((nsyn | nsyn1) != 0) && !heavy) != 0) { // rare: net != 0 somewhere
+        if (!heavy) {
+            // starts go right in front of the bin (position - 1, start class; position 0: among the
+            // starts at 0), ends to its head
+            const u32 pk = (lig << sh) << kKeyShift;
+            const u32 synkey = net > 0 ? max(pk, 4u) - 1u : pk;
+#pragma unroll 1
+            for (u32 t = 0; t < nsyn; t++) keys[base + keep + t] = synkey;
+            if (lig == 0) {
+                const u32 synkey1 = net1 > 0 ? lenk - 1u : lenk;
+#pragma unroll 1
+                for (u32 t = 0; t < nsyn1; t++) keys[tail_base + (u32)ke1 + t] = synkey1;
+            }
+        }
+    }
+    wave_lds_sync();
+
+    // ---- pass 2: every key asks the cursor it counted on
+#pragma unroll
+    for (int q0 = 0; q0 < K; q0 += 8) {
+        u32 got[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++)
+            got[q] = atomicAdd(reinterpret_cast<u32 *>(tb + ((q & 1) ? off_end(x[q0 + q]) : off_start(x[q0 + q]))), kTakeOne);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            if ((i32)got[q] >= 0x10000) keys[got[q] & 0xFFFFu] = x[q0 + q];
+        }
+    }
+    wave_lds_sync();
+    m_out = m;
+    if (__builtin_amdgcn_ballot_w64(m > (u32)LANES) == 0) { // every group fits one key per lane
+        y1[0] = keys[lig];
+        return 1;
+    }
+    const uint4 lo = my_keys[0], hi = my_keys[1];
+    y[0] = lo.x, y[1] = lo.y, y[2] = lo.z, y[3] = lo.w;
+    y[4] = hi.x, y[5] = hi.y, y[6] = hi.z, y[7] = hi.w;
+    return 2;
+}
+
+// ---- the bin filter without trimming (round 1): used by the builds that do not
+// defer (sweep_small_fused_kernel for short launches, the one-read-per-wavefront class), where the
+// 16-keys-per-lane fallback is part of the code path and this leaner filter fits 96 registers ------
 template <int LANES, int K>
 __device__ __forceinline__ bool prefilter(const u32 (&x)[K], u32 n, u32 len, i32 c, u32 (&y)[K / 2],
                                           u32 &m_out)
@@ -464,7 +628,7 @@ __device__ __forceinline__ bool prefilter(const u32 (&x)[K], u32 n, u32 len, i32
 }
 
 // ---- one read per group of LANES lanes: loads, keys, (pre-filter,) sweep ------------------------
-template <int LANES, int K, int XM>
+template <int LANES, int K, int XM, bool DEFER = false>
 __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u32 n, u32 len,
                                                  u32 cov, bool active, u32 r,
                                                  const SweepArgs &a, const LaneConst &lc)
@@ -525,7 +689,22 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
     // two zero-length intervals at one position: only looked for when the wavefront saw >= 2
     const bool zl_check = (zmask & (zmask - 1)) != 0 || __builtin_amdgcn_ballot_w64(nz > 2) != 0;
 
-    if constexpr (K == 16) {
+    if constexpr (K == 16 && DEFER) {
+        if (a.prefilter && plain) { // uniform
+            u32 y1[1], y[K / 2], mf;
+            bool heavy;
+            const int tier = trimfilter<LANES, K, true>(x, n, len, c, y1, y, mf, heavy);
+            (void)tier; // 1 or 2: with DEFER the filter always delivers
+            if (a.prefilter == 2 && lig == 0 && active && !heavy) atomicAdd(&a.ctr->prefiltered, 1u);
+            const bool act = active && !heavy; // a heavy read is finished by sweep_deferred_kernel
+            if (tier == 1) sweep_group_keys<LANES, 1, XM>(y1, mf, len, c, act, r, badmask, zmask, zl_check, a, lc);
+            else sweep_group_keys<LANES, K / 2, XM>(y, mf, len, c, act, r, badmask, zmask, zl_check, a, lc);
+            // a read the filter could not thin goes to the overflow list: sweep_deferred_kernel sorts it
+            // whole, one read per wavefront
+            if (heavy && lig == LANES - 1 && active) a.over_list[atomicAdd(a.over_count, 1u)] = r;
+            return;
+        }
+    } else if constexpr (K == 16) {
         if (a.prefilter && plain) { // uniform
             u32 y[K / 2], mf;
             if (prefilter<LANES, K>(x, n, len, c, y, mf)) {
@@ -540,7 +719,7 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
 }
 
 // Body of one workgroup (four wavefronts, 4 * 64/LANES reads) of class (LANES, K).
-template <int LANES, int K, int XM>
+template <int LANES, int K, int XM, bool DEFER = false>
 __device__ __forceinline__ void sweep_group_block(const SweepArgs &a, u32 block)
 {
     const u32 lane = lane_id();
@@ -564,7 +743,7 @@ __device__ __forceinline__ void sweep_group_block(const SweepArgs &a, u32 block)
         n = (u32)(a.off[r + 1] - o);
         len = a.len[r];
     }
-    sweep_group_read<LANES, K, XM>(a.iv + o, n, len, a.cov, active, r, a, lc);
+    sweep_group_read<LANES, K, XM, DEFER>(a.iv + o, n, len, a.cov, active, r, a, lc);
 }
 
 // One kernel per (LANES, K): small K keep small register footprints.
@@ -587,6 +766,28 @@ inline void launch_sweep_group(const SweepArgs &sa, u32 n_reads, hipStream_t str
                            stream, sa);
 }
 
+// The reads the filter deferred (low coverage throughout: every event kept), sorted whole: one read
+// per wavefront on all 64 lanes (4 keys per lane up to 128 intervals, 8 up to 256: a short serial
+// chain per wavefront instead of the 16-keys-per-lane sort their class would run).  A persistent
+// grid; the count is only known on the device.
+__global__ __launch_bounds__(256) void sweep_deferred_kernel(SweepArgs a)
+{
+    const u32 lane = lane_id();
+    LaneConst lc;
+#pragma unroll
+    for (int i = 0; i < 6; i++) lc.k[i] = (lane & (1u << i)) ? 0xFFFFFFFFu : 0u;
+    lc.k[6] = 0;
+    lc.addr32 = (lane ^ 32u) << 2;
+    const u32 n_list = *a.list_n;
+    for (u32 w = blockIdx.x * 4u + (threadIdx.x >> 6); w < n_list; w += gridDim.x * 4u) { // wave-uniform
+        const u32 r = a.list[w];
+        const u64 o = a.off[r];
+        const u32 n = (u32)(a.off[r + 1] - o), len = a.len[r];
+        if (n <= 128u) sweep_group_read<64, 4, 0>(a.iv + o, n, len, a.cov, true, r, a, lc);
+        else sweep_group_read<64, 8, 0>(a.iv + o, n, len, a.cov, true, r, a, lc);
+    }
+}
+
 // ---- every register-sort class in ONE launch ------------------------------------------------
 // The classes R2..H16 are independent; launched one after the other each pays its own ramp-up
 // and drain (~4-7 us for the minor ones on configs[1]).  Here the grid is the concatenation of
@@ -601,7 +802,8 @@ struct FusedArgs {
     const u32 *list_n[5];
 };
 
-__global__ __launch_bounds__(256, 5) void sweep_small_fused_kernel(FusedArgs f)
+template <bool DEFER>
+__device__ __forceinline__ void sweep_small_fused_body(const FusedArgs &f)
 {
     u32 e = 0, first = 0;
     while (e + 1 < f.n_entries && blockIdx.x >= f.block_end[e]) {
@@ -617,9 +819,23 @@ __global__ __launch_bounds__(256, 5) void sweep_small_fused_kernel(FusedArgs f)
     case CLS_R2: sweep_group_block<16, 2, 0>(a, b); break;
     case CLS_R4: sweep_group_block<16, 4, 0>(a, b); break;
     case CLS_R8: sweep_group_block<16, 8, 0>(a, b); break;
-    case CLS_R16: sweep_group_block<16, 16, 0>(a, b); break;
-    default: sweep_group_block<32, 16, 0>(a, b); break;
+    case CLS_R16: sweep_group_block<16, 16, 0, DEFER>(a, b); break;
+    default: sweep_group_block<32, 16, 0, DEFER>(a, b); break;
     }
+}
+// Two builds.  DEFER: a read the filter cannot thin goes to f.base.over_list (sweep_deferred_kernel
+// finishes it) instead of dragging its wavefront into the 16-keys-per-lane sort; without that sort
+// in the filtered path the kernel fits 80 registers, six workgroups per CU, and it is bound by how
+// many wavefronts overlap their latencies (configs[2]: 1.90 -> 1.43 ms).  The extra launch costs
+// ~6 us however little it has to do, so batches whose fused launch is shorter than ~0.2 ms use the
+// other build (the engine decides by the classes' interval count).
+__global__ __launch_bounds__(256, 6) void sweep_small_fused_defer_kernel(FusedArgs f)
+{
+    sweep_small_fused_body<true>(f);
+}
+__global__ __launch_bounds__(256, 5) void sweep_small_fused_kernel(FusedArgs f)
+{
+    sweep_small_fused_body<false>(f);
 }
 
 inline u32 sweep_group_reads_per_block(int cls)

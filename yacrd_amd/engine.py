@@ -23,6 +23,8 @@ F_NO_PREFILTER = 256
 F_COUNT_PREFILTERED = 512
 F_NO_TIMING = 1024
 F_BLOCKING_WAIT = 2048
+F_NO_DEFER = 4096
+F_ALWAYS_DEFER = 8192
 
 # every symbol include/yacrd_engine.h declares
 EXPORTED_SYMBOLS = [

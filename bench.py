@@ -193,6 +193,13 @@ def main():
         # launch itself (hipExtLaunchKernelGGL: the dispatch's own timestamps, the figure rocprofv3
         # --kernel-trace reports), averaged over every launch of the timed region.
         dom, cname, dom_ms, c_reads, c_iv = dominant(t, K, yacrd_amd)
+        # reads the fused kernel's filter could not thin are finished by sweep_deferred_kernel: the
+        # fused kernel loads and bins them, but its bytes only count the reads it completes
+        deferred = int(t.get("deferred_reads", 0)) if cname == "R2..H16" else 0
+        if deferred:
+            dom = "sweep_small_fused_defer_kernel"
+            c_iv -= c_iv * deferred // max(c_reads, 1)
+            c_reads -= deferred
         b_dom = 8 * c_iv + 21 * c_reads + 16 + 8 * (G * c_reads // max(R, 1))
         achieved = b_dom / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         avg["class_ms"] = {yacrd_amd.CLASS_NAMES[i]: t["class_ms"][i] / K for i in range(12) if t["class_ms"][i] > 0}
@@ -235,6 +242,7 @@ def main():
                          "traffic": traffic, "algorithmic_bytes": b_dom, "kernel_ms": dom_ms,
                          "empty_event_bracket_ms": ev_overhead_ms,
                          "kernel_reads": c_reads, "kernel_intervals": c_iv,
+                         "deferred_reads": deferred, "deferred_kernel_ms": t.get("deferred_ms", 0.0) / K,
                          "whole_path_algorithmic_bytes": b_alg,
                          "note": "batch (82 MB + scratch) fits the 256 MiB Infinity Cache: see large.roofline for the "
                                  "same kernel on a 3.3 GB input"},
@@ -506,6 +514,11 @@ def large_block(yacrd_amd, host, ydist, dist, dev, torch, eng, rank, world, args
         del d_off, d_iv, d_len
         return None
     dom, cname, dom_ms, c_reads, c_iv = dominant(t, K, yacrd_amd)
+    deferred = int(t.get("deferred_reads", 0)) if cname == "R2..H16" else 0
+    if deferred:
+        dom = "sweep_small_fused_defer_kernel"
+        c_iv -= c_iv * deferred // max(c_reads, 1)
+        c_reads -= deferred
     Gl = G
     b_dom = 8 * c_iv + 21 * c_reads + 16 + 8 * (Gl * c_reads // max(Rl, 1))
     ach = b_dom / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -526,6 +539,7 @@ def large_block(yacrd_amd, host, ydist, dist, dev, torch, eng, rank, world, args
                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                         "traffic": large_traffic(R, O) if world == 1 else None, "algorithmic_bytes": b_dom,
                         "kernel_ms": dom_ms, "kernel_reads": c_reads, "kernel_intervals": c_iv,
+                        "deferred_reads": deferred, "deferred_kernel_ms": t.get("deferred_ms", 0.0) / K,
                         "note": "rank 0's launch; input %.2f GB per GPU, outside the 256 MiB Infinity Cache" % (8 * Il / 1e9)}}
     del d_off, d_iv, d_len
     return out

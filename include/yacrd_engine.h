@@ -86,7 +86,7 @@ typedef struct {
  * turns with the dominant sweep launch, everything else overlaps. */
 #define YACRD_F_BLOCKING_WAIT 2048u
 /* the register-sort classes never defer the reads their filter cannot thin to a launch of their own
- * (by default they do when the fused launch holds >= 40 M intervals); 8192: always defer; A/B only */
+ * (by default they do when the fused launch holds >= 4 M intervals); 8192: always defer; A/B only */
 #define YACRD_F_NO_DEFER 4096u
 #define YACRD_F_ALWAYS_DEFER 8192u
 
@@ -135,6 +135,11 @@ typedef struct {
     /* reads whose events were thinned by the coverage pre-filter before the sort (counted only
      * under YACRD_F_COUNT_PREFILTERED) */
     uint64_t prefiltered_reads;
+    /* reads the fused kernel's filter could not thin and handed to sweep_deferred_kernel (they are
+     * part of fused_reads / fused_intervals: the fused kernel loads and bins them), and that launch's
+     * own time (start / stop events attached to it, like fused_ms) */
+    uint64_t deferred_reads;
+    float deferred_ms;
 } yacrd_timing;
 
 /* size classes, in the order of yacrd_timing.class_*: R<K> = four reads per wavefront (16-lane

@@ -349,3 +349,54 @@ def trimmed_events(intervals, length, cov, nb=16, F=32, wave=False):
         if a == b and (a & 3) == 1 and a != 1:
             return None  # two zero-length intervals at one position survive: exact general path
     return sweep_keys(keys, length, cov)
+
+
+def trim_keys_minmax(intervals, length, cov, nb):
+    """The filter of sweep_wave.h's deferring build (`trimfilter`): nb coarse bins of 2^sh positions
+    aligned at 0, plus one bin for the read's SMALLEST START and one for its LARGEST END — where the
+    clamped halves of the dovetail piles sit, at 0 and `length` for a healthy read, at the edges of
+    the covered window for a read that is only covered in part.  Nothing else can lie at those two
+    positions (an end is above its own start, a start below its own end), so in key order the
+    sequence is [starts at pmin][coarse bins][ends at pmax].  Plain reads only (0 <= s < e <= length)."""
+    sh = bin_shift(length, nb)
+    pmin = min(s for s, e in intervals)
+    pmax = max(e for s, e in intervals)
+    S, E = [0] * nb, [0] * nb
+    S0 = E1 = 0
+    keys = []
+    for s, e in intervals:
+        assert 0 <= s < e <= length
+        if s == pmin:
+            S0 += 1
+        else:
+            S[s >> sh] += 1
+        if e == pmax:
+            E1 += 1
+        else:
+            E[e >> sh] += 1
+        keys += [(s << SH) | 3, e << SH]
+    ks0, ke1 = min(S0, cov + 1), min(E1, cov + 1)
+    out = [(pmin << SH) | 3] * ks0 + [pmax << SH] * ke1
+    kmin = (pmin << SH) | 3
+    D, A = S0, ks0
+    for b in range(nb):
+        deep = D - E[b] > cov
+        if not deep and S[b] + E[b] > 0:      # keeps everything; empty bins keep nothing
+            net = D - A
+            pk = (b << sh) << SH
+            out += [max(pk, kmin + 1) - 1] * net if net > 0 else [pk] * (-net)
+            out += [k for k in keys if (k >> SH) >> sh == b and k != kmin and k != (pmax << SH)]
+            A = D - E[b] + S[b]
+        D += S[b] - E[b]
+    assert D == E1
+    net1 = ke1 - A
+    out += [(pmax << SH) - 1] * net1 if net1 > 0 else [pmax << SH] * (-net1)
+    return out
+
+
+def trimmed_minmax_events(intervals, length, cov, nb=16):
+    if len(intervals) == 0:
+        return [(0, length)] if length != 0 else []
+    if any(not (0 <= s < e <= length) for s, e in intervals) or length >= 2**30 - 1:
+        return None
+    return sweep_keys(sorted(trim_keys_minmax(intervals, length, cov, nb)), length, cov)

@@ -97,7 +97,7 @@ def _pile_read(rng, n, L, jitter):
 
 
 def test_pile_trimming_matches_oracle():
-    from formulation import trim_keys, trimmed_events
+    from formulation import trim_keys, trimmed_events, trimmed_minmax_events
     rng = np.random.default_rng(2024)
     kept = total = n_zl_checked = 0
     for it in range(1500):
@@ -121,8 +121,14 @@ def test_pile_trimming_matches_oracle():
                 got = trimmed_events(iv, L, cov, nb, F)
                 assert got == want or (got is None and has_zl), (iv, L, cov, nb, F)
                 n_zl_checked += has_zl and got is not None
-                gw = trimmed_events(iv, L, cov, nb, F, wave=True)  # sweep_wave.h's bin geometry
+                gw = trimmed_events(iv, L, cov, nb, F, wave=True)  # coarse bins aligned at 0
                 assert gw == want or (gw is None and has_zl), (iv, L, cov, nb, F, "wave")
+                if not has_zl:  # sweep_wave.h's deferring build: bins at the smallest start / largest end
+                    assert trimmed_minmax_events(iv, L, cov, nb) == want, (iv, L, cov, nb, "minmax")
+                    if it % 7 == 3:  # a read covered only inside a window: piles at the window's edges
+                        w0, w1 = L // 3, max(L // 3 + 2, 2 * L // 3)
+                        win = [(min(max(s, w0), w1 - 1), min(max(e, min(max(s, w0), w1 - 1) + 1), w1)) for s, e in iv]
+                        assert trimmed_minmax_events(win, L, cov, nb) == oracle.compute_bad_part(win, L, cov), (win, L, cov, nb)
             if cov == 4:
                 total += 2 * len(iv)
                 kept += len(trim_keys(iv, L, cov, 16, 32))
@@ -131,7 +137,7 @@ def test_pile_trimming_matches_oracle():
 
 def test_pile_trimming_tiny_exhaustive():
     import itertools
-    from formulation import trimmed_events
+    from formulation import trimmed_events, trimmed_minmax_events
     for L in range(1, 6):
         pairs = [(s, e) for s in range(L + 1) for e in range(s, L + 1)]  # zero-length ones included
         for k in range(1, 4):
@@ -143,4 +149,6 @@ def test_pile_trimming_tiny_exhaustive():
                         assert got is None or got == want, (iv, L, cov, nb, F)
                         gw = trimmed_events(list(iv), L, cov, nb, min(F, 1), wave=True)
                         assert gw is None or gw == want, (iv, L, cov, nb, F, "wave")
+                        if all(s < e for s, e in iv):
+                            assert trimmed_minmax_events(list(iv), L, cov, nb) == want, (iv, L, cov, nb, "minmax")
                         assert got is not None or regular_events(list(iv), L, cov) is None

@@ -450,10 +450,10 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
             yk::FusedArgs fa;
             fa.base = sa;
             // R16 / H16 reads their filter cannot thin: deferred to a launch of their own when the fused
-            // launch is long enough to pay for it (~6 us)
+            // launch is long enough to pay for it (~4 us: from ~4 M intervals on)
             const u64 fused_iv = set.iv[yk::CLS_R16] + set.iv[yk::CLS_H16];
             const bool defer = sa.prefilter && !(e->flags & YACRD_F_NO_DEFER) &&
-                               ((e->flags & YACRD_F_ALWAYS_DEFER) || fused_iv >= 40000000ull);
+                               ((e->flags & YACRD_F_ALWAYS_DEFER) || fused_iv >= 4000000ull);
             fa.base.over_list = defer ? over_small : nullptr;
             fa.base.over_count = defer ? over_small_n : nullptr;
             fa.n_entries = 0;
@@ -772,12 +772,14 @@ int conclude_run(yacrd_engine *e, yk::Counters c0, bool predicted, uint64_t n_re
     }
     t.class_ms[yk::CLS_GENERAL] = (full && c0.n[yk::CLS_GENERAL]) ? t.sweep_general_ms : 0.f;
     t.fused_ms = 0.f;
+    t.deferred_ms = 0.f;
+    t.deferred_reads = c1.n[12];
     t.fused_reads = t.fused_intervals = 0;
     t.prefiltered_reads = c1.prefiltered;
     if (fused_marked) {
         t.fused_ms = ev_ms(e->ev_cls[22], e->ev_cls[23]);
-        // (the launch that finishes the reads the fused kernel's filter deferred belongs to it)
-        if (deferred_marked) t.fused_ms += ev_ms(e->ev_cls[20], e->ev_cls[21]);
+        // the launch that finishes the reads the fused kernel's filter deferred: timed on its own
+        if (deferred_marked) t.deferred_ms = ev_ms(e->ev_cls[20], e->ev_cls[21]);
         for (int cls = yk::CLS_R2; cls <= yk::CLS_H16; cls++) {
             t.fused_reads += c0.n[cls];
             t.fused_intervals += c0.iv[cls];
@@ -797,6 +799,7 @@ int conclude_run(yacrd_engine *e, yk::Counters c0, bool predicted, uint64_t n_re
     ts.total_ms = keep.total_ms + t.total_ms;
     for (int i = 0; i < 12; i++) ts.class_ms[i] = keep.class_ms[i] + t.class_ms[i];
     ts.fused_ms = keep.fused_ms + t.fused_ms;
+    ts.deferred_ms = keep.deferred_ms + t.deferred_ms;
     e->timing_runs++;
     return YACRD_OK;
 }

@@ -371,14 +371,16 @@ __device__ __forceinline__ u32 *wave_filter_scratch()
 }
 
 // ---- coverage pre-filter with pile trimming at the two ends of the read (DESIGN.md §3.4 / §3.5;
-// tests/formulation.py::trim_keys is the emulation, F = 1) ------------------------------------------
-// Bins: NB = LANES coarse bins of 2^sh positions, one per lane, plus one bin for position 0 and
-// one for position `len` — where dovetail overlaps clamp: on configs[1] 15 % of a read's starts sit
-// at exactly 0 and 15 % of its ends at exactly len.  In key order: [starts at 0][coarse 0 .. NB-1]
-// [ends at len] (nothing else can lie at those two positions: an end is > 0, a start < len).
+// tests/formulation.py::trim_keys_minmax is the emulation) ------------------------------------------
+// Bins: NB = LANES coarse bins of 2^sh positions, one per lane, plus one bin for the read's SMALLEST
+// START position and one for its LARGEST END position — where dovetail overlaps clamp: 0 and `len`
+// for a healthy read (on configs[1] 15 % of a read's starts sit at exactly 0 and 15 % of its ends at
+// exactly len), the edges of the covered window for a read that is only covered in part.  In key
+// order: [starts at pmin][coarse 0 .. NB-1][ends at pmax] (nothing else can lie at those two
+// positions: an end is above its own start, a start below its own end).
 //   * coarse bin spanned by more than c intervals (depth at its head - its ends > c): every event in
 //     it is deep (depth above c on both sides) and dropped; otherwise the bin is kept whole;
-//   * starts at 0: the j-th one has depth j, so only the first c + 1 are kept; ends at len: the
+//   * starts at pmin: the j-th one has depth j, so only the first c + 1 are kept; ends at pmax: the
 //     depth before the j-th of E is E - j, so only the last c + 1 are kept.  Equal keys: which of
 //     them does not matter.
 // Each maximal run of dropped events is stood in for by |net| keys of one type in front of the next
@@ -414,7 +416,7 @@ __device__ __forceinline__ int trimfilter(const u32 (&x)[K], u32 n, u32 len, i32
 
     // smallest shift with (len >> sh) < NB: the bin holding `len` exists inside the table
     const i32 bits = 32 - (i32)__builtin_clz(len | 1u) - ilog2c(NB) + (len != 0 ? 0 : -1);
-    const u32 sh = (u32)max(bits, 0), ksh = sh + kKeyShift, lenk = len << kKeyShift;
+    const u32 sh = (u32)max(bits, 0), ksh = sh + kKeyShift;
 
     bins[lig] = make_uint4(0u, 0u, 0u, 0u);
     if (lig < 3u) bins[NB + lig] = make_uint4(0u, 0u, 0u, 0u);
@@ -425,10 +427,19 @@ __device__ __forceinline__ int trimfilter(const u32 (&x)[K], u32 n, u32 len, i32
     // ---- pass 1: count.  Byte offset of a key's counter = bin * 16 + (lane & 3) * 4; the pads
     // (0xFFFFFFFE, in the slots of intervals the read does not have) clamp into the pads' bin
     const u32 cp = (lig & 3u) * 4u, head_off = kHeadBin * 16u + cp, tail_off = kTailBin * 16u + cp;
-    // (computed again in pass 2 rather than kept: sixteen registers less between the passes buy one
-    // more wavefront per SIMD, and the kernel is bound by how many wavefronts overlap their latencies)
-    auto off_start = [&](u32 ks) { return ks == 3u ? head_off : (min(ks >> ksh, (u32)NB) << 4) + cp; };  // a start at 0
-    auto off_end = [&](u32 ke) { return ke == lenk ? tail_off : (min(ke >> ksh, (u32)NB) << 4) + cp; }; // an end at len
+    // the group's smallest start key and largest end key (the pads are end-like and huge: they never
+    // win the min, and are masked out of the max); a group without intervals matches nothing
+    const int last_addr = (int)((lane | (u32)(LANES - 1)) << 2);
+    auto row_total = [&](u32 v) { return (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)v); };
+    u32 smin = x[0], emax = 0;
+#pragma unroll
+    for (int j = 0; j < K / 2; j++) {
+        smin = min(smin, x[2 * j]);
+        emax = max(emax, x[2 * j + 1] == kPadKey ? 0u : x[2 * j + 1]);
+    }
+    const u32 kmin = n ? row_total(gscan_min<LANES>(smin)) : 1u, kmax = row_total(gscan_max<LANES>(emax));
+    auto off_start = [&](u32 ks) { return ks == kmin ? head_off : (min(ks >> ksh, (u32)NB) << 4) + cp; }; // the smallest start
+    auto off_end = [&](u32 ke) { return ke == kmax ? tail_off : (min(ke >> ksh, (u32)NB) << 4) + cp; };   // the largest end
 #pragma unroll
     for (int j = 0; j < K / 2; j++) {
         atomicAdd(reinterpret_cast<u32 *>(tb + off_start(x[2 * j])), 1u);
@@ -437,26 +448,25 @@ __device__ __forceinline__ int trimfilter(const u32 (&x)[K], u32 n, u32 len, i32
     wave_lds_sync();
 
     // ---- what the bins keep
-    const int last_addr = (int)((lane | (u32)(LANES - 1)) << 2);
-    auto row_total = [&](u32 v) { return (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)v); };
     const uint4 c4 = bins[lig], h4 = bins[kHeadBin], t4 = bins[kTailBin];
     const u32 w = c4.x + c4.y + c4.z + c4.w;
     const i32 S = (i32)(w & 0xFFFFu), E = (i32)(w >> 16);
-    const i32 S0 = (i32)((h4.x + h4.y + h4.z + h4.w) & 0xFFFFu);  // starts at 0
-    const i32 E1 = (i32)((t4.x + t4.y + t4.z + t4.w) >> 16);      // ends at len
+    const i32 S0 = (i32)((h4.x + h4.y + h4.z + h4.w) & 0xFFFFu);  // starts at the smallest start position
+    const i32 E1 = (i32)((t4.x + t4.y + t4.z + t4.w) >> 16);      // ends at the largest end position
     const i32 ks0 = min(S0, c + 1), ke1 = min(E1, c + 1);
     const u32 incl = gscan_add<LANES>(w); // packed: both halves scanned at once
     const u32 ex = incl - w;
     const i32 D = S0 + (i32)(ex & 0xFFFFu) - (i32)(ex >> 16);     // depth at the head of this lane's bin
     const bool deep = D - E > c;                                   // spanned by more than c intervals
-    // (sequence index + 1) << 16 | depth after the kept block, for bins that keep something
-    const u32 tag = deep ? 0u : (((lig + 2u) << 16) | (u32)(D - E + S));
+    // (sequence index + 1) << 16 | depth after the kept block, for bins that keep something (an empty
+    // bin keeps nothing: the bins in front of the smallest start, where D is not the depth, are empty)
+    const u32 tag = (deep || w == 0u) ? 0u : (((lig + 2u) << 16) | (u32)(D - E + S));
     const u32 tag0 = S0 > 0 ? ((1u << 16) | (u32)ks0) : 0u;
     const u32 mi = gscan_max<LANES>(tag);
     u32 exm = gshift_up1<LANES>(mi);
     if (LANES == 16 && lig == 0) exm = 0; // (row_shr pulls nothing in, bound_ctrl zero: explicit for clarity)
     const u32 prev = max(exm, tag0);
-    const i32 net = deep ? 0 : D - (i32)(prev & 0xFFFFu);
+    const i32 net = tag ? D - (i32)(prev & 0xFFFFu) : 0;
     const u32 nsyn = (u32)(net < 0 ? -net : net);
     const i32 a_last = (i32)(max(row_total(mi), tag0) & 0xFFFFu);
     const i32 net1 = E1 > 0 ? ke1 - a_last : 0;
@@ -492,14 +502,14 @@ __device__ __forceinline__ int trimfilter(const u32 (&x)[K], u32 n, u32 len, i32
     }
     if (__builtin_amdgcn_ballot_w64(((nsyn | nsyn1) != 0) && !heavy) != 0) { // rare: net != 0 somewhere
         if (!heavy) {
-            // starts go right in front of the bin (position - 1, start class; position 0: among the
-            // starts at 0), ends to its head
+            // starts go right in front of the bin (position - 1, start class; never in front of the
+            // kept starts at the smallest start position), ends to its head
             const u32 pk = (lig << sh) << kKeyShift;
-            const u32 synkey = net > 0 ? max(pk, 4u) - 1u : pk;
+            const u32 synkey = net > 0 ? max(pk, kmin + 1u) - 1u : pk;
 #pragma unroll 1
             for (u32 t = 0; t < nsyn; t++) keys[base + keep + t] = synkey;
             if (lig == 0) {
-                const u32 synkey1 = net1 > 0 ? lenk - 1u : lenk;
+                const u32 synkey1 = net1 > 0 ? kmax - 1u : kmax;
 #pragma unroll 1
                 for (u32 t = 0; t < nsyn1; t++) keys[tail_base + (u32)ke1 + t] = synkey1;
             }
@@ -826,8 +836,8 @@ __device__ __forceinline__ void sweep_small_fused_body(const FusedArgs &f)
 // Two builds.  DEFER: a read the filter cannot thin goes to f.base.over_list (sweep_deferred_kernel
 // finishes it) instead of dragging its wavefront into the 16-keys-per-lane sort; without that sort
 // in the filtered path the kernel fits 80 registers, six workgroups per CU, and it is bound by how
-// many wavefronts overlap their latencies (configs[2]: 1.90 -> 1.43 ms).  The extra launch costs
-// ~6 us however little it has to do, so batches whose fused launch is shorter than ~0.2 ms use the
+// many wavefronts overlap their latencies (configs[2]: 1.90 -> 1.43 ms; configs[1]: 47.9 -> 38.5 +
+// 4.4 us).  The extra launch costs ~4 us however little it has to do, so small batches use the
 // other build (the engine decides by the classes' interval count).
 __global__ __launch_bounds__(256, 6) void sweep_small_fused_defer_kernel(FusedArgs f)
 {

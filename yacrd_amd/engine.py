@@ -68,7 +68,8 @@ class _Timing(ctypes.Structure):
                [("class_ms", ctypes.c_float * 12), ("class_reads", ctypes.c_uint64 * 12),
                 ("class_intervals", ctypes.c_uint64 * 12), ("fused_ms", ctypes.c_float),
                 ("fused_reads", ctypes.c_uint64), ("fused_intervals", ctypes.c_uint64),
-                ("prefiltered_reads", ctypes.c_uint64)]
+                ("prefiltered_reads", ctypes.c_uint64), ("deferred_reads", ctypes.c_uint64),
+                ("deferred_ms", ctypes.c_float)]
 
 CLASS_NAMES = "R2,R4,R8,R16,H16,W2,W4,W8,W16,M1,M2,BIG".split(",")
 CLASS_KERNELS = {  # the HIP kernel behind each class, as rocprofv3 prints it

@@ -674,7 +674,14 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
             x[2 * j + 1] = real ? (v[j].y << kKeyShift) : kPadKey;
         }
         plain = __builtin_amdgcn_ballot_w64(irregular != 0) == 0; // wave-uniform
-        if (!plain) {
+        if constexpr (K == 16 && DEFER) {
+            // the deferring build holds neither the class / rejection logic nor the 16-keys-per-lane
+            // sort: the reads of such a wavefront are finished by sweep_deferred_kernel
+            if (!plain) {
+                if (lig == LANES - 1 && active) a.over_list[atomicAdd(a.over_count, 1u)] = r;
+                return;
+            }
+        } else if (!plain) {
 #pragma unroll
             for (int j = 0; j < K / 2; j++) {
                 u32 ks, ke, b = 0, z = 0;
@@ -700,7 +707,7 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
     const bool zl_check = (zmask & (zmask - 1)) != 0 || __builtin_amdgcn_ballot_w64(nz > 2) != 0;
 
     if constexpr (K == 16 && DEFER) {
-        if (a.prefilter && plain) { // uniform
+        { // (the engine only launches this build with the filter on; every wavefront here is plain)
             u32 y1[1], y[K / 2], mf;
             bool heavy;
             const int tier = trimfilter<LANES, K, true>(x, n, len, c, y1, y, mf, heavy);
@@ -712,8 +719,8 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
             // a read the filter could not thin goes to the overflow list: sweep_deferred_kernel sorts it
             // whole, one read per wavefront
             if (heavy && lig == LANES - 1 && active) a.over_list[atomicAdd(a.over_count, 1u)] = r;
-            return;
         }
+        return;
     } else if constexpr (K == 16) {
         if (a.prefilter && plain) { // uniform
             u32 y[K / 2], mf;
@@ -725,7 +732,8 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
             }
         }
     }
-    sweep_group_keys<LANES, K, XM>(x, 2 * n, len, c, active, r, badmask, zmask, zl_check, a, lc);
+    if constexpr (!(K == 16 && DEFER))
+        sweep_group_keys<LANES, K, XM>(x, 2 * n, len, c, active, r, badmask, zmask, zl_check, a, lc);
 }
 
 // Body of one workgroup (four wavefronts, 4 * 64/LANES reads) of class (LANES, K).

@@ -461,7 +461,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
             bool has_dom = false;
             for (int cls = yk::CLS_R2; cls <= yk::CLS_H16; cls++) {
                 if (!set.n[cls]) continue;
-                const u32 per = yk::sweep_group_reads_per_block(cls);
+                const u32 per = yk::sweep_group_reads_per_block(cls, defer ? yk::kDeferWaves : yk::kFusedWaves);
                 blocks += (set.n[cls] + per - 1) / per;
                 fa.cls[fa.n_entries] = (u32)cls;
                 fa.block_end[fa.n_entries] = blocks;
@@ -489,11 +489,11 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
                 // kernel's own dispatch timestamps, no event packets before and after it
                 const bool chain = shared || lane.n_engines > 1;
                 if (defer)
-                    hipExtLaunchKernelGGL(yk::sweep_small_fused_defer_kernel, dim3(blocks), dim3(256), 0,
+                    hipExtLaunchKernelGGL(yk::sweep_small_fused_defer_kernel, dim3(blocks), dim3(64 * yk::kDeferWaves), 0,
                                           e->stream, mark ? e->ev_cls[22] : (hipEvent_t) nullptr,
                                           (mark || chain) ? e->ev_cls[23] : (hipEvent_t) nullptr, 0, fa);
                 else
-                    hipExtLaunchKernelGGL(yk::sweep_small_fused_kernel, dim3(blocks), dim3(256), 0,
+                    hipExtLaunchKernelGGL(yk::sweep_small_fused_kernel, dim3(blocks), dim3(64 * yk::kFusedWaves), 0,
                                           e->stream, mark ? e->ev_cls[22] : (hipEvent_t) nullptr,
                                           (mark || chain) ? e->ev_cls[23] : (hipEvent_t) nullptr, 0, fa);
                 if (mark || chain) {

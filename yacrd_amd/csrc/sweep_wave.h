@@ -199,7 +199,7 @@ __device__ __forceinline__ u32 gscan_min(u32 v)
 // ---- everything after the event keys are in registers: sort, sweep, regions out ---------------
 // m = number of real keys of the group (the rest are pads); zl_check = the wavefront holds >= 2
 // zero-length intervals (duplicates must be looked for after the sort).
-template <int LANES, int K, int XM>
+template <int LANES, int K, int XM, bool SORTED = false>
 __device__ __forceinline__ void sweep_group_keys(u32 (&x)[K], u32 m, u32 len, i32 c,
                                                  bool active, u32 r, u64 badmask, u64 zmask,
                                                  bool zl_check, const SweepArgs &a,
@@ -214,7 +214,7 @@ __device__ __forceinline__ void sweep_group_keys(u32 (&x)[K], u32 m, u32 len, i3
         return a.stage + (a.off[rr] + 2 * (u64)rr);
     };
 
-    bitonic_sort<LANES, K, 2, XM>(x, lc);
+    if constexpr (!SORTED) bitonic_sort<LANES, K, 2, XM>(x, lc);
 
     // two zero-length intervals at one position cannot be expressed by the keys: after the sort
     // they are adjacent equal class-1 keys.  Only looked for when the wavefront saw >= 2 of them.
@@ -364,9 +364,10 @@ __device__ __forceinline__ void wave_lds_sync()
 // one-position bins, four counters each (one per lane & 3: the reads' hot bins would otherwise
 // serialise the LDS atomics of a row), then the compacted keys of every group.
 constexpr int kFilterTabWords = 304, kFilterKeyWords = 512;
+template <int WPB> // wavefronts per workgroup
 __device__ __forceinline__ u32 *wave_filter_scratch()
 {
-    __shared__ __attribute__((aligned(16))) u32 s_scratch[4][kFilterTabWords + kFilterKeyWords];
+    __shared__ __attribute__((aligned(16))) u32 s_scratch[WPB][kFilterTabWords + kFilterKeyWords];
     return s_scratch[threadIdx.x >> 6];
 }
 
@@ -394,9 +395,9 @@ __device__ __forceinline__ u32 *wave_filter_scratch()
 // such read does not drag the other reads of its wavefront into the full sort (and the full sort
 // is not even part of that code path: fewer registers, one more wavefront per SIMD).
 // Returns the tier: 0 = sort everything as before, 1 = every group kept <= LANES keys (y1: one
-// key per lane), 2 = y: K / 2 keys per lane.  Only for wavefronts whose intervals are all plain
+// key per lane), 2 = y: K / 2 keys per lane, 3 = y1 as in 1 and already in order.  Only for wavefronts whose intervals are all plain
 // (start < end <= len).
-template <int LANES, int K, bool DEFER>
+template <int LANES, int K, bool DEFER, int WPB>
 __device__ __forceinline__ int trimfilter(const u32 (&x)[K], u32 n, u32 len, i32 c,
                                           u32 (&y1)[1], u32 (&y)[K / 2], u32 &m_out, bool &heavy)
 {
@@ -406,7 +407,7 @@ __device__ __forceinline__ int trimfilter(const u32 (&x)[K], u32 n, u32 len, i32
     constexpr u32 kPadBin = NB, kHeadBin = NB + 1, kTailBin = NB + 2;
     static_assert(GROUPS * NBIN * 4 <= kFilterTabWords && GROUPS * CAP <= kFilterKeyWords, "scratch");
     const u32 lane = lane_id(), lig = lane & (u32)(LANES - 1), grp = lane / (u32)LANES;
-    u32 *scratch = wave_filter_scratch();
+    u32 *scratch = wave_filter_scratch<WPB>();
     u32 *tab = scratch + grp * (u32)(NBIN * 4);
     u32 *keys = scratch + kFilterTabWords + grp * (u32)CAP;
     uint4 *bins = reinterpret_cast<uint4 *>(tab);
@@ -420,8 +421,6 @@ __device__ __forceinline__ int trimfilter(const u32 (&x)[K], u32 n, u32 len, i32
 
     bins[lig] = make_uint4(0u, 0u, 0u, 0u);
     if (lig < 3u) bins[NB + lig] = make_uint4(0u, 0u, 0u, 0u);
-    my_keys[0] = make_uint4(kPadKey, kPadKey, kPadKey, kPadKey);
-    my_keys[1] = make_uint4(kPadKey, kPadKey, kPadKey, kPadKey);
     wave_lds_sync();
 
     // ---- pass 1: count.  Byte offset of a key's counter = bin * 16 + (lane & 3) * 4; the pads
@@ -481,6 +480,17 @@ __device__ __forceinline__ int trimfilter(const u32 (&x)[K], u32 n, u32 len, i32
     heavy = m > (u32)CAP;
     if constexpr (DEFER) m = heavy ? 0u : m; // its read goes to the overflow list; the group goes on empty
     else if (__builtin_amdgcn_ballot_w64(heavy) != 0) return 0; // the wavefront sorts everything
+    // The healthy read: every coarse bin that holds anything is deep and the two piles balance.  What is
+    // kept is then known without looking at the keys again — min(S0, c + 1) copies of the smallest start
+    // key and as many of the largest end key, in that order — so when every group of the wavefront is
+    // like that (nine wavefronts in ten on configs[1] and [2]) pass 2 and the sort are skipped.
+    if (__builtin_amdgcn_ballot_w64(keep != 0u || nsyn1 != 0u || heavy || m > (u32)LANES) == 0) {
+        y1[0] = lig < (u32)ks0 ? kmin : (lig < m ? kmax : kPadKey);
+        m_out = m;
+        return 3;
+    }
+    my_keys[0] = make_uint4(kPadKey, kPadKey, kPadKey, kPadKey);
+    my_keys[1] = make_uint4(kPadKey, kPadKey, kPadKey, kPadKey);
     {
         // cursors: a coarse bin's copies keep everything (quota 0x7FFF) or nothing
         const u32 q = (deep || heavy) ? 0u : 0x7FFF0000u;
@@ -544,7 +554,7 @@ __device__ __forceinline__ int trimfilter(const u32 (&x)[K], u32 n, u32 len, i32
 // ---- the bin filter without trimming (round 1): used by the builds that do not
 // defer (sweep_small_fused_kernel for short launches, the one-read-per-wavefront class), where the
 // 16-keys-per-lane fallback is part of the code path and this leaner filter fits 96 registers ------
-template <int LANES, int K>
+template <int LANES, int K, int WPB>
 __device__ __forceinline__ bool prefilter(const u32 (&x)[K], u32 n, u32 len, i32 c, u32 (&y)[K / 2],
                                           u32 &m_out)
 {
@@ -552,7 +562,7 @@ __device__ __forceinline__ bool prefilter(const u32 (&x)[K], u32 n, u32 len, i32
     constexpr int NB = LANES, CAP = LANES * K / 2, GROUPS = 64 / LANES;
     static_assert(GROUPS * (NB + 1) * 4 <= kFilterTabWords && GROUPS * CAP <= kFilterKeyWords, "scratch");
     const u32 lane = lane_id(), lig = lane & (u32)(LANES - 1), grp = lane / (u32)LANES;
-    u32 *scratch = wave_filter_scratch();
+    u32 *scratch = wave_filter_scratch<WPB>();
     u32 *tab = scratch + grp * (u32)((NB + 1) * 4);        // (NB bins + one for the pads) x 4 copies
     u32 *keys = scratch + kFilterTabWords + grp * (u32)CAP;
     uint4 *my_bin = reinterpret_cast<uint4 *>(tab) + lig;
@@ -638,7 +648,7 @@ __device__ __forceinline__ bool prefilter(const u32 (&x)[K], u32 n, u32 len, i32
 }
 
 // ---- one read per group of LANES lanes: loads, keys, (pre-filter,) sweep ------------------------
-template <int LANES, int K, int XM, bool DEFER = false>
+template <int LANES, int K, int XM, bool DEFER = false, int WPB = 4>
 __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u32 n, u32 len,
                                                  u32 cov, bool active, u32 r,
                                                  const SweepArgs &a, const LaneConst &lc)
@@ -710,11 +720,12 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
         { // (the engine only launches this build with the filter on; every wavefront here is plain)
             u32 y1[1], y[K / 2], mf;
             bool heavy;
-            const int tier = trimfilter<LANES, K, true>(x, n, len, c, y1, y, mf, heavy);
+            const int tier = trimfilter<LANES, K, true, WPB>(x, n, len, c, y1, y, mf, heavy);
             (void)tier; // 1 or 2: with DEFER the filter always delivers
             if (a.prefilter == 2 && lig == 0 && active && !heavy) atomicAdd(&a.ctr->prefiltered, 1u);
             const bool act = active && !heavy; // a heavy read is finished by sweep_deferred_kernel
-            if (tier == 1) sweep_group_keys<LANES, 1, XM>(y1, mf, len, c, act, r, badmask, zmask, zl_check, a, lc);
+            if (tier == 3) sweep_group_keys<LANES, 1, XM, true>(y1, mf, len, c, act, r, badmask, zmask, zl_check, a, lc);
+            else if (tier == 1) sweep_group_keys<LANES, 1, XM>(y1, mf, len, c, act, r, badmask, zmask, zl_check, a, lc);
             else sweep_group_keys<LANES, K / 2, XM>(y, mf, len, c, act, r, badmask, zmask, zl_check, a, lc);
             // a read the filter could not thin goes to the overflow list: sweep_deferred_kernel sorts it
             // whole, one read per wavefront
@@ -724,7 +735,7 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
     } else if constexpr (K == 16) {
         if (a.prefilter && plain) { // uniform
             u32 y[K / 2], mf;
-            if (prefilter<LANES, K>(x, n, len, c, y, mf)) {
+            if (prefilter<LANES, K, WPB>(x, n, len, c, y, mf)) {
                 if (a.prefilter == 2 && lig == 0 && active) atomicAdd(&a.ctr->prefiltered, 1u);
                 sweep_group_keys<LANES, K / 2, XM>(y, mf, len, c, active, r, badmask, zmask,
                                                    zl_check, a, lc);
@@ -737,7 +748,7 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
 }
 
 // Body of one workgroup (four wavefronts, 4 * 64/LANES reads) of class (LANES, K).
-template <int LANES, int K, int XM, bool DEFER = false>
+template <int LANES, int K, int XM, bool DEFER = false, int WPB = 4>
 __device__ __forceinline__ void sweep_group_block(const SweepArgs &a, u32 block)
 {
     const u32 lane = lane_id();
@@ -749,7 +760,7 @@ __device__ __forceinline__ void sweep_group_block(const SweepArgs &a, u32 block)
 
     constexpr u32 GROUPS = 64 / LANES; // reads per wavefront
     const u32 list_n = *a.list_n;
-    const u32 wave = block * 4u + (threadIdx.x >> 6);
+    const u32 wave = block * (u32)WPB + (threadIdx.x >> 6);
     if (a.first + wave * GROUPS >= list_n) return; // grids may be sized for more reads than the class holds
     const u32 idx = a.first + wave * GROUPS + lane / (u32)LANES;
     const bool active = idx < list_n;
@@ -761,7 +772,7 @@ __device__ __forceinline__ void sweep_group_block(const SweepArgs &a, u32 block)
         n = (u32)(a.off[r + 1] - o);
         len = a.len[r];
     }
-    sweep_group_read<LANES, K, XM, DEFER>(a.iv + o, n, len, a.cov, active, r, a, lc);
+    sweep_group_read<LANES, K, XM, DEFER, WPB>(a.iv + o, n, len, a.cov, active, r, a, lc);
 }
 
 // One kernel per (LANES, K): small K keep small register footprints.
@@ -810,6 +821,15 @@ __global__ __launch_bounds__(256) void sweep_deferred_kernel(SweepArgs a)
 // The classes R2..H16 are independent; launched one after the other each pays its own ramp-up
 // and drain (~4-7 us for the minor ones on configs[1]).  Here the grid is the concatenation of
 // the per-class grids and a workgroup looks up its class (<= 5 uniform compares).
+#ifndef YK_DEFER_WAVES
+#define YK_DEFER_WAVES 1
+#endif
+#ifndef YK_DEFER_OCC
+#define YK_DEFER_OCC 6
+#endif
+// wavefronts per workgroup of the fused launch: the deferring build runs one-wavefront workgroups (a
+// slot is free again as soon as its wavefront ends, not when the slowest of four does)
+constexpr int kFusedWaves = 4, kDeferWaves = YK_DEFER_WAVES, kDeferOcc = YK_DEFER_OCC;
 struct FusedArgs {
     SweepArgs base;           // list / list_n filled per class from the table below
     u32 n_entries;
@@ -820,7 +840,7 @@ struct FusedArgs {
     const u32 *list_n[5];
 };
 
-template <bool DEFER>
+template <bool DEFER, int WPB>
 __device__ __forceinline__ void sweep_small_fused_body(const FusedArgs &f)
 {
     u32 e = 0, first = 0;
@@ -834,11 +854,11 @@ __device__ __forceinline__ void sweep_small_fused_body(const FusedArgs &f)
     a.first = f.first[e];
     const u32 b = blockIdx.x - first;
     switch (f.cls[e]) { // the one-read-per-wavefront classes stay separate kernels (registers)
-    case CLS_R2: sweep_group_block<16, 2, 0>(a, b); break;
-    case CLS_R4: sweep_group_block<16, 4, 0>(a, b); break;
-    case CLS_R8: sweep_group_block<16, 8, 0>(a, b); break;
-    case CLS_R16: sweep_group_block<16, 16, 0, DEFER>(a, b); break;
-    default: sweep_group_block<32, 16, 0, DEFER>(a, b); break;
+    case CLS_R2: sweep_group_block<16, 2, 0, false, WPB>(a, b); break;
+    case CLS_R4: sweep_group_block<16, 4, 0, false, WPB>(a, b); break;
+    case CLS_R8: sweep_group_block<16, 8, 0, false, WPB>(a, b); break;
+    case CLS_R16: sweep_group_block<16, 16, 0, DEFER, WPB>(a, b); break;
+    default: sweep_group_block<32, 16, 0, DEFER, WPB>(a, b); break;
     }
 }
 // Two builds.  DEFER: a read the filter cannot thin goes to f.base.over_list (sweep_deferred_kernel
@@ -847,18 +867,19 @@ __device__ __forceinline__ void sweep_small_fused_body(const FusedArgs &f)
 // many wavefronts overlap their latencies (configs[2]: 1.90 -> 1.43 ms; configs[1]: 47.9 -> 38.5 +
 // 4.4 us).  The extra launch costs ~4 us however little it has to do, so small batches use the
 // other build (the engine decides by the classes' interval count).
-__global__ __launch_bounds__(256, 6) void sweep_small_fused_defer_kernel(FusedArgs f)
+// (__launch_bounds__' second argument: wavefronts per SIMD)
+__global__ __launch_bounds__(64 * kDeferWaves, kDeferOcc) void sweep_small_fused_defer_kernel(FusedArgs f)
 {
-    sweep_small_fused_body<true>(f);
+    sweep_small_fused_body<true, kDeferWaves>(f);
 }
-__global__ __launch_bounds__(256, 5) void sweep_small_fused_kernel(FusedArgs f)
+__global__ __launch_bounds__(64 * kFusedWaves, 5) void sweep_small_fused_kernel(FusedArgs f)
 {
-    sweep_small_fused_body<false>(f);
+    sweep_small_fused_body<false, kFusedWaves>(f);
 }
 
-inline u32 sweep_group_reads_per_block(int cls)
+inline u32 sweep_group_reads_per_block(int cls, int waves = 4)
 {
-    return (cls <= CLS_R16) ? 16u : (cls == CLS_H16) ? 8u : 4u;
+    return ((cls <= CLS_R16) ? 4u : (cls == CLS_H16) ? 2u : 1u) * (u32)waves;
 }
 
 } // namespace yk

@@ -76,8 +76,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--lds-sort", action="store_true", help="A/B: LDS-sort kernel for the small class")
     ap.add_argument("--flags", type=int, default=0, help="extra YACRD_F_* engine flags (A/B)")
-    ap.add_argument("--engines", type=int, default=2,
+    ap.add_argument("--engines", type=int, default=3,
                     help="engines (HIP streams) the batches are pipelined over on each GPU")
+    ap.add_argument("--host-threads", action="store_true",
+                    help="one host thread per engine instead of one thread pipelining all of them")
     ap.add_argument("--full-timing", action="store_true",
                     help="HIP events around every phase and class kernel (slower steps)")
     ap.add_argument("--strong", action="store_true",
@@ -125,8 +127,7 @@ def main():
         flags |= yacrd_amd.F_TIMING_FULL
     # Batches are pipelined over `--engines` engines on this GPU from this one host thread
     # (yacrd_engine_submit_device / yacrd_engine_wait): the plan / compaction kernels, the counter
-    # copy and the launch gaps of one batch hide behind the sweep of another (the engines take
-    # turns with that launch, so its start / stop events time the kernel, not the queue).
+    # copy, the launch gaps and the host's turn of one batch hide behind the sweep of another.
     NE = max(1, min(args.engines, args.steps))
     engs = [yacrd_amd.Engine(device_id=dev_index, flags=flags) for _ in range(NE)]
     eng = engs[0]
@@ -139,6 +140,20 @@ def main():
 
     def run_steps(k):
         """k passes over the batch, NE of them in flight; returns the last result."""
+        if args.host_threads and NE > 1:  # one host thread per engine (ctypes calls drop the GIL)
+            import threading
+            last = [None] * NE
+
+            def work(j, kj):
+                for _ in range(kj):
+                    last[j] = engs[j].run_device(*ptrs)
+            share = [k // NE + (1 if j < k % NE else 0) for j in range(NE)]
+            th = [threading.Thread(target=work, args=(j, share[j])) for j in range(NE) if share[j]]
+            for x in th:
+                x.start()
+            for x in th:
+                x.join()
+            return next(r for r in reversed(last) if r is not None)
         if NE == 1:
             res = None
             for _ in range(k):

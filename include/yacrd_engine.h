@@ -82,13 +82,16 @@ typedef struct {
 #define YACRD_F_NO_TIMING 1024u
 /* the run's final wait polls an event and sleeps in between instead of spinning in
  * hipStreamSynchronize: for several engines per CPU core (pipelined batches, many GPUs).
- * Engines created on the same device (one host thread each) pipeline their batches: they take
- * turns with the dominant sweep launch, everything else overlaps. */
+ * Engines created on the same device pipeline their batches (yacrd_engine_submit / _collect from
+ * one host thread, or one host thread each). */
 #define YACRD_F_BLOCKING_WAIT 2048u
 /* the register-sort classes never defer the reads their filter cannot thin to a launch of their own
  * (by default they do when the fused launch holds >= 4 M intervals); 8192: always defer; A/B only */
 #define YACRD_F_NO_DEFER 4096u
 #define YACRD_F_ALWAYS_DEFER 8192u
+/* engines that share a device take turns with the dominant sweep launch (a GPU-side event wait:
+ * the launch's start / stop events then time that kernel alone); A/B only */
+#define YACRD_F_SWEEP_TURNS 16384u
 
 /* Host-side result, allocated by the engine, released with yacrd_result_free(). */
 typedef struct {

@@ -474,20 +474,20 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
             if (fa.n_entries) {
                 any_small = true;
                 const bool mark = timing_on && (full || has_dom);
-                // Engines that share a device (batches pipelined over several engines, one host
-                // thread each) take turns with this launch: it fills the GPU on its own, two of
-                // them side by side would only stretch each other, while the small kernels,
-                // copies and launch gaps of one engine hide behind the sweep of another.  The
-                // turn is a GPU-side wait on the previous engine's end-of-sweep event, taken
-                // before the bracket opens, so the bracket times the kernel and not the queue.
-                // (All sweeps of a device in one shared stream instead: 0.072 vs 0.064 ms/batch.)
+                // Engines that share a device (batches pipelined over several engines) may take
+                // turns with this launch (YACRD_F_SWEEP_TURNS: a GPU-side wait on the previous engine's
+                // end-of-sweep event, taken before the bracket opens, so that the bracket times the
+                // kernel alone).  Not the default any more: the hand-over costs ~10 us per batch
+                // (configs[1], three engines: 47.0 us per batch with turns, 38.8 without), and a sweep
+                // that fills the GPU leaves the next one little room to overlap anyway (its bracket
+                // grows by ~1 us: what the roofline then reports is on the safe side).
                 BigLane &lane = g_big_lane[e->device & 63];
                 std::lock_guard<std::mutex> turn(lane.mu);
-                const bool shared = lane.owner != nullptr && lane.owner != e;
+                const bool shared = (e->flags & YACRD_F_SWEEP_TURNS) && lane.owner != nullptr && lane.owner != e;
                 if (shared) HIP_TRY(hipStreamWaitEvent(e->stream, lane.last, 0));
                 // start / stop events attached to the launch itself (hipExtLaunchKernelGGL): the
                 // kernel's own dispatch timestamps, no event packets before and after it
-                const bool chain = shared || lane.n_engines > 1;
+                const bool chain = (e->flags & YACRD_F_SWEEP_TURNS) && (shared || lane.n_engines > 1);
                 if (defer)
                     hipExtLaunchKernelGGL(yk::sweep_small_fused_defer_kernel, dim3(blocks), dim3(64 * yk::kDeferWaves), 0,
                                           e->stream, mark ? e->ev_cls[22] : (hipEvent_t) nullptr,

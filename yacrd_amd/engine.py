@@ -25,6 +25,7 @@ F_NO_TIMING = 1024
 F_BLOCKING_WAIT = 2048
 F_NO_DEFER = 4096
 F_ALWAYS_DEFER = 8192
+F_SWEEP_TURNS = 16384
 
 # every symbol include/yacrd_engine.h declares
 EXPORTED_SYMBOLS = [

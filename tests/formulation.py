@@ -400,3 +400,40 @@ def trimmed_minmax_events(intervals, length, cov, nb=16):
     if any(not (0 <= s < e <= length) for s, e in intervals) or length >= 2**30 - 1:
         return None
     return sweep_keys(sorted(trim_keys_minmax(intervals, length, cov, nb)), length, cov)
+
+
+def healthy_read_regions(intervals, length, cov, nb):
+    """sweep_wave.h's closed form for the healthy read (trimfilter tier 3): when every coarse bin
+    that holds an event is deep and min(S0, cov + 1) == min(E1, cov + 1) =: k, what trim_keys_minmax
+    keeps is k copies of the smallest start key and k of the largest end key, and the sweep over
+    those gives: the whole read when k <= cov (nothing exceeds the threshold), otherwise the part in
+    front of pmin and the part behind pmax.  Returns None when the read is not of that kind (the
+    kernel then runs pass 2, the sort and the sweep).  Plain reads only (0 <= s < e <= length)."""
+    if len(intervals) == 0:
+        return [(0, length)] if length != 0 else []
+    sh = bin_shift(length, nb)
+    pmin = min(s for s, e in intervals)
+    pmax = max(e for s, e in intervals)
+    S, E = [0] * nb, [0] * nb
+    S0 = E1 = 0
+    for s, e in intervals:
+        assert 0 <= s < e <= length
+        if s == pmin:
+            S0 += 1
+        else:
+            S[s >> sh] += 1
+        if e == pmax:
+            E1 += 1
+        else:
+            E[e >> sh] += 1
+    D = S0
+    for b in range(nb):
+        if not (D - E[b] > cov) and S[b] + E[b] > 0:
+            return None
+        D += S[b] - E[b]
+    k = min(S0, cov + 1)
+    if k != min(E1, cov + 1):
+        return None
+    if k <= cov:
+        return [(0, length)]
+    return ([(0, pmin)] if pmin != 0 else []) + ([(pmax, length)] if pmax != length else [])

@@ -97,9 +97,9 @@ def _pile_read(rng, n, L, jitter):
 
 
 def test_pile_trimming_matches_oracle():
-    from formulation import trim_keys, trimmed_events, trimmed_minmax_events
+    from formulation import healthy_read_regions, trim_keys, trimmed_events, trimmed_minmax_events
     rng = np.random.default_rng(2024)
-    kept = total = n_zl_checked = 0
+    kept = total = n_zl_checked = n_healthy = 0
     for it in range(1500):
         L = int(rng.integers(2, 200)) if it % 3 == 0 else int(rng.integers(200, 50000))
         n = int(rng.integers(1, 30)) if it % 4 == 0 else int(rng.integers(30, 400))
@@ -125,6 +125,9 @@ def test_pile_trimming_matches_oracle():
                 assert gw == want or (gw is None and has_zl), (iv, L, cov, nb, F, "wave")
                 if not has_zl:  # sweep_wave.h's deferring build: bins at the smallest start / largest end
                     assert trimmed_minmax_events(iv, L, cov, nb) == want, (iv, L, cov, nb, "minmax")
+                    hr = healthy_read_regions(iv, L, cov, nb)  # its closed form, where it applies
+                    assert hr is None or hr == want, (iv, L, cov, nb, "healthy")
+                    n_healthy += hr is not None
                     if it % 7 == 3:  # a read covered only inside a window: piles at the window's edges
                         w0, w1 = L // 3, max(L // 3 + 2, 2 * L // 3)
                         win = [(min(max(s, w0), w1 - 1), min(max(e, min(max(s, w0), w1 - 1) + 1), w1)) for s, e in iv]
@@ -132,12 +135,12 @@ def test_pile_trimming_matches_oracle():
             if cov == 4:
                 total += 2 * len(iv)
                 kept += len(trim_keys(iv, L, cov, 16, 32))
-    assert kept < total // 3 and n_zl_checked > 500
+    assert kept < total // 3 and n_zl_checked > 500 and n_healthy > 500
 
 
 def test_pile_trimming_tiny_exhaustive():
     import itertools
-    from formulation import trimmed_events, trimmed_minmax_events
+    from formulation import healthy_read_regions, trimmed_events, trimmed_minmax_events
     for L in range(1, 6):
         pairs = [(s, e) for s in range(L + 1) for e in range(s, L + 1)]  # zero-length ones included
         for k in range(1, 4):
@@ -151,4 +154,6 @@ def test_pile_trimming_tiny_exhaustive():
                         assert gw is None or gw == want, (iv, L, cov, nb, F, "wave")
                         if all(s < e for s, e in iv):
                             assert trimmed_minmax_events(list(iv), L, cov, nb) == want, (iv, L, cov, nb, "minmax")
+                            hr = healthy_read_regions(list(iv), L, cov, nb)
+                            assert hr is None or hr == want, (iv, L, cov, nb, "healthy")
                         assert got is not None or regular_events(list(iv), L, cov) is None

@@ -104,6 +104,16 @@ struct LaneConst {
     u32 addr32; // byte address of lane ^ 32 for ds_bpermute
 };
 
+__device__ __forceinline__ LaneConst make_lane_const(u32 lane)
+{
+    LaneConst lc;
+#pragma unroll
+    for (int i = 0; i < 6; i++) lc.k[i] = (lane & (1u << i)) ? 0xFFFFFFFFu : 0u;
+    lc.k[6] = 0;
+    lc.addr32 = (lane ^ 32u) << 2;
+    return lc;
+}
+
 constexpr int ilog2c(int v) { return v <= 1 ? 0 : 1 + ilog2c(v >> 1); }
 
 // ---- bitonic sort of LANES*K keys held as x[K] per lane, element index = lane_in_group*K + r --
@@ -199,7 +209,7 @@ __device__ __forceinline__ u32 gscan_min(u32 v)
 // ---- everything after the event keys are in registers: sort, sweep, regions out ---------------
 // m = number of real keys of the group (the rest are pads); zl_check = the wavefront holds >= 2
 // zero-length intervals (duplicates must be looked for after the sort).
-template <int LANES, int K, int XM, bool SORTED = false>
+template <int LANES, int K, int XM>
 __device__ __forceinline__ void sweep_group_keys(u32 (&x)[K], u32 m, u32 len, i32 c,
                                                  bool active, u32 r, u64 badmask, u64 zmask,
                                                  bool zl_check, const SweepArgs &a,
@@ -214,7 +224,7 @@ __device__ __forceinline__ void sweep_group_keys(u32 (&x)[K], u32 m, u32 len, i3
         return a.stage + (a.off[rr] + 2 * (u64)rr);
     };
 
-    if constexpr (!SORTED) bitonic_sort<LANES, K, 2, XM>(x, lc);
+    bitonic_sort<LANES, K, 2, XM>(x, lc);
 
     // two zero-length intervals at one position cannot be expressed by the keys: after the sort
     // they are adjacent equal class-1 keys.  Only looked for when the wavefront saw >= 2 of them.
@@ -395,11 +405,18 @@ __device__ __forceinline__ u32 *wave_filter_scratch()
 // such read does not drag the other reads of its wavefront into the full sort (and the full sort
 // is not even part of that code path: fewer registers, one more wavefront per SIMD).
 // Returns the tier: 0 = sort everything as before, 1 = every group kept <= LANES keys (y1: one
-// key per lane), 2 = y: K / 2 keys per lane, 3 = y1 as in 1 and already in order.  Only for wavefronts whose intervals are all plain
+// key per lane), 2 = y: K / 2 keys per lane, 3 = nothing to sort: every group is a healthy read (hr).  Only for wavefronts whose intervals are all plain
 // (start < end <= len).
+// What trimfilter hands back for a wavefront of healthy reads (tier 3): per group, the number of
+// starts kept at the smallest start position and the two positions.
+struct HealthyRead {
+    u32 kept_starts, pmin, pmax;
+};
+
 template <int LANES, int K, bool DEFER, int WPB>
 __device__ __forceinline__ int trimfilter(const u32 (&x)[K], u32 n, u32 len, i32 c,
-                                          u32 (&y1)[1], u32 (&y)[K / 2], u32 &m_out, bool &heavy)
+                                          u32 (&y1)[1], u32 (&y)[K / 2], u32 &m_out, bool &heavy,
+                                          HealthyRead &hr)
 {
     static_assert(K == 16, "a lane reads its K/2 = 8 compacted keys as two 16-byte vectors");
     constexpr int NB = LANES, NBIN = LANES + 3, CAP = LANES * K / 2, GROUPS = 64 / LANES;
@@ -447,16 +464,38 @@ __device__ __forceinline__ int trimfilter(const u32 (&x)[K], u32 n, u32 len, i32
     wave_lds_sync();
 
     // ---- what the bins keep
-    const uint4 c4 = bins[lig], h4 = bins[kHeadBin], t4 = bins[kTailBin];
-    const u32 w = c4.x + c4.y + c4.z + c4.w;
+    // (the two one-position bins are read again where lanes 0 and 1 deal out their quota: holding
+    // them until then costs eight registers at the kernel's high-water mark)
+    u32 w, n0, n01, n012; // this lane's bin: its total, and the running sizes of its first three copies
+    i32 S0, E1;
+    {
+        const uint4 c4 = bins[lig], h4 = bins[kHeadBin], t4 = bins[kTailBin];
+        n0 = (c4.x & 0xFFFFu) + (c4.x >> 16);
+        n01 = n0 + (c4.y & 0xFFFFu) + (c4.y >> 16);
+        n012 = n01 + (c4.z & 0xFFFFu) + (c4.z >> 16);
+        w = c4.x + c4.y + c4.z + c4.w;
+        S0 = (i32)((h4.x + h4.y + h4.z + h4.w) & 0xFFFFu);  // starts at the smallest start position
+        E1 = (i32)((t4.x + t4.y + t4.z + t4.w) >> 16);      // ends at the largest end position
+    }
     const i32 S = (i32)(w & 0xFFFFu), E = (i32)(w >> 16);
-    const i32 S0 = (i32)((h4.x + h4.y + h4.z + h4.w) & 0xFFFFu);  // starts at the smallest start position
-    const i32 E1 = (i32)((t4.x + t4.y + t4.z + t4.w) >> 16);      // ends at the largest end position
     const i32 ks0 = min(S0, c + 1), ke1 = min(E1, c + 1);
     const u32 incl = gscan_add<LANES>(w); // packed: both halves scanned at once
     const u32 ex = incl - w;
     const i32 D = S0 + (i32)(ex & 0xFFFFu) - (i32)(ex >> 16);     // depth at the head of this lane's bin
     const bool deep = D - E > c;                                   // spanned by more than c intervals
+    const u32 keep = deep ? 0u : (u32)(S + E);
+    // The healthy read: every coarse bin that holds anything is deep and the two piles balance.  What
+    // is kept is then min(S0, c + 1) copies of the smallest start key and as many of the largest end
+    // key, and what the sweep makes of those is known in closed form (sweep_group_read; DESIGN.md
+    // §3.5; tests/formulation.py::healthy_read_regions): when every group of the wavefront is like
+    // that — nine wavefronts in ten on configs[1] and [2] — the rest of the plan, pass 2, the sort and
+    // the sweep are skipped.
+    if (__builtin_amdgcn_ballot_w64(keep != 0u || ks0 != ke1) == 0) {
+        hr.kept_starts = (u32)ks0;
+        hr.pmin = kmin >> kKeyShift;
+        hr.pmax = kmax >> kKeyShift;
+        return 3;
+    }
     // (sequence index + 1) << 16 | depth after the kept block, for bins that keep something (an empty
     // bin keeps nothing: the bins in front of the smallest start, where D is not the depth, are empty)
     const u32 tag = (deep || w == 0u) ? 0u : (((lig + 2u) << 16) | (u32)(D - E + S));
@@ -470,7 +509,6 @@ __device__ __forceinline__ int trimfilter(const u32 (&x)[K], u32 n, u32 len, i32
     const i32 a_last = (i32)(max(row_total(mi), tag0) & 0xFFFFu);
     const i32 net1 = E1 > 0 ? ke1 - a_last : 0;
     const u32 nsyn1 = (u32)(net1 < 0 ? -net1 : net1);
-    const u32 keep = deep ? 0u : (u32)(S + E);
     const u32 mine = keep + nsyn;
     const u32 ri = gscan_add<LANES>(mine);
     const u32 coarse_total = row_total(ri);
@@ -480,26 +518,15 @@ __device__ __forceinline__ int trimfilter(const u32 (&x)[K], u32 n, u32 len, i32
     heavy = m > (u32)CAP;
     if constexpr (DEFER) m = heavy ? 0u : m; // its read goes to the overflow list; the group goes on empty
     else if (__builtin_amdgcn_ballot_w64(heavy) != 0) return 0; // the wavefront sorts everything
-    // The healthy read: every coarse bin that holds anything is deep and the two piles balance.  What is
-    // kept is then known without looking at the keys again — min(S0, c + 1) copies of the smallest start
-    // key and as many of the largest end key, in that order — so when every group of the wavefront is
-    // like that (nine wavefronts in ten on configs[1] and [2]) pass 2 and the sort are skipped.
-    if (__builtin_amdgcn_ballot_w64(keep != 0u || nsyn1 != 0u || heavy || m > (u32)LANES) == 0) {
-        y1[0] = lig < (u32)ks0 ? kmin : (lig < m ? kmax : kPadKey);
-        m_out = m;
-        return 3;
-    }
     my_keys[0] = make_uint4(kPadKey, kPadKey, kPadKey, kPadKey);
     my_keys[1] = make_uint4(kPadKey, kPadKey, kPadKey, kPadKey);
     {
         // cursors: a coarse bin's copies keep everything (quota 0x7FFF) or nothing
         const u32 q = (deep || heavy) ? 0u : 0x7FFF0000u;
-        const u32 n0 = (c4.x & 0xFFFFu) + (c4.x >> 16), n1 = (c4.y & 0xFFFFu) + (c4.y >> 16),
-                  n2 = (c4.z & 0xFFFFu) + (c4.z >> 16);
-        bins[lig] = make_uint4(q | base, q | (base + n0), q | (base + n0 + n1), q | (base + n0 + n1 + n2));
+        const uint4 s4 = bins[kHeadBin + min(lig, 1u)];
+        bins[lig] = make_uint4(q | base, q | (base + n0), q | (base + n01), q | (base + n012));
         // the two one-position bins hold one type each: their quota is dealt out to the four copies
         if (lig < 2u) {
-            const uint4 s4 = lig ? t4 : h4;
             const u32 sh2 = lig ? 16u : 0u;
             const u32 keep2 = heavy ? 0u : (u32)(lig ? ke1 : ks0), b2 = lig ? tail_base : 0u;
             const u32 k0 = (s4.x >> sh2) & 0xFFFFu, k1 = (s4.y >> sh2) & 0xFFFFu, k2 = (s4.z >> sh2) & 0xFFFFu;
@@ -720,13 +747,35 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
         { // (the engine only launches this build with the filter on; every wavefront here is plain)
             u32 y1[1], y[K / 2], mf;
             bool heavy;
-            const int tier = trimfilter<LANES, K, true, WPB>(x, n, len, c, y1, y, mf, heavy);
-            (void)tier; // 1 or 2: with DEFER the filter always delivers
+            HealthyRead hr;
+            const int tier = trimfilter<LANES, K, true, WPB>(x, n, len, c, y1, y, mf, heavy, hr);
             if (a.prefilter == 2 && lig == 0 && active && !heavy) atomicAdd(&a.ctr->prefiltered, 1u);
+            if (tier == 3) {
+                // k starts at pmin then k ends at pmax, k = min(S0, c + 1): the depth passes c only
+                // when k = c + 1, and then exactly between the two positions — the read is bad in
+                // front of pmin and behind pmax (the sweep's first closed region and finish_read's
+                // last one); with k <= c (or no interval at all) nothing ever exceeds c and the whole
+                // read is one bad region (finish_read's "mf_t == 0" branch).  len >= 1 whenever n >= 1.
+                if (lig == 0 && active) {
+                    uint2 *slot = a.stage + (a.off[r] + 2 * (u64)r);
+                    u32 g = 0;
+                    if ((i32)hr.kept_starts <= c) {
+                        if (len != 0) slot[g++] = make_uint2(0u, len);
+                    } else {
+                        if (hr.pmin != 0) slot[g++] = make_uint2(0u, hr.pmin);
+                        if (hr.pmax != len) slot[g++] = make_uint2(hr.pmax, len);
+                    }
+                    a.counts[r] = g;
+                }
+                return;
+            }
             const bool act = active && !heavy; // a heavy read is finished by sweep_deferred_kernel
-            if (tier == 3) sweep_group_keys<LANES, 1, XM, true>(y1, mf, len, c, act, r, badmask, zmask, zl_check, a, lc);
-            else if (tier == 1) sweep_group_keys<LANES, 1, XM>(y1, mf, len, c, act, r, badmask, zmask, zl_check, a, lc);
-            else sweep_group_keys<LANES, K / 2, XM>(y, mf, len, c, act, r, badmask, zmask, zl_check, a, lc);
+            // the sort's per-lane constants are derived here, not carried through the filter (8 registers)
+            u32 lane2 = lane;
+            asm volatile("" : "+v"(lane2));
+            const LaneConst lc2 = make_lane_const(lane2);
+            if (tier == 1) sweep_group_keys<LANES, 1, XM>(y1, mf, len, c, act, r, badmask, zmask, zl_check, a, lc2);
+            else sweep_group_keys<LANES, K / 2, XM>(y, mf, len, c, act, r, badmask, zmask, zl_check, a, lc2);
             // a read the filter could not thin goes to the overflow list: sweep_deferred_kernel sorts it
             // whole, one read per wavefront
             if (heavy && lig == LANES - 1 && active) a.over_list[atomicAdd(a.over_count, 1u)] = r;
@@ -752,11 +801,7 @@ template <int LANES, int K, int XM, bool DEFER = false, int WPB = 4>
 __device__ __forceinline__ void sweep_group_block(const SweepArgs &a, u32 block)
 {
     const u32 lane = lane_id();
-    LaneConst lc;
-#pragma unroll
-    for (int i = 0; i < 6; i++) lc.k[i] = (lane & (1u << i)) ? 0xFFFFFFFFu : 0u;
-    lc.k[6] = 0;
-    lc.addr32 = (lane ^ 32u) << 2;
+    const LaneConst lc = make_lane_const(lane);
 
     constexpr u32 GROUPS = 64 / LANES; // reads per wavefront
     const u32 list_n = *a.list_n;
@@ -802,11 +847,7 @@ inline void launch_sweep_group(const SweepArgs &sa, u32 n_reads, hipStream_t str
 __global__ __launch_bounds__(256) void sweep_deferred_kernel(SweepArgs a)
 {
     const u32 lane = lane_id();
-    LaneConst lc;
-#pragma unroll
-    for (int i = 0; i < 6; i++) lc.k[i] = (lane & (1u << i)) ? 0xFFFFFFFFu : 0u;
-    lc.k[6] = 0;
-    lc.addr32 = (lane ^ 32u) << 2;
+    const LaneConst lc = make_lane_const(lane);
     const u32 n_list = *a.list_n;
     for (u32 w = blockIdx.x * 4u + (threadIdx.x >> 6); w < n_list; w += gridDim.x * 4u) { // wave-uniform
         const u32 r = a.list[w];

@@ -61,6 +61,13 @@ struct Counters {
     u32 prefiltered;         // reads that took the pre-filtered sort (only counted when asked)
     u32 over_med;            // M2 reads whose filtered keys do not fit the 256-thread kernel's LDS
     u64 total_regions;       // G, written by the last scan workgroup
+    // reads finished by sweep_deferred_kernel, counted by the compaction (one atomic per workgroup of
+    // 1024 reads).  Counting where they are found or finished does not work on this 8-XCD part:
+    // same-address atomics are performed at the memory side one after the other, ~8 ns each — 1 500 of
+    // them (one per workgroup of the deferred launch) held a 10 us kernel for 22 us, 3 300 returning
+    // ones (a list appended to by the fused launch) a 20 us kernel for 45 us; and on the cache line of
+    // n[], which every wavefront of a sweep reads when it starts, they stall those loads as well.
+    alignas(128) u32 deferred;
 };
 
 struct SweepArgs {
@@ -79,7 +86,10 @@ struct SweepArgs {
     u32 *over_list;      // sweep_lds_kernel: reads with more events than its LDS holds even after the
     u32 *over_count;     // pre-filter: append here (the 1024-thread kernel takes them)
     Counters *ctr;
+    u32 count_tag;       // OR-ed into the region count a register sweep stores: kDeferredTag in the launch
+                         // that finishes the deferred reads (the compaction strips and counts it)
 };
+constexpr u32 kDeferredTag = 0x80000000u;
 
 __device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
 

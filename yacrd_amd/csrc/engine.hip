@@ -316,7 +316,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     }
 
     const u32 nb = (n_reads + yk::kScanBlock - 1) / yk::kScanBlock;
-    constexpr int kLists = yk::CLS_COUNT + 5; // class lists + three rejection lists + M2 overflow + R16 / H16 deferred
+    constexpr int kLists = yk::CLS_COUNT + 4; // class lists + three rejection lists + M2 overflow
     HIP_TRY(e->lists.reserve((size_t)kLists * n_reads * sizeof(u32)));
     const size_t ctrl_bytes = (sizeof(yk::Counters) + (size_t)nb * sizeof(u64) + 255) & ~(size_t)255;
     e->ctrl_cur ^= 1;
@@ -336,12 +336,8 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     e->last_list_stride = n_reads;
     auto list_of = [&](int i) { return lists + (size_t)i * n_reads; };
     u32 *rej_small = list_of(yk::CLS_COUNT), *rej_med = list_of(yk::CLS_COUNT + 1),
-        *rej_big = list_of(yk::CLS_COUNT + 2), *over_med = list_of(yk::CLS_COUNT + 3),
-        *over_small = list_of(yk::CLS_COUNT + 4);
+        *rej_big = list_of(yk::CLS_COUNT + 2), *over_med = list_of(yk::CLS_COUNT + 3);
     yk::Counters *ctr = e->ctrl2[cur].as<yk::Counters>();
-    // reads the fused kernel's filter deferred (it could not thin them): counted in a spare slot of
-    // Counters.n (the plan kernel only fills the class slots)
-    u32 *over_small_n = &ctr->n[12];
     const bool full = (e->flags & YACRD_F_TIMING_FULL) != 0;
     const int xm = (e->flags & YACRD_F_XLANE_DS) ? 1 : 0;
 
@@ -411,6 +407,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     sa.stage = e->stage.as<uint2>();
     sa.counts = e->counts.as<u32>();
     sa.ctr = ctr;
+    sa.count_tag = 0;
     sa.over_list = over_med;
     sa.over_count = &ctr->over_med;
 
@@ -454,8 +451,8 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
             const u64 fused_iv = set.iv[yk::CLS_R16] + set.iv[yk::CLS_H16];
             const bool defer = sa.prefilter && !(e->flags & YACRD_F_NO_DEFER) &&
                                ((e->flags & YACRD_F_ALWAYS_DEFER) || fused_iv >= 4000000ull);
-            fa.base.over_list = defer ? over_small : nullptr;
-            fa.base.over_count = defer ? over_small_n : nullptr;
+            fa.base.over_list = nullptr; // (the deferring build marks its reads in counts[])
+            fa.base.over_count = nullptr;
             fa.n_entries = 0;
             u32 blocks = 0;
             bool has_dom = false;
@@ -501,16 +498,27 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
                     lane.owner = e;
                 }
                 if (mark) fused_marked = true;
-                // the reads the filter deferred, sorted whole in a launch of their own
+                // the reads the screen deferred, sorted whole in a launch of their own
                 if (defer && (set.n[yk::CLS_R16] || set.n[yk::CLS_H16])) {
-                    yk::SweepArgs da = sa;
-                    da.prefilter = 0;
-                    da.over_list = nullptr;
-                    da.over_count = nullptr;
-                    da.first = 0;
-                    da.list = over_small;
-                    da.list_n = over_small_n;
-                    hipExtLaunchKernelGGL(yk::sweep_deferred_kernel, dim3(e->num_cu * 4), dim3(256), 0, e->stream,
+                    yk::DeferArgs da;
+                    da.base = sa;
+                    da.base.prefilter = 0;
+                    da.base.over_list = nullptr;
+                    da.base.over_count = nullptr;
+                    da.base.count_tag = yk::kDeferredTag;
+                    da.n_entries = 0;
+                    u64 chunks = 0;
+                    for (int cls = yk::CLS_R16; cls <= yk::CLS_H16; cls++) {
+                        if (!set.n[cls]) continue;
+                        da.first[da.n_entries] = set.first[cls];
+                        da.count[da.n_entries] = set.n[cls];
+                        da.list[da.n_entries] = list_of(cls);
+                        da.list_n[da.n_entries] = &ctr->n[cls];
+                        da.n_entries++;
+                        chunks += (set.n[cls] + yk::kDeferChunk - 1) / yk::kDeferChunk;
+                    }
+                    const u32 dgrid = (u32)std::min<u64>(chunks, (u64)e->num_cu * 64);
+                    hipExtLaunchKernelGGL(yk::sweep_deferred_kernel, dim3(dgrid ? dgrid : 1), dim3(256), 0, e->stream,
                                           mark ? e->ev_cls[20] : (hipEvent_t) nullptr,
                                           mark ? e->ev_cls[21] : (hipEvent_t) nullptr, 0, da);
                     if (mark) deferred_marked = true;
@@ -773,7 +781,7 @@ int conclude_run(yacrd_engine *e, yk::Counters c0, bool predicted, uint64_t n_re
     t.class_ms[yk::CLS_GENERAL] = (full && c0.n[yk::CLS_GENERAL]) ? t.sweep_general_ms : 0.f;
     t.fused_ms = 0.f;
     t.deferred_ms = 0.f;
-    t.deferred_reads = c1.n[12];
+    t.deferred_reads = c1.deferred;
     t.fused_reads = t.fused_intervals = 0;
     t.prefiltered_reads = c1.prefiltered;
     if (fused_marked) {

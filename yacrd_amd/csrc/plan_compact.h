@@ -99,11 +99,20 @@ __global__ __launch_bounds__(kScanBlock) void compact_classify_kernel(
     __shared__ u32 sc[kScanBlock / 64];
     __shared__ u32 s_bid;
     __shared__ u64 s_base;
-    if (threadIdx.x == 0) s_bid = atomicAdd(&ctr->scan_ticket, 1u);
+    __shared__ u32 s_tagged;
+    if (threadIdx.x == 0) {
+        s_bid = atomicAdd(&ctr->scan_ticket, 1u);
+        s_tagged = 0;
+    }
     __syncthreads();
     const u32 bid = s_bid;
     const u32 r = bid * kScanBlock + threadIdx.x;
-    const u32 g = (r < n_reads) ? counts[r] : 0u;
+    const u32 g_raw = (r < n_reads) ? counts[r] : 0u;
+    const u32 g = g_raw & ~kDeferredTag;
+    // reads finished by sweep_deferred_kernel carry a tag in their count: counted here, one atomic per
+    // workgroup (see Counters::deferred)
+    const u64 tagged = __builtin_amdgcn_ballot_w64((g_raw & kDeferredTag) != 0);
+    if (tagged && lane_id() == 0) atomicAdd(&s_tagged, (u32)__builtin_popcountll(tagged));
     u32 tot;
     const u32 local = block_excl_add<kScanBlock>(g, sc, tot);
     if (threadIdx.x < 64) { // decoupled look-back, 64 predecessors per round trip
@@ -142,6 +151,7 @@ __global__ __launch_bounds__(kScanBlock) void compact_classify_kernel(
         }
     }
     __syncthreads();
+    if (threadIdx.x == 0 && s_tagged) atomicAdd(&ctr->deferred, s_tagged);
     if (r < n_reads) {
         const u64 dst = s_base + local;
         bad_offsets[r] = dst;

@@ -341,7 +341,7 @@ __device__ __forceinline__ void sweep_group_keys(u32 (&x)[K], u32 m, u32 len, i3
             a.rej_list[atomicAdd(a.rej_count, 1u)] = r;
             a.counts[r] = 0;
         } else {
-            a.counts[r] = finish_read(slot_of(), g_closed, mf_incl ? (mf_incl ^ 2u) : 0u, ml_incl, min_ge, len);
+            a.counts[r] = finish_read(slot_of(), g_closed, mf_incl ? (mf_incl ^ 2u) : 0u, ml_incl, min_ge, len) | a.count_tag;
         }
     }
 }
@@ -381,201 +381,105 @@ __device__ __forceinline__ u32 *wave_filter_scratch()
     return s_scratch[threadIdx.x >> 6];
 }
 
-// ---- coverage pre-filter with pile trimming at the two ends of the read (DESIGN.md §3.4 / §3.5;
-// tests/formulation.py::trim_keys_minmax is the emulation) ------------------------------------------
+// ---- the healthy-read screen of the deferring build (tests/formulation.py::
+// healthy_read_regions is the emulation, fuzzed against the oracle) ----------------------------------
 // Bins: NB = LANES coarse bins of 2^sh positions, one per lane, plus one bin for the read's SMALLEST
 // START position and one for its LARGEST END position — where dovetail overlaps clamp: 0 and `len`
 // for a healthy read (on configs[1] 15 % of a read's starts sit at exactly 0 and 15 % of its ends at
 // exactly len), the edges of the covered window for a read that is only covered in part.  In key
 // order: [starts at pmin][coarse 0 .. NB-1][ends at pmax] (nothing else can lie at those two
 // positions: an end is above its own start, a start below its own end).
-//   * coarse bin spanned by more than c intervals (depth at its head - its ends > c): every event in
-//     it is deep (depth above c on both sides) and dropped; otherwise the bin is kept whole;
-//   * starts at pmin: the j-th one has depth j, so only the first c + 1 are kept; ends at pmax: the
-//     depth before the j-th of E is E - j, so only the last c + 1 are kept.  Equal keys: which of
-//     them does not matter.
-// Each maximal run of dropped events is stood in for by |net| keys of one type in front of the next
-// bin that keeps something (net = depth after the run - depth before it; 0 for a healthy read), so
-// the depth of every kept event is unchanged.  Pass 1 counts (one LDS atomic per key, starts in
-// the low half of a counter, ends in the high half), the lanes turn the counters into packed cursors
-// quota << 16 | next slot, pass 2 asks them (one LDS atomic per key: kept or not, and where).
-// A group that keeps more than LANES * K / 2 keys (a read with low coverage throughout: nothing
-// can be dropped) is HEAVY: with DEFER it is reported through `heavy` and goes on empty — the
-// caller appends the read to the overflow list, sweep_deferred_kernel sorts it whole — so that one
-// such read does not drag the other reads of its wavefront into the full sort (and the full sort
-// is not even part of that code path: fewer registers, one more wavefront per SIMD).
-// Returns the tier: 0 = sort everything as before, 1 = every group kept <= LANES keys (y1: one
-// key per lane), 2 = y: K / 2 keys per lane, 3 = nothing to sort: every group is a healthy read (hr).  Only for wavefronts whose intervals are all plain
-// (start < end <= len).
-// What trimfilter hands back for a wavefront of healthy reads (tier 3): per group, the number of
-// starts kept at the smallest start position and the two positions.
+//   * a coarse bin spanned by more than c intervals (depth at its head - its ends > c) is DEEP: every
+//     event in it has a depth above c on both sides and can neither open, close nor bound a bad region;
+//   * of the S0 starts at pmin the j-th has depth j: only the first c + 1 matter; of the E1 ends at
+//     pmax the depth before the j-th is E1 - j: only the last c + 1 matter.
+// A read is HEALTHY when every coarse bin that holds an event is deep and min(S0, c + 1) ==
+// min(E1, c + 1) =: k.  Its events then reduce to k starts at pmin followed by k ends at pmax, and
+// what the sweep (src/stack.rs:61-139 through the event formulation) makes of those is known in
+// closed form: nothing exceeds c when k <= c — the whole read is one bad region — and otherwise the
+// depth is above c exactly between the two positions: the read is bad in front of pmin and behind
+// pmax (the sweep's first closed region and finish_read's last one).  One counting pass (one LDS
+// atomic per key: starts in the low half of a counter, ends in the high half, four copies of every
+// counter by lane & 3 so that a read's hot bins do not serialise the atomics of a row), one packed
+// row scan, no sort.  Every other read — low coverage somewhere inside: the reads yacrd is looking
+// for — is marked in its region-count slot (kDeferredMark) and sorted whole by sweep_deferred_kernel,
+// which scans the two classes' lists for the marks.  (A list appended to with one global atomic per
+// read was the first attempt: at 3 800 deferred reads per 100 000 the same-address atomics, performed
+// at the memory side on this 8-XCD part, took ~7 ns each one after the other and doubled the kernel's
+// duration.)
+// Only for wavefronts whose intervals are all plain (start < end <= len).
+constexpr int kScreenTabWords = 304;
+constexpr u32 kDeferredMark = 0xFFFFFFFFu; // in counts[r]: not a region count (<= intervals + 2)
+template <int WPB> // wavefronts per workgroup
+__device__ __forceinline__ u32 *wave_screen_scratch()
+{
+    __shared__ __attribute__((aligned(16))) u32 s_tab[WPB][kScreenTabWords];
+    return s_tab[threadIdx.x >> 6];
+}
+
 struct HealthyRead {
-    u32 kept_starts, pmin, pmax;
+    u32 kept_starts, pmin, pmax; // k, and the two positions
 };
 
-template <int LANES, int K, bool DEFER, int WPB>
-__device__ __forceinline__ int trimfilter(const u32 (&x)[K], u32 n, u32 len, i32 c,
-                                          u32 (&y1)[1], u32 (&y)[K / 2], u32 &m_out, bool &heavy,
-                                          HealthyRead &hr)
+template <int LANES, int K, int WPB>
+__device__ __forceinline__ bool healthy_screen(const u32 (&x)[K], u32 n, u32 len, i32 c, HealthyRead &hr)
 {
-    static_assert(K == 16, "a lane reads its K/2 = 8 compacted keys as two 16-byte vectors");
-    constexpr int NB = LANES, NBIN = LANES + 3, CAP = LANES * K / 2, GROUPS = 64 / LANES;
-    constexpr u32 kTakeOne = 0xFFFF0001u; // quota - 1, slot + 1
-    constexpr u32 kPadBin = NB, kHeadBin = NB + 1, kTailBin = NB + 2;
-    static_assert(GROUPS * NBIN * 4 <= kFilterTabWords && GROUPS * CAP <= kFilterKeyWords, "scratch");
+    constexpr int NB = LANES, NBIN = LANES + 3, GROUPS = 64 / LANES;
+    constexpr u32 kHeadBin = NB + 1, kTailBin = NB + 2; // (bin NB takes the pads)
+    static_assert(GROUPS * NBIN * 4 <= kScreenTabWords, "scratch");
     const u32 lane = lane_id(), lig = lane & (u32)(LANES - 1), grp = lane / (u32)LANES;
-    u32 *scratch = wave_filter_scratch<WPB>();
-    u32 *tab = scratch + grp * (u32)(NBIN * 4);
-    u32 *keys = scratch + kFilterTabWords + grp * (u32)CAP;
+    u32 *tab = wave_screen_scratch<WPB>() + grp * (u32)(NBIN * 4);
     uint4 *bins = reinterpret_cast<uint4 *>(tab);
-    uint4 *my_keys = reinterpret_cast<uint4 *>(keys) + lig * 2u;
     char *tb = reinterpret_cast<char *>(tab);
-    heavy = false;
 
     // smallest shift with (len >> sh) < NB: the bin holding `len` exists inside the table
     const i32 bits = 32 - (i32)__builtin_clz(len | 1u) - ilog2c(NB) + (len != 0 ? 0 : -1);
-    const u32 sh = (u32)max(bits, 0), ksh = sh + kKeyShift;
+    const u32 ksh = (u32)max(bits, 0) + kKeyShift;
 
     bins[lig] = make_uint4(0u, 0u, 0u, 0u);
     if (lig < 3u) bins[NB + lig] = make_uint4(0u, 0u, 0u, 0u);
     wave_lds_sync();
 
-    // ---- pass 1: count.  Byte offset of a key's counter = bin * 16 + (lane & 3) * 4; the pads
-    // (0xFFFFFFFE, in the slots of intervals the read does not have) clamp into the pads' bin
+    // ---- count.  Byte offset of a key's counter = bin * 16 + (lane & 3) * 4; the pads (0xFFFFFFFE,
+    // in the slots of intervals the read does not have) clamp into the pads' bin
     const u32 cp = (lig & 3u) * 4u, head_off = kHeadBin * 16u + cp, tail_off = kTailBin * 16u + cp;
     // the group's smallest start key and largest end key (the pads are end-like and huge: they never
-    // win the min, and are masked out of the max); a group without intervals matches nothing
+    // win the min, and key + 2 wraps them to 0 for the max); a group without intervals matches nothing
     const int last_addr = (int)((lane | (u32)(LANES - 1)) << 2);
     auto row_total = [&](u32 v) { return (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)v); };
-    u32 smin = x[0], emax = 0;
+    u32 smin = x[0], emax2 = 0;
 #pragma unroll
     for (int j = 0; j < K / 2; j++) {
         smin = min(smin, x[2 * j]);
-        emax = max(emax, x[2 * j + 1] == kPadKey ? 0u : x[2 * j + 1]);
+        emax2 = max(emax2, x[2 * j + 1] + 2u);
     }
-    const u32 kmin = n ? row_total(gscan_min<LANES>(smin)) : 1u, kmax = row_total(gscan_max<LANES>(emax));
-    auto off_start = [&](u32 ks) { return ks == kmin ? head_off : (min(ks >> ksh, (u32)NB) << 4) + cp; }; // the smallest start
-    auto off_end = [&](u32 ke) { return ke == kmax ? tail_off : (min(ke >> ksh, (u32)NB) << 4) + cp; };   // the largest end
+    const u32 kmin = n ? row_total(gscan_min<LANES>(smin)) : 1u;
+    const u32 kmax = n ? row_total(gscan_max<LANES>(emax2)) - 2u : 0u;
 #pragma unroll
     for (int j = 0; j < K / 2; j++) {
-        atomicAdd(reinterpret_cast<u32 *>(tb + off_start(x[2 * j])), 1u);
-        atomicAdd(reinterpret_cast<u32 *>(tb + off_end(x[2 * j + 1])), 0x10000u);
+        const u32 ks = x[2 * j], ke = x[2 * j + 1];
+        atomicAdd(reinterpret_cast<u32 *>(tb + (ks == kmin ? head_off : (min(ks >> ksh, (u32)NB) << 4) + cp)), 1u);
+        atomicAdd(reinterpret_cast<u32 *>(tb + (ke == kmax ? tail_off : (min(ke >> ksh, (u32)NB) << 4) + cp)), 0x10000u);
     }
     wave_lds_sync();
 
-    // ---- what the bins keep
-    // (the two one-position bins are read again where lanes 0 and 1 deal out their quota: holding
-    // them until then costs eight registers at the kernel's high-water mark)
-    u32 w, n0, n01, n012; // this lane's bin: its total, and the running sizes of its first three copies
-    i32 S0, E1;
-    {
-        const uint4 c4 = bins[lig], h4 = bins[kHeadBin], t4 = bins[kTailBin];
-        n0 = (c4.x & 0xFFFFu) + (c4.x >> 16);
-        n01 = n0 + (c4.y & 0xFFFFu) + (c4.y >> 16);
-        n012 = n01 + (c4.z & 0xFFFFu) + (c4.z >> 16);
-        w = c4.x + c4.y + c4.z + c4.w;
-        S0 = (i32)((h4.x + h4.y + h4.z + h4.w) & 0xFFFFu);  // starts at the smallest start position
-        E1 = (i32)((t4.x + t4.y + t4.z + t4.w) >> 16);      // ends at the largest end position
-    }
-    const i32 S = (i32)(w & 0xFFFFu), E = (i32)(w >> 16);
-    const i32 ks0 = min(S0, c + 1), ke1 = min(E1, c + 1);
-    const u32 incl = gscan_add<LANES>(w); // packed: both halves scanned at once
-    const u32 ex = incl - w;
+    const uint4 c4 = bins[lig], h4 = bins[kHeadBin], t4 = bins[kTailBin];
+    const u32 w = c4.x + c4.y + c4.z + c4.w;
+    const i32 E = (i32)(w >> 16);
+    const i32 S0 = (i32)((h4.x + h4.y + h4.z + h4.w) & 0xFFFFu); // starts at the smallest start position
+    const i32 E1 = (i32)((t4.x + t4.y + t4.z + t4.w) >> 16);     // ends at the largest end position
+    const u32 ex = gscan_add<LANES>(w) - w;                       // packed: both halves scanned at once
     const i32 D = S0 + (i32)(ex & 0xFFFFu) - (i32)(ex >> 16);     // depth at the head of this lane's bin
-    const bool deep = D - E > c;                                   // spanned by more than c intervals
-    const u32 keep = deep ? 0u : (u32)(S + E);
-    // The healthy read: every coarse bin that holds anything is deep and the two piles balance.  What
-    // is kept is then min(S0, c + 1) copies of the smallest start key and as many of the largest end
-    // key, and what the sweep makes of those is known in closed form (sweep_group_read; DESIGN.md
-    // §3.5; tests/formulation.py::healthy_read_regions): when every group of the wavefront is like
-    // that — nine wavefronts in ten on configs[1] and [2] — the rest of the plan, pass 2, the sort and
-    // the sweep are skipped.
-    if (__builtin_amdgcn_ballot_w64(keep != 0u || ks0 != ke1) == 0) {
-        hr.kept_starts = (u32)ks0;
-        hr.pmin = kmin >> kKeyShift;
-        hr.pmax = kmax >> kKeyShift;
-        return 3;
-    }
-    // (sequence index + 1) << 16 | depth after the kept block, for bins that keep something (an empty
-    // bin keeps nothing: the bins in front of the smallest start, where D is not the depth, are empty)
-    const u32 tag = (deep || w == 0u) ? 0u : (((lig + 2u) << 16) | (u32)(D - E + S));
-    const u32 tag0 = S0 > 0 ? ((1u << 16) | (u32)ks0) : 0u;
-    const u32 mi = gscan_max<LANES>(tag);
-    u32 exm = gshift_up1<LANES>(mi);
-    if (LANES == 16 && lig == 0) exm = 0; // (row_shr pulls nothing in, bound_ctrl zero: explicit for clarity)
-    const u32 prev = max(exm, tag0);
-    const i32 net = tag ? D - (i32)(prev & 0xFFFFu) : 0;
-    const u32 nsyn = (u32)(net < 0 ? -net : net);
-    const i32 a_last = (i32)(max(row_total(mi), tag0) & 0xFFFFu);
-    const i32 net1 = E1 > 0 ? ke1 - a_last : 0;
-    const u32 nsyn1 = (u32)(net1 < 0 ? -net1 : net1);
-    const u32 mine = keep + nsyn;
-    const u32 ri = gscan_add<LANES>(mine);
-    const u32 coarse_total = row_total(ri);
-    const u32 base = (u32)ks0 + ri - mine;
-    const u32 tail_base = (u32)ks0 + coarse_total;
-    u32 m = tail_base + (u32)ke1 + nsyn1;
-    heavy = m > (u32)CAP;
-    if constexpr (DEFER) m = heavy ? 0u : m; // its read goes to the overflow list; the group goes on empty
-    else if (__builtin_amdgcn_ballot_w64(heavy) != 0) return 0; // the wavefront sorts everything
-    my_keys[0] = make_uint4(kPadKey, kPadKey, kPadKey, kPadKey);
-    my_keys[1] = make_uint4(kPadKey, kPadKey, kPadKey, kPadKey);
-    {
-        // cursors: a coarse bin's copies keep everything (quota 0x7FFF) or nothing
-        const u32 q = (deep || heavy) ? 0u : 0x7FFF0000u;
-        const uint4 s4 = bins[kHeadBin + min(lig, 1u)];
-        bins[lig] = make_uint4(q | base, q | (base + n0), q | (base + n01), q | (base + n012));
-        // the two one-position bins hold one type each: their quota is dealt out to the four copies
-        if (lig < 2u) {
-            const u32 sh2 = lig ? 16u : 0u;
-            const u32 keep2 = heavy ? 0u : (u32)(lig ? ke1 : ks0), b2 = lig ? tail_base : 0u;
-            const u32 k0 = (s4.x >> sh2) & 0xFFFFu, k1 = (s4.y >> sh2) & 0xFFFFu, k2 = (s4.z >> sh2) & 0xFFFFu;
-            const u32 q0 = min(k0, keep2), q1 = min(k1, keep2 - q0), q2 = min(k2, keep2 - q0 - q1),
-                      q3 = keep2 - q0 - q1 - q2;
-            bins[kHeadBin + lig] = make_uint4((q0 << 16) | b2, (q1 << 16) | (b2 + q0), (q2 << 16) | (b2 + q0 + q1),
-                                              (q3 << 16) | (b2 + q0 + q1 + q2));
-        }
-        if (lig == 2u) bins[kPadBin] = make_uint4(0u, 0u, 0u, 0u); // the pads: quota 0
-    }
-    if (__builtin_amdgcn_ballot_w64(((nsyn | nsyn1) != 0) && !heavy) != 0) { // rare: net != 0 somewhere
-        if (!heavy) {
-            // starts go right in front of the bin (position - 1, start class; never in front of the
-            // kept starts at the smallest start position), ends to its head
-            const u32 pk = (lig << sh) << kKeyShift;
-            const u32 synkey = net > 0 ? max(pk, kmin + 1u) - 1u : pk;
-#pragma unroll 1
-            for (u32 t = 0; t < nsyn; t++) keys[base + keep + t] = synkey;
-            if (lig == 0) {
-                const u32 synkey1 = net1 > 0 ? kmax - 1u : kmax;
-#pragma unroll 1
-                for (u32 t = 0; t < nsyn1; t++) keys[tail_base + (u32)ke1 + t] = synkey1;
-            }
-        }
-    }
-    wave_lds_sync();
-
-    // ---- pass 2: every key asks the cursor it counted on
-#pragma unroll
-    for (int q0 = 0; q0 < K; q0 += 8) {
-        u32 got[8];
-#pragma unroll
-        for (int q = 0; q < 8; q++)
-            got[q] = atomicAdd(reinterpret_cast<u32 *>(tb + ((q & 1) ? off_end(x[q0 + q]) : off_start(x[q0 + q]))), kTakeOne);
-#pragma unroll
-        for (int q = 0; q < 8; q++) {
-            if ((i32)got[q] >= 0x10000) keys[got[q] & 0xFFFFu] = x[q0 + q];
-        }
-    }
-    wave_lds_sync();
-    m_out = m;
-    if (__builtin_amdgcn_ballot_w64(m > (u32)LANES) == 0) { // every group fits one key per lane
-        y1[0] = keys[lig];
-        return 1;
-    }
-    const uint4 lo = my_keys[0], hi = my_keys[1];
-    y[0] = lo.x, y[1] = lo.y, y[2] = lo.z, y[3] = lo.w;
-    y[4] = hi.x, y[5] = hi.y, y[6] = hi.z, y[7] = hi.w;
-    return 2;
+    const bool shallow = w != 0u && !(D - E > c);                  // holds events and is not deep
+    const i32 k = min(S0, c + 1);
+    hr.kept_starts = (u32)k;
+    hr.pmin = kmin >> kKeyShift;
+    hr.pmax = kmax >> kKeyShift;
+    // the group's verdict, the same in all of its lanes
+    const u64 sb = __builtin_amdgcn_ballot_w64(shallow);
+    const u32 mine = LANES == 64 ? (u32)((sb | (sb >> 32)) != 0)
+                                 : (u32)(sb >> (lane & (u32)(64 - LANES))) & (u32)((1ull << (LANES & 63)) - 1ull);
+    return mine == 0u && k == min(E1, c + 1);
 }
 
 // ---- the bin filter without trimming (round 1): used by the builds that do not
@@ -715,7 +619,7 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
             // the deferring build holds neither the class / rejection logic nor the 16-keys-per-lane
             // sort: the reads of such a wavefront are finished by sweep_deferred_kernel
             if (!plain) {
-                if (lig == LANES - 1 && active) a.over_list[atomicAdd(a.over_count, 1u)] = r;
+                if (lig == 0 && active) a.counts[r] = kDeferredMark;
                 return;
             }
         } else if (!plain) {
@@ -744,41 +648,28 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
     const bool zl_check = (zmask & (zmask - 1)) != 0 || __builtin_amdgcn_ballot_w64(nz > 2) != 0;
 
     if constexpr (K == 16 && DEFER) {
-        { // (the engine only launches this build with the filter on; every wavefront here is plain)
-            u32 y1[1], y[K / 2], mf;
-            bool heavy;
-            HealthyRead hr;
-            const int tier = trimfilter<LANES, K, true, WPB>(x, n, len, c, y1, y, mf, heavy, hr);
-            if (a.prefilter == 2 && lig == 0 && active && !heavy) atomicAdd(&a.ctr->prefiltered, 1u);
-            if (tier == 3) {
-                // k starts at pmin then k ends at pmax, k = min(S0, c + 1): the depth passes c only
-                // when k = c + 1, and then exactly between the two positions — the read is bad in
-                // front of pmin and behind pmax (the sweep's first closed region and finish_read's
-                // last one); with k <= c (or no interval at all) nothing ever exceeds c and the whole
-                // read is one bad region (finish_read's "mf_t == 0" branch).  len >= 1 whenever n >= 1.
-                if (lig == 0 && active) {
-                    uint2 *slot = a.stage + (a.off[r] + 2 * (u64)r);
-                    u32 g = 0;
-                    if ((i32)hr.kept_starts <= c) {
-                        if (len != 0) slot[g++] = make_uint2(0u, len);
-                    } else {
-                        if (hr.pmin != 0) slot[g++] = make_uint2(0u, hr.pmin);
-                        if (hr.pmax != len) slot[g++] = make_uint2(hr.pmax, len);
-                    }
-                    a.counts[r] = g;
+        // (the engine only launches this build with the filter on; every wavefront here is plain)
+        HealthyRead hr;
+        const bool healthy = healthy_screen<LANES, K, WPB>(x, n, len, c, hr);
+        if (lig == 0 && active) {
+            if (healthy) {
+                // k starts at pmin then k ends at pmax (healthy_screen): one bad region over the
+                // whole read when k <= c (also the read without intervals; finish_read's
+                // "mf_t == 0" branch), else the parts in front of pmin and behind pmax.  len >= 1
+                // whenever n >= 1.
+                uint2 *slot = a.stage + (a.off[r] + 2 * (u64)r);
+                u32 g = 0;
+                if ((i32)hr.kept_starts <= c) {
+                    if (len != 0) slot[g++] = make_uint2(0u, len);
+                } else {
+                    if (hr.pmin != 0) slot[g++] = make_uint2(0u, hr.pmin);
+                    if (hr.pmax != len) slot[g++] = make_uint2(hr.pmax, len);
                 }
-                return;
+                a.counts[r] = g;
+                if (a.prefilter == 2) atomicAdd(&a.ctr->prefiltered, 1u);
+            } else {
+                a.counts[r] = kDeferredMark; // sweep_deferred_kernel sorts it whole
             }
-            const bool act = active && !heavy; // a heavy read is finished by sweep_deferred_kernel
-            // the sort's per-lane constants are derived here, not carried through the filter (8 registers)
-            u32 lane2 = lane;
-            asm volatile("" : "+v"(lane2));
-            const LaneConst lc2 = make_lane_const(lane2);
-            if (tier == 1) sweep_group_keys<LANES, 1, XM>(y1, mf, len, c, act, r, badmask, zmask, zl_check, a, lc2);
-            else sweep_group_keys<LANES, K / 2, XM>(y, mf, len, c, act, r, badmask, zmask, zl_check, a, lc2);
-            // a read the filter could not thin goes to the overflow list: sweep_deferred_kernel sorts it
-            // whole, one read per wavefront
-            if (heavy && lig == LANES - 1 && active) a.over_list[atomicAdd(a.over_count, 1u)] = r;
         }
         return;
     } else if constexpr (K == 16) {
@@ -840,21 +731,61 @@ inline void launch_sweep_group(const SweepArgs &sa, u32 n_reads, hipStream_t str
                            stream, sa);
 }
 
-// The reads the filter deferred (low coverage throughout: every event kept), sorted whole: one read
-// per wavefront on all 64 lanes (4 keys per lane up to 128 intervals, 8 up to 256: a short serial
-// chain per wavefront instead of the 16-keys-per-lane sort their class would run).  A persistent
-// grid; the count is only known on the device.
-__global__ __launch_bounds__(256) void sweep_deferred_kernel(SweepArgs a)
+// The reads the screen deferred (low coverage somewhere inside, or intervals that are not plain),
+// sorted whole: one read per wavefront on all 64 lanes (4 keys per lane up to 128 intervals, 8 up to
+// 256).  The kernel scans the lists of the two classes, 64 entries per wavefront and step, for the
+// marks the fused kernel left in counts[], and a wavefront works through the marked reads of its 64
+// one after the other (~4 % of the reads on configs[1]: two or three per wavefront).
+constexpr u32 kDeferChunk = 64; // list entries a workgroup scans per step
+struct DeferArgs {
+    SweepArgs base;
+    u32 n_entries;
+    u32 first[2], count[2];   // list entries [first, first + count) of each class, clipped to *list_n
+    const u32 *list[2];
+    const u32 *list_n[2];
+};
+
+__global__ __launch_bounds__(256) void sweep_deferred_kernel(DeferArgs d)
 {
-    const u32 lane = lane_id();
+    const u32 lane = lane_id(), wv = threadIdx.x >> 6;
     const LaneConst lc = make_lane_const(lane);
-    const u32 n_list = *a.list_n;
-    for (u32 w = blockIdx.x * 4u + (threadIdx.x >> 6); w < n_list; w += gridDim.x * 4u) { // wave-uniform
-        const u32 r = a.list[w];
-        const u64 o = a.off[r];
-        const u32 n = (u32)(a.off[r + 1] - o), len = a.len[r];
-        if (n <= 128u) sweep_group_read<64, 4, 0>(a.iv + o, n, len, a.cov, true, r, a, lc);
-        else sweep_group_read<64, 8, 0>(a.iv + o, n, len, a.cov, true, r, a, lc);
+    const SweepArgs &a = d.base;
+    for (u32 e = 0; e < d.n_entries; e++) {
+        const u32 end = min(d.first[e] + d.count[e], *d.list_n[e]);
+        const u32 *list = d.list[e];
+        // the four wavefronts of a workgroup look at the same 64 entries and share the marked reads
+        // among them (the k-th goes to wavefront k mod 4): the serial chain of a wavefront stays short
+        // even where the marks bunch up
+        for (u32 base = d.first[e] + blockIdx.x * 64u; base < end; base += gridDim.x * 64u) { // uniform
+            const u32 idx = base + lane;
+            u32 r = 0, n = 0, len = 0;
+            u64 o = 0;
+            bool marked = false;
+            if (idx < end) {
+                r = list[idx];
+                marked = a.counts[r] == kDeferredMark;
+            }
+            if (marked) { // every marked read's extent, fetched side by side
+                o = a.off[r];
+                n = (u32)(a.off[r + 1] - o);
+                len = a.len[r];
+            }
+            const u64 all = __builtin_amdgcn_ballot_w64(marked);
+            __syncthreads(); // every wavefront has looked before the first one replaces a mark by its count
+            const u32 rank = (u32)__builtin_popcountll(all & ((1ull << lane) - 1ull));
+            u64 todo = __builtin_amdgcn_ballot_w64(marked && (rank & 3u) == wv);
+            while (todo) {
+                const int l = (int)__builtin_ctzll(todo);
+                todo &= todo - 1;
+                const u32 rr = (u32)__builtin_amdgcn_readlane((int)r, l);
+                const u32 nn = (u32)__builtin_amdgcn_readlane((int)n, l);
+                const u32 ll = (u32)__builtin_amdgcn_readlane((int)len, l);
+                const u64 oo = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(o >> 32), l) << 32) |
+                               (u32)__builtin_amdgcn_readlane((int)(u32)o, l);
+                if (nn <= 128u) sweep_group_read<64, 4, 0>(a.iv + oo, nn, ll, a.cov, true, rr, a, lc);
+                else sweep_group_read<64, 8, 0>(a.iv + oo, nn, ll, a.cov, true, rr, a, lc);
+            }
+        }
     }
 }
 

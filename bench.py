@@ -259,7 +259,7 @@ def main():
                          "kernel_reads": c_reads, "kernel_intervals": c_iv,
                          "deferred_reads": deferred, "deferred_kernel_ms": t.get("deferred_ms", 0.0) / K,
                          "whole_path_algorithmic_bytes": b_alg,
-                         "note": "batch (82 MB + scratch) fits the 256 MiB Infinity Cache: see large.roofline for the "
+                         "note": "batch (82 MB) fits the 256 MiB Infinity Cache: see large.roofline for the "
                                  "same kernel on a 3.3 GB input"},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -263,9 +263,12 @@ def test_read_partitioned_multi_engine(engine):
             assert_same(got, want, "partitioned x%d" % len(engines))
 
 
-def test_class_prediction_is_validated():
+@pytest.mark.parametrize("flags", [0, yacrd_amd.F_ALWAYS_DEFER])
+def test_class_prediction_is_validated(flags):
     """Runs of identical shape (reads, intervals) reuse the previous run's class set instead of
-    waiting for the plan; a batch whose classes differ must still come out bit-exact."""
+    waiting for the plan; a batch whose classes differ must still come out bit-exact.  With the
+    deferring build as well: its remainder launches (SweepArgs.first > 0) mark and finish their own
+    reads."""
     R = 600
     a_sizes = [100] * R                                    # everything in one class
     b_sizes = [10] * 300 + [190] * 299 + [60000 - 3000 - 299 * 190]  # same totals, other classes
@@ -275,7 +278,7 @@ def test_class_prediction_is_validated():
     d_sizes = [100] * 200 + [36] * 200 + [164] * 200
     e_sizes = [100] * 400 + [36] * 100 + [164] * 100
     assert sum(d_sizes) == sum(e_sizes) == 60000
-    with yacrd_amd.Engine() as e, yacrd_amd.Engine(flags=yacrd_amd.F_NO_PREDICTION) as ref:
+    with yacrd_amd.Engine(flags=flags) as e, yacrd_amd.Engine(flags=flags | yacrd_amd.F_NO_PREDICTION) as ref:
         for rep, sizes in enumerate([a_sizes, a_sizes, b_sizes, b_sizes, c_sizes, a_sizes, c_sizes,
                                      d_sizes, d_sizes, e_sizes, e_sizes, a_sizes, d_sizes]):
             csr = make_csr(1200 + rep, sizes, REGULAR_MODES + ("degenerate",), len_lo=300000,
@@ -390,8 +393,9 @@ def test_skewed_profile_without_prefilter_and_with_degenerates():
             assert_same(e.run(offsets, intervals, lengths, 4, 0.4), want, "flags %d" % flags)
 
 
-# ---- the deferring build of the fused register-sort kernel (pile trimming at position 0 / len, reads
-# the filter cannot thin finished by sweep_deferred_kernel) against the oracle and the other build ----
+# ---- the deferring build of the fused register-sort kernel (healthy-read screen + closed form, every
+# other read marked and finished by sweep_deferred_kernel) against the oracle and the
+# other build ----
 @pytest.mark.parametrize("cov", [0, 1, 4, 9, 40])
 def test_fused_defer_build(cov):
     from yacrd_amd import host
@@ -406,8 +410,15 @@ def test_fused_defer_build(cov):
         for flags in (yacrd_amd.F_ALWAYS_DEFER, yacrd_amd.F_NO_DEFER):
             with yacrd_amd.Engine(flags=flags | yacrd_amd.F_COUNT_PREFILTERED) as e:
                 assert_same(e.run(o, iv, ln, cov, 0.4), w2, "profile %d flags %d" % (prof, flags))
+                t = e.timing()
                 if cov <= 4:
-                    assert e.timing()["prefiltered_reads"] > R // 2
+                    assert t["prefiltered_reads"] > R // 2
+                if flags == yacrd_amd.F_ALWAYS_DEFER:  # healthy + deferred = the two classes' reads
+                    n = np.diff(o.astype(np.int64))
+                    both = t["prefiltered_reads"] + t["deferred_reads"]  # (+ filtered reads of the one-read-per-wavefront class)
+                    assert 0 < t["deferred_reads"] and 0 <= both - int(((n > 64) & (n <= 256)).sum()) <= int((n > 256).sum())
+                else:
+                    assert t["deferred_reads"] == 0
     for flags in (yacrd_amd.F_ALWAYS_DEFER, yacrd_amd.F_NO_DEFER):
         with yacrd_amd.Engine(flags=flags) as e:
             assert_same(e.run(*csr, cov, 0.4), want, "cases flags %d" % flags)

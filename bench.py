@@ -54,7 +54,8 @@ def alg_bytes(R, I, G):
 
 
 def dominant(t, K, yacrd_amd):
-    """(kernel name, class name, ms per launch, reads, intervals) of the kernel with the most time."""
+    """(kernel name, class name, ms per launch, reads, intervals) of the kernel with the most time;
+    K = the launches that carried the events (yacrd_timing.timed_runs)."""
     cls_ms = list(t["class_ms"])
     ci = max(range(12), key=lambda i: cls_ms[i])
     if t["fused_ms"] >= cls_ms[ci]:  # the row / half-wavefront classes run as one launch
@@ -80,6 +81,9 @@ def main():
                     help="engines (HIP streams) the batches are pipelined over on each GPU")
     ap.add_argument("--host-threads", action="store_true",
                     help="one host thread per engine instead of one thread pipelining all of them")
+    ap.add_argument("--time-every-launch", action="store_true",
+                    help="start / stop events on the dominant kernel of EVERY step (default: every 8th step of an "
+                         "engine, YACRD_F_TIMING_SAMPLED: the events cost ~10 us per step against a 20 us kernel)")
     ap.add_argument("--full-timing", action="store_true",
                     help="HIP events around every phase and class kernel (slower steps)")
     ap.add_argument("--strong", action="store_true",
@@ -125,6 +129,8 @@ def main():
     flags = (yacrd_amd.F_FORCE_LDS_SORT if args.lds_sort else 0) | args.flags
     if args.full_timing:
         flags |= yacrd_amd.F_TIMING_FULL
+    elif not args.time_every_launch:
+        flags |= yacrd_amd.F_TIMING_SAMPLED
     # Batches are pipelined over `--engines` engines on this GPU from this one host thread
     # (yacrd_engine_submit_device / yacrd_engine_wait): the plan / compaction kernels, the counter
     # copy, the launch gaps and the host's turn of one batch hide behind the sweep of another.
@@ -191,10 +197,24 @@ def main():
             t = te
         else:
             for k2, v in te.items():
-                if k2.endswith("_ms"):
+                if k2.endswith("_ms") or k2 == "timed_runs":
                     t[k2] = [a + b for a, b in zip(t[k2], v)] if isinstance(v, list) else t[k2] + v
     assert n_timed == args.steps
     ev_overhead_ms = eng.event_overhead_ms()
+    # After the timed region: a few steps on one engine with events around every phase and class
+    # kernel (YACRD_F_TIMING_FULL: +40 us per step, so never part of `value`) for the per-phase table
+    # and the deferred launch's own duration.
+    phases = None
+    if rank == 0 and not args.full_timing:
+        with yacrd_amd.Engine(device_id=dev_index, flags=flags | yacrd_amd.F_TIMING_FULL) as fe:
+            for _ in range(5):
+                fe.run_device(*ptrs)
+            fe.timing_total(reset=True)
+            for _ in range(30):
+                fe.run_device(*ptrs)
+            phases, nf = fe.timing_total()
+            phases = {k: (v / nf if not isinstance(v, list) else [x / nf for x in v]) for k, v in phases.items()
+                      if k.endswith("_ms")}
     G = int(out.n_regions)
     elapsed = ydist.max_over_ranks(dist, elapsed, dev)
 
@@ -207,7 +227,8 @@ def main():
         # are those of the reads it processed.  dom_ms: HIP start / stop events attached to the
         # launch itself (hipExtLaunchKernelGGL: the dispatch's own timestamps, the figure rocprofv3
         # --kernel-trace reports), averaged over every launch of the timed region.
-        dom, cname, dom_ms, c_reads, c_iv = dominant(t, K, yacrd_amd)
+        n_timed_launches = int(t.get("timed_runs", 0)) or K
+        dom, cname, dom_ms, c_reads, c_iv = dominant(t, n_timed_launches, yacrd_amd)
         # reads the fused kernel's filter could not thin are finished by sweep_deferred_kernel: the
         # fused kernel loads and bins them, but its bytes only count the reads it completes
         deferred = int(t.get("deferred_reads", 0)) if cname == "R2..H16" else 0
@@ -217,9 +238,9 @@ def main():
             c_reads -= deferred
         b_dom = 8 * c_iv + 21 * c_reads + 16 + 8 * (G * c_reads // max(R, 1))
         achieved = b_dom / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        avg["class_ms"] = {yacrd_amd.CLASS_NAMES[i]: t["class_ms"][i] / K for i in range(12) if t["class_ms"][i] > 0}
+        avg["class_ms"] = {yacrd_amd.CLASS_NAMES[i]: t["class_ms"][i] / n_timed_launches for i in range(12) if t["class_ms"][i] > 0}
         if t["fused_ms"] > 0:
-            avg["class_ms"]["R2..H16 (one launch)"] = t["fused_ms"] / K
+            avg["class_ms"]["R2..H16 (one launch)"] = t["fused_ms"] / n_timed_launches
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
@@ -251,13 +272,17 @@ def main():
                        "parallelism": "read-partition x%d, no collective; %d batches in flight per GPU (one engine each)" % (world, NE)},
             "kernel_overlaps_per_sec": world * args.overlaps * K / elapsed,
             "kernel_ms": avg,
+            "phases_full_timing_ms": ({k: phases[k] for k in keys + ("fused_ms", "deferred_ms") if phases.get(k)}
+                                      if phases else None),
             "path_gbps": b_alg / (avg["total_ms"] * 1e-3) / 1e9 if avg.get("total_ms") else None,
             "roofline": {"bound": "hbm", "kernel": dom, "size_class": cname, "achieved": achieved,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes": b_dom, "kernel_ms": dom_ms,
                          "empty_event_bracket_ms": ev_overhead_ms,
+                         "timed_launches": n_timed_launches, "launches": K,
                          "kernel_reads": c_reads, "kernel_intervals": c_iv,
-                         "deferred_reads": deferred, "deferred_kernel_ms": t.get("deferred_ms", 0.0) / K,
+                         "deferred_reads": deferred,
+                         "deferred_kernel_ms": (phases or {}).get("deferred_ms", t.get("deferred_ms", 0.0) / K),
                          "whole_path_algorithmic_bytes": b_alg,
                          "note": "batch (82 MB) fits the 256 MiB Infinity Cache: see large.roofline for the "
                                  "same kernel on a 3.3 GB input"},
@@ -482,6 +507,7 @@ def large_block(yacrd_amd, host, ydist, dist, dev, torch, eng, rank, world, args
     d_len = torch.from_numpy(np.ascontiguousarray(ln).view(np.int32)).to(dev)
     torch.cuda.synchronize()
     upload_s = time.perf_counter() - t0
+    eng = yacrd_amd.Engine(device_id=dev.index)  # its own engine: every launch carries the events (1 ms kernels)
     ptrs = (d_off.data_ptr(), d_iv.data_ptr(), d_len.data_ptr(), Rl, Il, cov, nc)
     W, K = 2, max(1, args.large_steps)
     for _ in range(W):
@@ -500,6 +526,15 @@ def large_block(yacrd_amd, host, ydist, dist, dev, torch, eng, rank, world, args
     elapsed = ydist.max_over_ranks(dist, mine, dev)
     t, _ = eng.timing_total()
     G = int(res.n_regions)
+    deferred_ms = 0.0
+    if rank == 0:  # the deferred launch's own duration: two extra steps with events around everything
+        with yacrd_amd.Engine(device_id=dev.index, flags=yacrd_amd.F_TIMING_FULL) as fe:
+            fe.run_device(*ptrs)
+            fe.timing_total(reset=True)
+            fe.run_device(*ptrs)
+            fe.run_device(*ptrs)
+            tf, nf = fe.timing_total()
+            deferred_ms = tf.get("deferred_ms", 0.0) / max(nf, 1)
     # oracle parity on a sample of this rank's reads (every ~100th read, at most 20 000)
     import oracle
     got = eng.fetch()
@@ -554,7 +589,7 @@ def large_block(yacrd_amd, host, ydist, dist, dev, torch, eng, rank, world, args
                         "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                         "traffic": large_traffic(R, O) if world == 1 else None, "algorithmic_bytes": b_dom,
                         "kernel_ms": dom_ms, "kernel_reads": c_reads, "kernel_intervals": c_iv,
-                        "deferred_reads": deferred, "deferred_kernel_ms": t.get("deferred_ms", 0.0) / K,
+                        "deferred_reads": deferred, "deferred_kernel_ms": deferred_ms,
                         "note": "rank 0's launch; input %.2f GB per GPU, outside the 256 MiB Infinity Cache" % (8 * Il / 1e9)}}
     del d_off, d_iv, d_len
     return out

@@ -92,6 +92,10 @@ typedef struct {
 /* engines that share a device take turns with the dominant sweep launch (a GPU-side event wait:
  * the launch's start / stop events then time that kernel alone); A/B only */
 #define YACRD_F_SWEEP_TURNS 16384u
+/* the dominant kernel carries its start / stop events on every 8th run of the engine only: attached
+ * events cost ~10 us per batch (host + stream) against a 20 us kernel; yacrd_timing.timed_runs says how
+ * many runs were timed */
+#define YACRD_F_TIMING_SAMPLED 32768u
 
 /* Host-side result, allocated by the engine, released with yacrd_result_free(). */
 typedef struct {
@@ -143,6 +147,10 @@ typedef struct {
      * own time (start / stop events attached to it, like fused_ms) */
     uint64_t deferred_reads;
     float deferred_ms;
+    /* runs in which the dominant kernel carried its start / stop events: 1 or 0 for one run, the count
+     * in yacrd_engine_timing_total (fused_ms / class_ms are sums over these runs: with
+     * YACRD_F_TIMING_SAMPLED not every run is one) */
+    uint32_t timed_runs;
 } yacrd_timing;
 
 /* size classes, in the order of yacrd_timing.class_*: R<K> = four reads per wavefront (16-lane

@@ -418,6 +418,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     for (int i = 0; i < 12; i++) cls_b[i] = cls_e[i] = -1;
     int n_cls_ev = 0, dom_cls = -1;
     bool timing_on = !(e->flags & YACRD_F_NO_TIMING);
+    if ((e->flags & YACRD_F_TIMING_SAMPLED) && !full && (e->run_seq++ % 8u) != 0) timing_on = false;
     auto before_class = [&](int cls) -> hipError_t {
         if (!timing_on || !(full || cls == dom_cls)) return hipSuccess;
         if (n_cls_ev > 0 && full) { // the previous class's end mark is this one's begin mark
@@ -519,9 +520,11 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
                     }
                     const u32 dgrid = (u32)std::min<u64>(chunks, (u64)e->num_cu * 64);
                     hipExtLaunchKernelGGL(yk::sweep_deferred_kernel, dim3(dgrid ? dgrid : 1), dim3(256), 0, e->stream,
-                                          mark ? e->ev_cls[20] : (hipEvent_t) nullptr,
-                                          mark ? e->ev_cls[21] : (hipEvent_t) nullptr, 0, da);
-                    if (mark) deferred_marked = true;
+                                          (mark && full) ? e->ev_cls[20] : (hipEvent_t) nullptr,
+                                          (mark && full) ? e->ev_cls[21] : (hipEvent_t) nullptr, 0, da);
+                    // (its own start / stop events only with YACRD_F_TIMING_FULL: a pair costs the host
+                    // ~4 us and the stream ~5 us per batch)
+                    if (mark && full) deferred_marked = true;
                 }
             }
         }
@@ -781,6 +784,9 @@ int conclude_run(yacrd_engine *e, yk::Counters c0, bool predicted, uint64_t n_re
     t.class_ms[yk::CLS_GENERAL] = (full && c0.n[yk::CLS_GENERAL]) ? t.sweep_general_ms : 0.f;
     t.fused_ms = 0.f;
     t.deferred_ms = 0.f;
+    t.timed_runs = fused_marked ? 1u : 0u;
+    for (int cls = 0; cls < yk::CLS_GENERAL; cls++)
+        if (cls_b[cls] >= 0 && cls_e[cls] >= 0) t.timed_runs = 1u;
     t.deferred_reads = c1.deferred;
     t.fused_reads = t.fused_intervals = 0;
     t.prefiltered_reads = c1.prefiltered;
@@ -788,6 +794,9 @@ int conclude_run(yacrd_engine *e, yk::Counters c0, bool predicted, uint64_t n_re
         t.fused_ms = ev_ms(e->ev_cls[22], e->ev_cls[23]);
         // the launch that finishes the reads the fused kernel's filter deferred: timed on its own
         if (deferred_marked) t.deferred_ms = ev_ms(e->ev_cls[20], e->ev_cls[21]);
+    }
+    if (!(e->flags & (YACRD_F_FORCE_LDS_SORT | YACRD_F_XLANE_DS | YACRD_F_NO_FUSED_LAUNCH))) {
+        // what the one launch of the classes R2..H16 holds (whether or not this run timed it)
         for (int cls = yk::CLS_R2; cls <= yk::CLS_H16; cls++) {
             t.fused_reads += c0.n[cls];
             t.fused_intervals += c0.iv[cls];
@@ -808,6 +817,7 @@ int conclude_run(yacrd_engine *e, yk::Counters c0, bool predicted, uint64_t n_re
     for (int i = 0; i < 12; i++) ts.class_ms[i] = keep.class_ms[i] + t.class_ms[i];
     ts.fused_ms = keep.fused_ms + t.fused_ms;
     ts.deferred_ms = keep.deferred_ms + t.deferred_ms;
+    ts.timed_runs = keep.timed_runs + t.timed_runs;
     e->timing_runs++;
     return YACRD_OK;
 }

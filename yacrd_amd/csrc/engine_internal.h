@@ -144,6 +144,7 @@ struct yacrd_engine {
     yacrd_timing timing = {};
     yacrd_timing timing_sum = {};
     uint64_t timing_runs = 0;
+    uint32_t run_seq = 0; // runs since creation (YACRD_F_TIMING_SAMPLED times every 8th)
     // pinned bounce buffers for pageable inputs (yke::h2d), allocated on first use; an event per
     // buffer says when its DMA is done and it may be refilled
     static constexpr int kBounce = 12;

@@ -26,6 +26,7 @@ F_BLOCKING_WAIT = 2048
 F_NO_DEFER = 4096
 F_ALWAYS_DEFER = 8192
 F_SWEEP_TURNS = 16384
+F_TIMING_SAMPLED = 32768
 
 # every symbol include/yacrd_engine.h declares
 EXPORTED_SYMBOLS = [
@@ -70,7 +71,7 @@ class _Timing(ctypes.Structure):
                 ("class_intervals", ctypes.c_uint64 * 12), ("fused_ms", ctypes.c_float),
                 ("fused_reads", ctypes.c_uint64), ("fused_intervals", ctypes.c_uint64),
                 ("prefiltered_reads", ctypes.c_uint64), ("deferred_reads", ctypes.c_uint64),
-                ("deferred_ms", ctypes.c_float)]
+                ("deferred_ms", ctypes.c_float), ("timed_runs", ctypes.c_uint32)]
 
 CLASS_NAMES = "R2,R4,R8,R16,H16,W2,W4,W8,W16,M1,M2,BIG".split(",")
 CLASS_KERNELS = {  # the HIP kernel behind each class, as rocprofv3 prints it

@@ -815,8 +815,18 @@ struct FusedArgs {
 template <bool DEFER, int WPB>
 __device__ __forceinline__ void sweep_small_fused_body(const FusedArgs &f)
 {
+    // Workgroups are dealt out to the 8 XCDs round robin (XCD = blockIdx.x mod 8); reads that are
+    // neighbours in a class list are neighbours in memory and share cache lines at their boundaries,
+    // so every XCD (its own L2) gets one contiguous eighth of the grid instead of every 8th workgroup.
+    u32 g = blockIdx.x;
+#ifndef YK_NO_XCD_REMAP
+    {
+        const u32 nb = gridDim.x, x = g & 7u, q = nb >> 3, rem = nb & 7u;
+        g = x * q + min(x, rem) + (g >> 3);
+    }
+#endif
     u32 e = 0, first = 0;
-    while (e + 1 < f.n_entries && blockIdx.x >= f.block_end[e]) {
+    while (e + 1 < f.n_entries && g >= f.block_end[e]) {
         first = f.block_end[e];
         e++;
     }
@@ -824,7 +834,7 @@ __device__ __forceinline__ void sweep_small_fused_body(const FusedArgs &f)
     a.list = f.list[e];
     a.list_n = f.list_n[e];
     a.first = f.first[e];
-    const u32 b = blockIdx.x - first;
+    const u32 b = g - first;
     switch (f.cls[e]) { // the one-read-per-wavefront classes stay separate kernels (registers)
     case CLS_R2: sweep_group_block<16, 2, 0, false, WPB>(a, b); break;
     case CLS_R4: sweep_group_block<16, 4, 0, false, WPB>(a, b); break;

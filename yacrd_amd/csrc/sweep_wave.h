@@ -1,5 +1,7 @@
 // sweep_wave.h — small classes (<= 1024 events): one, two or four reads per wavefront, sorted in
-// registers; a coverage pre-filter in front of the sort for the 16-keys-per-lane classes.
+// registers; a coverage pre-filter in front of the sort for the 16-keys-per-lane classes, or — in
+// long launches — a screen that finishes healthy reads in closed form and leaves the sort to a
+// second launch for the rest (healthy_screen, sweep_deferred_kernel).
 //
 // Same event formulation as sweep_lds.h (reference src/stack.rs:61-139 for regular reads), but
 // the dominant cost — sorting the 2n event keys — runs as a bitonic network over VGPRs:
@@ -843,12 +845,12 @@ __device__ __forceinline__ void sweep_small_fused_body(const FusedArgs &f)
     default: sweep_group_block<32, 16, 0, DEFER, WPB>(a, b); break;
     }
 }
-// Two builds.  DEFER: a read the filter cannot thin goes to f.base.over_list (sweep_deferred_kernel
-// finishes it) instead of dragging its wavefront into the 16-keys-per-lane sort; without that sort
-// in the filtered path the kernel fits 80 registers, six workgroups per CU, and it is bound by how
-// many wavefronts overlap their latencies (configs[2]: 1.90 -> 1.43 ms; configs[1]: 47.9 -> 38.5 +
-// 4.4 us).  The extra launch costs ~4 us however little it has to do, so small batches use the
-// other build (the engine decides by the classes' interval count).
+// Two builds.  DEFER (long launches): the classes R16 / H16 run the healthy-read screen (one counting
+// pass + closed form) and mark every other read in counts[] for sweep_deferred_kernel;
+// no sort for those classes in this kernel: 56 registers, one-wavefront workgroups, bound by the
+// memory system (configs[1]: 47.9 -> 18.7 us, configs[2]: 1.90 -> 0.74 ms).  The second launch costs
+// ~10 us of stream time however little it has to do, so short launches use the other build: bin
+// filter + register sort for every read (the engine decides by the classes' interval count).
 // (__launch_bounds__' second argument: wavefronts per SIMD)
 __global__ __launch_bounds__(64 * kDeferWaves, kDeferOcc) void sweep_small_fused_defer_kernel(FusedArgs f)
 {

@@ -165,18 +165,9 @@ def main():
             for _ in range(k):
                 res = eng.run_device(*ptrs)
             return res
-        inflight = [False] * NE
-        res = None
-        for i in range(k):
-            j = i % NE
-            if inflight[j]:
-                res = engs[j].wait()
-            engs[j].submit_device(*ptrs)
-            inflight[j] = True
-        for j in range(NE):
-            if inflight[j]:
-                res = engs[j].wait()
-        return res
+        # the submit / wait loop itself lives behind the C ABI (yacrd_engines_run_device_batches):
+        # batch i on engine i mod NE, NE batches in flight, one call for the k batches
+        return yacrd_amd.run_device_batches(engs, [ptrs] * k)
 
     run_steps(max(args.warmup, 2 * NE))  # (a submit only pipelines once the engine has a prediction)
     keys = ("plan_ms", "sweep_small_ms", "sweep_medium_ms", "sweep_general_ms", "compact_ms", "total_ms")

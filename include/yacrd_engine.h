@@ -191,6 +191,24 @@ int yacrd_engine_submit_device(yacrd_engine *e, const void *d_offsets, const voi
                                uint32_t coverage, double not_coverage);
 int yacrd_engine_wait(yacrd_engine *e, yacrd_device_result *out);
 
+/* The submit / wait loop over a LIST of device-resident batches, kept on this side of the ABI (a
+ * streaming host that hands over many batches pays one call, not two per batch): batch i runs on
+ * engines[i % n_engines], all on one device, up to n_engines batches in flight.  `done`, when given,
+ * is called from the calling thread once per batch, in order, after its wait and before its engine
+ * is used again — the place to consume the batch's device-resident result (yacrd_engine_fetch) —
+ * and a non-zero return stops the loop (YACRD_EINVAL).  The replacement for the batch loop of
+ * FromOverlap::compute_all_bad_part (src/stack.rs:143-162) when the overlaps already sit in HBM. */
+typedef struct yacrd_device_batch {
+    const void *d_offsets, *d_intervals, *d_lengths;
+    uint64_t n_reads, n_intervals;
+    uint32_t coverage;
+    double not_coverage;
+} yacrd_device_batch;
+typedef int (*yacrd_batch_done_fn)(void *user, uint32_t batch, yacrd_engine *e, const yacrd_device_result *res);
+int yacrd_engines_run_device_batches(yacrd_engine *const *engines, uint32_t n_engines,
+                                     const yacrd_device_batch *batches, uint32_t n_batches,
+                                     yacrd_batch_done_fn done, void *user, yacrd_device_result *last);
+
 /* yacrd_engine_run in two halves for HOST inputs: submit validates the CSR, enqueues H2D + the whole
  * run on the engine's stream and returns; collect waits and brings the result home.  With two
  * engines per GPU a caller keeps PCIe and the kernels busy at the same time (batch k+1 crosses PCIe

@@ -288,6 +288,42 @@ def test_class_prediction_is_validated(flags):
             assert_same(ref.run(*csr, 3, 0.4), want, "unpredicted run %d" % rep)
 
 
+def test_device_batches_pipeline():
+    """yacrd_engines_run_device_batches: a list of device-resident batches over 1-3 engines, every
+    batch fetched in its callback and compared with the oracle; a callback can stop the loop."""
+    import torch
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(5)
+    host_batches = [make_csr(7000 + i, rng.integers(0, 300, size=int(rng.integers(200, 1500))), REGULAR_MODES)
+                    for i in range(4)]
+    host_batches.append(host_batches[1])  # a repeated shape: the predicted path
+    host_batches.append(host_batches[1])
+    wants = [oracle.run(b[0], b[1], b[2].astype(np.uint64), 3, 0.4, n_threads=4) for b in host_batches]
+    keep, dev_batches = [], []
+    for o, iv, ln in host_batches:
+        t = [torch.from_numpy(x).to(dev) for x in (o.view(np.int64), np.ascontiguousarray(iv).view(np.int32).reshape(-1) if len(iv) else np.zeros(2, np.int32), ln.view(np.int32))]
+        keep.append(t)
+        dev_batches.append((t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), len(ln), int(o[-1]), 3, 0.4))
+    torch.cuda.synchronize()
+    for n_eng in (1, 2, 3):
+        engs = [yacrd_amd.Engine() for _ in range(n_eng)]
+        seen = []
+
+        def done(i, e):
+            assert_same(e.fetch(), wants[i], "engines %d batch %d" % (n_eng, i))
+            seen.append(i)
+            return False
+        for rep in range(2):
+            del seen[:]
+            last = yacrd_amd.run_device_batches(engs, dev_batches, done)
+            assert seen == list(range(len(dev_batches))) and last.n_reads == len(host_batches[-1][2])
+        with pytest.raises(yacrd_amd.EngineError, match="callback"):
+            yacrd_amd.run_device_batches(engs, dev_batches, lambda i, e: i == 2)
+        assert_same(engs[0].run(*host_batches[0], 3, 0.4), wants[0], "engine usable after a stopped loop")
+        for e in engs:
+            e.close()
+
+
 def test_pipelined_engines_on_one_device():
     """Several engines on one GPU driven by one host thread each (bench.py's pipeline): the engines
     take turns with the dominant sweep, waits sleep (YACRD_F_BLOCKING_WAIT); every run of every

@@ -1094,6 +1094,48 @@ int yacrd_engine_wait(yacrd_engine *e, yacrd_device_result *out)
     return YACRD_OK;
 }
 
+int yacrd_engines_run_device_batches(yacrd_engine *const *engines, uint32_t n_engines,
+                                     const yacrd_device_batch *batches, uint32_t n_batches,
+                                     yacrd_batch_done_fn done, void *user, yacrd_device_result *last)
+{
+    if (!engines || n_engines == 0 || (!batches && n_batches)) return fail(YACRD_EINVAL, "bad argument");
+    for (uint32_t j = 0; j < n_engines; j++)
+        if (!engines[j]) return fail(YACRD_EINVAL, "engine is null");
+    std::vector<int64_t> inflight(n_engines, -1); // batch in flight on each engine
+    yacrd_device_result res{};
+    auto finish = [&](uint32_t j) -> int {
+        int rc = yacrd_engine_wait(engines[j], &res);
+        if (rc) return rc;
+        const uint32_t b = (uint32_t)inflight[j];
+        inflight[j] = -1;
+        if (done && done(user, b, engines[j], &res)) return fail(YACRD_EINVAL, "the batch callback asked to stop");
+        return YACRD_OK;
+    };
+    int rc = YACRD_OK;
+    for (uint32_t i = 0; i < n_batches && rc == YACRD_OK; i++) {
+        const uint32_t j = i % n_engines;
+        if (inflight[j] >= 0) rc = finish(j);
+        if (rc) break;
+        const yacrd_device_batch &b = batches[i];
+        rc = yacrd_engine_submit_device(engines[j], b.d_offsets, b.d_intervals, b.d_lengths, b.n_reads,
+                                        b.n_intervals, b.coverage, b.not_coverage);
+        if (rc == YACRD_OK) inflight[j] = i;
+    }
+    // drain in batch order (also after an error: no engine is left with a pending batch)
+    for (uint32_t k = 0; k < n_engines; k++) {
+        uint32_t j = 0;
+        int64_t lo = -1;
+        for (uint32_t q = 0; q < n_engines; q++)
+            if (inflight[q] >= 0 && (lo < 0 || inflight[q] < lo)) lo = inflight[q], j = q;
+        if (lo < 0) break;
+        const int rc2 = finish(j);
+        if (rc == YACRD_OK) rc = rc2;
+        inflight[j] = -1;
+    }
+    if (rc == YACRD_OK && last) *last = res;
+    return rc;
+}
+
 // validate a host CSR and enqueue its way to HBM on the engine's stream (shared by run / submit)
 static int stage_host_inputs(yacrd_engine *e, const uint64_t *offsets, const uint32_t *intervals,
                              const uint32_t *lengths, uint64_t n_reads, uint64_t *n_iv_out)

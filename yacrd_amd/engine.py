@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = [
     "yacrd_abi_version", "yacrd_last_error", "yacrd_engine_create", "yacrd_engine_destroy",
     "yacrd_engine_run", "yacrd_result_free", "yacrd_engine_run_device", "yacrd_engine_fetch",
     "yacrd_engine_last_timing", "yacrd_partition_reads", "yacrd_engine_classify",
-    "yacrd_engines_run_partitioned", "yacrd_engine_timing_total", "yacrd_engine_event_overhead", "yacrd_engine_submit_device", "yacrd_engine_wait",
+    "yacrd_engines_run_partitioned", "yacrd_engine_timing_total", "yacrd_engine_event_overhead", "yacrd_engine_submit_device", "yacrd_engine_wait", "yacrd_engines_run_device_batches",
     "yacrd_engine_submit", "yacrd_engine_collect", "yacrd_pinned_alloc", "yacrd_pinned_free",
     "yacrd_stream_open", "yacrd_stream_sink", "yacrd_stream_acquire", "yacrd_stream_commit",
     "yacrd_stream_finish", "yacrd_stream_last_stats", "yacrd_stream_close",
@@ -59,6 +59,17 @@ class _DevResult(ctypes.Structure):
     _fields_ = [("n_reads", ctypes.c_uint64), ("n_regions", ctypes.c_uint64),
                 ("d_bad_offsets", ctypes.c_void_p), ("d_bad_regions", ctypes.c_void_p),
                 ("d_read_type", ctypes.c_void_p)]
+
+
+class DeviceBatch(ctypes.Structure):
+    """yacrd_device_batch: a CSR resident in HBM + the run's parameters."""
+    _fields_ = [("d_offsets", ctypes.c_void_p), ("d_intervals", ctypes.c_void_p), ("d_lengths", ctypes.c_void_p),
+                ("n_reads", ctypes.c_uint64), ("n_intervals", ctypes.c_uint64), ("coverage", ctypes.c_uint32),
+                ("not_coverage", ctypes.c_double)]
+
+
+BATCH_DONE = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p,
+                              ctypes.POINTER(_DevResult))
 
 
 class _Timing(ctypes.Structure):
@@ -182,6 +193,9 @@ def load_library():
                                                ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64,
                                                ctypes.c_uint32, ctypes.c_double]
     lib.yacrd_engine_wait.argtypes = [ctypes.c_void_p, ctypes.POINTER(_DevResult)]
+    lib.yacrd_engines_run_device_batches.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32,
+                                                     ctypes.POINTER(DeviceBatch), ctypes.c_uint32, BATCH_DONE,
+                                                     ctypes.c_void_p, ctypes.POINTER(_DevResult)]
     lib.yacrd_engine_fetch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_Result)]
     lib.yacrd_engine_last_timing.argtypes = [ctypes.c_void_p, ctypes.POINTER(_Timing)]
     lib.yacrd_partition_reads.argtypes = [u64p, ctypes.c_uint64, ctypes.c_uint32, u64p]
@@ -261,6 +275,24 @@ def run_partitioned(engines, offsets, intervals, lengths, coverage, not_coverage
         _ptr(lengths, ctypes.c_uint32), offsets.shape[0] - 1, min(int(coverage), 0xFFFFFFFF),
         float(not_coverage), ctypes.byref(res)))
     return _take(lib, res)
+
+
+def run_device_batches(engines, batches, done=None):
+    """yacrd_engines_run_device_batches: `batches` = sequence of (d_offsets, d_intervals, d_lengths,
+    n_reads, n_intervals, coverage, not_coverage) with device pointers; batch i runs on
+    engines[i % len(engines)], len(engines) of them in flight; done(batch_index, engine) is called in
+    order after each batch's wait (return True to stop).  Returns the last batch's device result."""
+    lib = load_library()
+    arr = (DeviceBatch * len(batches))()
+    for i, b in enumerate(batches):
+        arr[i] = DeviceBatch(b[0], b[1], b[2], b[3], b[4], min(int(b[5]), 0xFFFFFFFF), float(b[6]))
+    handles = (ctypes.c_void_p * len(engines))(*[e._h for e in engines])
+    by_handle = {e._h.value: e for e in engines}
+    cb = BATCH_DONE(lambda user, i, h, res: 1 if done(i, by_handle[h]) else 0) if done else BATCH_DONE()
+    out = _DevResult()
+    _check(lib, lib.yacrd_engines_run_device_batches(handles, len(engines), arr, len(batches), cb, None,
+                                                     ctypes.byref(out)))
+    return out
 
 
 class Engine:

@@ -288,6 +288,50 @@ def test_class_prediction_is_validated(flags):
             assert_same(ref.run(*csr, 3, 0.4), want, "unpredicted run %d" % rep)
 
 
+def _crafted_screen_reads():
+    """Reads on the edges of the healthy-read screen: n in the R16 / H16 classes
+    (65..256 intervals), piles of k identical or nested intervals around k = c, c + 1, c + 2, windows
+    (pmin > 0, pmax < len), one hole, unbalanced piles, lengths below the bin count, ends at len."""
+    reads = []
+
+    def pad(iv, n, L):  # fill up to n intervals with deep copies of the first interval
+        return iv + [iv[0]] * (n - len(iv))
+    for n in (65, 100, 128, 129, 200, 256):
+        for L in (1, 7, 15, 16, 17, 33, 1000, 65537, 10**6):
+            full = (0, L)
+            reads.append(([full] * n, L))                                   # everything spans everything
+            if L >= 4:
+                w = (L // 4, max(L // 4 + 1, L - L // 4))
+                reads.append(([w] * n, L))                                  # a window: pmin > 0, pmax < len
+                reads.append((pad([full], n - 3, L) + [(0, L // 2)] * 3, L))   # three ends inside
+                reads.append((pad([full], n - 3, L) + [(L // 2, L)] * 3, L))   # three starts inside
+                reads.append(([(0, L // 2)] * (n // 2) + [(L // 2, L)] * (n - n // 2), L))      # abutting halves: a hole of depth 0
+                reads.append(([(0, L // 2 + 1)] * (n // 2) + [(L // 2, L)] * (n - n // 2), L))  # overlapping by one position
+            if L >= 40:
+                # dovetail pile-up with k intervals clamped at each end and the rest inside
+                for k in (1, 2, 3, 4, 5, 6, 9):
+                    inner = [(1 + (j % 7), L - 1 - (j % 5)) for j in range(n - 2 * k)]
+                    reads.append(([(0, L - 2)] * k + inner + [(2, L)] * k, L))
+                    reads.append(([(0, L - 2)] * k + inner + [(2, L)] * (k + 1), L))  # piles out of balance
+    return reads
+
+
+@pytest.mark.parametrize("cov", [0, 1, 2, 3, 4, 5, 8, 300])
+def test_healthy_screen_edges(cov):
+    reads = _crafted_screen_reads()
+    offsets = np.zeros(len(reads) + 1, np.uint64)
+    offsets[1:] = np.cumsum([len(iv) for iv, _ in reads])
+    intervals = np.array([p for iv, _ in reads for p in iv], dtype=np.uint32)
+    lengths = np.array([L for _, L in reads], dtype=np.uint32)
+    want = oracle.run(offsets, intervals, lengths.astype(np.uint64), cov, 0.4, n_threads=4)
+    for flags in (yacrd_amd.F_ALWAYS_DEFER, yacrd_amd.F_NO_DEFER, yacrd_amd.F_NO_PREFILTER):
+        with yacrd_amd.Engine(flags=flags | yacrd_amd.F_COUNT_PREFILTERED) as e:
+            assert_same(e.run(offsets, intervals, lengths, cov, 0.4), want, "cov %d flags %d" % (cov, flags))
+            if flags == yacrd_amd.F_ALWAYS_DEFER:
+                t = e.timing()
+                assert t["prefiltered_reads"] > 0 and t["deferred_reads"] > 0  # both sides of the screen are exercised
+
+
 def test_device_batches_pipeline():
     """yacrd_engines_run_device_batches: a list of device-resident batches over 1-3 engines, every
     batch fetched in its callback and compared with the oracle; a callback can stop the loop."""

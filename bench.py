@@ -129,8 +129,8 @@ def main():
     flags = (yacrd_amd.F_FORCE_LDS_SORT if args.lds_sort else 0) | args.flags
     if args.full_timing:
         flags |= yacrd_amd.F_TIMING_FULL
-    elif not args.time_every_launch and args.steps >= 24 * max(1, min(args.engines, args.steps)):
-        flags |= yacrd_amd.F_TIMING_SAMPLED  # (short runs time every launch: a sample needs launches)
+    elif not args.time_every_launch:
+        flags |= yacrd_amd.F_TIMING_SAMPLED  # (the first run of every engine in the timed region is a timed one)
     # Batches are pipelined over `--engines` engines on this GPU from this one host thread
     # (yacrd_engine_submit_device / yacrd_engine_wait): the plan / compaction kernels, the counter
     # copy, the launch gaps and the host's turn of one batch hide behind the sweep of another.

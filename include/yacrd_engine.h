@@ -92,7 +92,8 @@ typedef struct {
 /* engines that share a device take turns with the dominant sweep launch (a GPU-side event wait:
  * the launch's start / stop events then time that kernel alone); A/B only */
 #define YACRD_F_SWEEP_TURNS 16384u
-/* the dominant kernel carries its start / stop events on every 8th run of the engine only: attached
+/* the dominant kernel carries its start / stop events on every 8th run of the engine only (counted
+ * from its creation or the last yacrd_engine_timing_total(reset), whose next run is a timed one): attached
  * events cost ~10 us per batch (host + stream) against a 20 us kernel; yacrd_timing.timed_runs says how
  * many runs were timed */
 #define YACRD_F_TIMING_SAMPLED 32768u

@@ -1266,6 +1266,7 @@ int yacrd_engine_timing_total(yacrd_engine *e, yacrd_timing *sum, uint64_t *n_ru
     if (reset) {
         e->timing_sum = yacrd_timing{};
         e->timing_runs = 0;
+        e->run_seq = 0; // YACRD_F_TIMING_SAMPLED: the next run is a timed one
     }
     return YACRD_OK;
 }

@@ -196,6 +196,22 @@ def main():
     # kernel (YACRD_F_TIMING_FULL: +40 us per step, so never part of `value`) for the per-phase table
     # and the deferred launch's own duration.
     phases = None
+    unpredicted = None
+    if rank == 0 and not args.no_extras:
+        # one engine, no class-count prediction (YACRD_F_NO_PREDICTION: the plan's counts come home
+        # before the sweeps are launched), nothing in flight: what a caller with ONE batch per
+        # process sees once the inputs are in HBM (the CLI)
+        with yacrd_amd.Engine(device_id=dev_index, flags=yacrd_amd.F_NO_PREDICTION | yacrd_amd.F_NO_TIMING) as ue:
+            for _ in range(5):
+                ue.run_device(*ptrs)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                ue.run_device(*ptrs)
+            dt = (time.perf_counter() - t0) / 50
+            unpredicted = {"ms_per_batch": dt * 1e3, "reads_per_sec": R / dt,
+                           "what": "one engine, one batch at a time, no prediction of the class counts (a host sync "
+                                   "after the plan kernel), no timing events"}
     if rank == 0 and not args.full_timing:
         with yacrd_amd.Engine(device_id=dev_index, flags=flags | yacrd_amd.F_TIMING_FULL) as fe:
             for _ in range(5):
@@ -263,6 +279,7 @@ def main():
                        "parallelism": "read-partition x%d, no collective; %d batches in flight per GPU (one engine each)" % (world, NE)},
             "kernel_overlaps_per_sec": world * args.overlaps * K / elapsed,
             "kernel_ms": avg,
+            "unpredicted_single_batch": unpredicted,
             "phases_full_timing_ms": ({k: phases[k] for k in keys + ("fused_ms", "deferred_ms") if phases.get(k)}
                                       if phases else None),
             "path_gbps": b_alg / (avg["total_ms"] * 1e-3) / 1e9 if avg.get("total_ms") else None,

@@ -92,6 +92,10 @@ typedef struct {
 /* engines that share a device take turns with the dominant sweep launch (a GPU-side event wait:
  * the launch's start / stop events then time that kernel alone); A/B only */
 #define YACRD_F_SWEEP_TURNS 16384u
+/* large launches never compact their deferred reads into lists for the classes' own register sort
+ * (every deferred read is sorted whole by sweep_deferred_kernel, as in small launches); A/B only */
+#define YACRD_F_NO_COMPACT_DEFER 65536u
+#define YACRD_F_ALWAYS_COMPACT_DEFER 131072u /* ... and always does (with the deferring build); tests, A/B */
 /* the dominant kernel carries its start / stop events on every 8th run of the engine only (counted
  * from its creation or the last yacrd_engine_timing_total(reset), whose next run is a timed one): attached
  * events cost ~10 us per batch (host + stream) against a 20 us kernel; yacrd_timing.timed_runs says how

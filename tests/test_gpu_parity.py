@@ -263,7 +263,8 @@ def test_read_partitioned_multi_engine(engine):
             assert_same(got, want, "partitioned x%d" % len(engines))
 
 
-@pytest.mark.parametrize("flags", [0, yacrd_amd.F_ALWAYS_DEFER])
+@pytest.mark.parametrize("flags", [0, yacrd_amd.F_ALWAYS_DEFER,
+                                   yacrd_amd.F_ALWAYS_DEFER | yacrd_amd.F_ALWAYS_COMPACT_DEFER])
 def test_class_prediction_is_validated(flags):
     """Runs of identical shape (reads, intervals) reuse the previous run's class set instead of
     waiting for the plan; a batch whose classes differ must still come out bit-exact.  With the
@@ -324,12 +325,49 @@ def test_healthy_screen_edges(cov):
     intervals = np.array([p for iv, _ in reads for p in iv], dtype=np.uint32)
     lengths = np.array([L for _, L in reads], dtype=np.uint32)
     want = oracle.run(offsets, intervals, lengths.astype(np.uint64), cov, 0.4, n_threads=4)
-    for flags in (yacrd_amd.F_ALWAYS_DEFER, yacrd_amd.F_NO_DEFER, yacrd_amd.F_NO_PREFILTER):
+    for flags in (yacrd_amd.F_ALWAYS_DEFER, yacrd_amd.F_NO_DEFER, yacrd_amd.F_NO_PREFILTER,
+                  yacrd_amd.F_ALWAYS_DEFER | yacrd_amd.F_ALWAYS_COMPACT_DEFER):
         with yacrd_amd.Engine(flags=flags | yacrd_amd.F_COUNT_PREFILTERED) as e:
             assert_same(e.run(offsets, intervals, lengths, cov, 0.4), want, "cov %d flags %d" % (cov, flags))
             if flags == yacrd_amd.F_ALWAYS_DEFER:
                 t = e.timing()
                 assert t["prefiltered_reads"] > 0 and t["deferred_reads"] > 0  # both sides of the screen are exercised
+
+
+def test_compact_deferral_outgrows_its_predicted_grid():
+    """Deferred reads through compact lists (YACRD_F_ALWAYS_COMPACT_DEFER): the class launch over the
+    lists is sized from the previous batch of the same shape; a batch that defers many more reads than
+    its predecessor must still come out bit-exact — through run() (validated after the sync: what is
+    still marked is sorted whole, compaction redone) and through submit / wait (the batch runs again
+    unpredicted)."""
+    import torch
+    R, n, L = 3000, 100, 5000
+    healthy = [(0, L)] * n
+    holed = [(0, L // 2)] * (n // 2) + [(L // 2, L)] * (n - n // 2)
+
+    def batch(n_holed):
+        iv = np.array([p for r in range(R) for p in (holed if r < n_holed else healthy)], dtype=np.uint32)
+        off = np.arange(R + 1, dtype=np.uint64) * np.uint64(n)
+        return off, iv, np.full(R, L, dtype=np.uint32)
+    batches = [batch(0), batch(0), batch(2000), batch(2000), batch(10), batch(2900)]
+    wants = [oracle.run(b[0], b[1], b[2].astype(np.uint64), 4, 0.4, n_threads=4) for b in batches]
+    flags = yacrd_amd.F_ALWAYS_DEFER | yacrd_amd.F_ALWAYS_COMPACT_DEFER
+    with yacrd_amd.Engine(flags=flags) as e:
+        for i, b in enumerate(batches):
+            assert_same(e.run(*b, 4, 0.4), wants[i], "run %d" % i)
+            assert e.timing()["deferred_reads"] == [0, 0, 2000, 2000, 10, 2900][i]
+    dev = torch.device("cuda", 0)
+    keep, dev_batches = [], []
+    for o, iv, ln in batches:
+        t = [torch.from_numpy(x).to(dev) for x in (o.view(np.int64), iv.view(np.int32).reshape(-1), ln.view(np.int32))]
+        keep.append(t)
+        dev_batches.append((t[0].data_ptr(), t[1].data_ptr(), t[2].data_ptr(), R, int(o[-1]), 4, 0.4))
+    torch.cuda.synchronize()
+    engs = [yacrd_amd.Engine(flags=flags) for _ in range(2)]
+    yacrd_amd.run_device_batches(engs, dev_batches,
+                                 lambda i, e: assert_same(e.fetch(), wants[i], "pipelined batch %d" % i))
+    for e in engs:
+        e.close()
 
 
 def test_device_batches_pipeline():
@@ -487,9 +525,13 @@ def test_fused_defer_build(cov):
     for prof, R, O in ((host.SYNTH_ONT, 6000, 300000), (host.SYNTH_SEQUEL, 3000, 300000)):
         o, iv, ln = host.synth_csr(prof, R, O, 5 + cov)
         w2 = oracle.run(o, iv, ln.astype(np.uint64), cov, 0.4, n_threads=4)
-        for flags in (yacrd_amd.F_ALWAYS_DEFER, yacrd_amd.F_NO_DEFER):
+        compact = yacrd_amd.F_ALWAYS_DEFER | yacrd_amd.F_ALWAYS_COMPACT_DEFER  # deferred reads through compact lists
+        for flags in (yacrd_amd.F_ALWAYS_DEFER, yacrd_amd.F_NO_DEFER, compact):
             with yacrd_amd.Engine(flags=flags | yacrd_amd.F_COUNT_PREFILTERED) as e:
                 assert_same(e.run(o, iv, ln, cov, 0.4), w2, "profile %d flags %d" % (prof, flags))
+                if flags == compact:  # a second, predicted run: the compact lists' lengths come from the first
+                    assert_same(e.run(o, iv, ln, cov, 0.4), w2, "profile %d flags %d, predicted" % (prof, flags))
+                    continue
                 t = e.timing()
                 if cov <= 4:
                     assert t["prefiltered_reads"] > R // 2
@@ -499,7 +541,7 @@ def test_fused_defer_build(cov):
                     assert 0 < t["deferred_reads"] and 0 <= both - int(((n > 64) & (n <= 256)).sum()) <= int((n > 256).sum())
                 else:
                     assert t["deferred_reads"] == 0
-    for flags in (yacrd_amd.F_ALWAYS_DEFER, yacrd_amd.F_NO_DEFER):
+    for flags in (yacrd_amd.F_ALWAYS_DEFER, yacrd_amd.F_NO_DEFER, compact):
         with yacrd_amd.Engine(flags=flags) as e:
             assert_same(e.run(*csr, cov, 0.4), want, "cases flags %d" % flags)
             assert_same(e.run(*csr, cov, 0.4), want, "cases flags %d, predicted run" % flags)

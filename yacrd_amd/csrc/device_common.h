@@ -68,6 +68,9 @@ struct Counters {
     // ones (a list appended to by the fused launch) a 20 us kernel for 45 us; and on the cache line of
     // n[], which every wavefront of a sweep reads when it starts, they stall those loads as well.
     alignas(128) u32 deferred;
+    // lengths of the compact lists of deferred reads (mark_compact_kernel: R16, H16), again on a line
+    // of their own
+    alignas(128) u32 deferred_n[2];
 };
 
 struct SweepArgs {
@@ -90,6 +93,7 @@ struct SweepArgs {
                          // that finishes the deferred reads (the compaction strips and counts it)
 };
 constexpr u32 kDeferredTag = 0x80000000u;
+constexpr u32 kDeferredMark = 0xFFFFFFFFu; // in counts[r]: "deferred", not a region count (<= intervals + 2)
 
 __device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
 

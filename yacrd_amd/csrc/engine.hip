@@ -31,6 +31,10 @@
 
 using namespace yke;
 
+// reads in the classes R16 + H16 from which the deferred reads go through compact lists and the
+// classes' own register sort instead of sweep_deferred_kernel
+static constexpr uint64_t kCompactMinReads = 400000;
+
 namespace yke {
 std::string &err_slot()
 {
@@ -316,7 +320,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     }
 
     const u32 nb = (n_reads + yk::kScanBlock - 1) / yk::kScanBlock;
-    constexpr int kLists = yk::CLS_COUNT + 4; // class lists + three rejection lists + M2 overflow
+    constexpr int kLists = yk::CLS_COUNT + 6; // class lists + three rejection lists + M2 overflow + two compact lists of deferred reads
     HIP_TRY(e->lists.reserve((size_t)kLists * n_reads * sizeof(u32)));
     const size_t ctrl_bytes = (sizeof(yk::Counters) + (size_t)nb * sizeof(u64) + 255) & ~(size_t)255;
     e->ctrl_cur ^= 1;
@@ -337,6 +341,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     auto list_of = [&](int i) { return lists + (size_t)i * n_reads; };
     u32 *rej_small = list_of(yk::CLS_COUNT), *rej_med = list_of(yk::CLS_COUNT + 1),
         *rej_big = list_of(yk::CLS_COUNT + 2), *over_med = list_of(yk::CLS_COUNT + 3);
+    u32 *const defer_list[2] = {list_of(yk::CLS_COUNT + 4), list_of(yk::CLS_COUNT + 5)};
     yk::Counters *ctr = e->ctrl2[cur].as<yk::Counters>();
     const bool full = (e->flags & YACRD_F_TIMING_FULL) != 0;
     const int xm = (e->flags & YACRD_F_XLANE_DS) ? 1 : 0;
@@ -436,6 +441,8 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
 
     bool skip_rejected_small = predicted && e->pred.rej_small == 0, skipped_small = false;
     bool fused_marked = false, deferred_marked = false;
+    u32 defer_cover[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}; // what the deferred class launch covered of each compact list
+    bool remainder_pass = false; // launch_sweeps for what a prediction missed: after the final sync, nothing validates it
     // sweeps of the classes in `set`, then the LDS exact path for what they rejected
     auto launch_sweeps = [&](const LaunchSet &set) -> int {
         bool any_small = false;
@@ -499,7 +506,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
                     lane.owner = e;
                 }
                 if (mark) fused_marked = true;
-                // the reads the screen deferred, sorted whole in a launch of their own
+                // the reads the screen deferred
                 if (defer && (set.n[yk::CLS_R16] || set.n[yk::CLS_H16])) {
                     yk::DeferArgs da;
                     da.base = sa;
@@ -518,10 +525,70 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
                         da.n_entries++;
                         chunks += (set.n[cls] + yk::kDeferChunk - 1) / yk::kDeferChunk;
                     }
-                    const u32 dgrid = (u32)std::min<u64>(chunks, (u64)e->num_cu * 64);
-                    hipExtLaunchKernelGGL(yk::sweep_deferred_kernel, dim3(dgrid ? dgrid : 1), dim3(256), 0, e->stream,
-                                          (mark && full) ? e->ev_cls[20] : (hipEvent_t) nullptr,
-                                          (mark && full) ? e->ev_cls[21] : (hipEvent_t) nullptr, 0, da);
+                    // Large launches (first pass over the classes only): compact lists + the classes' own
+                    // register sort, 2.5x cheaper per read than sorting every marked read whole — but two
+                    // launches and, without a prediction, a round trip for the lists' lengths.
+                    const bool compacted = ((u64)set.n[yk::CLS_R16] + set.n[yk::CLS_H16] >= kCompactMinReads ||
+                                            (e->flags & YACRD_F_ALWAYS_COMPACT_DEFER)) &&
+                                           !remainder_pass && !(e->flags & YACRD_F_NO_COMPACT_DEFER);
+                    const hipEvent_t ev_b = (mark && full) ? e->ev_cls[20] : (hipEvent_t) nullptr;
+                    const hipEvent_t ev_e = (mark && full) ? e->ev_cls[21] : (hipEvent_t) nullptr;
+                    if (compacted) {
+                        yk::CompactArgs ca;
+                        ca.counts = sa.counts;
+                        ca.n_entries = da.n_entries;
+                        u64 c_chunks = 0;
+                        for (u32 k = 0; k < da.n_entries; k++) {
+                            const int slot = da.list[k] == list_of(yk::CLS_R16) ? 0 : 1;
+                            ca.first[k] = da.first[k];
+                            ca.count[k] = da.count[k];
+                            ca.list[k] = da.list[k];
+                            ca.list_n[k] = da.list_n[k];
+                            ca.out[k] = defer_list[slot];
+                            ca.out_n[k] = &ctr->deferred_n[slot];
+                            c_chunks += (da.count[k] + 4095) / 4096;
+                        }
+                        hipExtLaunchKernelGGL(yk::mark_compact_kernel,
+                                              dim3((u32)std::min<u64>(std::max<u64>(c_chunks, 1), (u64)e->num_cu * 2)),
+                                              dim3(yk::kCompactBlock), 0, e->stream, ev_b, (hipEvent_t) nullptr, 0, ca);
+                        u64 dn[2];
+                        if (predicted) { // the previous batch's lengths + a margin
+                            for (int k = 0; k < 2; k++) dn[k] = (u64)e->pred.deferred_n[k] + e->pred.deferred_n[k] / 8 + 256;
+                        } else {
+                            HIP_TRY(hipMemcpyAsync(e->h_ctr, ctr, sizeof(yk::Counters), hipMemcpyDeviceToHost, e->stream));
+                            HIP_TRY(hipStreamSynchronize(e->stream));
+                            for (int k = 0; k < 2; k++) dn[k] = e->h_ctr->deferred_n[k];
+                        }
+                        yk::FusedArgs fc;
+                        fc.base = da.base;
+                        fc.base.prefilter = sa.prefilter;
+                        fc.n_entries = 0;
+                        u32 cblocks = 0;
+                        for (int k = 0; k < 2; k++) {
+                            const int cls = k == 0 ? yk::CLS_R16 : yk::CLS_H16;
+                            dn[k] = std::min<u64>(dn[k], set.n[cls]);
+                            defer_cover[k] = 0;
+                            if (!dn[k]) continue;
+                            const u32 per = yk::sweep_group_reads_per_block(cls, yk::kFusedWaves);
+                            const u32 nblk = (u32)((dn[k] + per - 1) / per);
+                            defer_cover[k] = nblk * per;
+                            cblocks += nblk;
+                            fc.cls[fc.n_entries] = (u32)cls;
+                            fc.block_end[fc.n_entries] = cblocks;
+                            fc.list[fc.n_entries] = defer_list[k];
+                            fc.list_n[fc.n_entries] = &ctr->deferred_n[k];
+                            fc.first[fc.n_entries] = 0;
+                            fc.n_entries++;
+                        }
+                        if (fc.n_entries)
+                            hipExtLaunchKernelGGL(yk::sweep_small_fused_kernel, dim3(cblocks), dim3(64 * yk::kFusedWaves),
+                                                  0, e->stream, (hipEvent_t) nullptr, ev_e, 0, fc);
+                        else if (ev_e) HIP_TRY(hipEventRecord(ev_e, e->stream));
+                    } else {
+                        const u32 dgrid = (u32)std::min<u64>(chunks, (u64)e->num_cu * 64);
+                        hipExtLaunchKernelGGL(yk::sweep_deferred_kernel, dim3(dgrid ? dgrid : 1), dim3(256), 0, e->stream,
+                                              ev_b, ev_e, 0, da);
+                    }
                     // (its own start / stop events only with YACRD_F_TIMING_FULL: a pair costs the host
                     // ~4 us and the stream ~5 us per batch)
                     if (mark && full) deferred_marked = true;
@@ -658,6 +725,8 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         p.skipped_small = skipped_small;
         p.fused_marked = fused_marked;
         p.deferred_marked = deferred_marked;
+        p.defer_cover[0] = defer_cover[0];
+        p.defer_cover[1] = defer_cover[1];
         return YACRD_OK;
     }
     // (spinning on the pinned counter block instead of this call was tried: 0.0816 vs 0.078 ms/step)
@@ -682,6 +751,37 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
                                dim3(256), 0, e->stream, sa);
             redo = true;
         }
+        if (c0.deferred_n[0] > defer_cover[0] || c0.deferred_n[1] > defer_cover[1]) {
+            // more reads deferred than the predicted grid of the deferred class launch covered: what it
+            // left marked is sorted whole
+            if (!redo) HIP_TRY(hipEventRecord(e->ev[EV_X0], e->stream));
+            yk::DeferArgs da;
+            da.base = sa;
+            da.base.prefilter = 0;
+            da.base.over_list = nullptr;
+            da.base.over_count = nullptr;
+            da.base.count_tag = yk::kDeferredTag;
+            da.base.rej_list = rej_small;
+            da.base.rej_count = &ctr->rej_small;
+            da.n_entries = 0;
+            for (int cls = yk::CLS_R16; cls <= yk::CLS_H16; cls++) {
+                if (!c0.n[cls]) continue;
+                da.first[da.n_entries] = 0;
+                da.count[da.n_entries] = c0.n[cls];
+                da.list[da.n_entries] = list_of(cls);
+                da.list_n[da.n_entries] = &ctr->n[cls];
+                da.n_entries++;
+            }
+            hipLaunchKernelGGL(yk::sweep_deferred_kernel, dim3(e->num_cu * 16), dim3(256), 0, e->stream, da);
+            // its rejections (rare) go the exact way, with the earlier ones once more
+            sa.list = rej_small;
+            sa.list_n = &ctr->rej_small;
+            sa.rej_list = rej_med;
+            sa.rej_count = &ctr->rej_med;
+            hipLaunchKernelGGL((yk::sweep_general_lds_kernel<256, 512>), dim3(e->num_cu * 2), dim3(256), 0,
+                               e->stream, sa);
+            redo = true;
+        }
         LaunchSet missing{};
         bool any_missing = false;
         for (int cls = 0; cls < yk::CLS_GENERAL; cls++)
@@ -692,6 +792,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
             }
         if (any_missing || c0.n[yk::CLS_GENERAL]) {
             if (!redo) HIP_TRY(hipEventRecord(e->ev[EV_X0], e->stream));
+            remainder_pass = true;
             if (any_missing && (rc = launch_sweeps(missing))) return rc;
             if (c0.n[yk::CLS_GENERAL] && (rc = launch_huge(c0.n[yk::CLS_GENERAL], &gen_iv))) return rc;
             // the rejection counters may have grown: bring them home before looking at rej_big
@@ -717,6 +818,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         redo = false;
         // reset the scan state, the ticket and the overflow flag (keep the class counters)
         HIP_TRY(hipMemsetAsync(&ctr->region_overflow, 0, 3 * sizeof(u32), e->stream));
+        HIP_TRY(hipMemsetAsync(&ctr->deferred, 0, sizeof(u32), e->stream)); // (the compaction counts them again)
         HIP_TRY(hipMemsetAsync(ctr + 1, 0, (size_t)nb * sizeof(u64), e->stream));
         rc = launch_compact(e, d_off, d_len, n_reads, not_cov);
         if (rc) return rc;
@@ -837,6 +939,7 @@ int finish_pending(yacrd_engine *e)
     bool ok = !(p.skipped_small && c.rej_small) && !c.n[yk::CLS_GENERAL] && !c.rej_big &&
               !c.region_overflow;
     for (int cls = 0; cls < yk::CLS_GENERAL; cls++) ok = ok && c.n[cls] <= p.grid_n[cls];
+    ok = ok && c.deferred_n[0] <= p.defer_cover[0] && c.deferred_n[1] <= p.defer_cover[1];
     if (!ok) {
         e->pred_valid = false;
         return run_on_device(e, p.d_off, p.d_iv, p.d_len, p.n_reads, p.n_iv, p.cov, p.not_cov);

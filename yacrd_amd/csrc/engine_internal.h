@@ -107,6 +107,7 @@ struct Pending {
     double not_cov = 0;
     u32 grid_n[12] = {};      // reads each class's grid covers
     bool skipped_small = false, fused_marked = false, deferred_marked = false;
+    u32 defer_cover[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}; // compact-list entries the deferred class launch covered
     int cls_b[12] = {}, cls_e[12] = {};
 };
 

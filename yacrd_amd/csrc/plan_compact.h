@@ -107,7 +107,10 @@ __global__ __launch_bounds__(kScanBlock) void compact_classify_kernel(
     __syncthreads();
     const u32 bid = s_bid;
     const u32 r = bid * kScanBlock + threadIdx.x;
-    const u32 g_raw = (r < n_reads) ? counts[r] : 0u;
+    u32 g_raw = (r < n_reads) ? counts[r] : 0u;
+    // a mark that is still there (the predicted grid of the deferred class launch was too short: the
+    // host sees that at the final sync, finishes those reads and compacts again) counts as nothing
+    if (g_raw == kDeferredMark) g_raw = 0u;
     const u32 g = g_raw & ~kDeferredTag;
     // reads finished by sweep_deferred_kernel carry a tag in their count: counted here, one atomic per
     // workgroup (see Counters::deferred)

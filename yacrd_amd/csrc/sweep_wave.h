@@ -411,7 +411,6 @@ __device__ __forceinline__ u32 *wave_filter_scratch()
 // duration.)
 // Only for wavefronts whose intervals are all plain (start < end <= len).
 constexpr int kScreenTabWords = 304;
-constexpr u32 kDeferredMark = 0xFFFFFFFFu; // in counts[r]: not a region count (<= intervals + 2)
 template <int WPB> // wavefronts per workgroup
 __device__ __forceinline__ u32 *wave_screen_scratch()
 {
@@ -859,6 +858,72 @@ __global__ __launch_bounds__(64 * kDeferWaves, kDeferOcc) void sweep_small_fused
 __global__ __launch_bounds__(64 * kFusedWaves, 5) void sweep_small_fused_kernel(FusedArgs f)
 {
     sweep_small_fused_body<false, kFusedWaves>(f);
+}
+
+// ---- the deferred reads of a LARGE launch: compact lists + the classes' own register sort ------------
+// mark_compact_kernel turns the marks the screen left in counts[] into one compact list per class (one
+// returning atomic per workgroup of 4096 list entries and class, on a cache line of its own); the
+// non-deferring build of the fused kernel then runs over those lists (four / two reads per wavefront,
+// bin filter of §3.4, K/2 or K keys per lane) with a grid the host sizes from the lists' lengths — read
+// back in an unpredicted run, the previous batch's in a predicted one (validated at the final sync;
+// what a too-short grid leaves marked is finished by sweep_deferred_kernel).
+struct CompactArgs {
+    const u32 *counts;
+    u32 n_entries;
+    u32 first[2], count[2];
+    const u32 *list[2];
+    const u32 *list_n[2];
+    u32 *out[2];      // compact lists
+    u32 *out_n[2];    // their lengths (Counters::deferred_n)
+};
+constexpr int kCompactBlock = 1024, kCompactPer = 4;
+
+__global__ __launch_bounds__(kCompactBlock) void mark_compact_kernel(CompactArgs c)
+{
+    __shared__ u32 s_wave[kCompactBlock / 64];
+    __shared__ u32 s_base;
+    const u32 lane = lane_id(), wv = threadIdx.x >> 6;
+    for (u32 e = 0; e < c.n_entries; e++) {
+        const u32 end = min(c.first[e] + c.count[e], *c.list_n[e]);
+        for (u32 base = c.first[e] + blockIdx.x * (u32)(kCompactBlock * kCompactPer); base < end;
+             base += gridDim.x * (u32)(kCompactBlock * kCompactPer)) { // uniform
+            u32 r[kCompactPer];
+            u64 m[kCompactPer];
+            u32 mine = 0;
+#pragma unroll
+            for (int k = 0; k < kCompactPer; k++) {
+                const u32 idx = base + (u32)k * kCompactBlock + threadIdx.x;
+                bool marked = false;
+                r[k] = 0;
+                if (idx < end) {
+                    r[k] = c.list[e][idx];
+                    marked = c.counts[r[k]] == kDeferredMark;
+                }
+                m[k] = __builtin_amdgcn_ballot_w64(marked);
+                mine += (u32)__builtin_popcountll(m[k]);
+            }
+            if (lane == 0) s_wave[wv] = mine; // (uniform in the wavefront)
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                u32 tot = 0;
+                for (int w = 0; w < kCompactBlock / 64; w++) {
+                    const u32 x = s_wave[w];
+                    s_wave[w] = tot;
+                    tot += x;
+                }
+                s_base = tot ? atomicAdd(c.out_n[e], tot) : 0u;
+            }
+            __syncthreads();
+            u32 pos = s_base + s_wave[wv];
+#pragma unroll
+            for (int k = 0; k < kCompactPer; k++) {
+                if ((m[k] >> lane) & 1ull)
+                    c.out[e][pos + (u32)__builtin_popcountll(m[k] & ((1ull << lane) - 1ull))] = r[k];
+                pos += (u32)__builtin_popcountll(m[k]);
+            }
+            __syncthreads();
+        }
+    }
 }
 
 inline u32 sweep_group_reads_per_block(int cls, int waves = 4)

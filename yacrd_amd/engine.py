@@ -27,6 +27,8 @@ F_NO_DEFER = 4096
 F_ALWAYS_DEFER = 8192
 F_SWEEP_TURNS = 16384
 F_TIMING_SAMPLED = 32768
+F_NO_COMPACT_DEFER = 65536
+F_ALWAYS_COMPACT_DEFER = 131072
 
 # every symbol include/yacrd_engine.h declares
 EXPORTED_SYMBOLS = [

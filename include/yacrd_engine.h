@@ -96,6 +96,10 @@ typedef struct {
  * (every deferred read is sorted whole by sweep_deferred_kernel, as in small launches); A/B only */
 #define YACRD_F_NO_COMPACT_DEFER 65536u
 #define YACRD_F_ALWAYS_COMPACT_DEFER 131072u /* ... and always does (with the deferring build); tests, A/B */
+/* the screen of the deferring build takes one / two groups of list entries per wavefront whatever the
+ * launch's size (default: two from 40 M intervals on, i.e. inputs outside the Infinity Cache); tests, A/B */
+#define YACRD_F_SCREEN_ITEMS_1 262144u
+#define YACRD_F_SCREEN_ITEMS_2 524288u
 /* the dominant kernel carries its start / stop events on every 8th run of the engine only (counted
  * from its creation or the last yacrd_engine_timing_total(reset), whose next run is a timed one): attached
  * events cost ~10 us per batch (host + stream) against a 20 us kernel; yacrd_timing.timed_runs says how

@@ -264,7 +264,8 @@ def test_read_partitioned_multi_engine(engine):
 
 
 @pytest.mark.parametrize("flags", [0, yacrd_amd.F_ALWAYS_DEFER,
-                                   yacrd_amd.F_ALWAYS_DEFER | yacrd_amd.F_ALWAYS_COMPACT_DEFER])
+                                   yacrd_amd.F_ALWAYS_DEFER | yacrd_amd.F_ALWAYS_COMPACT_DEFER,
+                                   yacrd_amd.F_ALWAYS_DEFER | yacrd_amd.F_SCREEN_ITEMS_2])
 def test_class_prediction_is_validated(flags):
     """Runs of identical shape (reads, intervals) reuse the previous run's class set instead of
     waiting for the plan; a batch whose classes differ must still come out bit-exact.  With the
@@ -326,7 +327,8 @@ def test_healthy_screen_edges(cov):
     lengths = np.array([L for _, L in reads], dtype=np.uint32)
     want = oracle.run(offsets, intervals, lengths.astype(np.uint64), cov, 0.4, n_threads=4)
     for flags in (yacrd_amd.F_ALWAYS_DEFER, yacrd_amd.F_NO_DEFER, yacrd_amd.F_NO_PREFILTER,
-                  yacrd_amd.F_ALWAYS_DEFER | yacrd_amd.F_ALWAYS_COMPACT_DEFER):
+                  yacrd_amd.F_ALWAYS_DEFER | yacrd_amd.F_ALWAYS_COMPACT_DEFER,
+                  yacrd_amd.F_ALWAYS_DEFER | yacrd_amd.F_SCREEN_ITEMS_2):
         with yacrd_amd.Engine(flags=flags | yacrd_amd.F_COUNT_PREFILTERED) as e:
             assert_same(e.run(offsets, intervals, lengths, cov, 0.4), want, "cov %d flags %d" % (cov, flags))
             if flags == yacrd_amd.F_ALWAYS_DEFER:
@@ -526,10 +528,11 @@ def test_fused_defer_build(cov):
         o, iv, ln = host.synth_csr(prof, R, O, 5 + cov)
         w2 = oracle.run(o, iv, ln.astype(np.uint64), cov, 0.4, n_threads=4)
         compact = yacrd_amd.F_ALWAYS_DEFER | yacrd_amd.F_ALWAYS_COMPACT_DEFER  # deferred reads through compact lists
-        for flags in (yacrd_amd.F_ALWAYS_DEFER, yacrd_amd.F_NO_DEFER, compact):
+        two = yacrd_amd.F_ALWAYS_DEFER | yacrd_amd.F_SCREEN_ITEMS_2           # two groups of list entries per wavefront
+        for flags in (yacrd_amd.F_ALWAYS_DEFER, yacrd_amd.F_NO_DEFER, compact, two):
             with yacrd_amd.Engine(flags=flags | yacrd_amd.F_COUNT_PREFILTERED) as e:
                 assert_same(e.run(o, iv, ln, cov, 0.4), w2, "profile %d flags %d" % (prof, flags))
-                if flags == compact:  # a second, predicted run: the compact lists' lengths come from the first
+                if flags in (compact, two):  # a second, predicted run: the compact lists' lengths come from the first
                     assert_same(e.run(o, iv, ln, cov, 0.4), w2, "profile %d flags %d, predicted" % (prof, flags))
                     continue
                 t = e.timing()
@@ -541,7 +544,7 @@ def test_fused_defer_build(cov):
                     assert 0 < t["deferred_reads"] and 0 <= both - int(((n > 64) & (n <= 256)).sum()) <= int((n > 256).sum())
                 else:
                     assert t["deferred_reads"] == 0
-    for flags in (yacrd_amd.F_ALWAYS_DEFER, yacrd_amd.F_NO_DEFER, compact):
+    for flags in (yacrd_amd.F_ALWAYS_DEFER, yacrd_amd.F_NO_DEFER, compact, two):
         with yacrd_amd.Engine(flags=flags) as e:
             assert_same(e.run(*csr, cov, 0.4), want, "cases flags %d" % flags)
             assert_same(e.run(*csr, cov, 0.4), want, "cases flags %d, predicted run" % flags)

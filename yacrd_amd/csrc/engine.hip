@@ -459,6 +459,11 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
             const u64 fused_iv = set.iv[yk::CLS_R16] + set.iv[yk::CLS_H16];
             const bool defer = sa.prefilter && !(e->flags & YACRD_F_NO_DEFER) &&
                                ((e->flags & YACRD_F_ALWAYS_DEFER) || fused_iv >= 4000000ull);
+            // two groups of list entries per wavefront in the screened classes when the launch streams from
+            // HBM (more than the 256 MiB Infinity Cache holds): twice the loads in flight per wavefront
+            const int items = !defer ? 1
+                              : (e->flags & YACRD_F_SCREEN_ITEMS_1) ? 1
+                              : ((e->flags & YACRD_F_SCREEN_ITEMS_2) || fused_iv >= 40000000ull) ? 2 : 1;
             fa.base.over_list = nullptr; // (the deferring build marks its reads in counts[])
             fa.base.over_count = nullptr;
             fa.n_entries = 0;
@@ -466,7 +471,8 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
             bool has_dom = false;
             for (int cls = yk::CLS_R2; cls <= yk::CLS_H16; cls++) {
                 if (!set.n[cls]) continue;
-                const u32 per = yk::sweep_group_reads_per_block(cls, defer ? yk::kDeferWaves : yk::kFusedWaves);
+                const u32 per = yk::sweep_group_reads_per_block(cls, defer ? yk::kDeferWaves : yk::kFusedWaves) *
+                                (cls >= yk::CLS_R16 ? (u32)items : 1u);
                 blocks += (set.n[cls] + per - 1) / per;
                 fa.cls[fa.n_entries] = (u32)cls;
                 fa.block_end[fa.n_entries] = blocks;
@@ -493,7 +499,11 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
                 // start / stop events attached to the launch itself (hipExtLaunchKernelGGL): the
                 // kernel's own dispatch timestamps, no event packets before and after it
                 const bool chain = (e->flags & YACRD_F_SWEEP_TURNS) && (shared || lane.n_engines > 1);
-                if (defer)
+                if (defer && items == 2)
+                    hipExtLaunchKernelGGL(yk::sweep_small_fused_defer2_kernel, dim3(blocks), dim3(64), 0,
+                                          e->stream, mark ? e->ev_cls[22] : (hipEvent_t) nullptr,
+                                          (mark || chain) ? e->ev_cls[23] : (hipEvent_t) nullptr, 0, fa);
+                else if (defer)
                     hipExtLaunchKernelGGL(yk::sweep_small_fused_defer_kernel, dim3(blocks), dim3(64 * yk::kDeferWaves), 0,
                                           e->stream, mark ? e->ev_cls[22] : (hipEvent_t) nullptr,
                                           (mark || chain) ? e->ev_cls[23] : (hipEvent_t) nullptr, 0, fa);

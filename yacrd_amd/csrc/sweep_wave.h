@@ -688,6 +688,88 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
         sweep_group_keys<LANES, K, XM>(x, 2 * n, len, c, active, r, badmask, zmask, zl_check, a, lc);
 }
 
+// ---- the screen over ITEMS consecutive groups of list entries per wavefront (one-wavefront workgroups)
+// Every level of the dependent chain — list entries, offsets / lengths, intervals — is fetched for all
+// ITEMS at once, so a wavefront has ITEMS x 8 interval loads per lane in flight (8 KB at ITEMS = 2) and
+// pays each round trip once per ITEMS groups: what an HBM-resident input needs to keep the memory
+// system busy (configs[2]: ... ).  The screens then run one after the other on the same LDS table.
+template <int LANES, int ITEMS>
+__device__ __forceinline__ void screen_block(const SweepArgs &a, u32 block)
+{
+    constexpr int K = 16;
+    constexpr u32 GROUPS = 64 / LANES;
+    const u32 lane = lane_id(), lig = lane & (u32)(LANES - 1), grp = lane / (u32)LANES;
+    const u32 list_n = *a.list_n;
+    const u32 idx0 = a.first + block * (u32)ITEMS * GROUPS;
+    if (idx0 >= list_n) return; // grids may be sized for more reads than the class holds
+    const i32 c = (i32)min(a.cov, 0x3FFFFFFFu);
+    u32 r[ITEMS], n[ITEMS], len[ITEMS];
+    u64 o[ITEMS];
+    bool active[ITEMS];
+#pragma unroll
+    for (int t = 0; t < ITEMS; t++) {
+        const u32 idx = idx0 + (u32)t * GROUPS + grp;
+        active[t] = idx < list_n;
+        r[t] = active[t] ? a.list[idx] : 0u;
+    }
+#pragma unroll
+    for (int t = 0; t < ITEMS; t++) {
+        o[t] = 0, n[t] = 0, len[t] = 0;
+        if (active[t]) {
+            o[t] = a.off[r[t]];
+            n[t] = (u32)(a.off[r[t] + 1] - o[t]);
+            len[t] = a.len[r[t]];
+        }
+    }
+    uint2 v[ITEMS][K / 2];
+#pragma unroll
+    for (int t = 0; t < ITEMS; t++) {
+        // index clamped to the read's last interval (the duplicates become pads below); a group without
+        // intervals reads the first offsets instead (always mapped)
+        const uint2 *src = n[t] ? a.iv + o[t] : reinterpret_cast<const uint2 *>(a.off);
+        const u32 last = n[t] ? n[t] - 1u : 0u;
+#pragma unroll
+        for (int j = 0; j < K / 2; j++) v[t][j] = src[min(lig + (u32)LANES * j, last)];
+    }
+#pragma unroll
+    for (int t = 0; t < ITEMS; t++) {
+        if (t > 0 && idx0 + (u32)t * GROUPS >= list_n) break; // uniform: nothing left for this item
+        u32 x[K];
+        const u32 len_c = min(len[t], kMaxKeyPos);
+        u32 irregular = 0;
+#pragma unroll
+        for (int j = 0; j < K / 2; j++) {
+            const bool real = lig + (u32)LANES * j < n[t];
+            irregular |= (real && (v[t][j].x >= v[t][j].y || v[t][j].y > len_c)) ? 1u : 0u;
+            x[2 * j] = real ? ((v[t][j].x << kKeyShift) | 3u) : kPadKey;
+            x[2 * j + 1] = real ? (v[t][j].y << kKeyShift) : kPadKey;
+        }
+        if (__builtin_amdgcn_ballot_w64(irregular != 0) != 0) { // (uniform) not plain: sweep_deferred_kernel's
+            if (lig == 0 && active[t]) a.counts[r[t]] = kDeferredMark;
+            continue;
+        }
+        HealthyRead hr;
+        const bool healthy = healthy_screen<LANES, K, 1>(x, n[t], len[t], c, hr);
+        if (lig == 0 && active[t]) {
+            if (healthy) {
+                uint2 *slot = a.stage + (o[t] + 2 * (u64)r[t]);
+                u32 g = 0;
+                if ((i32)hr.kept_starts <= c) {
+                    if (len[t] != 0) slot[g++] = make_uint2(0u, len[t]);
+                } else {
+                    if (hr.pmin != 0) slot[g++] = make_uint2(0u, hr.pmin);
+                    if (hr.pmax != len[t]) slot[g++] = make_uint2(hr.pmax, len[t]);
+                }
+                a.counts[r[t]] = g;
+                if (a.prefilter == 2) atomicAdd(&a.ctr->prefiltered, 1u);
+            } else {
+                a.counts[r[t]] = kDeferredMark;
+            }
+        }
+        if (t + 1 < ITEMS) wave_lds_sync(); // the next item zeroes the table
+    }
+}
+
 // Body of one workgroup (four wavefronts, 4 * 64/LANES reads) of class (LANES, K).
 template <int LANES, int K, int XM, bool DEFER = false, int WPB = 4>
 __device__ __forceinline__ void sweep_group_block(const SweepArgs &a, u32 block)
@@ -813,7 +895,7 @@ struct FusedArgs {
     const u32 *list_n[5];
 };
 
-template <bool DEFER, int WPB>
+template <bool DEFER, int WPB, int ITEMS = 1>
 __device__ __forceinline__ void sweep_small_fused_body(const FusedArgs &f)
 {
     // Workgroups are dealt out to the 8 XCDs round robin (XCD = blockIdx.x mod 8); reads that are
@@ -840,8 +922,14 @@ __device__ __forceinline__ void sweep_small_fused_body(const FusedArgs &f)
     case CLS_R2: sweep_group_block<16, 2, 0, false, WPB>(a, b); break;
     case CLS_R4: sweep_group_block<16, 4, 0, false, WPB>(a, b); break;
     case CLS_R8: sweep_group_block<16, 8, 0, false, WPB>(a, b); break;
-    case CLS_R16: sweep_group_block<16, 16, 0, DEFER, WPB>(a, b); break;
-    default: sweep_group_block<32, 16, 0, DEFER, WPB>(a, b); break;
+    case CLS_R16:
+        if constexpr (DEFER && ITEMS > 1) screen_block<16, ITEMS>(a, b);
+        else sweep_group_block<16, 16, 0, DEFER, WPB>(a, b);
+        break;
+    default:
+        if constexpr (DEFER && ITEMS > 1) screen_block<32, ITEMS>(a, b);
+        else sweep_group_block<32, 16, 0, DEFER, WPB>(a, b);
+        break;
     }
 }
 // Two builds.  DEFER (long launches): the classes R16 / H16 run the healthy-read screen (one counting
@@ -854,6 +942,11 @@ __device__ __forceinline__ void sweep_small_fused_body(const FusedArgs &f)
 __global__ __launch_bounds__(64 * kDeferWaves, kDeferOcc) void sweep_small_fused_defer_kernel(FusedArgs f)
 {
     sweep_small_fused_body<true, kDeferWaves>(f);
+}
+// the same with two groups of list entries per wavefront in the screened classes (long launches from HBM)
+__global__ __launch_bounds__(64, kDeferOcc) void sweep_small_fused_defer2_kernel(FusedArgs f)
+{
+    sweep_small_fused_body<true, 1, 2>(f);
 }
 __global__ __launch_bounds__(64 * kFusedWaves, 5) void sweep_small_fused_kernel(FusedArgs f)
 {

@@ -29,6 +29,8 @@ F_SWEEP_TURNS = 16384
 F_TIMING_SAMPLED = 32768
 F_NO_COMPACT_DEFER = 65536
 F_ALWAYS_COMPACT_DEFER = 131072
+F_SCREEN_ITEMS_1 = 262144
+F_SCREEN_ITEMS_2 = 524288
 
 # every symbol include/yacrd_engine.h declares
 EXPORTED_SYMBOLS = [

@@ -53,6 +53,11 @@ def alg_bytes(R, I, G):
     return 8 * I + 8 * (R + 1) + 4 * R + 8 * (R + 1) + 8 * G + R
 
 
+def defer_kernel_name(fused_intervals):
+    """The deferring build's kernel: two groups of list entries per wavefront from 40 M intervals on."""
+    return "sweep_small_fused_defer2_kernel" if fused_intervals >= 40_000_000 else "sweep_small_fused_defer_kernel"
+
+
 def dominant(t, K, yacrd_amd):
     """(kernel name, class name, ms per launch, reads, intervals) of the kernel with the most time;
     K = the launches that carried the events (yacrd_timing.timed_runs)."""
@@ -240,7 +245,7 @@ def main():
         # fused kernel loads and bins them, but its bytes only count the reads it completes
         deferred = int(t.get("deferred_reads", 0)) if cname == "R2..H16" else 0
         if deferred:
-            dom = "sweep_small_fused_defer_kernel"
+            dom = defer_kernel_name(c_iv)
             c_iv -= c_iv * deferred // max(c_reads, 1)
             c_reads -= deferred
         b_dom = 8 * c_iv + 21 * c_reads + 16 + 8 * (G * c_reads // max(R, 1))
@@ -574,7 +579,7 @@ def large_block(yacrd_amd, host, ydist, dist, dev, torch, eng, rank, world, args
     dom, cname, dom_ms, c_reads, c_iv = dominant(t, K, yacrd_amd)
     deferred = int(t.get("deferred_reads", 0)) if cname == "R2..H16" else 0
     if deferred:
-        dom = "sweep_small_fused_defer_kernel"
+        dom = defer_kernel_name(c_iv)
         c_iv -= c_iv * deferred // max(c_reads, 1)
         c_reads -= deferred
     Gl = G

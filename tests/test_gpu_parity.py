@@ -318,7 +318,7 @@ def _crafted_screen_reads():
     return reads
 
 
-@pytest.mark.parametrize("cov", [0, 1, 2, 3, 4, 5, 8, 300])
+@pytest.mark.parametrize("cov", [0, 1, 2, 3, 4, 5, 8, 300, 0xFFFFFFFF])
 def test_healthy_screen_edges(cov):
     reads = _crafted_screen_reads()
     offsets = np.zeros(len(reads) + 1, np.uint64)

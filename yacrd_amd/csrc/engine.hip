@@ -360,7 +360,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     e->ctrl_clean[cur] = 0;
     const size_t other_bytes = std::min<size_t>(e->ctrl2[other].cap, (size_t)1 << 30) & ~(size_t)3;
     if (full) HIP_TRY(hipEventRecord(e->ev[EV_START], e->stream));
-    hipLaunchKernelGGL(yk::plan_kernel, dim3((n_reads + yk::kPlanBlock - 1) / yk::kPlanBlock),
+    hipLaunchKernelGGL(yk::plan_kernel, dim3((n_reads + yk::kPlanReads - 1) / yk::kPlanReads),
                        dim3(yk::kPlanBlock), 0, e->stream, d_off, n_reads, lists, ctr,
                        (u32)((e->flags & YACRD_F_FORCE_GENERAL) ? 1
                              : (e->flags & (YACRD_F_WAVE_ONLY | YACRD_F_FORCE_LDS_SORT)) ? 2

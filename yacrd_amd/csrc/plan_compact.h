@@ -8,10 +8,16 @@ namespace yk {
 // Ranks: one LDS atomic per (wavefront, class present in it) — lanes of a class are counted
 // with a ballot, their rank inside the wavefront is a popcount — then one global atomic per class
 // per workgroup.  (One LDS atomic per read serialised 1024 lanes on one address: 8 us -> 3 us.)
-constexpr int kPlanBlock = 1024;
+constexpr int kPlanBlock = 1024, kPlanPer = 4, kPlanReads = kPlanBlock * kPlanPer; // threads, reads per thread, reads per workgroup
 
 // `zero` / `zero_words`: the control block of the NEXT run (the engine alternates between two), left
 // zeroed here so that no run starts with a fill on its critical path.
+// A workgroup takes kPlanPer slabs of 1024 consecutive reads: its two global atomics (counts and
+// interval totals of the classes it met) hit the same two cache lines as every other workgroup's and
+// are performed at the memory side one after the other — 1 953 workgroups for configs[2]'s 2 M reads
+// made a 24 MB pass take 35 us; 489 take 19.  On configs[1] the kernel alone gets slower (7 -> 11 us: 25
+// workgroups), the pipelined batch faster (27.9 -> 26.0 us: fewer workgroups and atomics in the way of
+// another engine's sweep); two slabs: 28.0 us, eight: 29.7.
 __global__ __launch_bounds__(kPlanBlock) void plan_kernel(const u64 *off, u32 n_reads, u32 *lists,
                                                           Counters *ctr, u32 mode, u32 *zero,
                                                           u32 zero_words)
@@ -26,46 +32,53 @@ __global__ __launch_bounds__(kPlanBlock) void plan_kernel(const u64 *off, u32 n_
         s_iv[threadIdx.x] = 0;
     }
     __syncthreads();
-    const u32 r = blockIdx.x * kPlanBlock + threadIdx.x;
-    u32 cls = CLS_COUNT, local = 0; // CLS_COUNT = no read in this lane
-    u64 n = 0;
-    if (r < n_reads) {
-        n = off[r + 1] - off[r];
-        const u64 m = 2 * n;
-        // mode: 0 = default, 1 = every read to the general path, 2 = one read per wavefront only,
-        // 3 = rows (<= 128 intervals) but no 32-lane halves
-        if (mode == 1) cls = CLS_GENERAL;
-        else if (mode != 2 && m <= 32) cls = CLS_R2;
-        else if (mode != 2 && m <= 64) cls = CLS_R4;
-        else if (mode != 2 && m <= 128) cls = CLS_R8;
-        else if (mode != 2 && m <= 256) cls = CLS_R16;
-        else if (mode == 0 && m <= 512) cls = CLS_H16;
-        else if (m <= 128) cls = CLS_W2;
-        else if (m <= 256) cls = CLS_W4;
-        else if (m <= 512) cls = CLS_W8;
-        else if (m <= kSmallEvents) cls = CLS_W16;
-        else if (m <= kMedium1Events) cls = CLS_MED1;
-        else if (m <= kMedium2Events) cls = CLS_MED2;
-        else cls = CLS_GENERAL;
-    }
-    // wave-aggregated ranks: peel off one class at a time
+    u32 cls[kPlanPer], local[kPlanPer];
     const u64 lt = (1ull << lane_id()) - 1ull;
-    u64 todo = __builtin_amdgcn_ballot_w64(cls != CLS_COUNT);
-    while (todo) {
-        const u32 c = (u32)__builtin_amdgcn_readlane((int)cls, (int)__builtin_ctzll(todo));
-        const u64 mask = __builtin_amdgcn_ballot_w64(cls == c);
-        // interval total of the class inside the wavefront (lanes outside contribute 0)
-        u64 iv = (cls == c) ? n : 0;
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) iv += __shfl_xor(iv, d, 64);
-        u32 base = 0;
-        if (lane_id() == (u32)__builtin_ctzll(mask)) {
-            base = atomicAdd(&s_cnt[c], (u32)__builtin_popcountll(mask));
-            atomicAdd(&s_iv[c], (unsigned long long)iv);
+    for (int k = 0; k < kPlanPer; k++) {
+        const u32 r = blockIdx.x * (u32)kPlanReads + (u32)k * kPlanBlock + threadIdx.x;
+        cls[k] = CLS_COUNT; // CLS_COUNT = no read in this lane
+        local[k] = 0;
+        u64 n = 0;
+        if (r < n_reads) {
+            n = off[r + 1] - off[r];
+            const u64 m = 2 * n;
+            // mode: 0 = default, 1 = every read to the general path, 2 = one read per wavefront only,
+            // 3 = rows (<= 128 intervals) but no 32-lane halves
+            u32 c;
+            if (mode == 1) c = CLS_GENERAL;
+            else if (mode != 2 && m <= 32) c = CLS_R2;
+            else if (mode != 2 && m <= 64) c = CLS_R4;
+            else if (mode != 2 && m <= 128) c = CLS_R8;
+            else if (mode != 2 && m <= 256) c = CLS_R16;
+            else if (mode == 0 && m <= 512) c = CLS_H16;
+            else if (m <= 128) c = CLS_W2;
+            else if (m <= 256) c = CLS_W4;
+            else if (m <= 512) c = CLS_W8;
+            else if (m <= kSmallEvents) c = CLS_W16;
+            else if (m <= kMedium1Events) c = CLS_MED1;
+            else if (m <= kMedium2Events) c = CLS_MED2;
+            else c = CLS_GENERAL;
+            cls[k] = c;
         }
-        base = (u32)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(mask));
-        if (cls == c) local = base + (u32)__builtin_popcountll(mask & lt);
-        todo &= ~mask;
+        // wave-aggregated ranks: peel off one class at a time
+        u64 todo = __builtin_amdgcn_ballot_w64(cls[k] != CLS_COUNT);
+        while (todo) {
+            const u32 c = (u32)__builtin_amdgcn_readlane((int)cls[k], (int)__builtin_ctzll(todo));
+            const u64 mask = __builtin_amdgcn_ballot_w64(cls[k] == c);
+            // interval total of the class inside the wavefront (lanes outside contribute 0)
+            u64 iv = (cls[k] == c) ? n : 0;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) iv += __shfl_xor(iv, d, 64);
+            u32 base = 0;
+            if (lane_id() == (u32)__builtin_ctzll(mask)) {
+                base = atomicAdd(&s_cnt[c], (u32)__builtin_popcountll(mask));
+                atomicAdd(&s_iv[c], (unsigned long long)iv);
+            }
+            base = (u32)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(mask));
+            if (cls[k] == c) local[k] = base + (u32)__builtin_popcountll(mask & lt);
+            todo &= ~mask;
+        }
     }
     __syncthreads();
     if (threadIdx.x < CLS_COUNT && s_cnt[threadIdx.x]) {
@@ -73,7 +86,11 @@ __global__ __launch_bounds__(kPlanBlock) void plan_kernel(const u64 *off, u32 n_
         atomicAdd((unsigned long long *)&ctr->iv[threadIdx.x], s_iv[threadIdx.x]);
     }
     __syncthreads();
-    if (cls != CLS_COUNT) lists[(u64)cls * n_reads + s_base[cls] + local] = r;
+#pragma unroll
+    for (int k = 0; k < kPlanPer; k++) {
+        const u32 r = blockIdx.x * (u32)kPlanReads + (u32)k * kPlanBlock + threadIdx.x;
+        if (cls[k] != CLS_COUNT) lists[(u64)cls[k] * n_reads + s_base[cls[k]] + local[k]] = r;
+    }
 }
 
 constexpr int kScanBlock = 1024;

@@ -721,28 +721,39 @@ __device__ __forceinline__ void screen_block(const SweepArgs &a, u32 block)
             len[t] = a.len[r[t]];
         }
     }
-    uint2 v[ITEMS][K / 2];
+    // The screen does not care which lane holds which interval, so a lane takes its intervals two at a
+    // time (16-byte loads: half the memory instructions and address arithmetic).  Pair P = lig + LANES*j
+    // holds intervals 2P and 2P + 1; the load is clamped to the read's last pair (n - 2, n - 1), whose
+    // second half is interval 2P itself when 2P = n - 1.  (8-byte aligned 16-byte loads are fine for
+    // global memory; a read with fewer than two intervals — not in these classes — is left to
+    // sweep_deferred_kernel.)
+    uint4 v[ITEMS][K / 4];
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) {
-        // index clamped to the read's last interval (the duplicates become pads below); a group without
-        // intervals reads the first offsets instead (always mapped)
-        const uint2 *src = n[t] ? a.iv + o[t] : reinterpret_cast<const uint2 *>(a.off);
-        const u32 last = n[t] ? n[t] - 1u : 0u;
+        const bool two = n[t] >= 2u;
+        const uint2 *src = two ? a.iv + o[t] : reinterpret_cast<const uint2 *>(a.off);
+        const u32 last2 = two ? n[t] - 2u : 0u;
 #pragma unroll
-        for (int j = 0; j < K / 2; j++) v[t][j] = src[min(lig + (u32)LANES * j, last)];
+        for (int j = 0; j < K / 4; j++)
+            v[t][j] = *reinterpret_cast<const uint4 *>(src + min(2u * (lig + (u32)LANES * j), last2));
     }
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) {
         if (t > 0 && idx0 + (u32)t * GROUPS >= list_n) break; // uniform: nothing left for this item
         u32 x[K];
         const u32 len_c = min(len[t], kMaxKeyPos);
-        u32 irregular = 0;
+        u32 irregular = (active[t] && n[t] < 2u) ? 1u : 0u;
 #pragma unroll
-        for (int j = 0; j < K / 2; j++) {
-            const bool real = lig + (u32)LANES * j < n[t];
-            irregular |= (real && (v[t][j].x >= v[t][j].y || v[t][j].y > len_c)) ? 1u : 0u;
-            x[2 * j] = real ? ((v[t][j].x << kKeyShift) | 3u) : kPadKey;
-            x[2 * j + 1] = real ? (v[t][j].y << kKeyShift) : kPadKey;
+        for (int j = 0; j < K / 4; j++) {
+            const u32 i0 = 2u * (lig + (u32)LANES * j);
+            const bool real0 = i0 + 1u < n[t], real1 = i0 < n[t]; // .xy is interval i0 only when i0 + 1 exists too
+            const uint4 w = v[t][j];
+            irregular |= (real0 && (w.x >= w.y || w.y > len_c)) ? 1u : 0u;
+            irregular |= (real1 && (w.z >= w.w || w.w > len_c)) ? 1u : 0u;
+            x[4 * j] = real0 ? ((w.x << kKeyShift) | 3u) : kPadKey;
+            x[4 * j + 1] = real0 ? (w.y << kKeyShift) : kPadKey;
+            x[4 * j + 2] = real1 ? ((w.z << kKeyShift) | 3u) : kPadKey;
+            x[4 * j + 3] = real1 ? (w.w << kKeyShift) : kPadKey;
         }
         if (__builtin_amdgcn_ballot_w64(irregular != 0) != 0) { // (uniform) not plain: sweep_deferred_kernel's
             if (lig == 0 && active[t]) a.counts[r[t]] = kDeferredMark;
@@ -923,11 +934,11 @@ __device__ __forceinline__ void sweep_small_fused_body(const FusedArgs &f)
     case CLS_R4: sweep_group_block<16, 4, 0, false, WPB>(a, b); break;
     case CLS_R8: sweep_group_block<16, 8, 0, false, WPB>(a, b); break;
     case CLS_R16:
-        if constexpr (DEFER && ITEMS > 1) screen_block<16, ITEMS>(a, b);
+        if constexpr (DEFER) screen_block<16, ITEMS>(a, b);
         else sweep_group_block<16, 16, 0, DEFER, WPB>(a, b);
         break;
     default:
-        if constexpr (DEFER && ITEMS > 1) screen_block<32, ITEMS>(a, b);
+        if constexpr (DEFER) screen_block<32, ITEMS>(a, b);
         else sweep_group_block<32, 16, 0, DEFER, WPB>(a, b);
         break;
     }

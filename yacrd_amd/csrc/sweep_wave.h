@@ -580,7 +580,7 @@ __device__ __forceinline__ bool prefilter(const u32 (&x)[K], u32 n, u32 len, i32
 }
 
 // ---- one read per group of LANES lanes: loads, keys, (pre-filter,) sweep ------------------------
-template <int LANES, int K, int XM, bool DEFER = false, int WPB = 4>
+template <int LANES, int K, int XM, int WPB = 4>
 __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u32 n, u32 len,
                                                  u32 cov, bool active, u32 r,
                                                  const SweepArgs &a, const LaneConst &lc)
@@ -616,14 +616,7 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
             x[2 * j + 1] = real ? (v[j].y << kKeyShift) : kPadKey;
         }
         plain = __builtin_amdgcn_ballot_w64(irregular != 0) == 0; // wave-uniform
-        if constexpr (K == 16 && DEFER) {
-            // the deferring build holds neither the class / rejection logic nor the 16-keys-per-lane
-            // sort: the reads of such a wavefront are finished by sweep_deferred_kernel
-            if (!plain) {
-                if (lig == 0 && active) a.counts[r] = kDeferredMark;
-                return;
-            }
-        } else if (!plain) {
+        if (!plain) {
 #pragma unroll
             for (int j = 0; j < K / 2; j++) {
                 u32 ks, ke, b = 0, z = 0;
@@ -648,32 +641,7 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
     // two zero-length intervals at one position: only looked for when the wavefront saw >= 2
     const bool zl_check = (zmask & (zmask - 1)) != 0 || __builtin_amdgcn_ballot_w64(nz > 2) != 0;
 
-    if constexpr (K == 16 && DEFER) {
-        // (the engine only launches this build with the filter on; every wavefront here is plain)
-        HealthyRead hr;
-        const bool healthy = healthy_screen<LANES, K, WPB>(x, n, len, c, hr);
-        if (lig == 0 && active) {
-            if (healthy) {
-                // k starts at pmin then k ends at pmax (healthy_screen): one bad region over the
-                // whole read when k <= c (also the read without intervals; finish_read's
-                // "mf_t == 0" branch), else the parts in front of pmin and behind pmax.  len >= 1
-                // whenever n >= 1.
-                uint2 *slot = a.stage + (a.off[r] + 2 * (u64)r);
-                u32 g = 0;
-                if ((i32)hr.kept_starts <= c) {
-                    if (len != 0) slot[g++] = make_uint2(0u, len);
-                } else {
-                    if (hr.pmin != 0) slot[g++] = make_uint2(0u, hr.pmin);
-                    if (hr.pmax != len) slot[g++] = make_uint2(hr.pmax, len);
-                }
-                a.counts[r] = g;
-                if (a.prefilter == 2) atomicAdd(&a.ctr->prefiltered, 1u);
-            } else {
-                a.counts[r] = kDeferredMark; // sweep_deferred_kernel sorts it whole
-            }
-        }
-        return;
-    } else if constexpr (K == 16) {
+    if constexpr (K == 16) {
         if (a.prefilter && plain) { // uniform
             u32 y[K / 2], mf;
             if (prefilter<LANES, K, WPB>(x, n, len, c, y, mf)) {
@@ -684,8 +652,7 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
             }
         }
     }
-    if constexpr (!(K == 16 && DEFER))
-        sweep_group_keys<LANES, K, XM>(x, 2 * n, len, c, active, r, badmask, zmask, zl_check, a, lc);
+    sweep_group_keys<LANES, K, XM>(x, 2 * n, len, c, active, r, badmask, zmask, zl_check, a, lc);
 }
 
 // ---- the screen over ITEMS consecutive groups of list entries per wavefront (one-wavefront workgroups)
@@ -782,7 +749,7 @@ __device__ __forceinline__ void screen_block(const SweepArgs &a, u32 block)
 }
 
 // Body of one workgroup (four wavefronts, 4 * 64/LANES reads) of class (LANES, K).
-template <int LANES, int K, int XM, bool DEFER = false, int WPB = 4>
+template <int LANES, int K, int XM, int WPB = 4>
 __device__ __forceinline__ void sweep_group_block(const SweepArgs &a, u32 block)
 {
     const u32 lane = lane_id();
@@ -802,7 +769,7 @@ __device__ __forceinline__ void sweep_group_block(const SweepArgs &a, u32 block)
         n = (u32)(a.off[r + 1] - o);
         len = a.len[r];
     }
-    sweep_group_read<LANES, K, XM, DEFER, WPB>(a.iv + o, n, len, a.cov, active, r, a, lc);
+    sweep_group_read<LANES, K, XM, WPB>(a.iv + o, n, len, a.cov, active, r, a, lc);
 }
 
 // One kernel per (LANES, K): small K keep small register footprints.
@@ -896,6 +863,7 @@ __global__ __launch_bounds__(256) void sweep_deferred_kernel(DeferArgs d)
 // wavefronts per workgroup of the fused launch: the deferring build runs one-wavefront workgroups (a
 // slot is free again as soon as its wavefront ends, not when the slowest of four does)
 constexpr int kFusedWaves = 4, kDeferWaves = YK_DEFER_WAVES, kDeferOcc = YK_DEFER_OCC;
+static_assert(kDeferWaves == 1, "screen_block indexes list entries by workgroup: one wavefront each");
 struct FusedArgs {
     SweepArgs base;           // list / list_n filled per class from the table below
     u32 n_entries;
@@ -930,16 +898,16 @@ __device__ __forceinline__ void sweep_small_fused_body(const FusedArgs &f)
     a.first = f.first[e];
     const u32 b = g - first;
     switch (f.cls[e]) { // the one-read-per-wavefront classes stay separate kernels (registers)
-    case CLS_R2: sweep_group_block<16, 2, 0, false, WPB>(a, b); break;
-    case CLS_R4: sweep_group_block<16, 4, 0, false, WPB>(a, b); break;
-    case CLS_R8: sweep_group_block<16, 8, 0, false, WPB>(a, b); break;
+    case CLS_R2: sweep_group_block<16, 2, 0, WPB>(a, b); break;
+    case CLS_R4: sweep_group_block<16, 4, 0, WPB>(a, b); break;
+    case CLS_R8: sweep_group_block<16, 8, 0, WPB>(a, b); break;
     case CLS_R16:
         if constexpr (DEFER) screen_block<16, ITEMS>(a, b);
-        else sweep_group_block<16, 16, 0, DEFER, WPB>(a, b);
+        else sweep_group_block<16, 16, 0, WPB>(a, b);
         break;
     default:
         if constexpr (DEFER) screen_block<32, ITEMS>(a, b);
-        else sweep_group_block<32, 16, 0, DEFER, WPB>(a, b);
+        else sweep_group_block<32, 16, 0, WPB>(a, b);
         break;
     }
 }

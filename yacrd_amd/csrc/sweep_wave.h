@@ -683,8 +683,9 @@ __device__ __forceinline__ void screen_block(const SweepArgs &a, u32 block)
     for (int t = 0; t < ITEMS; t++) {
         o[t] = 0, n[t] = 0, len[t] = 0;
         if (active[t]) {
-            o[t] = a.off[r[t]];
-            n[t] = (u32)(a.off[r[t] + 1] - o[t]);
+            const ulonglong2 oo = *reinterpret_cast<const ulonglong2 *>(a.off + r[t]); // off[r], off[r + 1]: one load
+            o[t] = oo.x;
+            n[t] = (u32)(oo.y - oo.x);
             len[t] = a.len[r[t]];
         }
     }

@@ -423,7 +423,8 @@ struct HealthyRead {
 };
 
 template <int LANES, int K, int WPB>
-__device__ __forceinline__ bool healthy_screen(const u32 (&x)[K], u32 n, u32 len, i32 c, HealthyRead &hr)
+__device__ __forceinline__ bool healthy_screen(const u32 (&x)[K], u32 n, u32 len, i32 c, u32 kmin, u32 kmax,
+                                               HealthyRead &hr)
 {
     constexpr int NB = LANES, NBIN = LANES + 3, GROUPS = 64 / LANES;
     constexpr u32 kHeadBin = NB + 1, kTailBin = NB + 2; // (bin NB takes the pads)
@@ -444,18 +445,9 @@ __device__ __forceinline__ bool healthy_screen(const u32 (&x)[K], u32 n, u32 len
     // ---- count.  Byte offset of a key's counter = bin * 16 + (lane & 3) * 4; the pads (0xFFFFFFFE,
     // in the slots of intervals the read does not have) clamp into the pads' bin
     const u32 cp = (lig & 3u) * 4u, head_off = kHeadBin * 16u + cp, tail_off = kTailBin * 16u + cp;
-    // the group's smallest start key and largest end key (the pads are end-like and huge: they never
-    // win the min, and key + 2 wraps them to 0 for the max); a group without intervals matches nothing
-    const int last_addr = (int)((lane | (u32)(LANES - 1)) << 2);
-    auto row_total = [&](u32 v) { return (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)v); };
-    u32 smin = x[0], emax2 = 0;
-#pragma unroll
-    for (int j = 0; j < K / 2; j++) {
-        smin = min(smin, x[2 * j]);
-        emax2 = max(emax2, x[2 * j + 1] + 2u);
-    }
-    const u32 kmin = n ? row_total(gscan_min<LANES>(smin)) : 1u;
-    const u32 kmax = n ? row_total(gscan_max<LANES>(emax2)) - 2u : 0u;
+    // kmin / kmax: the group's smallest start key and largest end key (the caller's, from the raw
+    // positions); a group without intervals is given keys that match nothing
+    (void)n;
 #pragma unroll
     for (int j = 0; j < K / 2; j++) {
         const u32 ks = x[2 * j], ke = x[2 * j + 1];
@@ -710,14 +702,26 @@ __device__ __forceinline__ void screen_block(const SweepArgs &a, u32 block)
         if (t > 0 && idx0 + (u32)t * GROUPS >= list_n) break; // uniform: nothing left for this item
         u32 x[K];
         const u32 len_c = min(len[t], kMaxKeyPos);
-        u32 irregular = (active[t] && n[t] < 2u) ? 1u : 0u;
+        // The read's smallest start and largest end, from the raw positions of every slot: a slot beyond
+        // the read's last interval holds a copy of one of its intervals (the clamped load), so it cannot
+        // change either.  An end beyond the read (or beyond the key range) shows in the largest one.
+        u32 smin = v[t][0].x, emax = v[t][0].y;
+#pragma unroll
+        for (int j = 0; j < K / 4; j++) {
+            smin = min(smin, min(v[t][j].x, v[t][j].z));
+            emax = max(emax, max(v[t][j].y, v[t][j].w));
+        }
+        const int last_addr = (int)((lane | (u32)(LANES - 1)) << 2);
+        const u32 pmin = (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)gscan_min<LANES>(smin));
+        const u32 pmax = (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)gscan_max<LANES>(emax));
+        u32 irregular = (active[t] && (n[t] < 2u || pmax > len_c)) ? 1u : 0u;
 #pragma unroll
         for (int j = 0; j < K / 4; j++) {
             const u32 i0 = 2u * (lig + (u32)LANES * j);
             const bool real0 = i0 + 1u < n[t], real1 = i0 < n[t]; // .xy is interval i0 only when i0 + 1 exists too
             const uint4 w = v[t][j];
-            irregular |= (real0 && (w.x >= w.y || w.y > len_c)) ? 1u : 0u;
-            irregular |= (real1 && (w.z >= w.w || w.w > len_c)) ? 1u : 0u;
+            irregular |= (real0 && w.x >= w.y) ? 1u : 0u;
+            irregular |= (real1 && w.z >= w.w) ? 1u : 0u;
             x[4 * j] = real0 ? ((w.x << kKeyShift) | 3u) : kPadKey;
             x[4 * j + 1] = real0 ? (w.y << kKeyShift) : kPadKey;
             x[4 * j + 2] = real1 ? ((w.z << kKeyShift) | 3u) : kPadKey;
@@ -728,7 +732,8 @@ __device__ __forceinline__ void screen_block(const SweepArgs &a, u32 block)
             continue;
         }
         HealthyRead hr;
-        const bool healthy = healthy_screen<LANES, K, 1>(x, n[t], len[t], c, hr);
+        const bool healthy = healthy_screen<LANES, K, 1>(x, n[t], len[t], c, n[t] ? ((pmin << kKeyShift) | 3u) : 1u,
+                                                         n[t] ? (pmax << kKeyShift) : 0u, hr);
         if (lig == 0 && active[t]) {
             if (healthy) {
                 uint2 *slot = a.stage + (o[t] + 2 * (u64)r[t]);

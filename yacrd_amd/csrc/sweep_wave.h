@@ -422,37 +422,44 @@ struct HealthyRead {
     u32 kept_starts, pmin, pmax; // k, and the two positions
 };
 
-template <int LANES, int K, int WPB>
-__device__ __forceinline__ bool healthy_screen(const u32 (&x)[K], u32 n, u32 len, i32 c, u32 kmin, u32 kmax,
-                                               HealthyRead &hr)
+// The screen works on the raw positions (no event keys are made): v[j] = two intervals (x, y) and
+// (z, w) of this lane, real0[j] / real1[j] = whether those slots belong to the read (the others hold
+// copies and count into the pads' bin), pmin / pmax = the group's smallest start / largest end.
+// Only for wavefronts whose intervals are all plain (start < end <= len <= kMaxKeyPos).
+template <int LANES, int WPB>
+__device__ __forceinline__ bool healthy_screen(const uint4 (&v)[4], const bool (&real0)[4], const bool (&real1)[4],
+                                               u32 len, i32 c, u32 pmin, u32 pmax, HealthyRead &hr)
 {
     constexpr int NB = LANES, NBIN = LANES + 3, GROUPS = 64 / LANES;
-    constexpr u32 kHeadBin = NB + 1, kTailBin = NB + 2; // (bin NB takes the pads)
+    constexpr u32 kPadBin = NB, kHeadBin = NB + 1, kTailBin = NB + 2;
     static_assert(GROUPS * NBIN * 4 <= kScreenTabWords, "scratch");
     const u32 lane = lane_id(), lig = lane & (u32)(LANES - 1), grp = lane / (u32)LANES;
     u32 *tab = wave_screen_scratch<WPB>() + grp * (u32)(NBIN * 4);
     uint4 *bins = reinterpret_cast<uint4 *>(tab);
     char *tb = reinterpret_cast<char *>(tab);
 
-    // smallest shift with (len >> sh) < NB: the bin holding `len` exists inside the table
+    // smallest shift with (len >> sh) < NB: every position of a plain interval has its bin inside the table
     const i32 bits = 32 - (i32)__builtin_clz(len | 1u) - ilog2c(NB) + (len != 0 ? 0 : -1);
-    const u32 ksh = (u32)max(bits, 0) + kKeyShift;
+    const u32 sh = (u32)max(bits, 0);
 
     bins[lig] = make_uint4(0u, 0u, 0u, 0u);
     if (lig < 3u) bins[NB + lig] = make_uint4(0u, 0u, 0u, 0u);
     wave_lds_sync();
 
-    // ---- count.  Byte offset of a key's counter = bin * 16 + (lane & 3) * 4; the pads (0xFFFFFFFE,
-    // in the slots of intervals the read does not have) clamp into the pads' bin
-    const u32 cp = (lig & 3u) * 4u, head_off = kHeadBin * 16u + cp, tail_off = kTailBin * 16u + cp;
-    // kmin / kmax: the group's smallest start key and largest end key (the caller's, from the raw
-    // positions); a group without intervals is given keys that match nothing
-    (void)n;
+    // ---- count.  Byte offset of a position's counter = bin * 16 + (lane & 3) * 4: five instructions
+    // and one LDS atomic per event (shift, shift-add, compare, two selects)
+    const u32 cp = (lig & 3u) * 4u, head_off = kHeadBin * 16u + cp, tail_off = kTailBin * 16u + cp,
+              pad_off = kPadBin * 16u + cp;
+    auto count = [&](u32 s, u32 e, bool real) {
+        const u32 os = s == pmin ? head_off : ((s >> sh) << 4) + cp;
+        const u32 oe = e == pmax ? tail_off : ((e >> sh) << 4) + cp;
+        atomicAdd(reinterpret_cast<u32 *>(tb + (real ? os : pad_off)), 1u);
+        atomicAdd(reinterpret_cast<u32 *>(tb + (real ? oe : pad_off)), 0x10000u);
+    };
 #pragma unroll
-    for (int j = 0; j < K / 2; j++) {
-        const u32 ks = x[2 * j], ke = x[2 * j + 1];
-        atomicAdd(reinterpret_cast<u32 *>(tb + (ks == kmin ? head_off : (min(ks >> ksh, (u32)NB) << 4) + cp)), 1u);
-        atomicAdd(reinterpret_cast<u32 *>(tb + (ke == kmax ? tail_off : (min(ke >> ksh, (u32)NB) << 4) + cp)), 0x10000u);
+    for (int j = 0; j < 4; j++) {
+        count(v[j].x, v[j].y, real0[j]);
+        count(v[j].z, v[j].w, real1[j]);
     }
     wave_lds_sync();
 
@@ -466,8 +473,8 @@ __device__ __forceinline__ bool healthy_screen(const u32 (&x)[K], u32 n, u32 len
     const bool shallow = w != 0u && !(D - E > c);                  // holds events and is not deep
     const i32 k = min(S0, c + 1);
     hr.kept_starts = (u32)k;
-    hr.pmin = kmin >> kKeyShift;
-    hr.pmax = kmax >> kKeyShift;
+    hr.pmin = pmin;
+    hr.pmax = pmax;
     // the group's verdict, the same in all of its lanes
     const u64 sb = __builtin_amdgcn_ballot_w64(shallow);
     const u32 mine = LANES == 64 ? (u32)((sb | (sb >> 32)) != 0)
@@ -700,7 +707,6 @@ __device__ __forceinline__ void screen_block(const SweepArgs &a, u32 block)
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) {
         if (t > 0 && idx0 + (u32)t * GROUPS >= list_n) break; // uniform: nothing left for this item
-        u32 x[K];
         const u32 len_c = min(len[t], kMaxKeyPos);
         // The read's smallest start and largest end, from the raw positions of every slot: a slot beyond
         // the read's last interval holds a copy of one of its intervals (the clamped load), so it cannot
@@ -715,25 +721,21 @@ __device__ __forceinline__ void screen_block(const SweepArgs &a, u32 block)
         const u32 pmin = (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)gscan_min<LANES>(smin));
         const u32 pmax = (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)gscan_max<LANES>(emax));
         u32 irregular = (active[t] && (n[t] < 2u || pmax > len_c)) ? 1u : 0u;
+        bool real0[K / 4], real1[K / 4];
 #pragma unroll
         for (int j = 0; j < K / 4; j++) {
             const u32 i0 = 2u * (lig + (u32)LANES * j);
-            const bool real0 = i0 + 1u < n[t], real1 = i0 < n[t]; // .xy is interval i0 only when i0 + 1 exists too
-            const uint4 w = v[t][j];
-            irregular |= (real0 && w.x >= w.y) ? 1u : 0u;
-            irregular |= (real1 && w.z >= w.w) ? 1u : 0u;
-            x[4 * j] = real0 ? ((w.x << kKeyShift) | 3u) : kPadKey;
-            x[4 * j + 1] = real0 ? (w.y << kKeyShift) : kPadKey;
-            x[4 * j + 2] = real1 ? ((w.z << kKeyShift) | 3u) : kPadKey;
-            x[4 * j + 3] = real1 ? (w.w << kKeyShift) : kPadKey;
+            real0[j] = i0 + 1u < n[t]; // .xy is interval i0 only when i0 + 1 exists too
+            real1[j] = i0 < n[t];
+            irregular |= (real0[j] && v[t][j].x >= v[t][j].y) ? 1u : 0u;
+            irregular |= (real1[j] && v[t][j].z >= v[t][j].w) ? 1u : 0u;
         }
         if (__builtin_amdgcn_ballot_w64(irregular != 0) != 0) { // (uniform) not plain: sweep_deferred_kernel's
             if (lig == 0 && active[t]) a.counts[r[t]] = kDeferredMark;
             continue;
         }
         HealthyRead hr;
-        const bool healthy = healthy_screen<LANES, K, 1>(x, n[t], len[t], c, n[t] ? ((pmin << kKeyShift) | 3u) : 1u,
-                                                         n[t] ? (pmax << kKeyShift) : 0u, hr);
+        const bool healthy = healthy_screen<LANES, 1>(v[t], real0, real1, len[t], c, n[t] ? pmin : 1u, n[t] ? pmax : 0u, hr);
         if (lig == 0 && active[t]) {
             if (healthy) {
                 uint2 *slot = a.stage + (o[t] + 2 * (u64)r[t]);

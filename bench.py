@@ -77,6 +77,9 @@ def main():
     ap.add_argument("--reads", type=int, default=100_000)
     ap.add_argument("--overlaps", type=int, default=5_000_000)
     ap.add_argument("--profile", default="ont", choices=["ont", "sequel", "skewed"])
+    ap.add_argument("--jitter", type=int, default=0,
+                    help="dovetail ends reflected into the read instead of clamped onto 0 / len "
+                         "(YACRD_SYNTH_F_JITTER), sigma = this many positions (SURVEY.md 8d's is 30)")
     ap.add_argument("--coverage", type=int, default=None)
     ap.add_argument("--not-coverage", type=float, default=0.4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -123,7 +126,8 @@ def main():
     cov = args.coverage if args.coverage is not None else (3 if args.profile == "sequel" else 4)
     cfg_no = {"ont": 2, "sequel": 3, "skewed": 4}[args.profile]
     seed = 20241108 + cfg_no + 1000 * rank
-    offsets, intervals, lengths = host.synth_csr(prof, args.reads, args.overlaps, seed)
+    sflags = (host.SYNTH_F_JITTER | host.synth_f_sigma(args.jitter)) if args.jitter else 0
+    offsets, intervals, lengths = host.synth_csr(prof, args.reads, args.overlaps, seed, flags=sflags)
     R, I = args.reads, int(offsets[-1])
 
     d_off = torch.from_numpy(offsets.view(np.int64)).to(dev)

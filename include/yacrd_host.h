@@ -111,10 +111,16 @@ void yacrd_report_free(yacrd_report *r);
 
 /* ---- synthetic workloads ------------------------------------------------------ */
 enum { YACRD_SYNTH_ONT = 0, YACRD_SYNTH_SEQUEL = 1, YACRD_SYNTH_SKEWED = 2 };
+/* flags.  NO_INJECTION: no abutting / degenerate intervals.  JITTER: the N(0, sigma) offset of a
+ * dovetail end is REFLECTED into the read instead of clamped onto 0 / len (SURVEY.md §8d's clamp puts
+ * 15 % of all starts on exactly 0 and 15 % of all ends on exactly len; a real overlapper's chain ends
+ * are spread over a few dozen positions).  Bits 8..15: sigma of that offset in positions (0 = 30). */
+enum { YACRD_SYNTH_F_NO_INJECTION = 1u, YACRD_SYNTH_F_JITTER = 2u };
+#define YACRD_SYNTH_F_SIGMA(s) (((uint32_t)(s) & 0xFFu) << 8)
 
 typedef struct {
     uint32_t profile;       /* YACRD_SYNTH_* */
-    uint32_t flags;         /* bit0: no abutting/degenerate injection */
+    uint32_t flags;         /* YACRD_SYNTH_F_* */
     uint64_t n_reads;
     uint64_t n_overlaps;    /* PAF lines; intervals = 2 * n_overlaps */
     uint64_t seed;

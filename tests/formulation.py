@@ -437,3 +437,64 @@ def healthy_read_regions(intervals, length, cov, nb):
     if k <= cov:
         return [(0, length)]
     return ([(0, pmin)] if pmin != 0 else []) + ([(pmax, length)] if pmax != length else [])
+
+
+def window_screen_regions(intervals, length, cov, nb, W):
+    """sweep_wave.h's healthy-read screen on ORDER STATISTICS (round 3; replaces the exact-position
+    piles of healthy_read_regions).  With a = the (cov+1)-th smallest start and b = the (cov+1)-th
+    largest end, a plain read whose starts beyond the first cov+1 all find more than cov intervals open
+    is bad exactly in front of a and behind b: src/stack.rs:83-89 assigns first_covered at the first
+    cov+1 starts (heap sizes 0..cov, nothing popped yet) and never opens a gap afterwards, and the tail
+    loop :93-105 pops down to cov open intervals, i.e. ends on the (cov+1)-th largest end (or breaks on
+    an end == len, which then is that end as well).
+    The kernel finds a and b without a sort: W one-position bins counted from the read's smallest start
+    pmin upwards (starts only) and W from its largest end pmax downwards (ends only), next to the nb
+    coarse bins of 2^sh positions that hold every other event.  When every interval is at least W long
+    no end lies inside the head window and no start inside the tail window, so in event order the read
+    is [head window: F starts][coarse bins][tail window: G ends], and a coarse-counted start of bin i
+    has at least F + (starts of bins < i) - (ends of bins <= i) intervals open in front of it.
+    Returns None when the screen does not apply (the kernel then defers the read to the sort)."""
+    n = len(intervals)
+    if n == 0:
+        return [(0, length)] if length != 0 else []
+    if any(not (0 <= s < e <= length) for s, e in intervals) or length >= 2**30 - 1:
+        return None
+    if n <= cov:  # never more than cov intervals open: nothing is flagged, the whole read is bad
+        return [(0, length)]
+    if n < 2 or any(e - s < W for s, e in intervals):
+        return None
+    sh = bin_shift(length, nb)
+    pmin = min(s for s, e in intervals)
+    pmax = max(e for s, e in intervals)
+    S, E = [0] * nb, [0] * nb
+    FH, FT = [0] * W, [0] * W
+    for s, e in intervals:
+        if s - pmin < W:
+            FH[s - pmin] += 1
+        else:
+            S[s >> sh] += 1
+        if pmax - e < W:
+            FT[pmax - e] += 1
+        else:
+            E[e >> sh] += 1
+    F, G = sum(FH), sum(FT)
+    if F < cov + 1 or G < cov + 1:
+        return None
+    D = F
+    for b in range(nb):
+        if S[b] > 0 and not (D - E[b] > cov):
+            return None
+        D += S[b] - E[b]
+    acc, a = 0, None
+    for i in range(W):
+        acc += FH[i]
+        if acc >= cov + 1:
+            a = pmin + i
+            break
+    acc, bb = 0, None
+    for i in range(W):
+        acc += FT[i]
+        if acc >= cov + 1:
+            bb = pmax - i
+            break
+    return ([(0, a)] if a != 0 else []) + ([(bb, length)] if bb != length else [])

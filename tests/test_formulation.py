@@ -157,3 +157,49 @@ def test_pile_trimming_tiny_exhaustive():
                             hr = healthy_read_regions(list(iv), L, cov, nb)
                             assert hr is None or hr == want, (iv, L, cov, nb, "healthy")
                         assert got is not None or regular_events(list(iv), L, cov) is None
+
+
+def test_window_screen_matches_oracle():
+    """The order-statistics screen of sweep_wave.h (round 3): wherever it applies it equals the oracle —
+    piles on one exact position (jitter 0), spread piles, windows, ties on a coarse grid, every window
+    size the kernel can be built with and tiny ones that make the windows collide with everything."""
+    from formulation import window_screen_regions
+    rng = np.random.default_rng(31337)
+    n_fired = n_total = 0
+    for it in range(1500):
+        L = int(rng.integers(2, 300)) if it % 3 == 0 else int(rng.integers(300, 50000))
+        n = int(rng.integers(1, 30)) if it % 4 == 0 else int(rng.integers(30, 300))
+        jitter = (0.0, 1.0, 5.0, 30.0, 100.0)[it % 5]
+        iv = _pile_read(rng, n, L, jitter)
+        if it % 6 == 1:  # long intervals only: the screen's usual case
+            iv = [(s, min(max(e, s + 70), L)) for s, e in iv if s + 70 <= L] or iv
+        if it % 11 == 0:  # everything on a coarse grid: ties everywhere
+            g = max(1, L // 8)
+            iv = [(min((s // g) * g, L - 1), min(max((e // g) * g, (s // g) * g + 1), L)) for s, e in iv]
+            iv = [(s, max(e, s + 1)) for s, e in iv]
+        if it % 7 == 3:  # covered only inside a window: the order statistics sit at the window's edges
+            w0, w1 = L // 3, max(L // 3 + 2, 2 * L // 3)
+            iv = [(min(max(s, w0), w1 - 1), min(max(e, min(max(s, w0), w1 - 1) + 1), w1)) for s, e in iv]
+        for cov in (0, 1, 4, 9, 50, 400):
+            want = oracle.compute_bad_part(iv, L, cov)
+            for nb, W in ((16, 32), (32, 32), (16, 64), (16, 1), (4, 2), (8, 5)):
+                got = window_screen_regions(iv, L, cov, nb, W)
+                n_total += 1
+                if got is not None:
+                    n_fired += 1
+                    assert got == want, (iv, L, cov, nb, W)
+    assert n_fired > n_total // 5
+
+
+def test_window_screen_tiny_exhaustive():
+    import itertools
+    from formulation import window_screen_regions
+    for L in range(1, 7):
+        pairs = [(s, e) for s in range(L + 1) for e in range(s + 1, L + 1)]
+        for k in range(1, 4):
+            for iv in itertools.combinations_with_replacement(pairs, k):
+                for cov in range(0, 3):
+                    want = oracle.compute_bad_part(list(iv), L, cov)
+                    for nb, W in ((2, 1), (2, 2), (4, 1), (4, 3)):
+                        got = window_screen_regions(list(iv), L, cov, nb, W)
+                        assert got is None or got == want, (iv, L, cov, nb, W)

@@ -315,6 +315,20 @@ def _crafted_screen_reads():
                     inner = [(1 + (j % 7), L - 1 - (j % 5)) for j in range(n - 2 * k)]
                     reads.append(([(0, L - 2)] * k + inner + [(2, L)] * k, L))
                     reads.append(([(0, L - 2)] * k + inner + [(2, L)] * (k + 1), L))  # piles out of balance
+            if L >= 1000:
+                # spread piles (round 3: the screen works on order statistics): the j-th dovetail starts at
+                # j * step and the j-th from the other side ends at L - j * step, for steps that put the
+                # (c+1)-th of them inside, on the edge of and beyond the screen's windows (32 positions)
+                for step in (1, 3, 6, 7, 8, 15, 16, 31, 32, 33, 200):
+                    for k in (3, 5, 6, 12):
+                        if (k - 1) * step + 320 >= L - 320 - k:
+                            continue
+                        left = [(j * step, L - 300 - j) for j in range(k)]
+                        right = [(250 + j, L - j * step) for j in range(k)]
+                        inner = [(260 + (j % 7), L - 310 - (j % 5)) for j in range(n - 2 * k)]
+                        reads.append((left + inner + right, L))
+                        reads.append((left + inner + right[:-1] + [(L - 20, L)], L))   # one interval shorter than a window
+                        reads.append((left + inner[:-1] + right + [(400, 900)], L))     # an internal start where only the piles cover
     return reads
 
 
@@ -334,6 +348,31 @@ def test_healthy_screen_edges(cov):
             if flags == yacrd_amd.F_ALWAYS_DEFER:
                 t = e.timing()
                 assert t["prefiltered_reads"] > 0 and t["deferred_reads"] > 0  # both sides of the screen are exercised
+
+
+@pytest.mark.parametrize("prof,cov", [(0, 4), (1, 3), (0, 0), (1, 9)])
+def test_screen_on_jittered_profiles(prof, cov):
+    """dovetail ends spread over a few dozen positions (YACRD_SYNTH_F_JITTER: reflected
+    instead of clamped onto 0 / len) — no exact position holds a pile.  Bit-exact against the oracle in
+    every build, and the screen still finishes >= 90 % of the reads of the two classes in closed form at
+    BASELINE's thresholds (it finished 2 % of them when it needed c + 1 starts on ONE position)."""
+    from yacrd_amd import host
+    R, O = (6000, 300000) if prof == 0 else (3000, 300000)
+    for sflags in (host.SYNTH_F_JITTER, host.SYNTH_F_JITTER | host.synth_f_sigma(8),
+                   host.SYNTH_F_JITTER | host.synth_f_sigma(100)):
+        o, iv, ln = host.synth_csr(prof, R, O, 77 + cov, flags=sflags)
+        want = oracle.run(o, iv, ln.astype(np.uint64), cov, 0.4, n_threads=4)
+        n = np.diff(o.astype(np.int64))
+        in_classes = int(((n > 64) & (n <= 256)).sum())
+        for flags in (yacrd_amd.F_ALWAYS_DEFER, yacrd_amd.F_NO_DEFER,
+                      yacrd_amd.F_ALWAYS_DEFER | yacrd_amd.F_ALWAYS_COMPACT_DEFER,
+                      yacrd_amd.F_ALWAYS_DEFER | yacrd_amd.F_SCREEN_ITEMS_2):
+            with yacrd_amd.Engine(flags=flags | yacrd_amd.F_COUNT_PREFILTERED) as e:
+                assert_same(e.run(o, iv, ln, cov, 0.4), want, "profile %d synth flags %d flags %d" % (prof, sflags, flags))
+                t = e.timing()
+                if flags == yacrd_amd.F_ALWAYS_DEFER and sflags == host.SYNTH_F_JITTER and cov in (3, 4):
+                    assert t["deferred_reads"] <= in_classes // 10, (t["deferred_reads"], in_classes)
+                    assert t["prefiltered_reads"] >= in_classes * 9 // 10
 
 
 def test_compact_deferral_outgrows_its_predicted_grid():

@@ -151,8 +151,15 @@ struct Gen {
         int64_t st, en;
         if (rng.uniform() < 0.6) { // dovetail anchored near one end
             const int64_t ell = 500 + (int64_t)rng.below((uint64_t)std::max<int64_t>(1, (int64_t)(0.8 * span) - 500));
-            const int64_t jit = (int64_t)std::llround(30.0 * rng.normal());
-            if (rng.next() & 1) {
+            // N(0, sigma) around the read's end: clamped onto it below (SURVEY.md §8d as specified: half of
+            // the dovetail ends then sit on exactly 0 / len), or — YACRD_SYNTH_F_JITTER — reflected into
+            // the read, so that the ends are spread over a few dozen positions like the chain ends of a
+            // real overlapper and no exact position holds a pile
+            const unsigned sig = (cfg.flags >> 8) & 0xFFu;
+            int64_t jit = (int64_t)std::llround((sig ? (double)sig : 30.0) * rng.normal());
+            const bool start_side = (rng.next() & 1) != 0;
+            if (cfg.flags & YACRD_SYNTH_F_JITTER) jit = start_side ? std::llabs(jit) : -std::llabs(jit);
+            if (start_side) {
                 st = lo + jit;
                 en = st + ell;
             } else {

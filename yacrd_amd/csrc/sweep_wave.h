@@ -383,34 +383,39 @@ __device__ __forceinline__ u32 *wave_filter_scratch()
     return s_scratch[threadIdx.x >> 6];
 }
 
-// ---- the healthy-read screen of the deferring build (DESIGN.md §3.5; tests/formulation.py::
-// healthy_read_regions is the emulation, fuzzed against the oracle) ----------------------------------
-// Bins: NB = LANES coarse bins of 2^sh positions, one per lane, plus one bin for the read's SMALLEST
-// START position and one for its LARGEST END position — where dovetail overlaps clamp: 0 and `len`
-// for a healthy read (on configs[1] 15 % of a read's starts sit at exactly 0 and 15 % of its ends at
-// exactly len), the edges of the covered window for a read that is only covered in part.  In key
-// order: [starts at pmin][coarse 0 .. NB-1][ends at pmax] (nothing else can lie at those two
-// positions: an end is above its own start, a start below its own end).
-//   * a coarse bin spanned by more than c intervals (depth at its head - its ends > c) is DEEP: every
-//     event in it has a depth above c on both sides and can neither open, close nor bound a bad region;
-//   * of the S0 starts at pmin the j-th has depth j: only the first c + 1 matter; of the E1 ends at
-//     pmax the depth before the j-th is E1 - j: only the last c + 1 matter.
-// A read is HEALTHY when every coarse bin that holds an event is deep and min(S0, c + 1) ==
-// min(E1, c + 1) =: k.  Its events then reduce to k starts at pmin followed by k ends at pmax, and
-// what the sweep (src/stack.rs:61-139 through the event formulation) makes of those is known in
-// closed form: nothing exceeds c when k <= c — the whole read is one bad region — and otherwise the
-// depth is above c exactly between the two positions: the read is bad in front of pmin and behind
-// pmax (the sweep's first closed region and finish_read's last one).  One counting pass (one LDS
-// atomic per key: starts in the low half of a counter, ends in the high half, four copies of every
-// counter by lane & 3 so that a read's hot bins do not serialise the atomics of a row), one packed
-// row scan, no sort.  Every other read — low coverage somewhere inside: the reads yacrd is looking
-// for — is marked in its region-count slot (kDeferredMark) and sorted whole by sweep_deferred_kernel,
-// which scans the two classes' lists for the marks.  (A list appended to with one global atomic per
-// read was the first attempt: at 3 800 deferred reads per 100 000 the same-address atomics, performed
-// at the memory side on this 8-XCD part, took ~7 ns each one after the other and doubled the kernel's
-// duration.)
-// Only for wavefronts whose intervals are all plain (start < end <= len).
-constexpr int kScreenTabWords = 304;
+// ---- the healthy-read screen of the deferring build (DESIGN.md §3.6; tests/formulation.py::
+// window_screen_regions is the emulation, fuzzed against the oracle) -----------------------------------
+// With a = the (c+1)-th smallest start and b = the (c+1)-th largest end of a plain read: if every start
+// beyond the first c + 1 finds more than c intervals open, the reference (src/stack.rs:61-139) assigns
+// first_covered at the first c + 1 starts (heap sizes 0..c, nothing popped yet: :83-89), never opens a
+// gap afterwards, and its tail loop (:93-105) pops down to c open intervals, i.e. ends on the (c+1)-th
+// largest end (or breaks on an end == len, which then is that end as well).  The read is bad in front
+// of a and behind b and nowhere else: the HEALTHY read, 96-97 % of a well-covered data set.
+// a, b and the test come from ONE counting pass, no sort:
+//   * W one-position bins counted from the read's smallest start pmin upwards (starts only, low half
+//     of a counter) and from its largest end pmax downwards (ends only, high half) — the windows the
+//     two order statistics lie in when the dovetail overlaps end within a few dozen positions of each
+//     other (at exactly 0 / len in SURVEY.md §8d's clamped generator, spread by the overlapper's
+//     chain ends in real data);
+//   * NB = LANES coarse bins of 2^sh positions, one per lane, for every other event.
+// Every interval must be at least W long (anything shorter: deferred): then no end lies inside the head
+// window and no start inside the tail window, in event order the read is [head window: F starts]
+// [coarse bins][tail window: G ends], and a coarse-counted start of bin i has at least
+// F + (starts of bins < i) - (ends of bins <= i) intervals open in front of it.  A read is healthy when
+// F >= c + 1, G >= c + 1 and that bound exceeds c in every coarse bin that holds a start.
+// One LDS atomic per event (four copies of every counter by lane & 3 so that piled positions do not
+// serialise the atomics of a row), one packed row scan per table.  Every other read — low coverage
+// somewhere inside: the reads yacrd is looking for — is marked in its region-count slot (kDeferredMark)
+// and sorted by a second launch.  (A list appended to with one global atomic per read was the first
+// attempt: the same-address atomics, performed at the memory side on this 8-XCD part, took ~7 ns each
+// one after the other and doubled the kernel's duration.)
+// Only for wavefronts whose intervals are all plain (start < end <= len) and at least W long.
+#ifndef YK_SCREEN_WINDOW
+#define YK_SCREEN_WINDOW 32
+#endif
+constexpr int kScreenWindow = YK_SCREEN_WINDOW; // W: positions per window (a multiple of 32)
+// per group: W head-window bins + LANES coarse blocks + W tail-window bins, 16 bytes (four copies) each
+constexpr int kScreenTabWords = (64 / 16) * (16 + 2 * kScreenWindow) * 4;
 template <int WPB> // wavefronts per workgroup
 __device__ __forceinline__ u32 *wave_screen_scratch()
 {
@@ -418,43 +423,73 @@ __device__ __forceinline__ u32 *wave_screen_scratch()
     return s_tab[threadIdx.x >> 6];
 }
 
+// whether any lane of this lane's group has its bit set in a wavefront ballot
+template <int LANES>
+__device__ __forceinline__ bool group_any(u64 ballot)
+{
+    if (LANES == 64) return ballot != 0;
+    return ((u32)(ballot >> (lane_id() & (u32)(64 - LANES))) & (u32)((1ull << (LANES & 63)) - 1ull)) != 0u;
+}
+
 struct HealthyRead {
-    u32 kept_starts, pmin, pmax; // k, and the two positions
+    u32 a, b; // the (c+1)-th smallest start, the (c+1)-th largest end
 };
 
 // The screen works on the raw positions (no event keys are made): v[j] = two intervals (x, y) and
 // (z, w) of this lane, real0[j] / real1[j] = whether those slots belong to the read (the others hold
-// copies and count into the pads' bin), pmin / pmax = the group's smallest start / largest end.
-// Only for wavefronts whose intervals are all plain (start < end <= len <= kMaxKeyPos).
+// copies and are not counted), pmin / pmax = the group's smallest start / largest end.
+// The verdict and hr are valid in the group's LAST lane (it owns the inclusive scan totals).
+//
+// Bins.  With dx = position - pmin, span = pmax - pmin, T = span - W and 2^sh >= W, both maps are plain
+// arithmetic (no compare, no select: five instructions and one LDS atomic per event):
+//   start -> min(dx, W) + (dx >> sh)                bins 0..W-1: one position each (the head window);
+//                                                   W + i: the rest of coarse block i of 2^sh positions
+//   end   -> W + (dx >> sh) + max(dx - T, 0)        W + i: block i up to T; above that every position of
+//                                                   the tail window has a bin of its own (the map rises
+//                                                   by at least one per position there)
+// Starts never lie in the tail window and ends never in the head window (every interval is at least W
+// long), so bin W + i holds the coarse-counted starts and ends of block i, and what the bins above
+// W + (T >> sh) hold besides are ends of the tail window that precede the block: counting them there
+// errs on the safe side, and no start lives in those blocks anyway.
+// Counters hold starts in bits 0..9 and ends in bits 10..19 (a read of these classes has <= 256
+// intervals), which leaves the upper bits of the coarse bins' scan for the two window indices.
 template <int LANES, int WPB>
 __device__ __forceinline__ bool healthy_screen(const uint4 (&v)[4], const bool (&real0)[4], const bool (&real1)[4],
                                                u32 len, i32 c, u32 pmin, u32 pmax, HealthyRead &hr)
 {
-    constexpr int NB = LANES, NBIN = LANES + 3, GROUPS = 64 / LANES;
-    constexpr u32 kPadBin = NB, kHeadBin = NB + 1, kTailBin = NB + 2;
-    static_assert(GROUPS * NBIN * 4 <= kScreenTabWords, "scratch");
+    constexpr int NB = LANES, W = kScreenWindow, NBIN = 2 * W + NB, GROUPS = 64 / LANES, PER = W / LANES,
+                  ZPER = NBIN / LANES;
+    constexpr u32 kEnd = 1u << 10, kField = kEnd - 1u;
+    static_assert(W % LANES == 0 && PER >= 1 && W <= 64, "window bins per lane; a window index has six bits");
+    static_assert(NBIN % LANES == 0 && GROUPS * NBIN * 4 <= kScreenTabWords, "scratch");
     const u32 lane = lane_id(), lig = lane & (u32)(LANES - 1), grp = lane / (u32)LANES;
     u32 *tab = wave_screen_scratch<WPB>() + grp * (u32)(NBIN * 4);
     uint4 *bins = reinterpret_cast<uint4 *>(tab);
     char *tb = reinterpret_cast<char *>(tab);
 
-    // smallest shift with (len >> sh) < NB: every position of a plain interval has its bin inside the table
+    // smallest shift with (len >> sh) < NB, but blocks of at least W positions
     const i32 bits = 32 - (i32)__builtin_clz(len | 1u) - ilog2c(NB) + (len != 0 ? 0 : -1);
-    const u32 sh = (u32)max(bits, 0);
+    const u32 sh = (u32)max(bits, ilog2c(W));
+    const u32 span = pmax - pmin, T = span - (u32)W;
 
-    bins[lig] = make_uint4(0u, 0u, 0u, 0u);
-    if (lig < 3u) bins[NB + lig] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+    for (int q = 0; q < ZPER; q++) bins[lig + (u32)(LANES * q)] = make_uint4(0u, 0u, 0u, 0u);
     wave_lds_sync();
 
-    // ---- count.  Byte offset of a position's counter = bin * 16 + (lane & 3) * 4: five instructions
-    // and one LDS atomic per event (shift, shift-add, compare, two selects)
-    const u32 cp = (lig & 3u) * 4u, head_off = kHeadBin * 16u + cp, tail_off = kTailBin * 16u + cp,
-              pad_off = kPadBin * 16u + cp;
+    // ---- count.  Byte offset of a counter = bin * 16 + (lane & 3) * 4 (four copies of every counter, so
+    // that piled positions do not serialise the atomics of a row).  The slots beyond the read are masked
+    // out (counted into a bin of their own their atomics piled up on four addresses).
+    const u32 cp = (lig & 3u) * 4u;
+    u32 one = 1u, one_end = kEnd; // kept in registers (the compiler re-materialises them per atomic otherwise)
+    asm volatile("" : "+v"(one), "+v"(one_end));
     auto count = [&](u32 s, u32 e, bool real) {
-        const u32 os = s == pmin ? head_off : ((s >> sh) << 4) + cp;
-        const u32 oe = e == pmax ? tail_off : ((e >> sh) << 4) + cp;
-        atomicAdd(reinterpret_cast<u32 *>(tb + (real ? os : pad_off)), 1u);
-        atomicAdd(reinterpret_cast<u32 *>(tb + (real ? oe : pad_off)), 0x10000u);
+        const u32 ds = s - pmin, dx = e - pmin;
+        const u32 is = min(ds, (u32)W) + (ds >> sh);
+        const u32 ie = (dx >> sh) + __builtin_elementwise_sub_sat(dx, T) + (u32)W;
+        if (real) {
+            atomicAdd(reinterpret_cast<u32 *>(tb + ((is << 4) + cp)), one);
+            atomicAdd(reinterpret_cast<u32 *>(tb + ((ie << 4) + cp)), one_end);
+        }
     };
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -463,23 +498,46 @@ __device__ __forceinline__ bool healthy_screen(const uint4 (&v)[4], const bool (
     }
     wave_lds_sync();
 
-    const uint4 c4 = bins[lig], h4 = bins[kHeadBin], t4 = bins[kTailBin];
-    const u32 w = c4.x + c4.y + c4.z + c4.w;
-    const i32 E = (i32)(w >> 16);
-    const i32 S0 = (i32)((h4.x + h4.y + h4.z + h4.w) & 0xFFFFu); // starts at the smallest start position
-    const i32 E1 = (i32)((t4.x + t4.y + t4.z + t4.w) >> 16);     // ends at the largest end position
-    const u32 ex = gscan_add<LANES>(w) - w;                       // packed: both halves scanned at once
-    const i32 D = S0 + (i32)(ex & 0xFFFFu) - (i32)(ex >> 16);     // depth at the head of this lane's bin
-    const bool shallow = w != 0u && !(D - E > c);                  // holds events and is not deep
-    const i32 k = min(S0, c + 1);
-    hr.kept_starts = (u32)k;
-    hr.pmin = pmin;
-    hr.pmax = pmax;
-    // the group's verdict, the same in all of its lanes
-    const u64 sb = __builtin_amdgcn_ballot_w64(shallow);
-    const u32 mine = LANES == 64 ? (u32)((sb | (sb >> 32)) != 0)
-                                 : (u32)(sb >> (lane & (u32)(64 - LANES))) & (u32)((1ull << (LANES & 63)) - 1ull);
-    return mine == 0u && k == min(E1, c + 1);
+    // ---- the windows: where the counts of starts (from pmin upwards) and of ends (from pmax downwards)
+    // reach c + 1.  Window position d = lig * PER + q: the start bin d, the end bin of pmax - d.
+    u32 f[PER], fw = 0;
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const u32 d = lig * (u32)PER + q;
+        const u32 it = min((u32)(2 * W) - d + ((span - d) >> sh), (u32)(NBIN - 1)); // (clipped: an irregular group's span is anything)
+        const uint4 h4 = bins[d], t4 = bins[it];
+        f[q] = ((h4.x + h4.y + h4.z + h4.w) & kField) | ((t4.x + t4.y + t4.z + t4.w) & (kField << 10));
+        fw += f[q];
+    }
+    const uint4 c4 = bins[(u32)W + lig];
+    const u32 fincl = gscan_add<LANES>(fw); // last lane: F | G << 10
+    u32 cand = 0;
+    {
+        u32 run = fincl - fw; // counts in front of this lane's bins
+        const u32 k1 = (u32)min(c + 1, 0x3FF);
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            const u32 s0 = run & kField, e0 = run >> 10;
+            run += f[q];
+            const u32 d = lig * (u32)PER + q;
+            cand |= (s0 < k1 && (run & kField) >= k1) ? (d << 20) : 0u; // a - pmin
+            cand |= (e0 < k1 && (run >> 10) >= k1) ? (d << 26) : 0u;     // pmax - b
+        }
+    }
+    // ---- the coarse bins: a block that holds a coarse-counted start must have more than c intervals
+    // open at its head even after all of its ends: F + (starts before it) - (ends up to its last one) > c.
+    // One scan for the counts and the two window indices (each set in one lane only).
+    const u32 w = (c4.x + c4.y + c4.z + c4.w) & ((kField << 10) | kField);
+    const u32 wincl = gscan_add<LANES>(w | cand);
+    const u32 ex = wincl - w;
+    const i32 x = (i32)(ex & kField) - (i32)((wincl >> 10) & kField); // starts before - ends through this block
+    const u32 xm = gscan_min<LANES>((w & kField) != 0u ? (u32)(x + 0x10000) : 0xFFFFFFFFu);
+    // (meaningful in the group's last lane from here on)
+    const i32 F = (i32)(fincl & kField), G = (i32)(fincl >> 10);
+    hr.a = pmin + ((wincl >> 20) & 63u);
+    hr.b = pmax - (wincl >> 26);
+    const bool deep = xm == 0xFFFFFFFFu || (i32)(xm - 0x10000u) + F > c;
+    return deep && F > c && G > c;
 }
 
 // ---- the bin filter without trimming (round 1): used by the builds that do not
@@ -720,31 +778,38 @@ __device__ __forceinline__ void screen_block(const SweepArgs &a, u32 block)
         const int last_addr = (int)((lane | (u32)(LANES - 1)) << 2);
         const u32 pmin = (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)gscan_min<LANES>(smin));
         const u32 pmax = (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)gscan_max<LANES>(emax));
-        u32 irregular = (active[t] && (n[t] < 2u || pmax > len_c)) ? 1u : 0u;
+        // not plain (start >= end, an end beyond the read or the key range), or an interval shorter than
+        // the screen's windows: sweep_deferred_kernel's.  The slots beyond the read hold copies of its
+        // own intervals, so no mask is needed here.
+        u32 irregular = (n[t] < 2u || pmax > len_c) ? 1u : 0u;
+        u32 shortest = 0xFFFFFFFFu;
+#pragma unroll
+        for (int j = 0; j < K / 4; j++) {
+            irregular |= (v[t][j].x >= v[t][j].y || v[t][j].z >= v[t][j].w) ? 1u : 0u;
+            shortest = min(shortest, min(v[t][j].y - v[t][j].x, v[t][j].w - v[t][j].z));
+        }
+        irregular |= (shortest < (u32)kScreenWindow) ? 1u : 0u;
+        // per group: such a read counts nothing (its positions may lie outside the table) and is never healthy
+        const bool girr = group_any<LANES>(__builtin_amdgcn_ballot_w64(irregular != 0));
+        const u32 n_eff = girr ? 0u : n[t];
         bool real0[K / 4], real1[K / 4];
 #pragma unroll
         for (int j = 0; j < K / 4; j++) {
             const u32 i0 = 2u * (lig + (u32)LANES * j);
-            real0[j] = i0 + 1u < n[t]; // .xy is interval i0 only when i0 + 1 exists too
-            real1[j] = i0 < n[t];
-            irregular |= (real0[j] && v[t][j].x >= v[t][j].y) ? 1u : 0u;
-            irregular |= (real1[j] && v[t][j].z >= v[t][j].w) ? 1u : 0u;
-        }
-        if (__builtin_amdgcn_ballot_w64(irregular != 0) != 0) { // (uniform) not plain: sweep_deferred_kernel's
-            if (lig == 0 && active[t]) a.counts[r[t]] = kDeferredMark;
-            continue;
+            real0[j] = i0 + 1u < n_eff; // .xy is interval i0 only when i0 + 1 exists too
+            real1[j] = i0 < n_eff;
         }
         HealthyRead hr;
-        const bool healthy = healthy_screen<LANES, 1>(v[t], real0, real1, len[t], c, n[t] ? pmin : 1u, n[t] ? pmax : 0u, hr);
-        if (lig == 0 && active[t]) {
-            if (healthy) {
+        const bool healthy = healthy_screen<LANES, 1>(v[t], real0, real1, len[t], c, pmin, pmax, hr) && !girr;
+        if (lig == (u32)(LANES - 1) && active[t]) { // the group's last lane has the verdict
+            if (healthy || (!girr && (i32)n[t] <= c)) {
                 uint2 *slot = a.stage + (o[t] + 2 * (u64)r[t]);
                 u32 g = 0;
-                if ((i32)hr.kept_starts <= c) {
+                if ((i32)n[t] <= c) { // never more than c intervals open: the whole read is bad
                     if (len[t] != 0) slot[g++] = make_uint2(0u, len[t]);
                 } else {
-                    if (hr.pmin != 0) slot[g++] = make_uint2(0u, hr.pmin);
-                    if (hr.pmax != len[t]) slot[g++] = make_uint2(hr.pmax, len[t]);
+                    if (hr.a != 0) slot[g++] = make_uint2(0u, hr.a);
+                    if (hr.b != len[t]) slot[g++] = make_uint2(hr.b, len[t]);
                 }
                 a.counts[r[t]] = g;
                 if (a.prefilter == 2) atomicAdd(&a.ctr->prefiltered, 1u);

@@ -9,6 +9,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "lib", "libyacrd_host.so")
 
 SYNTH_ONT, SYNTH_SEQUEL, SYNTH_SKEWED = 0, 1, 2
+# yacrd_synth_cfg.flags (include/yacrd_host.h)
+SYNTH_F_NO_INJECTION, SYNTH_F_JITTER = 1, 2
+
+
+def synth_f_sigma(s):
+    """sigma (positions) of the dovetail ends' offset, 1..255 (default 30)"""
+    return (int(s) & 0xFF) << 8
 FMT_AUTO, FMT_PAF, FMT_M4 = 0, 1, 2
 
 EXPORTED_SYMBOLS = [

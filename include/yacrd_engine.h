@@ -274,7 +274,7 @@ int yacrd_stream_acquire(yacrd_stream *s, yacrd_ovl_rec **buf, uint64_t *capacit
 int yacrd_stream_commit(yacrd_stream *s, yacrd_ovl_rec *buf, uint64_t n_records);
 /* All records are in.  handle_map[n_handles] (or NULL), lengths[n_reads]: builds the CSR in HBM,
  * runs the engine (blocking) and returns the host result like yacrd_engine_run.  The stream is
- * empty again afterwards and can take the next file. */
+ * empty again afterwards — on success AND on every error return — and can take the next file. */
 int yacrd_stream_finish(yacrd_stream *s, const uint32_t *handle_map, uint64_t n_handles,
                         const uint32_t *lengths, uint64_t n_reads, uint32_t coverage,
                         double not_coverage, yacrd_result *out);
@@ -287,6 +287,9 @@ typedef struct {
     float d2h_ms;
 } yacrd_stream_stats;
 int yacrd_stream_last_stats(const yacrd_stream *s, yacrd_stream_stats *st);
+/* Discard every record committed so far (an ingest that failed half way through its file leaves its
+ * records in the stream: call this before the stream takes another file).  No buffer may be held. */
+int yacrd_stream_reset(yacrd_stream *s);
 void yacrd_stream_close(yacrd_stream *s);
 
 /* Copy the last device result to host (allocates like yacrd_engine_run). */

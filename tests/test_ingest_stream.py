@@ -128,6 +128,12 @@ CSV_CASES = [
     "a\t0x64\t+1\t0x32\t+\tb\t+200\t0x2\t60\n",
     # quoted numbers, a \r inside quotes is data
     '"a\rz"\t"100"\t"1"\t50\t"+"\tb\t200\t2\t60\n',
+    #  more than nine columns with CR-only line endings: every \r ends a record
+    "a\t100\t1\t50\t+\tb\t200\t2\t60\t49\t58\t255\rc\t300\t3\t70\t-\td\t400\t4\t80\t1\t2\t255\r",
+    "a\t100\t1\t50\t+\tb\t200\t2\t60\t49\t58\t255\tcm:i:5\rc\t300\t3\t70\t-\td\t400\t4\t80\n"
+    "e\t10\t1\t5\t+\tf\t20\t2\t6\ttp:A:S\r\re\t10\t2\t6\t-\tf\t20\t3\t7\t1\r\n",
+    # a quoted trailing column swallows a tab and a \r; a quote inside an unquoted trailing column is data
+    'a\t100\t1\t50\t+\tb\t200\t2\t60\t"x\ty\rz"\t7\nc\t5\t0\t1\t+\ta\t100\t5\t6\tk"q\n',
 ]
 
 
@@ -157,6 +163,9 @@ def test_csv_known_answers():
     "a\t100\t0x1g\t50\t+\tb\t200\t2\t60\n",
     "a\t100\t1\t0x100000000\t+\tb\t200\t2\t60\n",                         # u32 overflow in hex
     "1 2 0x1p3 2 0 20 4500 12000 0 5500 10000 10000\n",                   # hex float: not Rust's f64
+    "r\r2\t100\t1\t50\t+\tb\t200\t2\t60\t1\t2\t255\n",                 # a \r inside an id: a short record
+    "a\t100\t1\t50\t+\tb\t200\t2\t60\ttp:A:S\rjunk\n",                   # ... inside a tag column: ditto
+    'a\t100\t1\t50\t+\tb\t200\t2\t60\t"open\n',                          # a trailing quote that never closes
 ])
 def test_csv_rejections(bad):
     fmt = host.FMT_M4 if bad.startswith("1 2") else host.FMT_PAF

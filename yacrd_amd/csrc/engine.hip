@@ -1164,6 +1164,7 @@ int yacrd_engine_run_device(yacrd_engine *e, const void *d_offsets, const void *
     if (!e) return fail(YACRD_EINVAL, "engine is null");
     if (n_reads && (!d_offsets || !d_lengths)) return fail(YACRD_EINVAL, "null device input");
     if (n_intervals && !d_intervals) return fail(YACRD_EINVAL, "null device intervals");
+    if (e->host_pending) return fail(YACRD_EINVAL, "a submitted batch is pending: collect it first");
     DeviceGuard guard(e->device);
     int rc = run_on_device(e, (const u64 *)d_offsets, (const uint2 *)d_intervals,
                            (const u32 *)d_lengths, n_reads, n_intervals, coverage, not_coverage);
@@ -1185,6 +1186,7 @@ int yacrd_engine_submit_device(yacrd_engine *e, const void *d_offsets, const voi
     if (!e) return fail(YACRD_EINVAL, "engine is null");
     if (n_reads && (!d_offsets || !d_lengths)) return fail(YACRD_EINVAL, "null device input");
     if (n_intervals && !d_intervals) return fail(YACRD_EINVAL, "null device intervals");
+    if (e->host_pending) return fail(YACRD_EINVAL, "a submitted batch is pending: collect it first");
     DeviceGuard guard(e->device);
     return run_on_device(e, (const u64 *)d_offsets, (const uint2 *)d_intervals,
                          (const u32 *)d_lengths, n_reads, n_intervals, coverage, not_coverage, true);
@@ -1283,6 +1285,9 @@ int yacrd_engine_run(yacrd_engine *e, const uint64_t *offsets, const uint32_t *i
     if (!out) return fail(YACRD_EINVAL, "out is null");
     std::memset(out, 0, sizeof(*out));
     if (e->pending.active) return fail(YACRD_EINVAL, "a submitted batch is pending: yacrd_engine_wait first");
+    // (a submit that completed synchronously leaves pending.active false: the result buffers still
+    // belong to that batch until it is collected)
+    if (e->host_pending) return fail(YACRD_EINVAL, "a submitted batch is pending: collect it first");
     DeviceGuard guard(e->device);
     uint64_t n_iv = 0;
     int rc = stage_host_inputs(e, offsets, intervals, lengths, n_reads, &n_iv);

@@ -553,7 +553,10 @@ inline bool scan_id(const char *&p, const char *le, const char *&b, size_t &n)
     b = p;
     if (p < le && *p == '"') return false; // quoted field: the general parser's business
     const char *t = p;
-    while (t < le && *t != '\t') t++; // ids are short: a byte loop beats a memchr call
+    while (t < le && *t != '\t') { // ids are short: a byte loop beats a memchr call
+        if (*t == '\r') return false; // a lone \r ends a csv record: the general parser's business
+        t++;
+    }
     if (t == le) return false; // an id must be followed by more fields
     n = (size_t)(t - p);
     p = t + 1;
@@ -566,7 +569,7 @@ inline bool parse_paf_fast(const char *p, const char *le, Fields &f)
     if (!(scan_id(q, le, f.ida, f.na) && scan_uint(q, le, ~0ull, f.la, false) &&
           scan_uint(q, le, 0xFFFFFFFFull, sa, false) && scan_uint(q, le, 0xFFFFFFFFull, ea, false)))
         return false;
-    if (le - q >= 2 && (unsigned char)q[0] < 0x80 && q[0] != '"' && q[0] != '\t' && q[1] == '\t') {
+    if (le - q >= 2 && (unsigned char)q[0] < 0x80 && q[0] != '"' && q[0] != '\t' && q[0] != '\r' && q[1] == '\t') {
         q += 2; // strand: one ASCII character and a tab, the usual case
     } else { // exactly one UTF-8 scalar, then a tab
         const char *t = (const char *)std::memchr(q, '\t', (size_t)(le - q));
@@ -576,6 +579,24 @@ inline bool parse_paf_fast(const char *p, const char *le, Fields &f)
     if (!(scan_id(q, le, f.idb, f.nb) && scan_uint(q, le, ~0ull, f.lb, false) &&
           scan_uint(q, le, 0xFFFFFFFFull, sb, false) && scan_uint(q, le, 0xFFFFFFFFull, eb, true)))
         return false;
+    // The columns after the ninth are ignored, but not their syntax: a lone \r in them ends the csv
+    // record (what follows is another record), and a field that opens with a quote follows the quoting
+    // rules (it may swallow delimiters and the \r).  Eight bytes at a time: any \r or '"' sends the line
+    // to the general parser.
+    {
+        const uint64_t k01 = 0x0101010101010101ull, k80 = 0x8080808080808080ull;
+        auto has = [&](uint64_t w, unsigned char c) {
+            const uint64_t x = w ^ (k01 * c);
+            return ((x - k01) & ~x & k80) != 0;
+        };
+        const char *t = q;
+        for (; t + 8 <= le; t += 8) {
+            const uint64_t w = load64(t);
+            if (has(w, '\r') || has(w, '"')) return false;
+        }
+        for (; t < le; t++)
+            if (*t == '\r' || *t == '"') return false;
+    }
     f.sa = (uint32_t)sa;
     f.ea = (uint32_t)ea;
     f.sb = (uint32_t)sb;

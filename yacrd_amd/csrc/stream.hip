@@ -223,6 +223,29 @@ int yacrd_stream_commit(yacrd_stream *s, yacrd_ovl_rec *buf, uint64_t n)
     return YACRD_OK;
 }
 
+// forget every record the stream holds (s->mu held by the caller)
+static void stream_reset_locked(yacrd_stream *s)
+{
+    for (auto &sl : s->slabs) sl.used = 0;
+    s->cur_slab = 0;
+    s->n_records = 0;
+    s->busy_ms = 0;
+}
+
+int yacrd_stream_reset(yacrd_stream *s)
+{
+    if (!s) return fail(YACRD_EINVAL, "null argument");
+    DeviceGuard guard(s->e->device);
+    std::lock_guard<std::mutex> g(s->mu);
+    for (uint32_t b = 0; b < s->n_buffers; b++)
+        if (s->state[b] == BUF_HELD) return fail(YACRD_EINVAL, "a buffer is still held by a parser");
+    HIP_TRY(hipStreamSynchronize(s->copy)); // copies in flight land in slabs that are about to be reused
+    for (uint32_t b = 0; b < s->n_buffers; b++)
+        if (s->state[b] == BUF_FLYING) retire(s, b);
+    stream_reset_locked(s);
+    return YACRD_OK;
+}
+
 int yacrd_stream_finish(yacrd_stream *s, const uint32_t *handle_map, uint64_t n_handles,
                         const uint32_t *lengths, uint64_t n_reads, uint32_t coverage,
                         double not_coverage, yacrd_result *out)
@@ -246,16 +269,13 @@ int yacrd_stream_finish(yacrd_stream *s, const uint32_t *handle_map, uint64_t n_
     s->stats.h2d_bytes = n * sizeof(yacrd_ovl_rec);
     s->stats.h2d_busy_ms = (float)s->busy_ms;
 
-    auto reset = [&]() {
-        for (auto &sl : s->slabs) sl.used = 0;
-        s->cur_slab = 0;
-        s->n_records = 0;
-        s->busy_ms = 0;
-    };
-    if (n && n_reads == 0) {
-        reset();
-        return fail(YACRD_EINVAL, "records without reads");
-    }
+    // Whatever happens below, the stream is empty afterwards: records of a failed finish must not mix
+    // with the next file's (their handles come from another id table).
+    struct ResetOnExit {
+        yacrd_stream *s;
+        ~ResetOnExit() { stream_reset_locked(s); }
+    } reset_on_exit{s};
+    if (n && n_reads == 0) return fail(YACRD_EINVAL, "records without reads");
 
     const u64 nb = (n_reads + yk::kScanTile - 1) / yk::kScanTile;
     HIP_TRY(e->in_off.reserve((size_t)(n_reads + 1) * sizeof(u64)));
@@ -273,10 +293,7 @@ int yacrd_stream_finish(yacrd_stream *s, const uint32_t *handle_map, uint64_t n_
     int rc = YACRD_OK;
     if (d_map) rc = h2d(e, s->map.p, handle_map, (size_t)n_handles * sizeof(u32));
     if (!rc && n_reads) rc = h2d(e, e->in_len.p, lengths, (size_t)n_reads * sizeof(u32));
-    if (rc) {
-        reset();
-        return rc;
-    }
+    if (rc) return rc;
     HIP_TRY(hipMemsetAsync(s->cnt.p, 0, (size_t)(n_reads + 4) * sizeof(u32), e->stream));
     HIP_TRY(hipMemsetAsync(s->err.p, 0, 64, e->stream));
     const u32 R32 = (u32)n_reads;
@@ -309,7 +326,6 @@ int yacrd_stream_finish(yacrd_stream *s, const uint32_t *handle_map, uint64_t n_
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipGetLastError());
     s->stats.build_ms = ev_ms(s->evb0, s->evb1);
-    reset();
     if (h_err) return fail(YACRD_EINVAL, "a record names a read outside handle_map / n_reads");
 
     const double t0 = now_ms();

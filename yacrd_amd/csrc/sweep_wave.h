@@ -511,19 +511,21 @@ __device__ __forceinline__ bool healthy_screen(const uint4 (&v)[4], const bool (
     }
     const uint4 c4 = bins[(u32)W + lig];
     const u32 fincl = gscan_add<LANES>(fw); // last lane: F | G << 10
-    u32 cand = 0;
+    // a - pmin = the number of window positions whose running count of starts is still below c + 1 (the
+    // counts only grow), pmax - b likewise for the ends: both fields at once — adding 512 - (c + 1) to a
+    // field (counts <= 256) sets its bit 9 exactly when the count has reached c + 1.
+    u32 reached = 0;
     {
-        u32 run = fincl - fw; // counts in front of this lane's bins
-        const u32 k1 = (u32)min(c + 1, 0x3FF);
+        const u32 k1 = (u32)min(c + 1, 0x1FF);
+        u32 run = fincl - fw + (512u - k1) * (1u | kEnd); // counts in front of this lane's bins, biased
 #pragma unroll
         for (int q = 0; q < PER; q++) {
-            const u32 s0 = run & kField, e0 = run >> 10;
             run += f[q];
-            const u32 d = lig * (u32)PER + q;
-            cand |= (s0 < k1 && (run & kField) >= k1) ? (d << 20) : 0u; // a - pmin
-            cand |= (e0 < k1 && (run >> 10) >= k1) ? (d << 26) : 0u;     // pmax - b
+            reached += run & (0x200u | (0x200u << 10));
         }
     }
+    // bins that have NOT reached it, in the upper bits of the coarse scan: starts at bit 20, ends at bit 26
+    const u32 cand = (((u32)PER - ((reached >> 9) & 7u)) << 20) | (((u32)PER - (reached >> 19)) << 26);
     // ---- the coarse bins: a block that holds a coarse-counted start must have more than c intervals
     // open at its head even after all of its ends: F + (starts before it) - (ends up to its last one) > c.
     // One scan for the counts and the two window indices (each set in one lane only).
@@ -534,8 +536,8 @@ __device__ __forceinline__ bool healthy_screen(const uint4 (&v)[4], const bool (
     const u32 xm = gscan_min<LANES>((w & kField) != 0u ? (u32)(x + 0x10000) : 0xFFFFFFFFu);
     // (meaningful in the group's last lane from here on)
     const i32 F = (i32)(fincl & kField), G = (i32)(fincl >> 10);
-    hr.a = pmin + ((wincl >> 20) & 63u);
-    hr.b = pmax - (wincl >> 26);
+    hr.a = pmin + ((wincl >> 20) & 63u); // (a window that never reaches c + 1 overflows these fields: F > c
+    hr.b = pmax - (wincl >> 26);         // or G > c fails then)
     const bool deep = xm == 0xFFFFFFFFu || (i32)(xm - 0x10000u) + F > c;
     return deep && F > c && G > c;
 }
@@ -769,28 +771,26 @@ __device__ __forceinline__ void screen_block(const SweepArgs &a, u32 block)
         // The read's smallest start and largest end, from the raw positions of every slot: a slot beyond
         // the read's last interval holds a copy of one of its intervals (the clamped load), so it cannot
         // change either.  An end beyond the read (or beyond the key range) shows in the largest one.
-        u32 smin = v[t][0].x, emax = v[t][0].y;
+        // Also, for the test below: the largest start and the smallest (end - start) as a signed number.
+        u32 smin = v[t][0].x, emax = v[t][0].y, smax = v[t][0].x;
+        i32 tmin = 0x7FFFFFFF;
 #pragma unroll
         for (int j = 0; j < K / 4; j++) {
             smin = min(smin, min(v[t][j].x, v[t][j].z));
+            smax = max(smax, max(v[t][j].x, v[t][j].z));
             emax = max(emax, max(v[t][j].y, v[t][j].w));
+            tmin = min(tmin, min((i32)(v[t][j].y - v[t][j].x), (i32)(v[t][j].w - v[t][j].z)));
         }
         const int last_addr = (int)((lane | (u32)(LANES - 1)) << 2);
         const u32 pmin = (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)gscan_min<LANES>(smin));
         const u32 pmax = (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)gscan_max<LANES>(emax));
         // not plain (start >= end, an end beyond the read or the key range), or an interval shorter than
-        // the screen's windows: sweep_deferred_kernel's.  The slots beyond the read hold copies of its
-        // own intervals, so no mask is needed here.
-        u32 irregular = (n[t] < 2u || pmax > len_c) ? 1u : 0u;
-        u32 shortest = 0xFFFFFFFFu;
-#pragma unroll
-        for (int j = 0; j < K / 4; j++) {
-            irregular |= (v[t][j].x >= v[t][j].y || v[t][j].z >= v[t][j].w) ? 1u : 0u;
-            shortest = min(shortest, min(v[t][j].y - v[t][j].x, v[t][j].w - v[t][j].z));
-        }
-        irregular |= (shortest < (u32)kScreenWindow) ? 1u : 0u;
+        // the screen's windows: left to the sort.  With every position <= kMaxKeyPos < 2^30, end - start
+        // as a signed number is below W exactly for those intervals.  The slots beyond the read hold
+        // copies of its own intervals, so no mask is needed here.
+        const bool irregular = n[t] < 2u || pmax > len_c || smax > kMaxKeyPos || tmin < (i32)kScreenWindow;
         // per group: such a read counts nothing (its positions may lie outside the table) and is never healthy
-        const bool girr = group_any<LANES>(__builtin_amdgcn_ballot_w64(irregular != 0));
+        const bool girr = group_any<LANES>(__builtin_amdgcn_ballot_w64(irregular));
         const u32 n_eff = girr ? 0u : n[t];
         bool real0[K / 4], real1[K / 4];
 #pragma unroll

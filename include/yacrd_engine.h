@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define YACRD_ABI_VERSION 2
+#define YACRD_ABI_VERSION 3
 
 /* src/editor/mod.rs:42-59 ReadType; numeric encoding is ours, names are the reference's. */
 enum { YACRD_NOT_BAD = 0, YACRD_CHIMERIC = 1, YACRD_NOT_COVERED = 2 };
@@ -56,28 +56,9 @@ typedef struct {
 } yacrd_engine_cfg;
 
 #define YACRD_F_DEFAULT 0u
-/* route every read through the fully general (arbitrary-input) kernel; testing only */
-#define YACRD_F_FORCE_GENERAL 1u
-/* use the LDS-sort kernel for the small class instead of the register-sort kernel; A/B only */
-#define YACRD_F_FORCE_LDS_SORT 2u
-/* cross-lane exchanges of the register sort all through the LDS crossbar (ds_swizzle); A/B only */
-#define YACRD_F_XLANE_DS 4u
-/* no four-reads-per-wavefront row layout: every small read gets a whole wavefront; A/B only */
-#define YACRD_F_WAVE_ONLY 8u
-/* no two-reads-per-wavefront layout for reads of 129..256 intervals; A/B only */
-#define YACRD_F_NO_HALVES 16u
 /* record HIP events around every phase and every class kernel (costs ~3 us of stream time per
  * event); by default only the dominant class kernel is timed */
 #define YACRD_F_TIMING_FULL 32u
-/* always wait for the plan's class counts (no prediction from the previous run); A/B only */
-#define YACRD_F_NO_PREDICTION 64u
-/* one launch per register-sort class instead of the fused launch; A/B only */
-#define YACRD_F_NO_FUSED_LAUNCH 128u
-/* sort every event: skip the coverage pre-filter (register-sort and LDS classes; A/B, tests) */
-#define YACRD_F_NO_PREFILTER 256u
-/* count the reads the pre-filter thinned (yacrd_timing.prefiltered_reads); one global atomic per
- * read, so only for tests */
-#define YACRD_F_COUNT_PREFILTERED 512u
 /* record no HIP events at all (yacrd_timing stays 0): what a caller that only wants results uses */
 #define YACRD_F_NO_TIMING 1024u
 /* the run's final wait polls an event and sleeps in between instead of spinning in
@@ -85,26 +66,13 @@ typedef struct {
  * Engines created on the same device pipeline their batches (yacrd_engine_submit / _collect from
  * one host thread, or one host thread each). */
 #define YACRD_F_BLOCKING_WAIT 2048u
-/* the register-sort classes never defer the reads their filter cannot thin to a launch of their own
- * (by default they do when the fused launch holds >= 4 M intervals); 8192: always defer; A/B only */
-#define YACRD_F_NO_DEFER 4096u
-#define YACRD_F_ALWAYS_DEFER 8192u
-/* engines that share a device take turns with the dominant sweep launch (a GPU-side event wait:
- * the launch's start / stop events then time that kernel alone); A/B only */
-#define YACRD_F_SWEEP_TURNS 16384u
-/* large launches never compact their deferred reads into lists for the classes' own register sort
- * (every deferred read is sorted whole by sweep_deferred_kernel, as in small launches); A/B only */
-#define YACRD_F_NO_COMPACT_DEFER 65536u
-#define YACRD_F_ALWAYS_COMPACT_DEFER 131072u /* ... and always does (with the deferring build); tests, A/B */
-/* the screen of the deferring build takes one / two groups of list entries per wavefront whatever the
- * launch's size (default: two from 40 M intervals on, i.e. inputs outside the Infinity Cache); tests, A/B */
-#define YACRD_F_SCREEN_ITEMS_1 262144u
-#define YACRD_F_SCREEN_ITEMS_2 524288u
 /* the dominant kernel carries its start / stop events on every 8th run of the engine only (counted
  * from its creation or the last yacrd_engine_timing_total(reset), whose next run is a timed one): attached
  * events cost ~10 us per batch (host + stream) against a 20 us kernel; yacrd_timing.timed_runs says how
  * many runs were timed */
 #define YACRD_F_TIMING_SAMPLED 32768u
+/* (the A/B and test switches that pin a kernel family or a build live in yacrd_engine_debug.h; the
+ * product path is flags = 0) */
 
 /* Host-side result, allocated by the engine, released with yacrd_result_free(). */
 typedef struct {
@@ -151,11 +119,13 @@ typedef struct {
     /* reads whose events were thinned by the coverage pre-filter before the sort (counted only
      * under YACRD_F_COUNT_PREFILTERED) */
     uint64_t prefiltered_reads;
-    /* reads the fused kernel's filter could not thin and handed to sweep_deferred_kernel (they are
-     * part of fused_reads / fused_intervals: the fused kernel loads and bins them), and that launch's
-     * own time (start / stop events attached to it, like fused_ms) */
+    /* reads (and their intervals) the fused kernel's screen could not finish and left to the follow-on
+     * kernel's sort (they are part of fused_reads / fused_intervals: the screen loads and bins them);
+     * screened: 1 when the run's fused launch was the screening build (the count of such runs in
+     * yacrd_engine_timing_total) */
     uint64_t deferred_reads;
-    float deferred_ms;
+    uint64_t deferred_intervals;
+    uint32_t screened;
     /* runs in which the dominant kernel carried its start / stop events: 1 or 0 for one run, the count
      * in yacrd_engine_timing_total (fused_ms / class_ms are sums over these runs: with
      * YACRD_F_TIMING_SAMPLED not every run is one) */

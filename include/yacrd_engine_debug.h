@@ -1,0 +1,44 @@
+/*
+ * yacrd_engine_debug.h — A/B and test switches for yacrd_engine_cfg.flags.  Not part of the drop-in
+ * boundary (include/yacrd_engine.h): they pin one kernel family or one build of a launch so that the
+ * tests can run every path against the oracle and tools/ can measure one against the other.  The product
+ * path is flags = 0 (plus the timing flags of yacrd_engine.h).
+ */
+#ifndef YACRD_ENGINE_DEBUG_H
+#define YACRD_ENGINE_DEBUG_H
+
+#include "yacrd_engine.h"
+
+/* route every read through the fully general (arbitrary-input) kernel; testing only */
+#define YACRD_F_FORCE_GENERAL 1u
+/* use the LDS-sort kernel for the small class instead of the register-sort kernel; A/B only */
+#define YACRD_F_FORCE_LDS_SORT 2u
+/* cross-lane exchanges of the register sort all through the LDS crossbar (ds_swizzle); A/B only */
+#define YACRD_F_XLANE_DS 4u
+/* no four-reads-per-wavefront row layout: every small read gets a whole wavefront; A/B only */
+#define YACRD_F_WAVE_ONLY 8u
+/* no two-reads-per-wavefront layout for reads of 129..256 intervals; A/B only */
+#define YACRD_F_NO_HALVES 16u
+/* always wait for the plan's class counts (no prediction from the previous run); A/B only */
+#define YACRD_F_NO_PREDICTION 64u
+/* one launch per register-sort class instead of the fused launch; A/B only */
+#define YACRD_F_NO_FUSED_LAUNCH 128u
+/* sort every event: skip the coverage pre-filter (register-sort and LDS classes; A/B, tests) */
+#define YACRD_F_NO_PREFILTER 256u
+/* count the reads the pre-filter thinned (yacrd_timing.prefiltered_reads); one global atomic per
+ * read, so only for tests */
+#define YACRD_F_COUNT_PREFILTERED 512u
+/* the fused launch of the register-sort classes never runs the healthy-read screen (by default it does
+ * from 4 M intervals in the classes R16 + H16 on, unless the previous batches failed the screen too
+ * often); 8192: it always does; A/B, tests */
+#define YACRD_F_NO_DEFER 4096u
+#define YACRD_F_ALWAYS_DEFER 8192u
+/* engines that share a device take turns with the dominant sweep launch (a GPU-side event wait:
+ * the launch's start / stop events then time that kernel alone); A/B only */
+#define YACRD_F_SWEEP_TURNS 16384u
+/* the screen takes one / two groups of list entries per wavefront whatever the
+ * launch's size (default: two from 40 M intervals on, i.e. inputs outside the Infinity Cache); tests, A/B */
+#define YACRD_F_SCREEN_ITEMS_1 262144u
+#define YACRD_F_SCREEN_ITEMS_2 524288u
+
+#endif

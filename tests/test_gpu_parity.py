@@ -264,7 +264,6 @@ def test_read_partitioned_multi_engine(engine):
 
 
 @pytest.mark.parametrize("flags", [0, yacrd_amd.F_ALWAYS_DEFER,
-                                   yacrd_amd.F_ALWAYS_DEFER | yacrd_amd.F_ALWAYS_COMPACT_DEFER,
                                    yacrd_amd.F_ALWAYS_DEFER | yacrd_amd.F_SCREEN_ITEMS_2])
 def test_class_prediction_is_validated(flags):
     """Runs of identical shape (reads, intervals) reuse the previous run's class set instead of
@@ -341,7 +340,6 @@ def test_healthy_screen_edges(cov):
     lengths = np.array([L for _, L in reads], dtype=np.uint32)
     want = oracle.run(offsets, intervals, lengths.astype(np.uint64), cov, 0.4, n_threads=4)
     for flags in (yacrd_amd.F_ALWAYS_DEFER, yacrd_amd.F_NO_DEFER, yacrd_amd.F_NO_PREFILTER,
-                  yacrd_amd.F_ALWAYS_DEFER | yacrd_amd.F_ALWAYS_COMPACT_DEFER,
                   yacrd_amd.F_ALWAYS_DEFER | yacrd_amd.F_SCREEN_ITEMS_2):
         with yacrd_amd.Engine(flags=flags | yacrd_amd.F_COUNT_PREFILTERED) as e:
             assert_same(e.run(offsets, intervals, lengths, cov, 0.4), want, "cov %d flags %d" % (cov, flags))
@@ -365,7 +363,6 @@ def test_screen_on_jittered_profiles(prof, cov):
         n = np.diff(o.astype(np.int64))
         in_classes = int(((n > 64) & (n <= 256)).sum())
         for flags in (yacrd_amd.F_ALWAYS_DEFER, yacrd_amd.F_NO_DEFER,
-                      yacrd_amd.F_ALWAYS_DEFER | yacrd_amd.F_ALWAYS_COMPACT_DEFER,
                       yacrd_amd.F_ALWAYS_DEFER | yacrd_amd.F_SCREEN_ITEMS_2):
             with yacrd_amd.Engine(flags=flags | yacrd_amd.F_COUNT_PREFILTERED) as e:
                 assert_same(e.run(o, iv, ln, cov, 0.4), want, "profile %d synth flags %d flags %d" % (prof, sflags, flags))
@@ -375,12 +372,11 @@ def test_screen_on_jittered_profiles(prof, cov):
                     assert t["prefiltered_reads"] >= in_classes * 9 // 10
 
 
-def test_compact_deferral_outgrows_its_predicted_grid():
-    """Deferred reads through compact lists (YACRD_F_ALWAYS_COMPACT_DEFER): the class launch over the
-    lists is sized from the previous batch of the same shape; a batch that defers many more reads than
-    its predecessor must still come out bit-exact — through run() (validated after the sync: what is
-    still marked is sorted whole, compaction redone) and through submit / wait (the batch runs again
-    unpredicted)."""
+def test_deferral_rate_swings_between_batches():
+    """The follow-on kernel sorts what the screen marked, slab by slab (finish_compact.h): batches of one
+    shape whose share of marked reads swings between none and nearly all (far more than a wavefront's
+    worth per 1024-read slab, so every wavefront loops over several items) must come out bit-exact —
+    through run() and through submit / wait — and the count of deferred reads is exact."""
     import torch
     R, n, L = 3000, 100, 5000
     healthy = [(0, L)] * n
@@ -392,11 +388,13 @@ def test_compact_deferral_outgrows_its_predicted_grid():
         return off, iv, np.full(R, L, dtype=np.uint32)
     batches = [batch(0), batch(0), batch(2000), batch(2000), batch(10), batch(2900)]
     wants = [oracle.run(b[0], b[1], b[2].astype(np.uint64), 4, 0.4, n_threads=4) for b in batches]
-    flags = yacrd_amd.F_ALWAYS_DEFER | yacrd_amd.F_ALWAYS_COMPACT_DEFER
+    flags = yacrd_amd.F_ALWAYS_DEFER
     with yacrd_amd.Engine(flags=flags) as e:
         for i, b in enumerate(batches):
             assert_same(e.run(*b, 4, 0.4), wants[i], "run %d" % i)
-            assert e.timing()["deferred_reads"] == [0, 0, 2000, 2000, 10, 2900][i]
+            t = e.timing()
+            assert t["deferred_reads"] == [0, 0, 2000, 2000, 10, 2900][i]
+            assert t["deferred_intervals"] == t["deferred_reads"] * n and t["screened"] == 1
     dev = torch.device("cuda", 0)
     keep, dev_batches = [], []
     for o, iv, ln in batches:
@@ -566,12 +564,11 @@ def test_fused_defer_build(cov):
     for prof, R, O in ((host.SYNTH_ONT, 6000, 300000), (host.SYNTH_SEQUEL, 3000, 300000)):
         o, iv, ln = host.synth_csr(prof, R, O, 5 + cov)
         w2 = oracle.run(o, iv, ln.astype(np.uint64), cov, 0.4, n_threads=4)
-        compact = yacrd_amd.F_ALWAYS_DEFER | yacrd_amd.F_ALWAYS_COMPACT_DEFER  # deferred reads through compact lists
         two = yacrd_amd.F_ALWAYS_DEFER | yacrd_amd.F_SCREEN_ITEMS_2           # two groups of list entries per wavefront
-        for flags in (yacrd_amd.F_ALWAYS_DEFER, yacrd_amd.F_NO_DEFER, compact, two):
+        for flags in (yacrd_amd.F_ALWAYS_DEFER, yacrd_amd.F_NO_DEFER, two):
             with yacrd_amd.Engine(flags=flags | yacrd_amd.F_COUNT_PREFILTERED) as e:
                 assert_same(e.run(o, iv, ln, cov, 0.4), w2, "profile %d flags %d" % (prof, flags))
-                if flags in (compact, two):  # a second, predicted run: the compact lists' lengths come from the first
+                if flags == two:  # and a second, predicted run
                     assert_same(e.run(o, iv, ln, cov, 0.4), w2, "profile %d flags %d, predicted" % (prof, flags))
                     continue
                 t = e.timing()
@@ -583,7 +580,7 @@ def test_fused_defer_build(cov):
                     assert 0 < t["deferred_reads"] and 0 <= both - int(((n > 64) & (n <= 256)).sum()) <= int((n > 256).sum())
                 else:
                     assert t["deferred_reads"] == 0
-    for flags in (yacrd_amd.F_ALWAYS_DEFER, yacrd_amd.F_NO_DEFER, compact, two):
+    for flags in (yacrd_amd.F_ALWAYS_DEFER, yacrd_amd.F_NO_DEFER, two):
         with yacrd_amd.Engine(flags=flags) as e:
             assert_same(e.run(*csr, cov, 0.4), want, "cases flags %d" % flags)
             assert_same(e.run(*csr, cov, 0.4), want, "cases flags %d, predicted run" % flags)

@@ -61,16 +61,13 @@ struct Counters {
     u32 prefiltered;         // reads that took the pre-filtered sort (only counted when asked)
     u32 over_med;            // M2 reads whose filtered keys do not fit the 256-thread kernel's LDS
     u64 total_regions;       // G, written by the last scan workgroup
-    // reads finished by sweep_deferred_kernel, counted by the compaction (one atomic per workgroup of
-    // 1024 reads).  Counting where they are found or finished does not work on this 8-XCD part:
+    // reads the screen deferred and finish_compact_kernel sorted, and their intervals: one atomic each per
+    // workgroup of 1024 reads.  (Counting where they are found does not work on this 8-XCD part:
     // same-address atomics are performed at the memory side one after the other, ~8 ns each — 1 500 of
-    // them (one per workgroup of the deferred launch) held a 10 us kernel for 22 us, 3 300 returning
-    // ones (a list appended to by the fused launch) a 20 us kernel for 45 us; and on the cache line of
-    // n[], which every wavefront of a sweep reads when it starts, they stall those loads as well.
+    // them held a 10 us kernel for 22 us, 3 300 returning ones a 20 us kernel for 45 us; and on the cache
+    // line of n[], which every wavefront of a sweep reads when it starts, they stall those loads as well.)
     alignas(128) u32 deferred;
-    // lengths of the compact lists of deferred reads (mark_compact_kernel: R16, H16), again on a line
-    // of their own
-    alignas(128) u32 deferred_n[2];
+    u64 deferred_iv;
 };
 
 struct SweepArgs {
@@ -89,10 +86,7 @@ struct SweepArgs {
     u32 *over_list;      // sweep_lds_kernel: reads with more events than its LDS holds even after the
     u32 *over_count;     // pre-filter: append here (the 1024-thread kernel takes them)
     Counters *ctr;
-    u32 count_tag;       // OR-ed into the region count a register sweep stores: kDeferredTag in the launch
-                         // that finishes the deferred reads (the compaction strips and counts it)
 };
-constexpr u32 kDeferredTag = 0x80000000u;
 constexpr u32 kDeferredMark = 0xFFFFFFFFu; // in counts[r]: "deferred", not a region count (<= intervals + 2)
 
 __device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }

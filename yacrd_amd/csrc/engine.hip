@@ -28,12 +28,23 @@
 #include "sweep_general.h"
 #include "sweep_lds.h"
 #include "sweep_wave.h"
+#include "finish_compact.h"
 
 using namespace yke;
 
-// reads in the classes R16 + H16 from which the deferred reads go through compact lists and the
-// classes' own register sort instead of sweep_deferred_kernel
-static constexpr uint64_t kCompactMinReads = 400000;
+// The deferring build of the fused launch (healthy-read screen) is used from this many intervals in the
+// classes R16 + H16 on (YACRD_DEFER_MIN_IV overrides, for A/B), unless the previous batches deferred more
+// than a quarter of what they screened: then the sorting build runs for kProbeEvery - 1 batches before the
+// screen is tried again.
+static uint64_t defer_min_intervals()
+{
+    static const uint64_t v = [] {
+        const char *e = std::getenv("YACRD_DEFER_MIN_IV");
+        return e ? std::strtoull(e, nullptr, 10) : 4000000ull;
+    }();
+    return v;
+}
+static constexpr uint32_t kProbeEvery = 16;
 
 namespace yke {
 std::string &err_slot()
@@ -45,18 +56,33 @@ std::string &err_slot()
 
 namespace {
 
-// scan + compact + classify: one kernel (decoupled look-back), then the totals come home.
-int launch_compact(yacrd_engine *e, const u64 *d_off, const u32 *d_len, u32 n_reads, double not_cov)
+// finish the deferred reads + scan + compact + classify: one kernel (finish_compact.h), then the totals
+// come home.  `sa` carries the run's inputs, stage / counts and the small classes' rejection list.
+int launch_compact(yacrd_engine *e, const yk::SweepArgs &sa, u32 n_reads, double not_cov)
 {
     const u32 nb = (n_reads + yk::kScanBlock - 1) / yk::kScanBlock;
     yk::Counters *ctr = e->ctrl2[e->ctrl_cur].as<yk::Counters>();
-    u64 *scan_state = reinterpret_cast<u64 *>(ctr + 1);
-    hipLaunchKernelGGL(yk::compact_classify_kernel, dim3(nb), dim3(yk::kScanBlock), 0, e->stream,
-                       d_off, d_len, e->stage.as<uint2>(), e->counts.as<u32>(), scan_state, n_reads,
-                       not_cov, e->bad_offsets.as<u64>(), e->bad_regions.as<uint2>(),
-                       (u64)(e->bad_regions.cap / sizeof(uint2)), e->read_type.as<uint8_t>(), ctr);
-    // (handing the counters over through mapped pinned memory from the kernel's last workgroup
-    // was tried: the system-scope stores made the kernel 8 us slower than this 4 us copy)
+    yk::CompactArgs2 ca;
+    ca.sweep = sa;
+    ca.sweep.first = 0;
+    ca.sweep.list = nullptr;
+    ca.sweep.list_n = nullptr;
+    ca.sweep.over_list = nullptr;
+    ca.sweep.over_count = nullptr;
+    ca.sweep.rej_list = e->lists.as<u32>() + (size_t)yk::CLS_COUNT * e->last_list_stride;
+    ca.sweep.rej_count = &ctr->rej_small;
+    ca.scan_state = reinterpret_cast<u64 *>(ctr + 1);
+    ca.n_reads = n_reads;
+    ca.not_cov = not_cov;
+    ca.bad_offsets = e->bad_offsets.as<u64>();
+    ca.bad_regions = e->bad_regions.as<uint2>();
+    ca.region_cap = (u64)(e->bad_regions.cap / sizeof(uint2));
+    ca.read_type = e->read_type.as<uint8_t>();
+    hipLaunchKernelGGL(yk::finish_compact_kernel, dim3(nb), dim3(yk::kScanBlock), 0, e->stream, ca);
+    // (Handing the counters over from the kernel's last workgroup — a ticket per workgroup, the block copied
+    // to the pinned page by whoever draws the last one — was tried twice: with system-scope stores in round 2
+    // (kernel + 8 us) and with plain stores behind a release / acquire ticket in round 3: no gain on a
+    // 100 k-read batch, 140 -> 200 us on 2 M reads (1 953 same-address tickets).  The 4 us copy stays.)
     HIP_TRY(hipMemcpyAsync(e->h_ctr, ctr, sizeof(yk::Counters), hipMemcpyDeviceToHost, e->stream));
     return YACRD_OK;
 }
@@ -295,7 +321,7 @@ int wait_for_stream(yacrd_engine *e)
 }
 
 int conclude_run(yacrd_engine *e, yk::Counters c0, bool predicted, uint64_t n_reads64, uint64_t n_iv,
-                 const int *cls_b, const int *cls_e, bool fused_marked, bool deferred_marked, float extra_ms);
+                 const int *cls_b, const int *cls_e, bool fused_marked, bool screened, float extra_ms);
 
 } // namespace
 
@@ -320,7 +346,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     }
 
     const u32 nb = (n_reads + yk::kScanBlock - 1) / yk::kScanBlock;
-    constexpr int kLists = yk::CLS_COUNT + 6; // class lists + three rejection lists + M2 overflow + two compact lists of deferred reads
+    constexpr int kLists = yk::CLS_COUNT + 4; // class lists + three rejection lists + M2 overflow
     HIP_TRY(e->lists.reserve((size_t)kLists * n_reads * sizeof(u32)));
     const size_t ctrl_bytes = (sizeof(yk::Counters) + (size_t)nb * sizeof(u64) + 255) & ~(size_t)255;
     e->ctrl_cur ^= 1;
@@ -341,7 +367,6 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     auto list_of = [&](int i) { return lists + (size_t)i * n_reads; };
     u32 *rej_small = list_of(yk::CLS_COUNT), *rej_med = list_of(yk::CLS_COUNT + 1),
         *rej_big = list_of(yk::CLS_COUNT + 2), *over_med = list_of(yk::CLS_COUNT + 3);
-    u32 *const defer_list[2] = {list_of(yk::CLS_COUNT + 4), list_of(yk::CLS_COUNT + 5)};
     yk::Counters *ctr = e->ctrl2[cur].as<yk::Counters>();
     const bool full = (e->flags & YACRD_F_TIMING_FULL) != 0;
     const int xm = (e->flags & YACRD_F_XLANE_DS) ? 1 : 0;
@@ -412,7 +437,6 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     sa.stage = e->stage.as<uint2>();
     sa.counts = e->counts.as<u32>();
     sa.ctr = ctr;
-    sa.count_tag = 0;
     sa.over_list = over_med;
     sa.over_count = &ctr->over_med;
 
@@ -439,13 +463,9 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         return hipEventRecord(e->ev_cls[n_cls_ev++], e->stream);
     };
 
-    bool skip_rejected_small = predicted && e->pred.rej_small == 0, skipped_small = false;
-    bool fused_marked = false, deferred_marked = false;
-    u32 defer_cover[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}; // what the deferred class launch covered of each compact list
-    bool remainder_pass = false; // launch_sweeps for what a prediction missed: after the final sync, nothing validates it
-    // sweeps of the classes in `set`, then the LDS exact path for what they rejected
+    bool fused_marked = false, screened = false;
+    // sweeps of the classes in `set` (what the register sweeps reject is looked at after the final sync)
     auto launch_sweeps = [&](const LaunchSet &set) -> int {
-        bool any_small = false;
         sa.rej_list = rej_small;
         sa.rej_count = &ctr->rej_small;
         // the row / half-wavefront classes in one launch
@@ -454,11 +474,12 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         if (fuse) {
             yk::FusedArgs fa;
             fa.base = sa;
-            // R16 / H16 reads their filter cannot thin: deferred to a launch of their own when the fused
-            // launch is long enough to pay for it (~4 us: from ~4 M intervals on)
+            // R16 / H16: the healthy-read screen, the rest left to finish_compact_kernel — unless the last
+            // batches failed the screen too often (e->nodefer_left: see conclude_run)
             const u64 fused_iv = set.iv[yk::CLS_R16] + set.iv[yk::CLS_H16];
             const bool defer = sa.prefilter && !(e->flags & YACRD_F_NO_DEFER) &&
-                               ((e->flags & YACRD_F_ALWAYS_DEFER) || fused_iv >= 4000000ull);
+                               ((e->flags & YACRD_F_ALWAYS_DEFER) ||
+                                (fused_iv >= defer_min_intervals() && e->nodefer_left == 0));
             // two groups of list entries per wavefront in the screened classes when the launch streams from
             // HBM (more than the 256 MiB Infinity Cache holds): twice the loads in flight per wavefront
             const int items = !defer ? 1
@@ -483,7 +504,6 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
                 has_dom |= cls == dom_cls;
             }
             if (fa.n_entries) {
-                any_small = true;
                 const bool mark = timing_on && (full || has_dom);
                 // Engines that share a device (batches pipelined over several engines) may take
                 // turns with this launch (YACRD_F_SWEEP_TURNS: a GPU-side wait on the previous engine's
@@ -516,98 +536,11 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
                     lane.owner = e;
                 }
                 if (mark) fused_marked = true;
-                // the reads the screen deferred
-                if (defer && (set.n[yk::CLS_R16] || set.n[yk::CLS_H16])) {
-                    yk::DeferArgs da;
-                    da.base = sa;
-                    da.base.prefilter = 0;
-                    da.base.over_list = nullptr;
-                    da.base.over_count = nullptr;
-                    da.base.count_tag = yk::kDeferredTag;
-                    da.n_entries = 0;
-                    u64 chunks = 0;
-                    for (int cls = yk::CLS_R16; cls <= yk::CLS_H16; cls++) {
-                        if (!set.n[cls]) continue;
-                        da.first[da.n_entries] = set.first[cls];
-                        da.count[da.n_entries] = set.n[cls];
-                        da.list[da.n_entries] = list_of(cls);
-                        da.list_n[da.n_entries] = &ctr->n[cls];
-                        da.n_entries++;
-                        chunks += (set.n[cls] + yk::kDeferChunk - 1) / yk::kDeferChunk;
-                    }
-                    // Large launches (first pass over the classes only): compact lists + the classes' own
-                    // register sort, 2.5x cheaper per read than sorting every marked read whole — but two
-                    // launches and, without a prediction, a round trip for the lists' lengths.
-                    const bool compacted = ((u64)set.n[yk::CLS_R16] + set.n[yk::CLS_H16] >= kCompactMinReads ||
-                                            (e->flags & YACRD_F_ALWAYS_COMPACT_DEFER)) &&
-                                           !remainder_pass && !(e->flags & YACRD_F_NO_COMPACT_DEFER);
-                    const hipEvent_t ev_b = (mark && full) ? e->ev_cls[20] : (hipEvent_t) nullptr;
-                    const hipEvent_t ev_e = (mark && full) ? e->ev_cls[21] : (hipEvent_t) nullptr;
-                    if (compacted) {
-                        yk::CompactArgs ca;
-                        ca.counts = sa.counts;
-                        ca.n_entries = da.n_entries;
-                        u64 c_chunks = 0;
-                        for (u32 k = 0; k < da.n_entries; k++) {
-                            const int slot = da.list[k] == list_of(yk::CLS_R16) ? 0 : 1;
-                            ca.first[k] = da.first[k];
-                            ca.count[k] = da.count[k];
-                            ca.list[k] = da.list[k];
-                            ca.list_n[k] = da.list_n[k];
-                            ca.out[k] = defer_list[slot];
-                            ca.out_n[k] = &ctr->deferred_n[slot];
-                            c_chunks += (da.count[k] + 4095) / 4096;
-                        }
-                        hipExtLaunchKernelGGL(yk::mark_compact_kernel,
-                                              dim3((u32)std::min<u64>(std::max<u64>(c_chunks, 1), (u64)e->num_cu * 2)),
-                                              dim3(yk::kCompactBlock), 0, e->stream, ev_b, (hipEvent_t) nullptr, 0, ca);
-                        u64 dn[2];
-                        if (predicted) { // the previous batch's lengths + a margin
-                            for (int k = 0; k < 2; k++) dn[k] = (u64)e->pred.deferred_n[k] + e->pred.deferred_n[k] / 8 + 256;
-                        } else {
-                            HIP_TRY(hipMemcpyAsync(e->h_ctr, ctr, sizeof(yk::Counters), hipMemcpyDeviceToHost, e->stream));
-                            HIP_TRY(hipStreamSynchronize(e->stream));
-                            for (int k = 0; k < 2; k++) dn[k] = e->h_ctr->deferred_n[k];
-                        }
-                        yk::FusedArgs fc;
-                        fc.base = da.base;
-                        fc.base.prefilter = sa.prefilter;
-                        fc.n_entries = 0;
-                        u32 cblocks = 0;
-                        for (int k = 0; k < 2; k++) {
-                            const int cls = k == 0 ? yk::CLS_R16 : yk::CLS_H16;
-                            dn[k] = std::min<u64>(dn[k], set.n[cls]);
-                            defer_cover[k] = 0;
-                            if (!dn[k]) continue;
-                            const u32 per = yk::sweep_group_reads_per_block(cls, yk::kFusedWaves);
-                            const u32 nblk = (u32)((dn[k] + per - 1) / per);
-                            defer_cover[k] = nblk * per;
-                            cblocks += nblk;
-                            fc.cls[fc.n_entries] = (u32)cls;
-                            fc.block_end[fc.n_entries] = cblocks;
-                            fc.list[fc.n_entries] = defer_list[k];
-                            fc.list_n[fc.n_entries] = &ctr->deferred_n[k];
-                            fc.first[fc.n_entries] = 0;
-                            fc.n_entries++;
-                        }
-                        if (fc.n_entries)
-                            hipExtLaunchKernelGGL(yk::sweep_small_fused_kernel, dim3(cblocks), dim3(64 * yk::kFusedWaves),
-                                                  0, e->stream, (hipEvent_t) nullptr, ev_e, 0, fc);
-                        else if (ev_e) HIP_TRY(hipEventRecord(ev_e, e->stream));
-                    } else {
-                        const u32 dgrid = (u32)std::min<u64>(chunks, (u64)e->num_cu * 64);
-                        hipExtLaunchKernelGGL(yk::sweep_deferred_kernel, dim3(dgrid ? dgrid : 1), dim3(256), 0, e->stream,
-                                              ev_b, ev_e, 0, da);
-                    }
-                    // (its own start / stop events only with YACRD_F_TIMING_FULL: a pair costs the host
-                    // ~4 us and the stream ~5 us per batch)
-                    if (mark && full) deferred_marked = true;
-                }
+                if (defer && (set.n[yk::CLS_R16] || set.n[yk::CLS_H16])) screened = true;
             }
         }
         for (int cls = yk::CLS_R2; cls <= yk::CLS_W16; cls++) { // register sort per lane group
             if (!set.n[cls] || (fuse && cls <= yk::CLS_H16)) continue;
-            any_small = true;
             HIP_TRY(before_class(cls));
             sa.list = list_of(cls);
             sa.list_n = &ctr->n[cls];
@@ -669,19 +602,6 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         }
         if (full && timing_on) HIP_TRY(hipEventRecord(e->ev[EV_MED], e->stream));
 
-        // exact path for reads a sweep rejected, scratch in LDS, no host round trip (skipped when
-        // the prediction says nothing gets rejected; checked at the final sync)
-        if (any_small && skip_rejected_small) skipped_small = true;
-        else if (any_small) {
-            sa.list = rej_small;
-            sa.list_n = &ctr->rej_small;
-            sa.rej_list = rej_med; // cannot happen (n <= 512), kept well defined
-            sa.rej_count = &ctr->rej_med;
-            // (a single wavefront per read was tried: 23.9 us vs 20.2 us — the stages are latency
-            // chains, more threads shorten each one)
-            hipLaunchKernelGGL((yk::sweep_general_lds_kernel<256, 512>), dim3(e->num_cu * 2),
-                               dim3(256), 0, e->stream, sa);
-        }
         if (set.n[yk::CLS_MED1]) {
             sa.list = rej_med;
             sa.list_n = &ctr->rej_med;
@@ -714,7 +634,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     if (full) HIP_TRY(hipEventRecord(e->ev[EV_GEN], e->stream));
 
     // ---- follow-on kernel: scan + compact + classify
-    rc = launch_compact(e, d_off, d_len, n_reads, not_cov);
+    rc = launch_compact(e, sa, n_reads, not_cov);
     if (rc) return rc;
     if (full) HIP_TRY(hipEventRecord(e->ev[EV_COMPACT], e->stream));
     if (defer && predicted) { // yacrd_engine_submit_device: the caller waits later (finish_pending)
@@ -732,11 +652,8 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
             p.cls_b[cls] = cls_b[cls];
             p.cls_e[cls] = cls_e[cls];
         }
-        p.skipped_small = skipped_small;
         p.fused_marked = fused_marked;
-        p.deferred_marked = deferred_marked;
-        p.defer_cover[0] = defer_cover[0];
-        p.defer_cover[1] = defer_cover[1];
+        p.screened = screened;
         return YACRD_OK;
     }
     // (spinning on the pinned counter block instead of this call was tried: 0.0816 vs 0.078 ms/step)
@@ -748,50 +665,8 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     // LDS exact path; region overflow.  Each ends with a redo of the compaction.
     float extra_ms = 0.f;
     bool redo = false;
-    skip_rejected_small = false;
     if (predicted) {
         c0 = *e->h_ctr; // the plan's real counts
-        if (skipped_small && c0.rej_small) { // rejections the prediction did not expect
-            HIP_TRY(hipEventRecord(e->ev[EV_X0], e->stream));
-            sa.list = rej_small;
-            sa.list_n = &ctr->rej_small;
-            sa.rej_list = rej_med;
-            sa.rej_count = &ctr->rej_med;
-            hipLaunchKernelGGL((yk::sweep_general_lds_kernel<256, 512>), dim3(e->num_cu * 2),
-                               dim3(256), 0, e->stream, sa);
-            redo = true;
-        }
-        if (c0.deferred_n[0] > defer_cover[0] || c0.deferred_n[1] > defer_cover[1]) {
-            // more reads deferred than the predicted grid of the deferred class launch covered: what it
-            // left marked is sorted whole
-            if (!redo) HIP_TRY(hipEventRecord(e->ev[EV_X0], e->stream));
-            yk::DeferArgs da;
-            da.base = sa;
-            da.base.prefilter = 0;
-            da.base.over_list = nullptr;
-            da.base.over_count = nullptr;
-            da.base.count_tag = yk::kDeferredTag;
-            da.base.rej_list = rej_small;
-            da.base.rej_count = &ctr->rej_small;
-            da.n_entries = 0;
-            for (int cls = yk::CLS_R16; cls <= yk::CLS_H16; cls++) {
-                if (!c0.n[cls]) continue;
-                da.first[da.n_entries] = 0;
-                da.count[da.n_entries] = c0.n[cls];
-                da.list[da.n_entries] = list_of(cls);
-                da.list_n[da.n_entries] = &ctr->n[cls];
-                da.n_entries++;
-            }
-            hipLaunchKernelGGL(yk::sweep_deferred_kernel, dim3(e->num_cu * 16), dim3(256), 0, e->stream, da);
-            // its rejections (rare) go the exact way, with the earlier ones once more
-            sa.list = rej_small;
-            sa.list_n = &ctr->rej_small;
-            sa.rej_list = rej_med;
-            sa.rej_count = &ctr->rej_med;
-            hipLaunchKernelGGL((yk::sweep_general_lds_kernel<256, 512>), dim3(e->num_cu * 2), dim3(256), 0,
-                               e->stream, sa);
-            redo = true;
-        }
         LaunchSet missing{};
         bool any_missing = false;
         for (int cls = 0; cls < yk::CLS_GENERAL; cls++)
@@ -802,7 +677,6 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
             }
         if (any_missing || c0.n[yk::CLS_GENERAL]) {
             if (!redo) HIP_TRY(hipEventRecord(e->ev[EV_X0], e->stream));
-            remainder_pass = true;
             if (any_missing && (rc = launch_sweeps(missing))) return rc;
             if (c0.n[yk::CLS_GENERAL] && (rc = launch_huge(c0.n[yk::CLS_GENERAL], &gen_iv))) return rc;
             // the rejection counters may have grown: bring them home before looking at rej_big
@@ -812,6 +686,26 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
             redo = true;
         }
     }
+    // Reads a register sweep (or the follow-on kernel's sort) rejected — an interval the keys cannot
+    // express: the exact path with its scratch in LDS, then the compaction once more.  Rare, so nothing is
+    // launched for them before their number is known.  (A redo may reject more: the loop below looks again.)
+    auto exact_small = [&]() {
+        sa.list = rej_small;
+        sa.list_n = &ctr->rej_small;
+        sa.rej_list = rej_med; // cannot happen (n <= 512), kept well defined
+        sa.rej_count = &ctr->rej_med;
+        // (a single wavefront per read was tried: 23.9 us vs 20.2 us — the stages are latency
+        // chains, more threads shorten each one)
+        hipLaunchKernelGGL((yk::sweep_general_lds_kernel<256, 512>), dim3(e->num_cu * 2), dim3(256), 0,
+                           e->stream, sa);
+    };
+    u32 rej_small_done = 0;
+    if (e->h_ctr->rej_small) {
+        if (!redo) HIP_TRY(hipEventRecord(e->ev[EV_X0], e->stream));
+        exact_small();
+        rej_small_done = e->h_ctr->rej_small;
+        redo = true;
+    }
     const u32 n_rej_big = e->h_ctr->rej_big;
     if (n_rej_big) {
         if (!redo) HIP_TRY(hipEventRecord(e->ev[EV_X0], e->stream));
@@ -819,7 +713,13 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         if (rc) return rc;
         redo = true;
     }
-    for (int attempt = 0; attempt < 3; attempt++) {
+    for (int attempt = 0; attempt < 4; attempt++) {
+        if (!redo && e->h_ctr->rej_small > rej_small_done) { // the redone follow-on kernel rejected reads of its own
+            HIP_TRY(hipEventRecord(e->ev[EV_X0], e->stream));
+            exact_small();
+            rej_small_done = e->h_ctr->rej_small;
+            redo = true;
+        }
         if (!redo) {
             if (!e->h_ctr->region_overflow) break;
             HIP_TRY(e->bad_regions.reserve((size_t)(e->h_ctr->total_regions + 16) * sizeof(uint2)));
@@ -828,9 +728,8 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         redo = false;
         // reset the scan state, the ticket and the overflow flag (keep the class counters)
         HIP_TRY(hipMemsetAsync(&ctr->region_overflow, 0, 3 * sizeof(u32), e->stream));
-        HIP_TRY(hipMemsetAsync(&ctr->deferred, 0, sizeof(u32), e->stream)); // (the compaction counts them again)
         HIP_TRY(hipMemsetAsync(ctr + 1, 0, (size_t)nb * sizeof(u64), e->stream));
-        rc = launch_compact(e, d_off, d_len, n_reads, not_cov);
+        rc = launch_compact(e, sa, n_reads, not_cov);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(e->ev[EV_X1], e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
@@ -838,8 +737,9 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         extra_ms += ev_ms(e->ev[EV_X0], e->ev[EV_X1]);
     }
     if (e->h_ctr->region_overflow) return fail(YACRD_EINTERNAL, "bad_regions overflow persisted");
+    if (e->h_ctr->rej_small > rej_small_done) return fail(YACRD_EINTERNAL, "rejected reads persisted");
 
-    return conclude_run(e, c0, predicted, n_reads64, n_iv, cls_b, cls_e, fused_marked, deferred_marked, extra_ms);
+    return conclude_run(e, c0, predicted, n_reads64, n_iv, cls_b, cls_e, fused_marked, screened, extra_ms);
 }
 } // namespace yke
 
@@ -847,7 +747,7 @@ namespace {
 
 // Bookkeeping after a run's last sync: result sizes, the next run's prediction, timing.
 int conclude_run(yacrd_engine *e, yk::Counters c0, bool predicted, uint64_t n_reads64, uint64_t n_iv,
-                 const int *cls_b, const int *cls_e, bool fused_marked, bool deferred_marked, float extra_ms)
+                 const int *cls_b, const int *cls_e, bool fused_marked, bool screened, float extra_ms)
 {
     const bool full = (e->flags & YACRD_F_TIMING_FULL) != 0;
     const u32 n_reads = (u32)n_reads64;
@@ -895,18 +795,23 @@ int conclude_run(yacrd_engine *e, yk::Counters c0, bool predicted, uint64_t n_re
     }
     t.class_ms[yk::CLS_GENERAL] = (full && c0.n[yk::CLS_GENERAL]) ? t.sweep_general_ms : 0.f;
     t.fused_ms = 0.f;
-    t.deferred_ms = 0.f;
     t.timed_runs = fused_marked ? 1u : 0u;
     for (int cls = 0; cls < yk::CLS_GENERAL; cls++)
         if (cls_b[cls] >= 0 && cls_e[cls] >= 0) t.timed_runs = 1u;
     t.deferred_reads = c1.deferred;
+    t.deferred_intervals = c1.deferred_iv;
+    // The next batch's build of the fused launch: when this one screened and more than a quarter of what it
+    // screened had to be sorted after all, the sorting build takes the next kProbeEvery - 1 batches.
+    if (screened) {
+        const uint64_t looked_at = (uint64_t)c0.n[yk::CLS_R16] + c0.n[yk::CLS_H16];
+        e->nodefer_left = (!(e->flags & YACRD_F_ALWAYS_DEFER) && 4 * (uint64_t)c1.deferred > looked_at) ? kProbeEvery - 1 : 0;
+    } else if (e->nodefer_left) {
+        e->nodefer_left--;
+    }
+    t.screened = screened ? 1u : 0u;
     t.fused_reads = t.fused_intervals = 0;
     t.prefiltered_reads = c1.prefiltered;
-    if (fused_marked) {
-        t.fused_ms = ev_ms(e->ev_cls[22], e->ev_cls[23]);
-        // the launch that finishes the reads the fused kernel's filter deferred: timed on its own
-        if (deferred_marked) t.deferred_ms = ev_ms(e->ev_cls[20], e->ev_cls[21]);
-    }
+    if (fused_marked) t.fused_ms = ev_ms(e->ev_cls[22], e->ev_cls[23]);
     if (!(e->flags & (YACRD_F_FORCE_LDS_SORT | YACRD_F_XLANE_DS | YACRD_F_NO_FUSED_LAUNCH))) {
         // what the one launch of the classes R2..H16 holds (whether or not this run timed it)
         for (int cls = yk::CLS_R2; cls <= yk::CLS_H16; cls++) {
@@ -928,7 +833,7 @@ int conclude_run(yacrd_engine *e, yk::Counters c0, bool predicted, uint64_t n_re
     ts.total_ms = keep.total_ms + t.total_ms;
     for (int i = 0; i < 12; i++) ts.class_ms[i] = keep.class_ms[i] + t.class_ms[i];
     ts.fused_ms = keep.fused_ms + t.fused_ms;
-    ts.deferred_ms = keep.deferred_ms + t.deferred_ms;
+    ts.screened = keep.screened + t.screened;
     ts.timed_runs = keep.timed_runs + t.timed_runs;
     e->timing_runs++;
     return YACRD_OK;
@@ -946,15 +851,13 @@ int finish_pending(yacrd_engine *e)
     int rc = wait_for_stream(e);
     if (rc) return rc;
     const yk::Counters c = *e->h_ctr;
-    bool ok = !(p.skipped_small && c.rej_small) && !c.n[yk::CLS_GENERAL] && !c.rej_big &&
-              !c.region_overflow;
+    bool ok = !c.rej_small && !c.n[yk::CLS_GENERAL] && !c.rej_big && !c.region_overflow;
     for (int cls = 0; cls < yk::CLS_GENERAL; cls++) ok = ok && c.n[cls] <= p.grid_n[cls];
-    ok = ok && c.deferred_n[0] <= p.defer_cover[0] && c.deferred_n[1] <= p.defer_cover[1];
     if (!ok) {
         e->pred_valid = false;
         return run_on_device(e, p.d_off, p.d_iv, p.d_len, p.n_reads, p.n_iv, p.cov, p.not_cov);
     }
-    return conclude_run(e, c, true, p.n_reads, p.n_iv, p.cls_b, p.cls_e, p.fused_marked, p.deferred_marked, 0.f);
+    return conclude_run(e, c, true, p.n_reads, p.n_iv, p.cls_b, p.cls_e, p.fused_marked, p.screened, 0.f);
 }
 
 } // namespace

@@ -1,7 +1,7 @@
 // engine_internal.h — host-side internals shared by the translation units of libyacrd_hip.so
 // (engine.hip: batch runs; stream.hip: streaming ingest + CSR build on the GPU).
 #pragma once
-#include "../../include/yacrd_engine.h"
+#include "../../include/yacrd_engine_debug.h"
 
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
@@ -106,8 +106,7 @@ struct Pending {
     uint32_t cov = 0;
     double not_cov = 0;
     u32 grid_n[12] = {};      // reads each class's grid covers
-    bool skipped_small = false, fused_marked = false, deferred_marked = false;
-    u32 defer_cover[2] = {0xFFFFFFFFu, 0xFFFFFFFFu}; // compact-list entries the deferred class launch covered
+    bool fused_marked = false, screened = false;
     int cls_b[12] = {}, cls_e[12] = {};
 };
 
@@ -146,6 +145,7 @@ struct yacrd_engine {
     yacrd_timing timing_sum = {};
     uint64_t timing_runs = 0;
     uint32_t run_seq = 0; // runs since creation (YACRD_F_TIMING_SAMPLED times every 8th)
+    uint32_t nodefer_left = 0; // batches the sorting build of the fused launch still takes before the screen is tried again
     // pinned bounce buffers for pageable inputs (yke::h2d), allocated on first use; an event per
     // buffer says when its DMA is done and it may be refilled
     static constexpr int kBounce = 12;

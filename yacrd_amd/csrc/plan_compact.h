@@ -93,7 +93,10 @@ __global__ __launch_bounds__(kPlanBlock) void plan_kernel(const u64 *off, u32 n_
     }
 }
 
-constexpr int kScanBlock = 1024;
+#ifndef YK_SCAN_BLOCK
+#define YK_SCAN_BLOCK 1024
+#endif
+constexpr int kScanBlock = YK_SCAN_BLOCK; // reads per workgroup of the follow-on kernel (one thread each)
 
 // ---- follow-on kernel: compact each read's regions into the CSR and tag the read ------------
 // Classification is reference src/editor/mod.rs:85-100 (type_of_read): u32 wrapping sum of
@@ -104,94 +107,8 @@ __device__ __forceinline__ u32 classify(u32 bad, bool middle_gap, u32 len, doubl
     return middle_gap ? 1u : 0u;                        // YACRD_CHIMERIC : YACRD_NOT_BAD
 }
 
-// bad_offsets is the exclusive scan of the per-read region counts: single pass, decoupled
-// look-back over workgroup aggregates.  scan_state[i] = flag<<62 | value, flag 1 = aggregate of
-// workgroup i, 2 = inclusive prefix through workgroup i (one 64-bit word, so relaxed agent-scope
-// atomics are enough); workgroup ids come from a ticket so a predecessor is always running.
-__global__ __launch_bounds__(kScanBlock) void compact_classify_kernel(
-    const u64 *off, const u32 *len, const uint2 *stage, const u32 *counts, u64 *scan_state,
-    u32 n_reads, double not_cov, u64 *bad_offsets, uint2 *bad_regions, u64 region_cap,
-    uint8_t *read_type, Counters *ctr)
-{
-    __shared__ u32 sc[kScanBlock / 64];
-    __shared__ u32 s_bid;
-    __shared__ u64 s_base;
-    __shared__ u32 s_tagged;
-    if (threadIdx.x == 0) {
-        s_bid = atomicAdd(&ctr->scan_ticket, 1u);
-        s_tagged = 0;
-    }
-    __syncthreads();
-    const u32 bid = s_bid;
-    const u32 r = bid * kScanBlock + threadIdx.x;
-    u32 g_raw = (r < n_reads) ? counts[r] : 0u;
-    // a mark that is still there (the predicted grid of the deferred class launch was too short: the
-    // host sees that at the final sync, finishes those reads and compacts again) counts as nothing
-    if (g_raw == kDeferredMark) g_raw = 0u;
-    const u32 g = g_raw & ~kDeferredTag;
-    // reads finished by sweep_deferred_kernel carry a tag in their count: counted here, one atomic per
-    // workgroup (see Counters::deferred)
-    const u64 tagged = __builtin_amdgcn_ballot_w64((g_raw & kDeferredTag) != 0);
-    if (tagged && lane_id() == 0) atomicAdd(&s_tagged, (u32)__builtin_popcountll(tagged));
-    u32 tot;
-    const u32 local = block_excl_add<kScanBlock>(g, sc, tot);
-    if (threadIdx.x < 64) { // decoupled look-back, 64 predecessors per round trip
-        constexpr u64 kAgg = 1ull << 62, kPre = 2ull << 62, kVal = (1ull << 62) - 1;
-        const u32 lane = threadIdx.x;
-        u64 base = 0;
-        if (bid > 0) {
-            if (lane == 0)
-                __hip_atomic_store(&scan_state[bid], kAgg | tot, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
-            for (i32 hi = (i32)bid - 1;; hi -= 64) {
-                const i32 idx = hi - (i32)lane; // lane 0 looks at the nearest predecessor
-                u64 v, pre;
-                for (;;) { // until the window holds no empty entry before its nearest prefix
-                    v = idx >= 0 ? __hip_atomic_load(&scan_state[idx], __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT)
-                                 : kPre; // before the first workgroup: prefix 0
-                    pre = __builtin_amdgcn_ballot_w64((v >> 62) == 2);
-                    const u64 before = pre ? ((pre & (0 - pre)) - 1ull) : ~0ull; // lanes nearer than it
-                    if ((__builtin_amdgcn_ballot_w64((v >> 62) == 0) & before) == 0) break;
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                const u32 first_pre = pre ? (u32)__builtin_ctzll(pre) : 64u;
-                u64 part = lane <= first_pre ? (v & kVal) : 0;
-#pragma unroll
-                for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
-                base += part;
-                if (pre) break;
-            }
-        }
-        if (lane == 0) {
-            __hip_atomic_store(&scan_state[bid], kPre | (base + tot), __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
-            s_base = base;
-            if ((u64)(bid + 1) * kScanBlock >= n_reads) ctr->total_regions = base + tot;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0 && s_tagged) atomicAdd(&ctr->deferred, s_tagged);
-    if (r < n_reads) {
-        const u64 dst = s_base + local;
-        bad_offsets[r] = dst;
-        if (r == n_reads - 1) bad_offsets[n_reads] = dst + g;
-
-        const uint2 *slot = stage + (off[r] + 2 * (u64)r);
-        const u32 L = len[r];
-        u32 bad = 0;
-        bool middle = false;
-        const bool fits = dst + g <= region_cap;
-        for (u32 k = 0; k < g; k++) {
-            const uint2 v = slot[k];
-            if (fits) bad_regions[dst + k] = v;
-            bad += v.y - v.x;
-            middle |= (v.x != 0u) & (v.y != L);
-        }
-        if (!fits) atomicOr(&ctr->region_overflow, 1u);
-        read_type[r] = (uint8_t)classify(bad, middle, L, not_cov);
-    }
-}
+// (the scan + compaction + classification kernel lives in finish_compact.h: it first finishes the reads the
+// screen deferred)
 
 // Standalone classification over an existing region CSR (editors re-classify per record,
 // e.g. reference src/editor/scrubbing.rs:181).

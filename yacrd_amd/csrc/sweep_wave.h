@@ -1,7 +1,7 @@
 // sweep_wave.h — small classes (<= 1024 events): one, two or four reads per wavefront, sorted in
 // registers; a coverage pre-filter in front of the sort for the 16-keys-per-lane classes, or — in
 // long launches — a screen that finishes healthy reads in closed form and leaves the sort to a
-// second launch for the rest (healthy_screen, sweep_deferred_kernel).
+// the follow-on kernel for the rest (healthy_screen; finish_compact.h).
 //
 // Same event formulation as sweep_lds.h (reference src/stack.rs:61-139 for regular reads), but
 // the dominant cost — sorting the 2n event keys — runs as a bitonic network over VGPRs:
@@ -343,7 +343,7 @@ __device__ __forceinline__ void sweep_group_keys(u32 (&x)[K], u32 m, u32 len, i3
             a.rej_list[atomicAdd(a.rej_count, 1u)] = r;
             a.counts[r] = 0;
         } else {
-            a.counts[r] = finish_read(slot_of(), g_closed, mf_incl ? (mf_incl ^ 2u) : 0u, ml_incl, min_ge, len) | a.count_tag;
+            a.counts[r] = finish_read(slot_of(), g_closed, mf_incl ? (mf_incl ^ 2u) : 0u, ml_incl, min_ge, len);
         }
     }
 }
@@ -406,7 +406,7 @@ __device__ __forceinline__ u32 *wave_filter_scratch()
 // One LDS atomic per event (four copies of every counter by lane & 3 so that piled positions do not
 // serialise the atomics of a row), one packed row scan per table.  Every other read — low coverage
 // somewhere inside: the reads yacrd is looking for — is marked in its region-count slot (kDeferredMark)
-// and sorted by a second launch.  (A list appended to with one global atomic per read was the first
+// and sorted by the follow-on kernel (finish_compact.h), which finds the marks.  (A list appended to with one global atomic per read was the first
 // attempt: the same-address atomics, performed at the memory side on this 8-XCD part, took ~7 ns each
 // one after the other and doubled the kernel's duration.)
 // Only for wavefronts whose intervals are all plain (start < end <= len) and at least W long.
@@ -752,8 +752,8 @@ __device__ __forceinline__ void screen_block(const SweepArgs &a, u32 block)
     // time (16-byte loads: half the memory instructions and address arithmetic).  Pair P = lig + LANES*j
     // holds intervals 2P and 2P + 1; the load is clamped to the read's last pair (n - 2, n - 1), whose
     // second half is interval 2P itself when 2P = n - 1.  (8-byte aligned 16-byte loads are fine for
-    // global memory; a read with fewer than two intervals — not in these classes — is left to
-    // sweep_deferred_kernel.)
+    // global memory; a read with fewer than two intervals — not in these classes — is left to the
+    // follow-on kernel.)
     uint4 v[ITEMS][K / 4];
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) {
@@ -865,64 +865,6 @@ inline void launch_sweep_group(const SweepArgs &sa, u32 n_reads, hipStream_t str
                            stream, sa);
 }
 
-// The reads the screen deferred (low coverage somewhere inside, or intervals that are not plain),
-// sorted whole: one read per wavefront on all 64 lanes (4 keys per lane up to 128 intervals, 8 up to
-// 256).  The kernel scans the lists of the two classes, 64 entries per wavefront and step, for the
-// marks the fused kernel left in counts[], and a wavefront works through the marked reads of its 64
-// one after the other (~4 % of the reads on configs[1]: two or three per wavefront).
-constexpr u32 kDeferChunk = 64; // list entries a workgroup scans per step
-struct DeferArgs {
-    SweepArgs base;
-    u32 n_entries;
-    u32 first[2], count[2];   // list entries [first, first + count) of each class, clipped to *list_n
-    const u32 *list[2];
-    const u32 *list_n[2];
-};
-
-__global__ __launch_bounds__(256) void sweep_deferred_kernel(DeferArgs d)
-{
-    const u32 lane = lane_id(), wv = threadIdx.x >> 6;
-    const LaneConst lc = make_lane_const(lane);
-    const SweepArgs &a = d.base;
-    for (u32 e = 0; e < d.n_entries; e++) {
-        const u32 end = min(d.first[e] + d.count[e], *d.list_n[e]);
-        const u32 *list = d.list[e];
-        // the four wavefronts of a workgroup look at the same 64 entries and share the marked reads
-        // among them (the k-th goes to wavefront k mod 4): the serial chain of a wavefront stays short
-        // even where the marks bunch up
-        for (u32 base = d.first[e] + blockIdx.x * 64u; base < end; base += gridDim.x * 64u) { // uniform
-            const u32 idx = base + lane;
-            u32 r = 0, n = 0, len = 0;
-            u64 o = 0;
-            bool marked = false;
-            if (idx < end) {
-                r = list[idx];
-                marked = a.counts[r] == kDeferredMark;
-            }
-            if (marked) { // every marked read's extent, fetched side by side
-                o = a.off[r];
-                n = (u32)(a.off[r + 1] - o);
-                len = a.len[r];
-            }
-            const u64 all = __builtin_amdgcn_ballot_w64(marked);
-            __syncthreads(); // every wavefront has looked before the first one replaces a mark by its count
-            const u32 rank = (u32)__builtin_popcountll(all & ((1ull << lane) - 1ull));
-            u64 todo = __builtin_amdgcn_ballot_w64(marked && (rank & 3u) == wv);
-            while (todo) {
-                const int l = (int)__builtin_ctzll(todo);
-                todo &= todo - 1;
-                const u32 rr = (u32)__builtin_amdgcn_readlane((int)r, l);
-                const u32 nn = (u32)__builtin_amdgcn_readlane((int)n, l);
-                const u32 ll = (u32)__builtin_amdgcn_readlane((int)len, l);
-                const u64 oo = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(o >> 32), l) << 32) |
-                               (u32)__builtin_amdgcn_readlane((int)(u32)o, l);
-                if (nn <= 128u) sweep_group_read<64, 4, 0>(a.iv + oo, nn, ll, a.cov, true, rr, a, lc);
-                else sweep_group_read<64, 8, 0>(a.iv + oo, nn, ll, a.cov, true, rr, a, lc);
-            }
-        }
-    }
-}
-
 // ---- every register-sort class in ONE launch ------------------------------------------------
 // The classes R2..H16 are independent; launched one after the other each pays its own ramp-up
 // and drain (~4-7 us for the minor ones on configs[1]).  Here the grid is the concatenation of
@@ -984,12 +926,12 @@ __device__ __forceinline__ void sweep_small_fused_body(const FusedArgs &f)
         break;
     }
 }
-// Two builds.  DEFER (long launches): the classes R16 / H16 run the healthy-read screen (one counting
-// pass + closed form) and mark every other read in counts[] for sweep_deferred_kernel;
-// no sort for those classes in this kernel: 56 registers, one-wavefront workgroups, bound by the
-// memory system (configs[1]: 47.9 -> 18.7 us, configs[2]: 1.90 -> 0.74 ms).  The second launch costs
-// ~10 us of stream time however little it has to do, so short launches use the other build: bin
-// filter + register sort for every read (the engine decides by the classes' interval count).
+// Two builds.  DEFER: the classes R16 / H16 run the healthy-read screen (one counting pass + closed
+// form) and mark every other read in counts[] for finish_compact_kernel; no sort for
+// those classes in this kernel: 56 registers, one-wavefront workgroups, bound by the memory system
+// (configs[1]: 47.9 -> 17.5 us, configs[2]: 1.90 -> 0.65 ms).  The other build sorts every read behind
+// the bin filter: for batches whose reads mostly fail the screen (the engine looks at the previous
+// batch's deferral rate) and for very short launches.
 // (__launch_bounds__' second argument: wavefronts per SIMD)
 __global__ __launch_bounds__(64 * kDeferWaves, kDeferOcc) void sweep_small_fused_defer_kernel(FusedArgs f)
 {
@@ -1003,72 +945,6 @@ __global__ __launch_bounds__(64, kDeferOcc) void sweep_small_fused_defer2_kernel
 __global__ __launch_bounds__(64 * kFusedWaves, 5) void sweep_small_fused_kernel(FusedArgs f)
 {
     sweep_small_fused_body<false, kFusedWaves>(f);
-}
-
-// ---- the deferred reads of a LARGE launch: compact lists + the classes' own register sort ------------
-// mark_compact_kernel turns the marks the screen left in counts[] into one compact list per class (one
-// returning atomic per workgroup of 4096 list entries and class, on a cache line of its own); the
-// non-deferring build of the fused kernel then runs over those lists (four / two reads per wavefront,
-// bin filter of §3.4, K/2 or K keys per lane) with a grid the host sizes from the lists' lengths — read
-// back in an unpredicted run, the previous batch's in a predicted one (validated at the final sync;
-// what a too-short grid leaves marked is finished by sweep_deferred_kernel).
-struct CompactArgs {
-    const u32 *counts;
-    u32 n_entries;
-    u32 first[2], count[2];
-    const u32 *list[2];
-    const u32 *list_n[2];
-    u32 *out[2];      // compact lists
-    u32 *out_n[2];    // their lengths (Counters::deferred_n)
-};
-constexpr int kCompactBlock = 1024, kCompactPer = 4;
-
-__global__ __launch_bounds__(kCompactBlock) void mark_compact_kernel(CompactArgs c)
-{
-    __shared__ u32 s_wave[kCompactBlock / 64];
-    __shared__ u32 s_base;
-    const u32 lane = lane_id(), wv = threadIdx.x >> 6;
-    for (u32 e = 0; e < c.n_entries; e++) {
-        const u32 end = min(c.first[e] + c.count[e], *c.list_n[e]);
-        for (u32 base = c.first[e] + blockIdx.x * (u32)(kCompactBlock * kCompactPer); base < end;
-             base += gridDim.x * (u32)(kCompactBlock * kCompactPer)) { // uniform
-            u32 r[kCompactPer];
-            u64 m[kCompactPer];
-            u32 mine = 0;
-#pragma unroll
-            for (int k = 0; k < kCompactPer; k++) {
-                const u32 idx = base + (u32)k * kCompactBlock + threadIdx.x;
-                bool marked = false;
-                r[k] = 0;
-                if (idx < end) {
-                    r[k] = c.list[e][idx];
-                    marked = c.counts[r[k]] == kDeferredMark;
-                }
-                m[k] = __builtin_amdgcn_ballot_w64(marked);
-                mine += (u32)__builtin_popcountll(m[k]);
-            }
-            if (lane == 0) s_wave[wv] = mine; // (uniform in the wavefront)
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                u32 tot = 0;
-                for (int w = 0; w < kCompactBlock / 64; w++) {
-                    const u32 x = s_wave[w];
-                    s_wave[w] = tot;
-                    tot += x;
-                }
-                s_base = tot ? atomicAdd(c.out_n[e], tot) : 0u;
-            }
-            __syncthreads();
-            u32 pos = s_base + s_wave[wv];
-#pragma unroll
-            for (int k = 0; k < kCompactPer; k++) {
-                if ((m[k] >> lane) & 1ull)
-                    c.out[e][pos + (u32)__builtin_popcountll(m[k] & ((1ull << lane) - 1ull))] = r[k];
-                pos += (u32)__builtin_popcountll(m[k]);
-            }
-            __syncthreads();
-        }
-    }
 }
 
 inline u32 sweep_group_reads_per_block(int cls, int waves = 4)

@@ -11,6 +11,8 @@ _LIB = os.path.join(_HERE, "lib", "libyacrd_hip.so")
 
 NOT_BAD, CHIMERIC, NOT_COVERED = 0, 1, 2
 TYPE_NAMES = {NOT_BAD: "NotBad", CHIMERIC: "Chimeric", NOT_COVERED: "NotCovered"}
+# yacrd_engine_cfg.flags: the timing flags are part of include/yacrd_engine.h, everything else is an A/B or
+# test switch from include/yacrd_engine_debug.h
 F_FORCE_GENERAL = 1
 F_FORCE_LDS_SORT = 2
 F_XLANE_DS = 4
@@ -27,8 +29,6 @@ F_NO_DEFER = 4096
 F_ALWAYS_DEFER = 8192
 F_SWEEP_TURNS = 16384
 F_TIMING_SAMPLED = 32768
-F_NO_COMPACT_DEFER = 65536
-F_ALWAYS_COMPACT_DEFER = 131072
 F_SCREEN_ITEMS_1 = 262144
 F_SCREEN_ITEMS_2 = 524288
 
@@ -40,7 +40,7 @@ EXPORTED_SYMBOLS = [
     "yacrd_engines_run_partitioned", "yacrd_engine_timing_total", "yacrd_engine_event_overhead", "yacrd_engine_submit_device", "yacrd_engine_wait", "yacrd_engines_run_device_batches",
     "yacrd_engine_submit", "yacrd_engine_collect", "yacrd_pinned_alloc", "yacrd_pinned_free",
     "yacrd_stream_open", "yacrd_stream_sink", "yacrd_stream_acquire", "yacrd_stream_commit",
-    "yacrd_stream_finish", "yacrd_stream_last_stats", "yacrd_stream_close",
+    "yacrd_stream_finish", "yacrd_stream_last_stats", "yacrd_stream_reset", "yacrd_stream_close",
 ]
 
 
@@ -86,7 +86,8 @@ class _Timing(ctypes.Structure):
                 ("class_intervals", ctypes.c_uint64 * 12), ("fused_ms", ctypes.c_float),
                 ("fused_reads", ctypes.c_uint64), ("fused_intervals", ctypes.c_uint64),
                 ("prefiltered_reads", ctypes.c_uint64), ("deferred_reads", ctypes.c_uint64),
-                ("deferred_ms", ctypes.c_float), ("timed_runs", ctypes.c_uint32)]
+                ("deferred_intervals", ctypes.c_uint64), ("screened", ctypes.c_uint32),
+                ("timed_runs", ctypes.c_uint32)]
 
 CLASS_NAMES = "R2,R4,R8,R16,H16,W2,W4,W8,W16,M1,M2,BIG".split(",")
 CLASS_KERNELS = {  # the HIP kernel behind each class, as rocprofv3 prints it
@@ -502,6 +503,10 @@ class Stream:
             _ptr(lengths, ctypes.c_uint32) if lengths.size else None, lengths.shape[0],
             min(int(coverage), 0xFFFFFFFF), float(not_coverage), ctypes.byref(res)))
         return _take(self._lib, res)
+
+    def reset(self):
+        """Discard every record committed so far (after a failed ingest)."""
+        _check(self._lib, self._lib.yacrd_stream_reset(self._h))
 
     def stats(self):
         st = _StreamStats()

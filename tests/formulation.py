@@ -449,10 +449,10 @@ def window_screen_regions(intervals, length, cov, nb, W):
     an end == len, which then is that end as well).
     The kernel finds a and b without a sort: W one-position bins counted from the read's smallest start
     pmin upwards (starts only) and W from its largest end pmax downwards (ends only), next to the nb
-    coarse bins of 2^sh positions that hold every other event.  When every interval is at least W long
-    no end lies inside the head window and no start inside the tail window, so in event order the read
-    is [head window: F starts][coarse bins][tail window: G ends], and a coarse-counted start of bin i
-    has at least F + (starts of bins < i) - (ends of bins <= i) intervals open in front of it.
+    coarse bins of 2^sh positions that hold every other event.  When no end lies inside the head window
+    and no start inside the tail window (smallest end >= pmin + W, largest start <= pmax - W), in event
+    order the read is [head window: F starts][coarse bins][tail window: G ends], and a coarse-counted
+    start of bin i has at least F + (starts of bins < i) - (ends of bins <= i) intervals open in front of it.
     Returns None when the screen does not apply (the kernel then defers the read to the sort)."""
     n = len(intervals)
     if n == 0:
@@ -461,11 +461,13 @@ def window_screen_regions(intervals, length, cov, nb, W):
         return None
     if n <= cov:  # never more than cov intervals open: nothing is flagged, the whole read is bad
         return [(0, length)]
-    if n < 2 or any(e - s < W for s, e in intervals):
+    if n < 2:
         return None
     sh = bin_shift(length, nb)
     pmin = min(s for s, e in intervals)
     pmax = max(e for s, e in intervals)
+    if min(e for s, e in intervals) - pmin < W or pmax - max(s for s, e in intervals) < W:
+        return None
     S, E = [0] * nb, [0] * nb
     FH, FT = [0] * W, [0] * W
     for s, e in intervals:
@@ -498,3 +500,68 @@ def window_screen_regions(intervals, length, cov, nb, W):
             bb = pmax - i
             break
     return ([(0, a)] if a != 0 else []) + ([(bb, length)] if bb != length else [])
+
+
+def unified_screen_regions(intervals, length, cov, nb, W):
+    """screen_wg.h / screen_big.h: the order-statistics screen with ONE position map for starts and ends,
+        idx(x) = min(dx, W) + (dx >> sh) + max(dx - T, 0),   dx = x - pmin,  T = (pmax - pmin) - W,  2^sh >= W:
+    a bin per position in the first W and the last W positions of the covered span, coarse blocks of 2^sh
+    positions in between, monotone in x.  With cs / ce the running counts of starts / ends in bin order:
+      * a = position of the bin where cs reaches cov + 1: it must be a head-window bin, with no end at or
+        before it (src/stack.rs:83-89 then assigns first_covered at exactly the first cov + 1 starts);
+      * b = position of the bin where the count of ends from the top reaches cov + 1: a tail-window bin
+        (the tail loop :93-105 stops there);
+      * every bin that holds a start beyond the first cov + 1 must have more than cov intervals open even
+        after all of its own ends: cs_before - ce_through > cov.
+    Unlike window_screen_regions (the register classes) it tolerates intervals shorter than W anywhere —
+    a read of thousands of intervals nearly always has one — because starts inside the tail window and ends
+    inside the head window have bins of their own.  None = not decided here."""
+    n = len(intervals)
+    if n == 0:
+        return [(0, length)] if length != 0 else []
+    # (zero-length intervals are taken: where more than cov intervals are open on both sides of one it changes
+    # nothing — its start is not low, its flagged end is superseded before the next low start — and the
+    # tests below put it nowhere else: as an end it may not lie at or before a, as a start its bin must be deep)
+    if any(not (0 <= s <= e <= length) for s, e in intervals) or length >= 2**30 - 1:
+        return None
+    # (0, 0) intervals are inert in the reference — popped at once, their pop re-assigns last_covered = 0 while
+    # it still is 0, their low start sets first_covered = 0 — and are left out of every count
+    intervals = [iv for iv in intervals if iv != (0, 0)]
+    n = len(intervals)
+    if n < 2 or n <= cov:
+        return None
+    pmin = min(s for s, e in intervals)
+    pmax = max(e for s, e in intervals)
+    span = pmax - pmin
+    if span < 2 * W:
+        return None
+    sh = bin_shift(length, nb)
+    while (1 << sh) < W:
+        sh += 1
+    T = span - W
+
+    def idx(x):
+        dx = x - pmin
+        return min(dx, W) + (dx >> sh) + max(dx - T, 0)
+
+    nbins = idx(pmax) + 1
+    assert nbins <= 2 * W + nb
+    S, E = [0] * nbins, [0] * nbins
+    for s, e in intervals:
+        S[idx(s)] += 1
+        E[idx(e)] += 1
+    k1 = cov + 1
+    # a / b: the kernel walks the head window upwards from pmin (start bins) and the tail window downwards
+    # from pmax (end bins, idx(pmax - d)) until the running count reaches cov + 1
+    a = sorted(s for s, e in intervals)[cov]
+    b = sorted(e for s, e in intervals)[n - 1 - cov]
+    if a - pmin >= W or pmax - b >= W or any(e <= a for s, e in intervals):
+        return None
+    cs = ce = 0
+    for i in range(nbins):
+        cs_ex = cs
+        cs += S[i]
+        ce += E[i]
+        if S[i] and cs_ex >= k1 and not (cs_ex - ce > cov):
+            return None
+    return ([(0, a)] if a != 0 else []) + ([(b, length)] if b != length else [])

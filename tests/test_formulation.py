@@ -203,3 +203,54 @@ def test_window_screen_tiny_exhaustive():
                     for nb, W in ((2, 1), (2, 2), (4, 1), (4, 3)):
                         got = window_screen_regions(list(iv), L, cov, nb, W)
                         assert got is None or got == want, (iv, L, cov, nb, W)
+
+
+def test_unified_screen_matches_oracle():
+    """The workgroup / device-wide screen (one position map for starts and ends): wherever it decides, it
+    equals the oracle — short intervals anywhere, starts inside the tail window, ends inside the head
+    window, ties, windows, tiny W."""
+    from formulation import unified_screen_regions
+    rng = np.random.default_rng(4242)
+    n_fired = n_total = 0
+    for it in range(1500):
+        L = int(rng.integers(2, 600)) if it % 3 == 0 else int(rng.integers(600, 50000))
+        n = int(rng.integers(1, 30)) if it % 4 == 0 else int(rng.integers(30, 400))
+        jitter = (0.0, 1.0, 5.0, 30.0, 100.0)[it % 5]
+        iv = _pile_read(rng, n, L, jitter)
+        if it % 6 == 1:  # a few one-position intervals at the very ends and in the middle
+            iv += [(L - 1, L), (0, 1), (L // 2, L // 2 + 1)][: int(rng.integers(1, 4))]
+        if it % 5 == 2:  # zero-length intervals: in the piles, in the middle, doubled, at 0 and at len
+            for _ in range(int(rng.integers(1, 5))):
+                j = int(rng.integers(0, len(iv)))
+                p0 = (iv[j][0], iv[j][1], 0, 0, L, L // 2, L // 2)[int(rng.integers(0, 7))]
+                iv.append((p0, p0))
+        if it % 11 == 0:
+            g = max(1, L // 8)
+            iv = [(min((s // g) * g, L - 1), min(max((e // g) * g, (s // g) * g + 1), L)) for s, e in iv]
+            iv = [(s, max(e, s + 1)) for s, e in iv]
+        if it % 7 == 3:
+            w0, w1 = L // 3, max(L // 3 + 2, 2 * L // 3)
+            iv = [(min(max(s, w0), w1 - 1), min(max(e, min(max(s, w0), w1 - 1) + 1), w1)) for s, e in iv]
+        for cov in (0, 1, 4, 9, 50, 400):
+            want = oracle.compute_bad_part(iv, L, cov)
+            for nb, W in ((256, 128), (16, 32), (64, 4), (4, 1), (8, 5), (1024, 512)):
+                got = unified_screen_regions(iv, L, cov, nb, W)
+                n_total += 1
+                if got is not None:
+                    n_fired += 1
+                    assert got == want, (iv, L, cov, nb, W)
+    assert n_fired > n_total // 6
+
+
+def test_unified_screen_tiny_exhaustive():
+    import itertools
+    from formulation import unified_screen_regions
+    for L in range(1, 8):
+        pairs = [(s, e) for s in range(L + 1) for e in range(s, L + 1)]  # zero-length ones included
+        for k in range(1, 4):
+            for iv in itertools.combinations_with_replacement(pairs, k):
+                for cov in range(0, 3):
+                    want = oracle.compute_bad_part(list(iv), L, cov)
+                    for nb, W in ((2, 1), (4, 1), (4, 2), (8, 3)):
+                        got = unified_screen_regions(list(iv), L, cov, nb, W)
+                        assert got is None or got == want, (iv, L, cov, nb, W)

@@ -289,16 +289,17 @@ def test_class_prediction_is_validated(flags):
             assert_same(ref.run(*csr, 3, 0.4), want, "unpredicted run %d" % rep)
 
 
-def _crafted_screen_reads():
+def _crafted_screen_reads(ns=(65, 100, 128, 129, 200, 256), Ls=(1, 7, 15, 16, 17, 33, 1000, 65537, 10**6),
+                          steps=(1, 3, 6, 7, 8, 15, 16, 31, 32, 33, 200)):
     """Reads on the edges of the healthy-read screen: n in the R16 / H16 classes
-    (65..256 intervals), piles of k identical or nested intervals around k = c, c + 1, c + 2, windows
-    (pmin > 0, pmax < len), one hole, unbalanced piles, lengths below the bin count, ends at len."""
+    (65..256 intervals) by default, piles of k identical or nested intervals around k = c, c + 1, c + 2,
+    windows (pmin > 0, pmax < len), one hole, unbalanced piles, lengths below the bin count, ends at len."""
     reads = []
 
     def pad(iv, n, L):  # fill up to n intervals with deep copies of the first interval
         return iv + [iv[0]] * (n - len(iv))
-    for n in (65, 100, 128, 129, 200, 256):
-        for L in (1, 7, 15, 16, 17, 33, 1000, 65537, 10**6):
+    for n in ns:
+        for L in Ls:
             full = (0, L)
             reads.append(([full] * n, L))                                   # everything spans everything
             if L >= 4:
@@ -318,7 +319,7 @@ def _crafted_screen_reads():
                 # spread piles (round 3: the screen works on order statistics): the j-th dovetail starts at
                 # j * step and the j-th from the other side ends at L - j * step, for steps that put the
                 # (c+1)-th of them inside, on the edge of and beyond the screen's windows (32 positions)
-                for step in (1, 3, 6, 7, 8, 15, 16, 31, 32, 33, 200):
+                for step in steps:
                     for k in (3, 5, 6, 12):
                         if (k - 1) * step + 320 >= L - 320 - k:
                             continue
@@ -370,6 +371,63 @@ def test_screen_on_jittered_profiles(prof, cov):
                 if flags == yacrd_amd.F_ALWAYS_DEFER and sflags == host.SYNTH_F_JITTER and cov in (3, 4):
                     assert t["deferred_reads"] <= in_classes // 10, (t["deferred_reads"], in_classes)
                     assert t["prefiltered_reads"] >= in_classes * 9 // 10
+
+
+@pytest.mark.parametrize("cov", [0, 4, 5, 11, 300, 0xFFFFFFFF])
+def test_workgroup_screen_edges(cov):
+    """The same edges for the workgroup classes' screen (screen_wg.h: one read per workgroup, 128-position
+    windows): reads of 513 .. 16 384 intervals, one or two register chunks, windows' edges at 127 / 128 / 129."""
+    reads = _crafted_screen_reads(ns=(513, 4096, 4097, 8192, 8193, 16384), Ls=(15, 1000, 65537, 10**6),
+                                  steps=(1, 7, 31, 32, 33, 42, 43, 127, 128, 129))
+    offsets = np.zeros(len(reads) + 1, np.uint64)
+    offsets[1:] = np.cumsum([len(iv) for iv, _ in reads])
+    intervals = np.array([p for iv, _ in reads for p in iv], dtype=np.uint32)
+    lengths = np.array([L for _, L in reads], dtype=np.uint32)
+    want = oracle.run(offsets, intervals, lengths.astype(np.uint64), cov, 0.4, n_threads=8)
+    for flags in (0, yacrd_amd.F_NO_PREFILTER):
+        with yacrd_amd.Engine(flags=flags | yacrd_amd.F_COUNT_PREFILTERED) as e:
+            assert_same(e.run(offsets, intervals, lengths, cov, 0.4), want, "cov %d flags %d" % (cov, flags))
+            if flags == 0 and cov <= 11:
+                assert e.timing()["prefiltered_reads"] > len(reads) // 10  # the screen fires
+
+
+@pytest.mark.parametrize("cov", [0, 4, 600])
+def test_device_wide_screen_edges(cov):
+    """screen_big.h (reads of more than 16 384 intervals, 512-position windows): piles spread so that the
+    (c+1)-th start / end lies inside, on the edge of and beyond the windows, a read covered only inside a
+    window, zero-length intervals in the deep middle / in a pile / doubled, a one-position interval at the
+    very end (a start inside the tail window), a shallow block in the middle, reads the screen must refuse."""
+    rng = np.random.default_rng(99)
+    reads = []
+    L = 300000
+    for n in (16385, 20000, 70000):
+        deep = [(int(s), int(s) + 150000) for s in rng.integers(600, 140000, size=n - 40)]
+        for step in (1, 100, 511, 512, 513, 5000):
+            left = [(j * step, L - 90000 - j) for j in range(20)]
+            right = [(80000 + j, L - j * step) for j in range(20)]
+            base = left + deep + right
+            reads.append((base, L))
+            reads.append((base[:-1] + [(L - 1, L)], L))                         # a start inside the tail window
+            reads.append((base[:-2] + [(150000, 150000)] * 2, L))                # zero-length, doubled, where the read is deep
+            reads.append((base[:-1] + [(0, 0)], L))                             # ... at position 0
+            reads.append((base[:-1] + [(step, step)], L))                       # ... inside the head pile
+            reads.append((base[:-1] + [(3, 2)], L))                             # a reversed interval: the exact path's
+        win = [(100000 + int(a), 200000 - int(b)) for a, b in rng.integers(0, 300, size=(n, 2))]
+        reads.append((win, L))                                                  # covered only inside a window
+        holed = [(int(s), int(s) + 60000) for s in rng.integers(0, 80000, size=n // 2)] + \
+                [(int(s), int(s) + 60000) for s in rng.integers(160000, 240000, size=n - n // 2)]
+        reads.append((holed, L))                                                # nothing covers the middle
+    offsets = np.zeros(len(reads) + 1, np.uint64)
+    offsets[1:] = np.cumsum([len(iv) for iv, _ in reads])
+    intervals = np.array([p for iv, _ in reads for p in iv], dtype=np.uint32)
+    lengths = np.array([L for _, L in reads], dtype=np.uint32)
+    want = oracle.run(offsets, intervals, lengths.astype(np.uint64), cov, 0.4, n_threads=8)
+    for flags in (0, yacrd_amd.F_NO_PREFILTER):
+        with yacrd_amd.Engine(flags=flags | yacrd_amd.F_COUNT_PREFILTERED) as e:
+            assert_same(e.run(offsets, intervals, lengths, cov, 0.4), want, "cov %d flags %d" % (cov, flags))
+            assert_same(e.run(offsets, intervals, lengths, cov, 0.4), want, "cov %d flags %d, again" % (cov, flags))
+            if flags == 0 and cov <= 4:
+                assert e.timing()["prefiltered_reads"] > len(reads) // 6  # the screen fires
 
 
 def test_deferral_rate_swings_between_batches():

@@ -60,6 +60,9 @@ struct Counters {
     u32 scan_done;           // workgroups of the scan kernel that finished
     u32 prefiltered;         // reads that took the pre-filtered sort (only counted when asked)
     u32 over_med;            // M2 reads whose filtered keys do not fit the 256-thread kernel's LDS
+    u32 fb_med[2];           // M1 / M2 reads the workgroup screen (screen_wg.h) left to the trimming filter + sort
+    u32 fb_big;              // BIG reads the device-wide screen (screen_big.h) left to sweep_big_trim.h / sweep_big.h
+    u32 bs_chunks;           // chunks of the device-wide screen (written by its setup kernel)
     u64 total_regions;       // G, written by the last scan workgroup
     // reads the screen deferred and finish_compact_kernel sorted, and their intervals: one atomic each per
     // workgroup of 1024 reads.  (Counting where they are found does not work on this 8-XCD part:

@@ -29,6 +29,8 @@
 #include "sweep_lds.h"
 #include "sweep_wave.h"
 #include "finish_compact.h"
+#include "screen_wg.h"
+#include "screen_big.h"
 
 using namespace yke;
 
@@ -346,7 +348,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     }
 
     const u32 nb = (n_reads + yk::kScanBlock - 1) / yk::kScanBlock;
-    constexpr int kLists = yk::CLS_COUNT + 4; // class lists + three rejection lists + M2 overflow
+    constexpr int kLists = yk::CLS_COUNT + 7; // class lists + three rejection lists + M2 overflow + what the screens leave of M1 / M2 / BIG
     HIP_TRY(e->lists.reserve((size_t)kLists * n_reads * sizeof(u32)));
     const size_t ctrl_bytes = (sizeof(yk::Counters) + (size_t)nb * sizeof(u64) + 255) & ~(size_t)255;
     e->ctrl_cur ^= 1;
@@ -367,6 +369,8 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     auto list_of = [&](int i) { return lists + (size_t)i * n_reads; };
     u32 *rej_small = list_of(yk::CLS_COUNT), *rej_med = list_of(yk::CLS_COUNT + 1),
         *rej_big = list_of(yk::CLS_COUNT + 2), *over_med = list_of(yk::CLS_COUNT + 3);
+    u32 *const fb_med[2] = {list_of(yk::CLS_COUNT + 4), list_of(yk::CLS_COUNT + 5)};
+    u32 *const fb_big = list_of(yk::CLS_COUNT + 6);
     yk::Counters *ctr = e->ctrl2[cur].as<yk::Counters>();
     const bool full = (e->flags & YACRD_F_TIMING_FULL) != 0;
     const int xm = (e->flags & YACRD_F_XLANE_DS) ? 1 : 0;
@@ -465,7 +469,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
 
     bool fused_marked = false, screened = false;
     // sweeps of the classes in `set` (what the register sweeps reject is looked at after the final sync)
-    auto launch_sweeps = [&](const LaunchSet &set) -> int {
+    auto launch_sweeps = [&](const LaunchSet &set, bool again = false) -> int {
         sa.rej_list = rej_small;
         sa.rej_count = &ctr->rej_small;
         // the row / half-wavefront classes in one launch
@@ -567,38 +571,46 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         sa.first = 0;
         if (full && timing_on) HIP_TRY(hipEventRecord(e->ev[EV_SMALL], e->stream));
 
-        if (set.n[yk::CLS_MED1]) { // one read per workgroup, LDS resident
-            HIP_TRY(before_class(yk::CLS_MED1));
-            sa.list = list_of(yk::CLS_MED1);
-            sa.list_n = &ctr->n[yk::CLS_MED1];
-            sa.rej_list = rej_med;
-            sa.rej_count = &ctr->rej_med;
-            const u32 grid = (u32)std::min<uint64_t>(set.n[yk::CLS_MED1], (uint64_t)e->num_cu * 4);
-            hipLaunchKernelGGL((yk::sweep_lds_kernel<256, (int)yk::kMedium1Events>), dim3(grid),
-                               dim3(256), 0, e->stream, sa);
-            HIP_TRY(mark_class(yk::CLS_MED1));
-        }
-        if (set.n[yk::CLS_MED2]) {
-            HIP_TRY(before_class(yk::CLS_MED2));
-            sa.list = list_of(yk::CLS_MED2);
-            sa.list_n = &ctr->n[yk::CLS_MED2];
-            sa.rej_list = rej_big;
-            sa.rej_count = &ctr->rej_big;
+        // One read per workgroup.  First the healthy-read screen (screen_wg.h: the read in registers, one pass,
+        // closed form); what it cannot finish lands in a fallback list for the trimming filter + LDS sort.
+        for (int k = 0; k < 2; k++) {
+            const int cls = k == 0 ? yk::CLS_MED1 : yk::CLS_MED2;
+            if (!set.n[cls]) continue;
+            HIP_TRY(before_class(cls));
+            sa.list = list_of(cls);
+            sa.list_n = &ctr->n[cls];
+            if (sa.prefilter) {
+                if (again) HIP_TRY(hipMemsetAsync(&ctr->fb_med[k], 0, sizeof(u32), e->stream)); // (its entries are done)
+                sa.over_list = fb_med[k];
+                sa.over_count = &ctr->fb_med[k];
+                const u32 gs = (u32)std::min<uint64_t>(set.n[cls], (uint64_t)e->num_cu * 4);
+                hipLaunchKernelGGL(yk::screen_wg_kernel, dim3(gs), dim3(yk::kWsT), 0, e->stream, sa);
+                sa.list = fb_med[k];
+                sa.list_n = &ctr->fb_med[k];
+            }
+            sa.rej_list = k == 0 ? rej_med : rej_big;
+            sa.rej_count = k == 0 ? &ctr->rej_med : &ctr->rej_big;
             sa.over_list = over_med;
             sa.over_count = &ctr->over_med;
-            if (sa.prefilter) {
-                // first through the 256-thread kernel (five workgroups per CU): a read whose
-                // filtered keys fit its 8192-key array is done there, the others land in over_med
-                const u32 g256 = (u32)std::min<uint64_t>(set.n[yk::CLS_MED2], (uint64_t)e->num_cu * 5);
-                hipLaunchKernelGGL((yk::sweep_lds_kernel<256, (int)yk::kMedium1Events>), dim3(g256),
-                                   dim3(256), 0, e->stream, sa);
-                sa.list = over_med;
-                sa.list_n = &ctr->over_med;
+            if (k == 0) {
+                const u32 grid = (u32)std::min<uint64_t>(set.n[cls], (uint64_t)e->num_cu * 4);
+                hipLaunchKernelGGL((yk::sweep_lds_kernel<256, (int)yk::kMedium1Events>), dim3(grid), dim3(256), 0,
+                                   e->stream, sa);
+            } else {
+                if (sa.prefilter) {
+                    // first through the 256-thread kernel (five workgroups per CU): a read whose
+                    // filtered keys fit its 8192-key array is done there, the others land in over_med
+                    const u32 g256 = (u32)std::min<uint64_t>(set.n[cls], (uint64_t)e->num_cu * 5);
+                    hipLaunchKernelGGL((yk::sweep_lds_kernel<256, (int)yk::kMedium1Events>), dim3(g256), dim3(256), 0,
+                                       e->stream, sa);
+                    sa.list = over_med;
+                    sa.list_n = &ctr->over_med;
+                }
+                const u32 grid = (u32)std::min<uint64_t>(set.n[cls], (uint64_t)e->num_cu);
+                hipLaunchKernelGGL((yk::sweep_lds_kernel<1024, (int)yk::kMedium2Events>), dim3(grid), dim3(1024), 0,
+                                   e->stream, sa);
             }
-            const u32 grid = (u32)std::min<uint64_t>(set.n[yk::CLS_MED2], (uint64_t)e->num_cu);
-            hipLaunchKernelGGL((yk::sweep_lds_kernel<1024, (int)yk::kMedium2Events>), dim3(grid),
-                               dim3(1024), 0, e->stream, sa);
-            HIP_TRY(mark_class(yk::CLS_MED2));
+            HIP_TRY(mark_class(cls));
         }
         if (full && timing_on) HIP_TRY(hipEventRecord(e->ev[EV_MED], e->stream));
 
@@ -612,13 +624,43 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         }
         return YACRD_OK;
     };
-    // reads beyond the LDS classes (or every read under YACRD_F_FORCE_GENERAL); host-driven
-    auto launch_huge = [&](u32 count, u64 *iv_total) -> int {
-        return (e->flags & YACRD_F_FORCE_GENERAL)
-                   ? run_general_global(e, d_off, d_iv, d_len, list_of(yk::CLS_GENERAL), count, cov,
-                                        e->stream, iv_total)
-                   : run_big(e, d_off, d_iv, d_len, list_of(yk::CLS_GENERAL), count, cov, e->stream,
-                             iv_total);
+    // Reads beyond the LDS classes (the host knows their number and their intervals: batches that hold such
+    // reads are never predicted).  The device-wide healthy-read screen (screen_big.h) first; what it cannot
+    // decide lands in fb_big and takes the trimming filter / the segmented sort after the final sync.
+    // YACRD_F_FORCE_GENERAL / YACRD_F_NO_PREFILTER: the host-driven paths directly.
+    bool big_screened = false;
+    auto launch_huge = [&](u32 count, u64 iv_big, u64 *iv_total) -> int {
+        if (e->flags & YACRD_F_FORCE_GENERAL)
+            return run_general_global(e, d_off, d_iv, d_len, list_of(yk::CLS_GENERAL), count, cov, e->stream, iv_total);
+        if (!sa.prefilter)
+            return run_big(e, d_off, d_iv, d_len, list_of(yk::CLS_GENERAL), count, cov, e->stream, iv_total);
+        if (iv_total) *iv_total = iv_big;
+        const u64 max_chunks = iv_big / yk::kBsChunk + count;
+        if (max_chunks >= 0x7FFFFFFFull) return fail(YACRD_EINVAL, "too many intervals in reads beyond 16384");
+        HIP_TRY(e->bs_seg.reserve((size_t)count * sizeof(yk::BsSeg)));
+        HIP_TRY(e->bs_chunk.reserve((size_t)max_chunks * sizeof(u32)));
+        HIP_TRY(e->bs_hist.reserve((size_t)count * 2 * yk::kBsBins * sizeof(u32)));
+        yk::BsArgs ba;
+        ba.off = d_off, ba.iv = d_iv, ba.len = d_len;
+        ba.list = list_of(yk::CLS_GENERAL);
+        ba.list_n = &ctr->n[yk::CLS_GENERAL];
+        ba.seg = e->bs_seg.as<yk::BsSeg>();
+        ba.chunk_seg = e->bs_chunk.as<u32>();
+        ba.n_chunks = &ctr->bs_chunks;
+        ba.hist = e->bs_hist.as<u32>();
+        ba.max_chunks = (u32)max_chunks, ba.max_segs = count;
+        ba.cov = cov, ba.count_healthy = sa.prefilter == 2 ? 1u : 0u;
+        ba.stage = sa.stage, ba.counts = sa.counts;
+        ba.fb_list = fb_big, ba.fb_count = &ctr->fb_big;
+        ba.ctr = ctr;
+        if (big_screened) HIP_TRY(hipMemsetAsync(&ctr->fb_big, 0, sizeof(u32), e->stream)); // (a second pass: its entries are done)
+        HIP_TRY(hipMemsetAsync(ba.hist, 0, (size_t)count * 2 * yk::kBsBins * sizeof(u32), e->stream));
+        hipLaunchKernelGGL(yk::bs_setup_kernel, dim3(1), dim3(1024), 0, e->stream, ba);
+        hipLaunchKernelGGL(yk::bs_minmax_kernel, dim3((u32)max_chunks), dim3(yk::kBsT), 0, e->stream, ba);
+        hipLaunchKernelGGL(yk::bs_hist_kernel, dim3((u32)max_chunks), dim3(yk::kBsT), 0, e->stream, ba);
+        hipLaunchKernelGGL(yk::bs_verdict_kernel, dim3(count), dim3(yk::kBsVT), 0, e->stream, ba);
+        big_screened = true;
+        return YACRD_OK;
     };
 
     for (int cls = 0; cls < yk::CLS_GENERAL; cls++)
@@ -628,7 +670,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     if (rc) return rc;
     u64 gen_iv = 0;
     if (!predicted && c0.n[yk::CLS_GENERAL]) {
-        rc = launch_huge(c0.n[yk::CLS_GENERAL], &gen_iv);
+        rc = launch_huge(c0.n[yk::CLS_GENERAL], c0.iv[yk::CLS_GENERAL], &gen_iv);
         if (rc) return rc;
     }
     if (full) HIP_TRY(hipEventRecord(e->ev[EV_GEN], e->stream));
@@ -677,8 +719,8 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
             }
         if (any_missing || c0.n[yk::CLS_GENERAL]) {
             if (!redo) HIP_TRY(hipEventRecord(e->ev[EV_X0], e->stream));
-            if (any_missing && (rc = launch_sweeps(missing))) return rc;
-            if (c0.n[yk::CLS_GENERAL] && (rc = launch_huge(c0.n[yk::CLS_GENERAL], &gen_iv))) return rc;
+            if (any_missing && (rc = launch_sweeps(missing, true))) return rc;
+            if (c0.n[yk::CLS_GENERAL] && (rc = launch_huge(c0.n[yk::CLS_GENERAL], c0.iv[yk::CLS_GENERAL], &gen_iv))) return rc;
             // the rejection counters may have grown: bring them home before looking at rej_big
             HIP_TRY(hipMemcpyAsync(e->h_ctr, ctr, sizeof(yk::Counters), hipMemcpyDeviceToHost,
                                    e->stream));
@@ -704,6 +746,16 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         if (!redo) HIP_TRY(hipEventRecord(e->ev[EV_X0], e->stream));
         exact_small();
         rej_small_done = e->h_ctr->rej_small;
+        redo = true;
+    }
+    if (big_screened && e->h_ctr->fb_big) { // BIG reads the screen could not decide: trimming filter / segmented sort
+        if (!redo) HIP_TRY(hipEventRecord(e->ev[EV_X0], e->stream));
+        rc = run_big(e, d_off, d_iv, d_len, fb_big, e->h_ctr->fb_big, cov, e->stream, nullptr);
+        if (rc) return rc;
+        // (its rejections — a degenerate interval in a huge read — went the exact way inside run_big; the other
+        // rejection counters may have grown)
+        HIP_TRY(hipMemcpyAsync(e->h_ctr, ctr, sizeof(yk::Counters), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
         redo = true;
     }
     const u32 n_rej_big = e->h_ctr->rej_big;
@@ -1040,7 +1092,7 @@ void yacrd_engine_destroy(yacrd_engine *e)
     }
     DevBuf *bufs[] = {&e->in_off, &e->in_iv, &e->in_len, &e->lists, &e->ctrl2[0], &e->ctrl2[1], &e->stage,
                       &e->counts, &e->gen_sizes, &e->gen_scratch_off,
-                      &e->gen_scratch, &e->big_tab, &e->big_keys, &e->big_redo, &e->bt_tab, &e->bt_hist, &e->bt_cur, &e->bt_keys,
+                      &e->gen_scratch, &e->big_tab, &e->big_keys, &e->big_redo, &e->bt_tab, &e->bt_hist, &e->bt_cur, &e->bt_keys, &e->bs_seg, &e->bs_chunk, &e->bs_hist,
                       &e->bad_offsets, &e->bad_regions, &e->read_type};
     for (DevBuf *b : bufs) b->release();
     if (e->h_ctr) (void)hipHostFree(e->h_ctr);

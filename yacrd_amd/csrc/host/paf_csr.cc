@@ -28,6 +28,8 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <emmintrin.h>
+
 #include <algorithm>
 #include <atomic>
 #include <cerrno>
@@ -113,6 +115,19 @@ using Rec = yacrd_ovl_rec; // a / b hold IdTable handles until the global number
 
 // Zero-filled memory for the id table, carved out of 64 MiB anonymous regions with MADV_HUGEPAGE:
 // the table is probed at random, and on 4 KiB pages every probe also misses the TLB.
+inline uint64_t load64(const char *p)
+{
+    uint64_t w;
+    std::memcpy(&w, p, 8);
+    return w;
+}
+inline uint64_t load32(const char *p)
+{
+    uint32_t w;
+    std::memcpy(&w, p, 4);
+    return w;
+}
+
 struct HugePool {
     std::mutex mu;
     char *cur = nullptr;
@@ -173,18 +188,33 @@ struct IdTable {
         uint64_t first_len; // length given at first_pos (written under the lock)
         uint32_t nlen;
     };
-    struct Slot {
+    // One cache line per slot: the id's first bytes and a copy of its first position sit next to the hash, so
+    // a hit on an id of up to kInline bytes (a 36-character UUID fits) touches this line and nothing else (with
+    // the name and the position behind two more pointers a lookup was three dependent cache misses: 60 % of the
+    // parse).  `pos_hint` is never below the entry's true first position (both are lowered under the shard lock,
+    // the entry first), so `pos >= pos_hint` is a safe reason to skip the lock.
+    static constexpr uint32_t kInline = 36;
+    struct alignas(64) Slot {
         uint64_t hash;
-        uint32_t nlen;
         std::atomic<uint32_t> idx1; // entry number + 1, 0 = empty; stored last (release)
+        uint32_t nlen;
+        std::atomic<uint64_t> pos_hint;
+        uint32_t handle;            // what intern() returns for this id
+        char name[kInline];
     };
+    static_assert(sizeof(Slot) == 64, "one cache line");
+    // An index is one word — the slots' address (64-byte aligned) | log2 of their number — so that a shard
+    // publishes a bigger one with one store and a lookup finds its first slot from one load.
     struct Index {
         uint32_t mask;
         Slot *slots;
+        explicit Index(uint64_t w = 0) : mask(w ? (1u << (w & 63u)) - 1u : 0u), slots(reinterpret_cast<Slot *>(w & ~(uint64_t)63)) {}
+        explicit operator bool() const { return slots != nullptr; }
+        uint64_t word() const { return slots ? (reinterpret_cast<uint64_t>(slots) | (uint64_t)__builtin_ctz(mask + 1u)) : 0; }
     };
     struct alignas(64) Shard {
         alignas(64) std::atomic<bool> lock{false};
-        alignas(64) std::atomic<Index *> index{nullptr};
+        alignas(64) std::atomic<uint64_t> index{0}; // Index::word()
         Hot *hot[kBlocks] = {};
         Cold *cold[kBlocks] = {};
         uint32_t handle_base[kBlocks] = {}; // handle of the block's first entry
@@ -226,56 +256,81 @@ struct IdTable {
         locate(idx, k, at);
         return sh.handle_base[k] + at;
     }
-    Index *new_index(uint32_t cap)
+    Index new_index(uint32_t cap)
     {
-        Index *ix = (Index *)pool.alloc(sizeof(Index));
-        Slot *sl = (Slot *)pool.alloc((size_t)cap * sizeof(Slot)); // all-zero = empty slots
-        ix->mask = cap - 1;
-        ix->slots = sl;
+        Index ix;
+        ix.slots = (Slot *)pool.alloc((size_t)cap * sizeof(Slot)); // all-zero = empty slots
+        ix.mask = cap - 1;
         return ix;
     }
     // lock held.  Puts entry idx into ix (no duplicates possible).
-    static void place(Index *ix, uint64_t hash, uint32_t nlen, uint32_t idx)
+    static void place(const Index &ix, uint64_t hash, uint32_t nlen, uint32_t idx, const char *name, uint64_t first_pos,
+                      uint32_t handle)
     {
-        uint32_t s2 = (uint32_t)hash & ix->mask;
-        while (ix->slots[s2].idx1.load(std::memory_order_relaxed)) s2 = (s2 + 1) & ix->mask;
-        ix->slots[s2].hash = hash;
-        ix->slots[s2].nlen = nlen;
-        ix->slots[s2].idx1.store(idx + 1, std::memory_order_release);
+        uint32_t s2 = (uint32_t)hash & ix.mask;
+        while (ix.slots[s2].idx1.load(std::memory_order_relaxed)) s2 = (s2 + 1) & ix.mask;
+        Slot &sl = ix.slots[s2];
+        sl.hash = hash;
+        sl.nlen = nlen;
+        sl.handle = handle;
+        sl.pos_hint.store(first_pos, std::memory_order_relaxed);
+        std::memcpy(sl.name, name, std::min<size_t>(nlen, kInline));
+        sl.idx1.store(idx + 1, std::memory_order_release);
     }
-    // returns the entry number, or ~0u when absent
-    static uint32_t probe(const Shard &sh, const Index *ix, const char *p, size_t n, uint64_t h)
+    // a slot's inline bytes against an id (n <= kInline bytes are compared here; both sides are readable for
+    // 8 bytes at every offset used: the slot is 64 bytes, an id of >= 8 bytes is read inside itself)
+    static bool same_inline(const char *a, const char *b, size_t n)
     {
-        uint32_t s2 = (uint32_t)h & ix->mask;
+        if (n > kInline) n = kInline;
+        if (n >= 8) {
+            size_t i = 0;
+            for (; i + 8 < n; i += 8)
+                if (load64(a + i) != load64(b + i)) return false;
+            return load64(a + n - 8) == load64(b + n - 8);
+        }
+        return std::memcmp(a, b, n) == 0;
+    }
+    // returns the entry number, or ~0u when absent; `slot` = where it was found
+    static uint32_t probe(const Shard &sh, const Index &ix, const char *p, size_t n, uint64_t h, Slot **slot = nullptr)
+    {
+        uint32_t s2 = (uint32_t)h & ix.mask;
         for (;;) {
-            const Slot &sl = ix->slots[s2];
+            Slot &sl = ix.slots[s2];
             const uint32_t v = sl.idx1.load(std::memory_order_acquire);
             if (!v) return ~0u;
-            if (sl.hash == h && sl.nlen == n && std::memcmp(hot(sh, v - 1).name, p, n) == 0) return v - 1;
-            s2 = (s2 + 1) & ix->mask;
+            if (sl.hash == h && sl.nlen == n && same_inline(sl.name, p, n) &&
+                (n <= kInline || std::memcmp(hot(sh, v - 1).name, p, n) == 0)) {
+                if (slot) *slot = &sl;
+                return v - 1;
+            }
+            s2 = (s2 + 1) & ix.mask;
         }
+    }
+    // the cache line a lookup of hash h will look at first (for prefetching ahead of intern())
+    const void *first_slot(uint64_t h) const
+    {
+        const Index ix(shards[(size_t)(h >> shard_shift)].index.load(std::memory_order_acquire));
+        return ix ? (const void *)&ix.slots[(uint32_t)h & ix.mask] : nullptr;
     }
     // returns the id's handle
     uint32_t intern(const char *p, size_t n, uint64_t h, uint64_t length, uint64_t pos)
     {
         Shard &sh = shards[(size_t)(h >> shard_shift)];
-        const Index *ix = sh.index.load(std::memory_order_acquire);
-        uint32_t idx = ix ? probe(sh, ix, p, n, h) : ~0u;
-        if (idx != ~0u) {
-            uint32_t k, at;
-            locate(idx, k, at);
-            if (pos >= sh.hot[k][at].first_pos.load(std::memory_order_relaxed))
-                return sh.handle_base[k] + at; // the common case: nothing shared is written
-        }
+        const Index ix(sh.index.load(std::memory_order_acquire));
+        Slot *hit = nullptr;
+        uint32_t idx = ix ? probe(sh, ix, p, n, h, &hit) : ~0u;
+        if (idx != ~0u && pos >= hit->pos_hint.load(std::memory_order_relaxed))
+            return hit->handle; // the common case: nothing shared is written, the shard's word and one slot are read
 
         while (sh.lock.exchange(true, std::memory_order_acquire))
             while (sh.lock.load(std::memory_order_relaxed)) __builtin_ia32_pause();
-        Index *cur = sh.index.load(std::memory_order_relaxed);
+        Index cur(sh.index.load(std::memory_order_relaxed));
         if (!cur) {
             cur = new_index(64);
-            sh.index.store(cur, std::memory_order_release);
+            sh.index.store(cur.word(), std::memory_order_release);
         }
-        if (idx == ~0u) idx = probe(sh, cur, p, n, h); // somebody else may have inserted it
+        Slot *cur_slot = nullptr;
+        idx = probe(sh, cur, p, n, h, &cur_slot); // in the CURRENT index (somebody else may have inserted the id meanwhile)
         uint32_t k, at;
         if (idx == ~0u) {
             idx = sh.n_entries;
@@ -309,15 +364,17 @@ struct IdTable {
             sh.name_cur += n;
             sh.name_left -= n;
             sh.n_entries = idx + 1;
-            if ((uint64_t)(idx + 2) * 2 > (uint64_t)cur->mask + 1) { // keep the load below 1/2
-                Index *bigger = new_index((cur->mask + 1) * 2);
+            if ((uint64_t)(idx + 2) * 2 > (uint64_t)cur.mask + 1) { // keep the load below 1/2
+                const Index bigger = new_index((cur.mask + 1) * 2);
                 for (uint32_t k2 = 0; k2 <= idx; k2++) {
                     const Cold &c2 = cold(sh, k2);
-                    place(bigger, c2.hash, c2.nlen, k2);
+                    const Hot &h2 = hot(sh, k2);
+                    place(bigger, c2.hash, c2.nlen, k2, h2.name, h2.first_pos.load(std::memory_order_relaxed),
+                          handle_of(sh, k2));
                 }
-                sh.index.store(bigger, std::memory_order_release);
+                sh.index.store(bigger.word(), std::memory_order_release);
             } else {
-                place(cur, h, (uint32_t)n, idx);
+                place(cur, h, (uint32_t)n, idx, e->name, pos, sh.handle_base[k] + at);
             }
         } else {
             locate(idx, k, at);
@@ -326,6 +383,9 @@ struct IdTable {
                 sh.cold[k][at].first_len = length;
                 e.first_pos.store(pos, std::memory_order_relaxed);
             }
+            // (the slot of the current index follows the entry; slots of replaced indexes keep their larger
+            // hints and send their readers here)
+            if (pos < cur_slot->pos_hint.load(std::memory_order_relaxed)) cur_slot->pos_hint.store(pos, std::memory_order_relaxed);
         }
         const uint32_t handle = sh.handle_base[k] + at;
         sh.lock.store(false, std::memory_order_release);
@@ -481,18 +541,6 @@ inline uint64_t mix64(uint64_t x)
     x ^= x >> 32;
     return x;
 }
-inline uint64_t load64(const char *p)
-{
-    uint64_t w;
-    std::memcpy(&w, p, 8);
-    return w;
-}
-inline uint64_t load32(const char *p)
-{
-    uint32_t w;
-    std::memcpy(&w, p, 4);
-    return w;
-}
 // whole words, then the LAST eight bytes again (overlapping the previous word when n % 8 != 0);
 // short ids take two overlapping 4-byte loads or three single bytes: no byte loops, no calls
 inline uint64_t hash_id(const char *p, size_t n)
@@ -524,8 +572,9 @@ struct Fields { // one overlap record, syntax checked
 // ---- PAF fast path: one forward scan per line ----------------------------------------------------
 // Accepts the plain form of a record (src/io.rs:23-34): 9 leading tab-separated fields, decimal
 // u64 lengths and u32 positions with an optional '+', one-character strand, anything after
-// ignored, no quote at the start of a field.  Whatever it does not accept gets a second look by
-// parse_record_general (quotes, 0x integers, \r inside the line).
+// ignored.  Only for lines that hold neither a '"' nor a '\r' (scan_line says so): a quote may open a
+// quoted field — also in the ignored columns, where it may swallow delimiters — and a lone \r ends a
+// csv record.  Whatever it does not accept gets a second look by parse_record_general (0x integers ...).
 inline bool scan_uint(const char *&p, const char *le, uint64_t limit, uint64_t &out, bool last)
 {
     if (p < le && *p == '+') p++;
@@ -553,10 +602,7 @@ inline bool scan_id(const char *&p, const char *le, const char *&b, size_t &n)
     b = p;
     if (p < le && *p == '"') return false; // quoted field: the general parser's business
     const char *t = p;
-    while (t < le && *t != '\t') { // ids are short: a byte loop beats a memchr call
-        if (*t == '\r') return false; // a lone \r ends a csv record: the general parser's business
-        t++;
-    }
+    while (t < le && *t != '\t') t++; // ids are short: a byte loop beats a memchr call
     if (t == le) return false; // an id must be followed by more fields
     n = (size_t)(t - p);
     p = t + 1;
@@ -569,7 +615,7 @@ inline bool parse_paf_fast(const char *p, const char *le, Fields &f)
     if (!(scan_id(q, le, f.ida, f.na) && scan_uint(q, le, ~0ull, f.la, false) &&
           scan_uint(q, le, 0xFFFFFFFFull, sa, false) && scan_uint(q, le, 0xFFFFFFFFull, ea, false)))
         return false;
-    if (le - q >= 2 && (unsigned char)q[0] < 0x80 && q[0] != '"' && q[0] != '\t' && q[0] != '\r' && q[1] == '\t') {
+    if (le - q >= 2 && (unsigned char)q[0] < 0x80 && q[0] != '\t' && q[1] == '\t') {
         q += 2; // strand: one ASCII character and a tab, the usual case
     } else { // exactly one UTF-8 scalar, then a tab
         const char *t = (const char *)std::memchr(q, '\t', (size_t)(le - q));
@@ -579,29 +625,38 @@ inline bool parse_paf_fast(const char *p, const char *le, Fields &f)
     if (!(scan_id(q, le, f.idb, f.nb) && scan_uint(q, le, ~0ull, f.lb, false) &&
           scan_uint(q, le, 0xFFFFFFFFull, sb, false) && scan_uint(q, le, 0xFFFFFFFFull, eb, true)))
         return false;
-    // The columns after the ninth are ignored, but not their syntax: a lone \r in them ends the csv
-    // record (what follows is another record), and a field that opens with a quote follows the quoting
-    // rules (it may swallow delimiters and the \r).  Eight bytes at a time: any \r or '"' sends the line
-    // to the general parser.
-    {
-        const uint64_t k01 = 0x0101010101010101ull, k80 = 0x8080808080808080ull;
-        auto has = [&](uint64_t w, unsigned char c) {
-            const uint64_t x = w ^ (k01 * c);
-            return ((x - k01) & ~x & k80) != 0;
-        };
-        const char *t = q;
-        for (; t + 8 <= le; t += 8) {
-            const uint64_t w = load64(t);
-            if (has(w, '\r') || has(w, '"')) return false;
-        }
-        for (; t < le; t++)
-            if (*t == '\r' || *t == '"') return false;
-    }
     f.sa = (uint32_t)sa;
     f.ea = (uint32_t)ea;
     f.sb = (uint32_t)sb;
     f.eb = (uint32_t)eb;
     return true;
+}
+
+// ---- one line: where it ends, and whether it holds a character the fast path must not see ('"', '\r').
+// Sixteen bytes at a time (SSE2 is part of x86-64): one pass instead of memchr + a second look at the
+// ignored columns.
+inline const char *scan_line(const char *p, const char *end, bool &special)
+{
+    special = false;
+    const __m128i nl = _mm_set1_epi8('\n'), cr = _mm_set1_epi8('\r'), qt = _mm_set1_epi8('"');
+    unsigned sp = 0;
+    for (; p + 16 <= end; p += 16) {
+        const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(p));
+        const unsigned m_nl = (unsigned)_mm_movemask_epi8(_mm_cmpeq_epi8(v, nl));
+        const unsigned m_sp = (unsigned)_mm_movemask_epi8(_mm_or_si128(_mm_cmpeq_epi8(v, cr), _mm_cmpeq_epi8(v, qt)));
+        if (m_nl) {
+            const unsigned at = (unsigned)__builtin_ctz(m_nl);
+            special = (sp | (m_sp & ((1u << at) - 1u))) != 0;
+            return p + at;
+        }
+        sp |= m_sp;
+    }
+    for (; p < end; p++) {
+        if (*p == '\n') break;
+        sp |= (*p == '\r' || *p == '"') ? 1u : 0u;
+    }
+    special = sp != 0;
+    return p;
 }
 
 // ---- general record parser: csv-crate field syntax, PAF and M4 --------------------------------
@@ -699,7 +754,17 @@ void parse_block(const char *begin, const char *end, uint64_t pos0, int format, 
 {
     std::string scratch;
     const char *p = begin;
-    auto emit = [&](const Fields &f, const char *rec_start) -> bool {
+    // Records are interned in batches: the fast path only tokenises a line, hashes its two ids and asks for the
+    // cache lines their lookups will read first; the lookups of a batch then run over lines that are already on
+    // their way (one at a time each lookup waited for its own miss: 60 % of the parse).
+    constexpr int kBatch = 16;
+    struct Pending {
+        Fields f;
+        uint64_t ha, hb, pos;
+        uint64_t line;
+    } pend[kBatch];
+    int n_pend = 0;
+    auto emit_hashed = [&](const Fields &f, uint64_t ha, uint64_t hb, uint64_t pos) -> bool {
         if (f.la > 0xFFFFFFFFull || f.lb > 0xFFFFFFFFull) {
             res.error = "read length >= 2^32 is not supported by the engine";
             return false;
@@ -708,34 +773,61 @@ void parse_block(const char *begin, const char *end, uint64_t pos0, int format, 
             res.error = out.error;
             return false;
         }
-        const uint64_t pos = (pos0 + (uint64_t)(rec_start - begin)) * 2;
         Rec &r = *out.cur++;
         r.sa = f.sa;
         r.ea = f.ea;
         r.sb = f.sb;
         r.eb = f.eb;
-        // (ids that live in `scratch` are copied by the table before the next record reuses it)
-        r.a = ids.intern(f.ida, f.na, hash_id(f.ida, f.na), f.la, pos);
-        r.b = ids.intern(f.idb, f.nb, hash_id(f.idb, f.nb), f.lb, pos + 1);
+        r.a = ids.intern(f.ida, f.na, ha, f.la, pos);
+        r.b = ids.intern(f.idb, f.nb, hb, f.lb, pos + 1);
         res.records++;
         return true;
+    };
+    auto flush = [&]() -> bool { // the pending records, in line order
+        for (int i = 0; i < n_pend; i++) {
+            if (!emit_hashed(pend[i].f, pend[i].ha, pend[i].hb, pend[i].pos)) {
+                res.error_line = pend[i].line;
+                n_pend = 0;
+                return false;
+            }
+        }
+        n_pend = 0;
+        return true;
+    };
+    auto defer = [&](const Fields &f, const char *rec_start) -> bool { // ids point into the block: they stay valid
+        Pending &q = pend[n_pend];
+        q.f = f;
+        q.ha = hash_id(f.ida, f.na);
+        q.hb = hash_id(f.idb, f.nb);
+        q.pos = (pos0 + (uint64_t)(rec_start - begin)) * 2;
+        q.line = res.lines;
+        if (const void *l = ids.first_slot(q.ha)) __builtin_prefetch(l, 0, 1);
+        if (const void *l = ids.first_slot(q.hb)) __builtin_prefetch(l, 0, 1);
+        return ++n_pend < kBatch || flush();
+    };
+    auto emit = [&](const Fields &f, const char *rec_start) -> bool { // (ids that live in `scratch`: at once, in order)
+        if (!flush()) return false;
+        return emit_hashed(f, hash_id(f.ida, f.na), hash_id(f.idb, f.nb), (pos0 + (uint64_t)(rec_start - begin)) * 2);
     };
     const char *what = format == FMT_PAF ? "Reading of the file in paf format failed"
                                          : "Reading of the file in m4 format failed";
     while (p < end) {
-        const char *eol = (const char *)std::memchr(p, '\n', (size_t)(end - p));
-        if (!eol) eol = end;
+        bool special;
+        const char *eol = scan_line(p, end, special);
         const char *le = eol;
-        if (le > p && le[-1] == '\r') le--;
+        if (le > p && le[-1] == '\r') { // CRLF: the line's own terminator does not count
+            le--;
+            if (special) special = std::memchr(p, '\r', (size_t)(le - p)) != nullptr || std::memchr(p, '"', (size_t)(le - p)) != nullptr;
+        }
         res.lines++;
         if (le == p) { // csv skips empty lines
             p = eol + 1;
             continue;
         }
         Fields f;
-        if (format == FMT_PAF && parse_paf_fast(p, le, f)) {
-            if (!emit(f, p)) {
-                res.error_line = res.lines;
+        if (format == FMT_PAF && !special && parse_paf_fast(p, le, f)) {
+            if (!defer(f, p)) {
+                if (!res.error_line) res.error_line = res.lines;
                 return;
             }
             p = eol + 1;
@@ -758,13 +850,14 @@ void parse_block(const char *begin, const char *end, uint64_t pos0, int format, 
                 return;
             }
             if (!emit(f, s)) {
-                res.error_line = res.lines;
+                if (!res.error_line) res.error_line = res.lines;
                 return;
             }
             s = rec_end;
         }
         p = eol + 1;
     }
+    if (!flush() && !res.error_line) res.error_line = res.lines;
 }
 
 // run fn(task) for task in [0, n_tasks) on up to n_threads threads (dynamic hand-out)

@@ -45,7 +45,8 @@ enum {
     YACRD_EINVAL = 1,  /* bad argument / malformed CSR */
     YACRD_ENODEV = 2,  /* no usable gfx950 device, or HIP runtime error */
     YACRD_ENOMEM = 3,  /* host or device allocation failed */
-    YACRD_EINTERNAL = 4
+    YACRD_EINTERNAL = 4,
+    YACRD_EFALLBACK = 5 /* yacrd_engine_ingest_paf: the input is not for the device parser; use the host parser */
 };
 
 typedef struct yacrd_engine yacrd_engine;
@@ -261,6 +262,35 @@ int yacrd_stream_last_stats(const yacrd_stream *s, yacrd_stream_stats *st);
  * records in the stream: call this before the stream takes another file).  No buffer may be held. */
 int yacrd_stream_reset(yacrd_stream *s);
 void yacrd_stream_close(yacrd_stream *s);
+
+/* ---- PAF text -> read types with the parse on the GPU ------------------------------------------------
+ * Reads2Ovl::init_paf (src/reads2ovl/mod.rs:83-113) + FullMemory (src/reads2ovl/fullmemory.rs:82-90) +
+ * compute_all_bad_part in one call: the host only moves the text (pread chunks -> pinned buffers ->
+ * hipMemcpyAsync), the device parses it (nine tab-separated columns as src/io.rs:23-34 names them), interns the
+ * ids, numbers the reads by first appearance (a read's length = the first one seen), builds the CSR and runs
+ * the engine.  `reads` receives what the report and the editors need to name the reads (host arrays, released
+ * with yacrd_reads_free).  Plain PAF files only; returns YACRD_EFALLBACK (nothing else happened) for whatever
+ * only the host parser handles — a '"' or a lone CR anywhere (csv quoting / record rules), a 0x integer, a
+ * malformed line (the host parser words the error), a read length beyond u32, a file that is not regular:
+ * the caller then takes yacrd_ingest_stream + yacrd_stream_finish. */
+typedef struct {
+    uint64_t n_reads;
+    uint64_t n_records;  /* overlap lines */
+    uint32_t *lengths;   /* [n_reads] */
+    uint64_t *name_off;  /* [n_reads + 1] */
+    char *names;         /* name_off[n_reads] bytes, reads in first-appearance order */
+} yacrd_reads;
+typedef struct {
+    uint64_t text_bytes, n_records, n_reads;
+    float text_ms;   /* file -> pinned -> HBM (wall clock) */
+    float parse_ms;  /* scan + parse + id table on the device */
+    float build_ms;  /* numbering, names, CSR */
+    float run_ms;    /* the engine */
+    float d2h_ms;
+} yacrd_ingest_stats;
+int yacrd_engine_ingest_paf(yacrd_engine *e, const char *path, int n_threads, uint32_t coverage, double not_coverage,
+                            yacrd_result *out, yacrd_reads *reads, yacrd_ingest_stats *stats /* may be NULL */);
+void yacrd_reads_free(yacrd_reads *r);
 
 /* Copy the last device result to host (allocates like yacrd_engine_run). */
 int yacrd_engine_fetch(yacrd_engine *e, yacrd_result *out);

@@ -39,7 +39,8 @@ def test_single_gpu_line_scaled():
     assert sb["parity"].startswith("bit-exact") and sb["roofline"]["timed_launches"] == 20
     assert d["pcie_inclusive"]["h2d_GBps"] > 5 and d["pcie_inclusive"]["reads_per_sec"] < sb["reads_per_sec"]
     e = d["end_to_end"]
-    assert e["overlaps"] == 100000 and e["stream"]["reads_found"] == 2000 and e["overlaps_per_sec"] > 1e6
+    assert e["overlaps"] == 100000 and e["host_parser"]["stream"]["reads_found"] == 2000 and e["overlaps_per_sec"] > 1e6
+    assert e["device_parser"]["same_result_as_host_parser"] and e["device_parser"]["phases"]["reads_found"] == 2000
     ns = d["north_star"]
     assert ns["parity"].startswith("bit-exact") and ns["reads"] == 100000 and "configs[4]" in ns["workload"]
     for k in ("configs[1]", "configs[2]"):

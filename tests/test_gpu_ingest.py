@@ -1,0 +1,115 @@
+"""yacrd_engine_ingest_paf — PAF text to read types with the PARSE on the GPU — against the host parser, the
+oracle's ingest (oracle.parse_paf, pinned on the reference's vectors) and the reference fixture; whatever only the
+host parser handles must come back as NeedsHostParser, never as a wrong answer."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import yacrd_amd
+from yacrd_amd import host
+from cases import assert_same
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    with yacrd_amd.Engine() as e:
+        yield e
+
+
+def _check(engine, path, cov, nc):
+    got, names, lengths, stats = engine.ingest_paf(path, cov, nc)
+    with open(path, newline="") as f:
+        reads = oracle.parse_paf(f.read())
+    w_names, off, iv, ln = oracle.to_csr(reads)
+    assert names == list(w_names), "first-appearance order of the reads"
+    assert np.array_equal(lengths.astype(np.uint64), ln), "first length seen"
+    assert stats["n_reads"] == len(names) and stats["n_records"] * 2 == int(off[-1])
+    want = oracle.run(off, iv, ln, cov, nc, n_threads=4)
+    assert_same(got, want, path)
+    return got, names, lengths, stats
+
+
+def test_reference_fixture(engine, golden_dir):
+    got, names, lengths, _ = _check(engine, os.path.join(golden_dir, "reads.paf"), 0, 0.8)
+    with open(os.path.join(golden_dir, "truth.yacrd")) as f:
+        truth = set(line.rstrip("\n") for line in f)
+    lines = oracle.report_from_csr(names, lengths.astype(np.uint64), got.bad_offsets, got.bad_regions, got.read_type)
+    assert set(lines) == truth
+
+
+@pytest.mark.parametrize("prof,R,O,cov", [(host.SYNTH_ONT, 3000, 60000, 4), (host.SYNTH_SEQUEL, 800, 90000, 3),
+                                         (host.SYNTH_ONT, 40000, 45000, 0)])
+def test_synthetic_paf_matches_host_parser_and_oracle(engine, tmp_path, prof, R, O, cov):
+    paf = str(tmp_path / "s.paf")
+    host.synth_paf(prof, R, O, 11 + cov, paf)
+    got, names, lengths, stats = _check(engine, paf, cov, 0.4)
+    c = host.csr_from_file(paf, n_threads=3)
+    assert c.names == names and np.array_equal(c.lengths, lengths)
+    assert stats["text_bytes"] == os.path.getsize(paf)
+
+
+def test_text_variants(engine, tmp_path):
+    base = "a\t100\t1\t50\t+\tb\t200\t2\t60\t49\t58\t255\tcm:i:5\n" \
+           "b\t999\t3\t70\t-\tc\t300\t4\t80\n" \
+           "\n" \
+           "c\t+300\t+5\t+90\t\u00e9\ta\t100\t0\t100\textra\n"
+    for i, text in enumerate([base, base.replace("\n", "\r\n"), base.rstrip("\n"), "", "\n\n",
+                              "x\t10\t0\t5\t+\tx\t10\t5\t10"]):
+        p = str(tmp_path / ("v%d.paf" % i))
+        with open(p, "w", newline="") as f:
+            f.write(text)
+        _check(engine, p, 0, 0.8)
+
+
+@pytest.mark.parametrize("text", [
+    '"a"\t100\t1\t50\t+\tb\t200\t2\t60\n',                       # a quoted field
+    "a\t100\t1\t50\t+\tb\t200\t2\t60\t1\rb\t9\t0\t1\t+\ta\t100\t5\t6\n",  # a lone CR ends a record
+    "a\t0x64\t1\t50\t+\tb\t200\t2\t60\n",                            # the csv crate reads 0x integers
+    "a\t100\t1\t50\t+\tb\t200\t2\n",                                  # eight columns: the host words the error
+    "a\t100\t1\t50\t++\tb\t200\t2\t60\n",                            # strand is not one character
+    "a\t100\t1\t4294967296\t+\tb\t200\t2\t60\n",                     # u32 overflow
+    "a\t4294967296\t1\t5\t+\tb\t200\t2\t60\n",                       # a length beyond the engine
+])
+def test_inputs_for_the_host_parser(engine, tmp_path, text):
+    p = str(tmp_path / "h.paf")
+    with open(p, "w", newline="") as f:
+        f.write(text)
+    with pytest.raises(yacrd_amd.NeedsHostParser):
+        engine.ingest_paf(p, 0, 0.8)
+    # and the engine is still usable
+    off = np.array([0, 1], dtype=np.uint64)
+    assert engine.run(off, np.array([[0, 5]], dtype=np.uint32), np.array([10], dtype=np.uint32), 0, 0.8).bad_regions.tolist() == [[5, 10]]
+
+
+def test_long_lines_and_ids_across_tiles(engine, tmp_path):
+    """Lines of a few bytes up to several KB (trailing tag columns, as minimap2 -c writes them), ids of up to 3000
+    bytes, empty lines, CRLF — over a few hundred KB, so that line starts, ids and fields fall on and across the
+    32 KiB tiles the parse kernel stages in LDS and the 1 KiB it stages beyond them."""
+    rng = np.random.default_rng(5)
+    ids = ["r%d" % i for i in range(300)] + ["x" * int(n) + str(i) for i, n in enumerate(rng.integers(40, 3000, size=12))]
+    lens = {k: int(rng.integers(1000, 100000)) for k in ids}
+    for crlf in (False, True):
+        out = []
+        for i in range(6000):
+            a, b = ids[int(rng.integers(len(ids)))], ids[int(rng.integers(len(ids)))]
+            sa, sb = int(rng.integers(0, lens[a] - 1)), int(rng.integers(0, lens[b] - 1))
+            ea, eb = int(rng.integers(sa + 1, lens[a] + 1)), int(rng.integers(sb + 1, lens[b] + 1))
+            line = "%s\t%d\t%d\t%d\t%s\t%s\t%d\t%d\t%d" % (a, lens[a], sa, ea, "+-"[i & 1], b, lens[b], sb, eb)
+            k = int(rng.integers(0, 6))
+            if k >= 2:
+                line += "\t%d\t%d\t255" % (ea - sa, eb - sb)
+            if k >= 4:
+                line += "\tcg:Z:" + "12M3I" * int(rng.integers(1, 1200))
+            out.append(line)
+            if rng.random() < 0.02:
+                out.append("")
+        eol = "\r\n" if crlf else "\n"
+        p = str(tmp_path / ("long%d.paf" % crlf))
+        with open(p, "w", newline="") as f:
+            f.write(eol.join(out) + eol)
+        assert os.path.getsize(p) > 300000
+        _check(engine, p, 2, 0.4)

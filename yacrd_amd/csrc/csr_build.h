@@ -13,10 +13,6 @@
 
 namespace yk {
 
-struct OvlRec { // == yacrd_ovl_rec
-    u32 a, b, sa, ea, sb, eb;
-};
-
 // Lanes whose read id equals their left neighbour's form a run (PAF is grouped by query: runs of
 // tens of lines); the head of a run does ONE atomic for all of it.  `key` must be ~0u on lanes
 // without work.  Returns the run's length on its head lane (0 elsewhere) and the lane's rank

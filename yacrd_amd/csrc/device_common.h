@@ -11,6 +11,10 @@ namespace yk {
 
 constexpr u32 kNoKey = 0xFFFFFFFFu;
 
+struct OvlRec { // == yacrd_ovl_rec: one overlap line, both reads (handles) and their intervals
+    u32 a, b, sa, ea, sb, eb;
+};
+
 // Event keys of the regular sweeps: position << 2 | class, so that sorting the keys reproduces
 // the reference's push/pop order (src/stack.rs:66-91) at one position:
 //   0 end of a regular interval     (popped first: `head <= interval.0`, stack.rs:72-81)

@@ -1097,6 +1097,7 @@ void yacrd_engine_destroy(yacrd_engine *e)
     for (DevBuf *b : bufs) b->release();
     if (e->h_ctr) (void)hipHostFree(e->h_ctr);
     if (e->h_out) (void)hipHostFree(e->h_out);
+    if (e->paf_arena) (void)hipHostFree(e->paf_arena);
     for (int b = 0; b < yacrd_engine::kBounce; b++) {
         if (e->bounce[b]) (void)hipHostFree(e->bounce[b]);
         if (e->bounce_ev[b]) (void)hipEventDestroy(e->bounce_ev[b]);

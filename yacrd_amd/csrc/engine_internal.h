@@ -158,6 +158,9 @@ struct yacrd_engine {
     size_t h_out_cap = 0;
     // a batch submitted from host buffers (yacrd_engine_submit): collect() fetches the result
     bool host_pending = false;
+    // pinned buffers the PAF text passes through on its way to HBM (gpu_paf.hip), grow-only
+    void *paf_arena = nullptr;
+    size_t paf_arena_cap = 0;
 };
 
 
@@ -167,6 +170,14 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
                   uint64_t n_reads64, uint64_t n_iv, uint32_t cov, double not_cov, bool defer = false);
 // D2H of the last result into a freshly allocated yacrd_result
 int fetch_result(yacrd_engine *e, yacrd_result *out);
+// overlap records in HBM -> the engine's input CSR (stream.hip; blocking), and a u32 -> u64 exclusive scan
+struct RecSlab {
+    const yk::OvlRec *recs;
+    uint64_t n;
+};
+int csr_from_records(yacrd_engine *e, const RecSlab *slabs, size_t n_slabs, const u32 *d_map, u64 n_handles, u64 n_reads,
+                     DevBuf &cnt, DevBuf &part, DevBuf &err, hipEvent_t done);
+int scan_u32_to_u64(yacrd_engine *e, const u32 *in, u64 n, u64 *out, DevBuf &part);
 // host -> HBM at PCIe rate: direct DMA when `src` is pinned, otherwise through the engine's pinned
 // bounce buffers filled by a few copy threads; asynchronous on e->stream only for pinned sources
 int h2d(yacrd_engine *e, void *dst, const void *src, size_t bytes);

@@ -1,0 +1,601 @@
+// gpu_paf.hip — PAF text -> read types with the PARSE on the GPU (include/yacrd_engine.h:
+// yacrd_engine_ingest_paf).
+//
+// Reference: Reads2Ovl::init_paf (src/reads2ovl/mod.rs:83-113; one csv record = one PafRecord,
+// src/io.rs:23-34: nine leading tab-separated columns, the rest ignored) feeding
+// FullMemory::add_overlap_and_length (src/reads2ovl/fullmemory.rs:82-90: a read's length is the first one
+// seen; reads are numbered by first appearance here, the reference's order is a hash map's).
+//
+// The host parser (host/paf_csr.cc) is bound by its id table: two hash lookups per line, cache misses the CPUs
+// cannot hide (133 M overlaps/s on 16 CPUs).  Here the host only MOVES the text: threads pread fixed chunks of
+// the file into pinned buffers, every chunk crosses PCIe at once (hipMemcpyAsync) into a mirror of the file in
+// HBM.  Then, on the device:
+//   scan     newlines counted (the number of records to expect), '"' / lone CR looked for
+//   parse    32 KiB of text staged in LDS per workgroup; a thread takes the lines that START in its 128 bytes: nine
+//            fields checked as the host's fast path checks them, both ids hashed and looked up in an open-addressing table whose slots name the text
+//            position of the id's FIRST CLAIMANT (an id is compared against the text itself: no copies), the
+//            smallest position of every id kept with atomicMin; one 24-byte overlap record per line
+//   number   occupied slots sorted by first position (hipcub radix sort) = first-appearance numbering; the
+//            length that follows the id at that position = the read's length; names gathered for the host
+//   build    csr_build.h's count / scan / scatter on the records, then the engine's launch sequence
+// Whatever the fast path does not take — a quote, a lone CR, a 0x integer, a malformed line, a length beyond
+// u32 — makes the call return YACRD_EFALLBACK: the caller runs the host parser, which knows the csv crate's
+// whole syntax and the error messages.  Plain files only (the codecs live in the host library).
+#include "engine_internal.h"
+
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include <hipcub/hipcub.hpp>
+
+using namespace yke;
+
+namespace yk {
+
+struct GpArgs {
+    const unsigned char *text;
+    u64 n;              // bytes
+    u64 *claim;         // [cap]: 0 = empty, else text position of the id that claimed the slot + 1
+    u64 *first_pos;     // [cap]: smallest (byte offset * 2 + side) at which the slot's id was seen
+    u32 mask;           // cap - 1
+    OvlRec *recs;
+    u64 rec_cap;
+    unsigned long long *n_recs;
+    u32 *status;        // bit 0: the text needs the host parser; bit 1: the id table is full
+    unsigned long long *n_lines; // newline-terminated lines + an unterminated last one
+};
+
+constexpr int kGpT = 256; // threads per workgroup
+constexpr u32 kNeedHost = 1u, kTableFull = 2u;
+
+// ---- pass 1: how many lines, and is there anything the fast path must not see ------------------------------
+__global__ __launch_bounds__(kGpT) void gp_scan_kernel(GpArgs a)
+{
+    const u64 stride = (u64)gridDim.x * kGpT * 16u;
+    u32 lines = 0, special = 0;
+    for (u64 base = ((u64)blockIdx.x * kGpT + threadIdx.x) * 16u; base < a.n; base += stride) {
+        // 16 bytes per thread and step (the mirror is padded: reads beyond n see zeros)
+        const uint4 v = *reinterpret_cast<const uint4 *>(a.text + base);
+        const u32 w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const u64 i = base + (u64)k;
+            const u32 c = (w[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+            if (i < a.n) {
+                lines += c == '\n' ? 1u : 0u;
+                special |= c == '"' ? 1u : 0u;
+                if (c == '\r') { // fine only as the first half of CRLF
+                    const u32 nx = i + 1 < a.n ? a.text[i + 1] : 0u;
+                    special |= nx != '\n' ? 1u : 0u;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) lines += (u32)__shfl_xor((int)lines, d, 64);
+    special = wave_or(special);
+    if (lane_id() == 0) {
+        if (lines) atomicAdd(a.n_lines, (unsigned long long)lines);
+        if (special) atomicOr(a.status, kNeedHost);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && a.n && a.text[a.n - 1] != '\n') atomicAdd(a.n_lines, 1ull);
+}
+
+// ---- pass 2: parse ---------------------------------------------------------------------------------------------
+// A workgroup stages 32 KiB of text (+ 1 KiB beyond it) in LDS with coalesced 16-byte loads; a thread then takes
+// the lines that START in its 128 bytes and reads their first nine fields byte by byte from LDS (byte loads from
+// global memory, one cache line per lane and instruction, ran this kernel at 24 GB/s).  A record needs nothing
+// behind its ninth field, so a line of any length costs its start only; fields that reach beyond the staged
+// window (ids of hundreds of bytes) are read from global memory.
+constexpr int kGpTile = kGpT * 128, kGpOver = 1024;
+
+struct GpText {
+    const unsigned char *lds, *glob;
+    u64 t0, t1; // the staged window [t0, t1)
+    __device__ __forceinline__ u32 operator[](u64 i) const { return i - t0 < t1 - t0 ? lds[i - t0] : glob[i]; }
+};
+
+__device__ __forceinline__ u64 gp_hash(const GpText &t, u64 p, u32 n)
+{
+    u64 h = 0xcbf29ce484222325ull ^ ((u64)n * 0x9E3779B97F4A7C15ull);
+    for (u32 i = 0; i < n; i++) h = (h ^ t[p + i]) * 0x100000001b3ull;
+    h ^= h >> 29;
+    h *= 0xbf58476d1ce4e5b9ull;
+    return h ^ (h >> 32);
+}
+// decimal u64 with an optional '+', at least one digit, then a tab (or, for the last field, the line's end);
+// clears `ok` when the field is anything else.  `le` = the text's end: a line ends at '\n' (or "\r\n").
+__device__ __forceinline__ u64 gp_uint(const GpText &t, u64 &q, u64 n, u64 limit, bool last, bool &ok)
+{
+    u64 i = q;
+    u32 c = i < n ? t[i] : '\n';
+    if (c == '+') {
+        i++;
+        c = i < n ? t[i] : '\n';
+    }
+    const u64 b = i;
+    u64 v = 0;
+    bool good = true;
+    while (c - '0' <= 9u) {
+        const u32 d = c - '0';
+        good = good && v <= (0xFFFFFFFFFFFFFFFFull - d) / 10u;
+        v = v * 10u + d;
+        i++;
+        c = i < n ? t[i] : '\n';
+    }
+    good = good && i != b && v <= limit;
+    if (c == '\t') {
+        i++;
+    } else { // the line's end: '\n', or '\r' in front of one (a lone CR never gets here: the scan refused it)
+        good = good && last && (c == '\n' || c == '\r');
+    }
+    q = i;
+    ok = ok && good;
+    return v;
+}
+// the slot of the id at text position p (n bytes, hash h): claimed for it if it is new.  ~0u = table full.
+__device__ __forceinline__ u32 gp_intern(const GpArgs &a, const GpText &t, u64 p, u32 n, u64 h)
+{
+    const unsigned char *g = a.text;
+    u32 s = (u32)h & a.mask;
+    for (u32 probes = 0; probes <= a.mask; probes++, s = (s + 1u) & a.mask) {
+        u64 w = __hip_atomic_load(&a.claim[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w == 0) {
+            const u64 old = atomicCAS((unsigned long long *)&a.claim[s], 0ull, (unsigned long long)(p + 1));
+            if (old == 0) return s;
+            w = old;
+        }
+        const u64 c = w - 1; // the claimant's id starts there and ends at a tab (or it would not have been parsed)
+        if (c == p) return s;
+        bool same = g[c + n] == '\t';
+        for (u32 i = 0; same && i < n; i++) same = g[c + i] == t[p + i];
+        if (same) return s;
+    }
+    return ~0u;
+}
+
+__global__ __launch_bounds__(kGpT) void gp_parse_kernel(GpArgs a)
+{
+    __shared__ __attribute__((aligned(16))) unsigned char win[kGpTile + kGpOver];
+    const u64 tile0 = (u64)blockIdx.x * (u64)kGpTile;
+    if (tile0 >= a.n) return;
+    {
+        // the window, 16 bytes per thread and step (the mirror is padded by 64 zero bytes and the last step is clipped
+        // to whole 16-byte pieces inside it)
+        const u64 want = min((u64)(kGpTile + kGpOver), ((a.n + 63) & ~(u64)15) - tile0);
+        for (u64 i = (u64)threadIdx.x * 16u; i < want; i += (u64)kGpT * 16u)
+            *reinterpret_cast<uint4 *>(win + i) = *reinterpret_cast<const uint4 *>(a.text + tile0 + i);
+    }
+    __syncthreads();
+    GpText t;
+    t.lds = win;
+    t.glob = a.text;
+    t.t0 = tile0;
+    t.t1 = min(a.n, tile0 + (u64)(kGpTile + kGpOver));
+    const u64 n = a.n;
+    const u64 lo = tile0 + (u64)threadIdx.x * 128u;
+    if (lo >= n) return;
+    const u64 hi = min(n, lo + 128u);
+    u32 status = 0;
+    // lines that start in [lo, hi): position 0, or the byte after a newline
+    u64 p = lo;
+    if (lo != 0) {
+        u64 q = lo - 1;
+        while (q < hi && (q < tile0 ? (u32)a.text[q] : t[q]) != '\n') q++;
+        p = q + 1; // (>= hi when no line starts here)
+    }
+    while (p < hi) {
+        // the line's first byte decides: empty lines are skipped (csv), "\r\n" alone is one as well
+        const u32 c0 = t[p];
+        u64 next = p; // where to look for the next line start: filled in below
+        bool ok = false;
+        u64 la = 0, lb = 0, sa = 0, ea = 0, sb = 0, eb = 0, ia = p, ib = p;
+        u32 na = 0, nb = 0;
+        if (c0 == '\n') { // an empty line: the next one starts right behind it
+            p = p + 1;
+            continue;
+        } else if (c0 == '\r' && p + 1 < n && t[p + 1] == '\n') {
+            p = p + 2;
+            continue;
+        } else {
+            ok = true;
+            u64 q = p;
+            u32 c = c0;
+            while (c != '\t' && c != '\n') { // id_a
+                q++;
+                c = q < n ? t[q] : '\n';
+            }
+            ok = c == '\t';
+            na = (u32)(q - ia);
+            q++;
+            la = gp_uint(t, q, n, ~0ull, false, ok);
+            sa = gp_uint(t, q, n, 0xFFFFFFFFull, false, ok);
+            ea = gp_uint(t, q, n, 0xFFFFFFFFull, false, ok);
+            if (ok) { // strand: exactly one UTF-8 scalar (serde char), judged by its lead byte like the host
+                u64 tb = q;
+                c = tb < n ? t[tb] : '\n';
+                const u32 lead = c;
+                while (c != '\t' && c != '\n') {
+                    tb++;
+                    c = tb < n ? t[tb] : '\n';
+                }
+                const u32 want = lead < 0x80u ? 1u : (lead >> 5) == 6u ? 2u : (lead >> 4) == 14u ? 3u : (lead >> 3) == 30u ? 4u : 0u;
+                ok = c == '\t' && want != 0u && tb - q == (u64)want;
+                q = tb + 1;
+            }
+            ib = q;
+            if (ok) {
+                c = q < n ? t[q] : '\n';
+                while (c != '\t' && c != '\n') {
+                    q++;
+                    c = q < n ? t[q] : '\n';
+                }
+                ok = c == '\t';
+                nb = (u32)(q - ib);
+                q++;
+            }
+            lb = gp_uint(t, q, n, ~0ull, false, ok);
+            sb = gp_uint(t, q, n, 0xFFFFFFFFull, false, ok);
+            eb = gp_uint(t, q, n, 0xFFFFFFFFull, true, ok);
+            ok = ok && la <= 0xFFFFFFFFull && lb <= 0xFFFFFFFFull; // (the engine's limit; the host parser says so)
+            if (!ok) status |= kNeedHost;
+            next = q; // the rest of the line holds nothing for the record: its newline is looked for below
+        }
+        u32 s1 = 0, s2 = 0;
+        if (ok) {
+            s1 = gp_intern(a, t, ia, na, gp_hash(t, ia, na));
+            s2 = gp_intern(a, t, ib, nb, gp_hash(t, ib, nb));
+            if (s1 == ~0u || s2 == ~0u) {
+                status |= kTableFull;
+                ok = false;
+            }
+        }
+        // One slot per record, handed out per wavefront: the lanes that have a record now ask together.
+        const u64 m = __builtin_amdgcn_ballot_w64(ok);
+        if (ok) {
+            const u32 leader = (u32)__builtin_ctzll(m);
+            u64 base = 0;
+            if (lane_id() == leader) base = atomicAdd(a.n_recs, (unsigned long long)__builtin_popcountll(m));
+            base = ((u64)(u32)__builtin_amdgcn_readlane((int)(u32)(base >> 32), (int)leader) << 32) |
+                   (u32)__builtin_amdgcn_readlane((int)(u32)base, (int)leader);
+            const u64 at = base + (u64)__builtin_popcountll(m & ((1ull << lane_id()) - 1ull));
+            const u64 pa = p * 2u, pb = p * 2u + 1u;
+            if (pa < __hip_atomic_load(&a.first_pos[s1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMin((unsigned long long *)&a.first_pos[s1], (unsigned long long)pa);
+            if (pb < __hip_atomic_load(&a.first_pos[s2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                atomicMin((unsigned long long *)&a.first_pos[s2], (unsigned long long)pb);
+            if (at < a.rec_cap) {
+                OvlRec r;
+                r.a = s1, r.b = s2, r.sa = (u32)sa, r.ea = (u32)ea, r.sb = (u32)sb, r.eb = (u32)eb;
+                a.recs[at] = r;
+            }
+        }
+        // the next line start inside this thread's bytes, if any
+        while (next < hi && t[next] != '\n') next++;
+        p = next + 1;
+        if (next >= hi) break;
+    }
+    if (status) atomicOr(a.status, status);
+}
+
+// ---- pass 3: the reads -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gp_collect_kernel(const u64 *claim, const u64 *first_pos, u32 cap, u64 *keys,
+                                                         u32 *slots, u32 *n_out)
+{
+    const u32 s = blockIdx.x * 256u + threadIdx.x;
+    const bool used = s < cap && claim[s] != 0;
+    const u64 m = __builtin_amdgcn_ballot_w64(used);
+    if (!m) return;
+    u32 base = 0;
+    if (lane_id() == (u32)__builtin_ctzll(m)) base = atomicAdd(n_out, (u32)__builtin_popcountll(m));
+    base = (u32)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(m));
+    if (used) {
+        const u32 at = base + (u32)__builtin_popcountll(m & ((1ull << lane_id()) - 1ull));
+        keys[at] = first_pos[s];
+        slots[at] = s;
+    }
+}
+// read g (first-appearance order) = the id first seen at keys[g]: its slot -> g, its length (the field after the
+// id there), the extent of its name
+__global__ __launch_bounds__(256) void gp_number_kernel(const unsigned char *t, const u64 *keys, const u32 *slots,
+                                                        u32 n_reads, u32 *handle_map, u32 *lengths, u32 *name_len,
+                                                        u64 *name_at)
+{
+    const u32 g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= n_reads) return;
+    handle_map[slots[g]] = g;
+    const u64 pos = keys[g];
+    u64 q = pos >> 1; // the line's start
+    if (pos & 1u) {   // the second id: behind five fields
+        for (int f = 0; f < 5; f++) {
+            while (t[q] != '\t') q++;
+            q++;
+        }
+    }
+    const u64 id0 = q;
+    while (t[q] != '\t') q++;
+    name_at[g] = id0;
+    name_len[g] = (u32)(q - id0);
+    q++;
+    if (t[q] == '+') q++;
+    u64 v = 0;
+    while ((u32)t[q] - '0' <= 9u) v = v * 10u + ((u32)t[q++] - '0');
+    lengths[g] = (u32)v; // (checked <= u32 by the parse)
+}
+__global__ __launch_bounds__(256) void gp_names_kernel(const unsigned char *t, const u64 *name_at, const u64 *name_off,
+                                                       u32 n_reads, unsigned char *names)
+{
+    const u32 g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= n_reads) return;
+    const u64 from = name_at[g], to = name_off[g], n = name_off[g + 1] - to;
+    for (u64 i = 0; i < n; i++) names[to + i] = t[from + i];
+}
+
+} // namespace yk
+
+namespace {
+
+double now_ms()
+{
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct Scratch { // device buffers of one call, released on every exit
+    DevBuf text, claim, first_pos, recs, ctl, keys, keys2, slots, slots2, tmp, map, name_len, name_at, name_off,
+        names, cnt, part, err;
+    ~Scratch()
+    {
+        DevBuf *all[] = {&text, &claim, &first_pos, &recs, &ctl, &keys, &keys2, &slots, &slots2, &tmp, &map, &name_len,
+                         &name_at, &name_off, &names, &cnt, &part, &err};
+        for (DevBuf *b : all) b->release();
+    }
+};
+
+} // namespace
+
+extern "C" {
+
+void yacrd_reads_free(yacrd_reads *r)
+{
+    if (!r) return;
+    std::free(r->lengths);
+    std::free(r->name_off);
+    std::free(r->names);
+    std::memset(r, 0, sizeof(*r));
+}
+
+int yacrd_engine_ingest_paf(yacrd_engine *e, const char *path, int n_threads, uint32_t coverage, double not_coverage,
+                            yacrd_result *out, yacrd_reads *reads, yacrd_ingest_stats *stats)
+{
+    if (!e || !path || !out || !reads) return fail(YACRD_EINVAL, "null argument");
+    std::memset(out, 0, sizeof(*out));
+    std::memset(reads, 0, sizeof(*reads));
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if (e->pending.active || e->host_pending) return fail(YACRD_EINVAL, "the engine has a submitted batch pending");
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) return fail(YACRD_EINVAL, std::string("cannot open ") + path);
+    struct FdGuard {
+        int fd;
+        ~FdGuard() { ::close(fd); }
+    } fdg{fd};
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) return fail(YACRD_EFALLBACK, "not a regular file: the host parser reads it");
+    const u64 n = (u64)st.st_size;
+    DeviceGuard guard(e->device);
+    Scratch S;
+    const double t_start = now_ms();
+
+    // ---- the text: pread chunks -> pinned buffers -> HBM, all chunks in flight at once
+    HIP_TRY(S.text.reserve((size_t)n + 64));
+    HIP_TRY(hipMemsetAsync(S.text.as<char>() + n, 0, 64, e->stream)); // (the scan reads 16 bytes at a time)
+    {
+        // (the pinned arena stays with the engine: pinning 100 MB costs more than moving 367 MB through it)
+        constexpr size_t kChunk = (size_t)4 << 20;
+        const size_t n_chunks = (size_t)((n + kChunk - 1) / kChunk);
+        unsigned T = n_threads > 0 ? (unsigned)n_threads : 6u; // (more threads only get in each other's way: 367 MB in 10 ms with 4-8)
+        T = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(T, 32u), n_chunks));
+        const size_t n_buf = (size_t)2 * T;
+        if (e->paf_arena_cap < n_buf * kChunk) {
+            if (e->paf_arena) (void)hipHostFree(e->paf_arena);
+            e->paf_arena = nullptr;
+            e->paf_arena_cap = 0;
+            HIP_TRY(hipHostMalloc(&e->paf_arena, n_buf * kChunk));
+            e->paf_arena_cap = n_buf * kChunk;
+        }
+        char *arena = (char *)e->paf_arena;
+        std::vector<hipStream_t> copy(T, nullptr);
+        std::vector<hipEvent_t> ev(n_buf, nullptr);
+        std::atomic<size_t> next(0);
+        std::atomic<int> bad(0);
+        for (unsigned t = 0; t < T; t++)
+            if (hipStreamCreateWithFlags(&copy[t], hipStreamNonBlocking) != hipSuccess) bad = 1;
+        for (size_t b = 0; b < n_buf; b++)
+            if (hipEventCreateWithFlags(&ev[b], hipEventDisableTiming) != hipSuccess) bad = 1;
+        auto work = [&](unsigned t) { // thread t owns buffers 2t and 2t + 1: one fills while the other flies
+            if (hipSetDevice(e->device) != hipSuccess) bad = 1;
+            bool flying[2] = {false, false};
+            for (int turn = 0; !bad.load(); turn ^= 1) {
+                const size_t c = next.fetch_add(1);
+                if (c >= n_chunks) break;
+                const size_t b = (size_t)2 * t + (size_t)turn;
+                if (flying[turn] && hipEventSynchronize(ev[b]) != hipSuccess) bad = 1;
+                char *dst = arena + b * kChunk;
+                const size_t off = c * kChunk, len = (size_t)std::min<u64>(kChunk, n - off);
+                size_t got = 0;
+                while (got < len) {
+                    const ssize_t k = ::pread(fd, dst + got, len - got, (off_t)(off + got));
+                    if (k < 0 && errno == EINTR) continue;
+                    if (k <= 0) {
+                        bad = 2;
+                        break;
+                    }
+                    got += (size_t)k;
+                }
+                if (bad.load()) break;
+                if (hipMemcpyAsync(S.text.as<char>() + off, dst, len, hipMemcpyHostToDevice, copy[t]) != hipSuccess ||
+                    hipEventRecord(ev[b], copy[t]) != hipSuccess)
+                    bad = 1;
+                flying[turn] = true;
+            }
+            if (copy[t]) (void)hipStreamSynchronize(copy[t]);
+        };
+        if (!bad.load()) {
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < T; t++) th.emplace_back(work, t);
+            work(0);
+            for (auto &x : th) x.join();
+        }
+        for (hipStream_t s : copy)
+            if (s) (void)hipStreamDestroy(s);
+        for (hipEvent_t x : ev)
+            if (x) (void)hipEventDestroy(x);
+        if (bad.load() == 2) return fail(YACRD_EINVAL, "read error in the overlap file");
+        if (bad.load()) return fail(YACRD_ENODEV, "PAF text to HBM: a HIP call failed");
+        (void)hipGetLastError();
+    }
+    const double t_text = now_ms();
+
+    // ---- scan: the number of lines, anything for the host parser?
+    HIP_TRY(S.ctl.reserve(64));
+    HIP_TRY(hipMemsetAsync(S.ctl.p, 0, 64, e->stream));
+    yk::GpArgs ga{};
+    ga.text = S.text.as<unsigned char>();
+    ga.n = n;
+    ga.n_lines = S.ctl.as<unsigned long long>();
+    ga.n_recs = S.ctl.as<unsigned long long>() + 1;
+    ga.status = reinterpret_cast<u32 *>(S.ctl.as<unsigned long long>() + 2);
+    u32 *d_nreads = reinterpret_cast<u32 *>(S.ctl.as<unsigned long long>() + 3);
+    const u32 scan_grid = (u32)std::min<u64>((n / (yk::kGpT * 16u)) + 1, (u64)e->num_cu * 16);
+    hipLaunchKernelGGL(yk::gp_scan_kernel, dim3(scan_grid), dim3(yk::kGpT), 0, e->stream, ga);
+    unsigned long long h_ctl[4] = {0, 0, 0, 0};
+    HIP_TRY(hipMemcpyAsync(h_ctl, S.ctl.p, sizeof(h_ctl), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if ((u32)h_ctl[2] & yk::kNeedHost)
+        return fail(YACRD_EFALLBACK, "the text holds a '\"' or a lone CR: csv quoting / record rules are the host parser's");
+    const u64 n_lines = h_ctl[0];
+    if (n_lines >= 0x7FFFFFFFull * 2) return fail(YACRD_EFALLBACK, "too many lines for the device parser");
+
+    // ---- parse
+    u64 cap = (u64)1 << 20;
+    while (cap < n / 64 && cap < ((u64)1 << 31)) cap <<= 1; // ids are a small fraction of the lines; a full table = fallback
+    HIP_TRY(S.claim.reserve((size_t)cap * sizeof(u64)));
+    HIP_TRY(S.first_pos.reserve((size_t)cap * sizeof(u64)));
+    HIP_TRY(S.recs.reserve((size_t)(n_lines + 1) * sizeof(yk::OvlRec)));
+    HIP_TRY(hipMemsetAsync(S.claim.p, 0, (size_t)cap * sizeof(u64), e->stream));
+    HIP_TRY(hipMemsetAsync(S.first_pos.p, 0xFF, (size_t)cap * sizeof(u64), e->stream));
+    ga.claim = S.claim.as<u64>();
+    ga.first_pos = S.first_pos.as<u64>();
+    ga.mask = (u32)(cap - 1);
+    ga.recs = S.recs.as<yk::OvlRec>();
+    ga.rec_cap = n_lines + 1;
+    const u64 n_tiles = (n + yk::kGpTile - 1) / yk::kGpTile;
+    if (n_tiles >= 0x7FFFFFFFull) return fail(YACRD_EFALLBACK, "file too large for the device parser");
+    if (n) hipLaunchKernelGGL(yk::gp_parse_kernel, dim3((u32)n_tiles), dim3(yk::kGpT), 0, e->stream, ga);
+    HIP_TRY(hipMemcpyAsync(h_ctl, S.ctl.p, sizeof(h_ctl), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipGetLastError());
+    if ((u32)h_ctl[2] & yk::kNeedHost)
+        return fail(YACRD_EFALLBACK, "a line is not a plain PAF record (fewer than nine columns, a 0x integer, a length "
+                                     "beyond u32 ...): the host parser decides");
+    if ((u32)h_ctl[2] & yk::kTableFull) return fail(YACRD_EFALLBACK, "more read ids than the device table holds");
+    const u64 n_recs = h_ctl[1];
+    if (n_recs > n_lines + 1) return fail(YACRD_EINTERNAL, "device parser: more records than lines");
+    // ---- the reads: occupied slots by first position
+    HIP_TRY(S.keys.reserve((size_t)cap * sizeof(u64) + 64));
+    HIP_TRY(S.slots.reserve((size_t)cap * sizeof(u32) + 64));
+    hipLaunchKernelGGL(yk::gp_collect_kernel, dim3((u32)((cap + 255) / 256)), dim3(256), 0, e->stream, ga.claim, ga.first_pos,
+                       (u32)cap, S.keys.as<u64>(), S.slots.as<u32>(), d_nreads);
+    HIP_TRY(hipMemcpyAsync(h_ctl, S.ctl.p, sizeof(h_ctl), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    const u32 R = (u32)h_ctl[3];
+    const double t_parse = now_ms();
+    if ((u64)R * 2 > cap && R > 1024) return fail(YACRD_EFALLBACK, "more read ids than the device table holds comfortably");
+
+    // sort (first position, slot)
+    HIP_TRY(S.keys2.reserve((size_t)R * sizeof(u64) + 64));
+    HIP_TRY(S.slots2.reserve((size_t)R * sizeof(u32) + 64));
+    size_t tmp_bytes = 0;
+    if (R) {
+        if (hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, S.keys.as<u64>(), S.keys2.as<u64>(), S.slots.as<u32>(),
+                                               S.slots2.as<u32>(), (int)R, 0, 64, e->stream) != hipSuccess)
+            return fail(YACRD_ENODEV, "hipcub sort (size query) failed");
+        HIP_TRY(S.tmp.reserve(tmp_bytes + 64));
+        if (hipcub::DeviceRadixSort::SortPairs(S.tmp.p, tmp_bytes, S.keys.as<u64>(), S.keys2.as<u64>(), S.slots.as<u32>(),
+                                               S.slots2.as<u32>(), (int)R, 0, 64, e->stream) != hipSuccess)
+            return fail(YACRD_ENODEV, "hipcub sort failed");
+    }
+    HIP_TRY(S.map.reserve((size_t)cap * sizeof(u32)));
+    HIP_TRY(S.name_len.reserve((size_t)(R + 4) * sizeof(u32)));
+    HIP_TRY(S.name_at.reserve((size_t)(R + 1) * sizeof(u64)));
+    HIP_TRY(S.name_off.reserve((size_t)(R + 2) * sizeof(u64)));
+    HIP_TRY(e->in_len.reserve((size_t)(R + 1) * sizeof(u32)));
+    HIP_TRY(hipMemsetAsync(S.map.p, 0xFF, (size_t)cap * sizeof(u32), e->stream));
+    const u32 rg = (R + 255) / 256;
+    if (R)
+        hipLaunchKernelGGL(yk::gp_number_kernel, dim3(rg), dim3(256), 0, e->stream, ga.text, S.keys2.as<u64>(), S.slots2.as<u32>(),
+                           R, S.map.as<u32>(), e->in_len.as<u32>(), S.name_len.as<u32>(), S.name_at.as<u64>());
+    {
+        const int rcs = scan_u32_to_u64(e, S.name_len.as<u32>(), (u64)R, S.name_off.as<u64>(), S.part);
+        if (rcs) return rcs;
+    }
+    u64 name_bytes = 0;
+    HIP_TRY(hipMemcpyAsync(&name_bytes, S.name_off.as<u64>() + R, sizeof(u64), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(S.names.reserve((size_t)name_bytes + 64));
+    if (R)
+        hipLaunchKernelGGL(yk::gp_names_kernel, dim3(rg), dim3(256), 0, e->stream, ga.text, S.name_at.as<u64>(), S.name_off.as<u64>(), R,
+                           S.names.as<unsigned char>());
+    // the reads, to the host (while the CSR is built)
+    reads->n_reads = R;
+    reads->n_records = n_recs;
+    reads->lengths = (uint32_t *)std::malloc(((size_t)R + 1) * sizeof(uint32_t));
+    reads->name_off = (uint64_t *)std::malloc(((size_t)R + 1) * sizeof(uint64_t));
+    reads->names = (char *)std::malloc((size_t)name_bytes + 1);
+    if (!reads->lengths || !reads->name_off || !reads->names) {
+        yacrd_reads_free(reads);
+        return fail(YACRD_ENOMEM, "host allocation failed");
+    }
+    int rc = YACRD_OK;
+    auto body = [&]() -> int {
+        if (R) HIP_TRY(hipMemcpyAsync(reads->lengths, e->in_len.p, (size_t)R * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(reads->name_off, S.name_off.p, ((size_t)R + 1) * sizeof(u64), hipMemcpyDeviceToHost, e->stream));
+        if (name_bytes) HIP_TRY(hipMemcpyAsync(reads->names, S.names.p, (size_t)name_bytes, hipMemcpyDeviceToHost, e->stream));
+        // ---- CSR on the device (csr_build.h through stream.hip's helper), then the engine
+        const u64 n_iv = 2 * n_recs;
+        const RecSlab slab{S.recs.as<yk::OvlRec>(), n_recs};
+        const int rcb = csr_from_records(e, &slab, 1, S.map.as<u32>(), cap, R, S.cnt, S.part, S.err, nullptr);
+        if (rcb) return rcb;
+        const double t_build = now_ms();
+        int rc2 = run_on_device(e, e->in_off.as<u64>(), e->in_iv.as<uint2>(), e->in_len.as<u32>(), R, n_iv, coverage, not_coverage);
+        if (rc2) return rc2;
+        const double t_run = now_ms();
+        rc2 = fetch_result(e, out);
+        if (stats) {
+            stats->text_bytes = n;
+            stats->n_records = n_recs;
+            stats->n_reads = R;
+            stats->text_ms = (float)(t_text - t_start);
+            stats->parse_ms = (float)(t_parse - t_text);
+            stats->build_ms = (float)(t_build - t_parse);
+            stats->run_ms = (float)(t_run - t_build);
+            stats->d2h_ms = (float)(now_ms() - t_run);
+        }
+        return rc2;
+    };
+    rc = body();
+    if (rc) yacrd_reads_free(reads);
+    return rc;
+}
+
+} // extern "C"

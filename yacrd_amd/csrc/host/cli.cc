@@ -142,6 +142,7 @@ int main(int argc, char **argv)
     std::vector<uint8_t> rep_types;
     yacrd_badparts_view bp{};
     yacrd_csr_view view{};
+    yacrd_reads dev_reads{};
 
     // src/main.rs:43-60: a .yacrd input bypasses detection (FromReport), anything else is overlaps
     const bool m4 = has(input, ".m4") || has(input, ".mhap"), paf = has(input, ".paf");
@@ -159,7 +160,22 @@ int main(int argc, char **argv)
         view.names = bp.names;
         view.lengths = bp.lengths;
     } else {
-        if (engines.size() == 1) {
+        int dev_parse = YACRD_EFALLBACK;
+        if (engines.size() == 1 && paf && !m4) {
+            // one GPU, PAF text: the host only moves the file to HBM, the device parses it, numbers the reads,
+            // builds the CSR and runs the engine (yacrd_engine_ingest_paf).  Whatever is not a plain PAF file
+            // (compressed, quoted fields, lone CRs, 0x integers, malformed lines ...) comes back as
+            // YACRD_EFALLBACK and takes the host parser below, which knows the whole syntax and the messages.
+            dev_parse = yacrd_engine_ingest_paf(engines[0], input.c_str(), (int)std::min<unsigned long long>(threads, 8),
+                                                cov32, not_coverage, &res, &dev_reads, nullptr);
+            if (dev_parse != YACRD_OK && dev_parse != YACRD_EFALLBACK) die(yacrd_last_error());
+        }
+        if (dev_parse == YACRD_OK) {
+            view.n_reads = dev_reads.n_reads;
+            view.name_off = dev_reads.name_off;
+            view.names = dev_reads.names;
+            view.lengths = dev_reads.lengths;
+        } else if (engines.size() == 1) {
             // one GPU: the parser's records cross PCIe from pinned buffers while it is still
             // parsing, the CSR is built in HBM (yacrd_stream_*), then the engine runs on it
             yacrd_stream *st = nullptr;
@@ -207,6 +223,7 @@ int main(int argc, char **argv)
     }
 
     yacrd_result_free(&res);
+    yacrd_reads_free(&dev_reads);
     if (csr) yacrd_csr_free(csr);
     if (rep) yacrd_report_free(rep);
     for (yacrd_engine *e : engines) yacrd_engine_destroy(e);

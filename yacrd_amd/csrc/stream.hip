@@ -93,6 +93,70 @@ int sink_commit(void *ctx, yacrd_ovl_rec *buf, uint64_t n)
 
 } // namespace
 
+namespace yke {
+// Overlap records in HBM -> the engine's input CSR (in_off, in_iv; in_len holds the lengths already): count,
+// scan, scatter (csr_build.h).  `map` (or null) translates the records' handles to read ids.  Blocking.
+int csr_from_records(yacrd_engine *e, const RecSlab *slabs, size_t n_slabs, const u32 *d_map, u64 n_handles, u64 n_reads,
+                     DevBuf &cnt, DevBuf &part, DevBuf &err, hipEvent_t done)
+{
+    u64 n = 0;
+    for (size_t i = 0; i < n_slabs; i++) n += slabs[i].n;
+    const u64 n_iv = 2 * n;
+    const u64 nb = (n_reads + yk::kScanTile - 1) / yk::kScanTile;
+    HIP_TRY(e->in_off.reserve((size_t)(n_reads + 1) * sizeof(u64)));
+    HIP_TRY(e->in_iv.reserve((size_t)(n_iv + 1) * sizeof(uint2)));
+    HIP_TRY(cnt.reserve((size_t)(n_reads + 4) * sizeof(u32)));
+    HIP_TRY(part.reserve((size_t)(nb + 1) * sizeof(u64)));
+    HIP_TRY(err.reserve(64));
+    HIP_TRY(hipMemsetAsync(cnt.p, 0, (size_t)(n_reads + 4) * sizeof(u32), e->stream));
+    HIP_TRY(hipMemsetAsync(err.p, 0, 64, e->stream));
+    const u32 R32 = (u32)n_reads;
+    auto grid_for = [&](uint64_t recs) {
+        return (u32)std::min<uint64_t>((recs + yk::kCsrThreads - 1) / yk::kCsrThreads, (uint64_t)e->num_cu * 16);
+    };
+    for (size_t i = 0; i < n_slabs; i++)
+        if (slabs[i].n)
+            hipLaunchKernelGGL(yk::csr_count_kernel, dim3(grid_for(slabs[i].n)), dim3(yk::kCsrThreads), 0, e->stream,
+                               slabs[i].recs, (u64)slabs[i].n, d_map, (u64)n_handles, R32, cnt.as<u32>(), err.as<u32>());
+    if (n_reads) {
+        hipLaunchKernelGGL(yk::scan_tile_sums_kernel, dim3((u32)nb), dim3(yk::kScanT), 0, e->stream, cnt.as<u32>(),
+                           (u64)n_reads, part.as<u64>());
+        hipLaunchKernelGGL(yk::scan_parts_kernel, dim3(1), dim3(yk::kScanT), 0, e->stream, part.as<u64>(), nb,
+                           e->in_off.as<u64>() + n_reads);
+        hipLaunchKernelGGL(yk::scan_tiles_kernel, dim3((u32)nb), dim3(yk::kScanT), 0, e->stream, cnt.as<u32>(),
+                           (u64)n_reads, part.as<u64>(), e->in_off.as<u64>());
+    } else {
+        HIP_TRY(hipMemsetAsync(e->in_off.p, 0, sizeof(u64), e->stream));
+    }
+    for (size_t i = 0; i < n_slabs; i++)
+        if (slabs[i].n)
+            hipLaunchKernelGGL(yk::csr_scatter_kernel, dim3(grid_for(slabs[i].n)), dim3(yk::kCsrThreads), 0, e->stream,
+                               slabs[i].recs, (u64)slabs[i].n, d_map, (u64)n_handles, R32, e->in_off.as<u64>(),
+                               cnt.as<u32>(), e->in_iv.as<uint2>());
+    if (done) HIP_TRY(hipEventRecord(done, e->stream));
+    u32 h_err = 0;
+    HIP_TRY(hipMemcpyAsync(&h_err, err.p, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    HIP_TRY(hipGetLastError());
+    if (h_err) return fail(YACRD_EINVAL, "a record names a read outside handle_map / n_reads");
+    return YACRD_OK;
+}
+// exclusive prefix sums u32[n] -> u64[n + 1] on the engine's stream (asynchronous)
+int scan_u32_to_u64(yacrd_engine *e, const u32 *in, u64 n, u64 *out, DevBuf &part)
+{
+    const u64 nb = (n + yk::kScanTile - 1) / yk::kScanTile;
+    HIP_TRY(part.reserve((size_t)(nb + 1) * sizeof(u64)));
+    if (!n) {
+        HIP_TRY(hipMemsetAsync(out, 0, sizeof(u64), e->stream));
+        return YACRD_OK;
+    }
+    hipLaunchKernelGGL(yk::scan_tile_sums_kernel, dim3((u32)nb), dim3(yk::kScanT), 0, e->stream, in, n, part.as<u64>());
+    hipLaunchKernelGGL(yk::scan_parts_kernel, dim3(1), dim3(yk::kScanT), 0, e->stream, part.as<u64>(), nb, out + n);
+    hipLaunchKernelGGL(yk::scan_tiles_kernel, dim3((u32)nb), dim3(yk::kScanT), 0, e->stream, in, n, part.as<u64>(), out);
+    return YACRD_OK;
+}
+} // namespace yke
+
 extern "C" {
 
 int yacrd_stream_open(yacrd_engine *e, uint64_t chunk_records, uint32_t n_buffers, yacrd_stream **out)
@@ -277,13 +341,7 @@ int yacrd_stream_finish(yacrd_stream *s, const uint32_t *handle_map, uint64_t n_
     } reset_on_exit{s};
     if (n && n_reads == 0) return fail(YACRD_EINVAL, "records without reads");
 
-    const u64 nb = (n_reads + yk::kScanTile - 1) / yk::kScanTile;
-    HIP_TRY(e->in_off.reserve((size_t)(n_reads + 1) * sizeof(u64)));
-    HIP_TRY(e->in_iv.reserve((size_t)(n_iv + 1) * sizeof(uint2)));
     HIP_TRY(e->in_len.reserve((size_t)(n_reads + 1) * sizeof(u32)));
-    HIP_TRY(s->cnt.reserve((size_t)(n_reads + 4) * sizeof(u32)));
-    HIP_TRY(s->part.reserve((size_t)(nb + 1) * sizeof(u64)));
-    HIP_TRY(s->err.reserve(64));
     const u32 *d_map = nullptr;
     if (handle_map && n_handles) {
         HIP_TRY(s->map.reserve((size_t)n_handles * sizeof(u32)));
@@ -294,40 +352,12 @@ int yacrd_stream_finish(yacrd_stream *s, const uint32_t *handle_map, uint64_t n_
     if (d_map) rc = h2d(e, s->map.p, handle_map, (size_t)n_handles * sizeof(u32));
     if (!rc && n_reads) rc = h2d(e, e->in_len.p, lengths, (size_t)n_reads * sizeof(u32));
     if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(s->cnt.p, 0, (size_t)(n_reads + 4) * sizeof(u32), e->stream));
-    HIP_TRY(hipMemsetAsync(s->err.p, 0, 64, e->stream));
-    const u32 R32 = (u32)n_reads;
-    auto grid_for = [&](uint64_t recs) {
-        return (u32)std::min<uint64_t>((recs + yk::kCsrThreads - 1) / yk::kCsrThreads, (uint64_t)e->num_cu * 16);
-    };
+    std::vector<RecSlab> rs;
     for (auto &sl : s->slabs)
-        if (sl.used)
-            hipLaunchKernelGGL(yk::csr_count_kernel, dim3(grid_for(sl.used)), dim3(yk::kCsrThreads), 0,
-                               e->stream, sl.buf.as<yk::OvlRec>(), (u64)sl.used, d_map, (u64)n_handles,
-                               R32, s->cnt.as<u32>(), s->err.as<u32>());
-    if (n_reads) {
-        hipLaunchKernelGGL(yk::scan_tile_sums_kernel, dim3((u32)nb), dim3(yk::kScanT), 0, e->stream,
-                           s->cnt.as<u32>(), (u64)n_reads, s->part.as<u64>());
-        hipLaunchKernelGGL(yk::scan_parts_kernel, dim3(1), dim3(yk::kScanT), 0, e->stream,
-                           s->part.as<u64>(), nb, e->in_off.as<u64>() + n_reads);
-        hipLaunchKernelGGL(yk::scan_tiles_kernel, dim3((u32)nb), dim3(yk::kScanT), 0, e->stream,
-                           s->cnt.as<u32>(), (u64)n_reads, s->part.as<u64>(), e->in_off.as<u64>());
-    } else {
-        HIP_TRY(hipMemsetAsync(e->in_off.p, 0, sizeof(u64), e->stream));
-    }
-    for (auto &sl : s->slabs)
-        if (sl.used)
-            hipLaunchKernelGGL(yk::csr_scatter_kernel, dim3(grid_for(sl.used)), dim3(yk::kCsrThreads), 0,
-                               e->stream, sl.buf.as<yk::OvlRec>(), (u64)sl.used, d_map, (u64)n_handles,
-                               R32, e->in_off.as<u64>(), s->cnt.as<u32>(), e->in_iv.as<uint2>());
-    HIP_TRY(hipEventRecord(s->evb1, e->stream));
-    u32 h_err = 0;
-    HIP_TRY(hipMemcpyAsync(&h_err, s->err.p, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    HIP_TRY(hipGetLastError());
+        if (sl.used) rs.push_back(RecSlab{sl.buf.as<yk::OvlRec>(), sl.used});
+    rc = csr_from_records(e, rs.data(), rs.size(), d_map, n_handles, n_reads, s->cnt, s->part, s->err, s->evb1);
+    if (rc) return rc;
     s->stats.build_ms = ev_ms(s->evb0, s->evb1);
-    if (h_err) return fail(YACRD_EINVAL, "a record names a read outside handle_map / n_reads");
-
     const double t0 = now_ms();
     rc = run_on_device(e, e->in_off.as<u64>(), e->in_iv.as<uint2>(), e->in_len.as<u32>(), n_reads, n_iv,
                        coverage, not_coverage);

@@ -41,11 +41,30 @@ EXPORTED_SYMBOLS = [
     "yacrd_engine_submit", "yacrd_engine_collect", "yacrd_pinned_alloc", "yacrd_pinned_free",
     "yacrd_stream_open", "yacrd_stream_sink", "yacrd_stream_acquire", "yacrd_stream_commit",
     "yacrd_stream_finish", "yacrd_stream_last_stats", "yacrd_stream_reset", "yacrd_stream_close",
+    "yacrd_engine_ingest_paf", "yacrd_reads_free",
 ]
 
 
 class EngineError(RuntimeError):
     pass
+
+
+class NeedsHostParser(EngineError):
+    """yacrd_engine_ingest_paf returned YACRD_EFALLBACK: the input is for the host parser."""
+
+
+E_FALLBACK = 5
+
+
+class _Reads(ctypes.Structure):
+    _fields_ = [("n_reads", ctypes.c_uint64), ("n_records", ctypes.c_uint64),
+                ("lengths", ctypes.POINTER(ctypes.c_uint32)), ("name_off", ctypes.POINTER(ctypes.c_uint64)),
+                ("names", ctypes.POINTER(ctypes.c_char))]
+
+
+class _IngestStats(ctypes.Structure):
+    _fields_ = [("text_bytes", ctypes.c_uint64), ("n_records", ctypes.c_uint64), ("n_reads", ctypes.c_uint64)] + \
+               [(n, ctypes.c_float) for n in ("text_ms", "parse_ms", "build_ms", "run_ms", "d2h_ms")]
 
 
 class _Cfg(ctypes.Structure):
@@ -202,6 +221,11 @@ def load_library():
                                                      ctypes.POINTER(DeviceBatch), ctypes.c_uint32, BATCH_DONE,
                                                      ctypes.c_void_p, ctypes.POINTER(_DevResult)]
     lib.yacrd_engine_fetch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_Result)]
+    lib.yacrd_engine_ingest_paf.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_double,
+                                            ctypes.POINTER(_Result), ctypes.POINTER(_Reads), ctypes.POINTER(_IngestStats)]
+    lib.yacrd_reads_free.argtypes = [ctypes.POINTER(_Reads)]
+    lib.yacrd_reads_free.restype = None
+    lib.yacrd_stream_reset.argtypes = [ctypes.c_void_p]
     lib.yacrd_engine_last_timing.argtypes = [ctypes.c_void_p, ctypes.POINTER(_Timing)]
     lib.yacrd_partition_reads.argtypes = [u64p, ctypes.c_uint64, ctypes.c_uint32, u64p]
     lib.yacrd_engine_classify.argtypes = [ctypes.c_void_p, u64p, u32p, u32p, ctypes.c_uint64,
@@ -364,6 +388,24 @@ class Engine:
         out = _DevResult()
         _check(self._lib, self._lib.yacrd_engine_wait(self._h, ctypes.byref(out)))
         return out
+
+    def ingest_paf(self, path, coverage, not_coverage, n_threads=0):
+        """yacrd_engine_ingest_paf: PAF text -> (Result, names, lengths, stats) with the parse on the GPU; raises
+        NeedsHostParser when the input is not for the device parser."""
+        res, rd, st = _Result(), _Reads(), _IngestStats()
+        rc = self._lib.yacrd_engine_ingest_paf(self._h, os.fsencode(path), int(n_threads), min(int(coverage), 0xFFFFFFFF),
+                                               float(not_coverage), ctypes.byref(res), ctypes.byref(rd), ctypes.byref(st))
+        if rc == E_FALLBACK:
+            raise NeedsHostParser(self._lib.yacrd_last_error().decode())
+        _check(self._lib, rc)
+        R = int(rd.n_reads)
+        lengths = np.ctypeslib.as_array(rd.lengths, shape=(R,)).copy() if R else np.zeros(0, np.uint32)
+        off = np.ctypeslib.as_array(rd.name_off, shape=(R + 1,)).copy()
+        blob = ctypes.string_at(rd.names, int(off[-1])) if R else b""
+        names = [blob[int(off[i]):int(off[i + 1])].decode("utf-8", "surrogateescape") for i in range(R)]
+        stats = {n: getattr(st, n) for n, _ in _IngestStats._fields_}
+        self._lib.yacrd_reads_free(ctypes.byref(rd))
+        return _take(self._lib, res), names, lengths, stats
 
     def fetch(self):
         res = _Result()

@@ -263,6 +263,33 @@ int yacrd_stream_last_stats(const yacrd_stream *s, yacrd_stream_stats *st);
 int yacrd_stream_reset(yacrd_stream *s);
 void yacrd_stream_close(yacrd_stream *s);
 
+/* ---- streaming ingest over several GPUs --------------------------------------------------------
+ * The read-partitioned form of the stream (the reference's equivalent is its batch loop over reads,
+ * src/stack.rs:143-162, fed by src/reads2ovl/mod.rs:83-113): a read belongs to device
+ * yacrd_stream_device_of(handle, N) = handle mod N, a fact known the moment the parser has interned
+ * the id, so the group's sink routes every record while the parse is still running — to the device of
+ * its read a and, when that is another one, also to the device of its read b (every record crosses
+ * PCIe at most twice, whatever N is) — through one yacrd_stream per device.  At the end each device
+ * gets its own handle map (its reads numbered densely in first-appearance order, every other read
+ * YACRD_HANDLE_ELSEWHERE: csr_build takes only the half of a record that names a read of its own),
+ * builds its CSR, runs; the results are merged back into first-appearance order.  No collective.
+ * With one engine the sink is the stream's own (no routing, no extra copy). */
+#define YACRD_HANDLE_ELSEWHERE 0xFFFFFFFEu /* in a handle map: this read lives on another device */
+typedef struct yacrd_stream_group yacrd_stream_group;
+uint32_t yacrd_stream_device_of(uint32_t handle, uint32_t n_devices);
+int yacrd_stream_group_open(yacrd_engine *const *engines, uint32_t n_engines, uint64_t chunk_records,
+                            uint32_t n_buffers, yacrd_stream_group **out);
+int yacrd_stream_group_sink(yacrd_stream_group *g, yacrd_rec_sink *sink);
+/* like yacrd_stream_finish; handle_map / lengths are the GLOBAL ones (handle -> first-appearance id) */
+int yacrd_stream_group_finish(yacrd_stream_group *g, const uint32_t *handle_map, uint64_t n_handles,
+                              const uint32_t *lengths, uint64_t n_reads, uint32_t coverage,
+                              double not_coverage, yacrd_result *out);
+/* stats of device `index`'s stream and the number of reads it owned in the last finish */
+int yacrd_stream_group_last_stats(const yacrd_stream_group *g, uint32_t index, yacrd_stream_stats *st,
+                                  uint64_t *n_reads_owned);
+int yacrd_stream_group_reset(yacrd_stream_group *g);
+void yacrd_stream_group_close(yacrd_stream_group *g);
+
 /* ---- PAF text -> read types with the parse on the GPU ------------------------------------------------
  * Reads2Ovl::init_paf (src/reads2ovl/mod.rs:83-113) + FullMemory (src/reads2ovl/fullmemory.rs:82-90) +
  * compute_all_bad_part in one call: the host only moves the text (pread chunks -> pinned buffers ->

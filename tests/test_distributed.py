@@ -61,3 +61,85 @@ def test_shards_cover_all_reads_once():
         spans = [ydist.shard(offsets, r, world, yacrd_amd.partition_reads) for r in range(world)]
         assert spans[0][0] == 0 and spans[-1][1] == 1000
         assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+
+
+GROUP_WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import oracle, yacrd_amd
+from yacrd_amd import dist as ydist, host
+# what yacrd_stream_group does, with the oracle standing in for the device: a record belongs to the ranks of
+# its two reads (handle mod world, include/yacrd_engine.h::yacrd_stream_device_of), every rank keeps the halves
+# that name its own reads, numbers them in first-appearance order and sweeps them; merged by first appearance
+# the result must be the whole file's.
+paf = os.path.join(sys.argv[2], "g.paf")
+rank, local_rank, world = ydist.env_rank()
+d = ydist.init(backend="gloo")
+if rank == 0:
+    host.synth_paf(host.SYNTH_ONT, 2500, 50000, 20250302, paf)
+d.barrier()
+from test_ingest_stream import PySink  # (the yacrd_rec_sink ABI over numpy buffers)
+ref = host.csr_from_file(paf, n_threads=2)
+box = [None]
+if rank == 0:  # one parser (handles depend on the parser threads' timing), its records go to every rank
+    sink = PySink()
+    c = host.ingest_stream(paf, sink.struct, n_threads=3)
+    box = [(sink.records(), np.array(c.handle_map), np.array(c.lengths))]
+d.broadcast_object_list(box, src=0)
+records, hmap, lengths = box[0]
+mine = np.array([yacrd_amd.stream_device_of(h, world) == rank for h in range(len(hmap))])
+owned = np.flatnonzero(mine & (hmap != 0xFFFFFFFF))
+gids = np.sort(hmap[owned])                       # first-appearance order of this rank's reads
+local_of = np.full(len(lengths), -1, np.int64); local_of[gids] = np.arange(len(gids))
+per = [[] for _ in gids]
+for r in records:
+    for h, s, e in ((r["a"], r["sa"], r["ea"]), (r["b"], r["sb"], r["eb"])):
+        if mine[h]:
+            per[local_of[hmap[h]]].append((s, e))
+off = np.zeros(len(gids) + 1, np.uint64); off[1:] = np.cumsum([len(x) for x in per])
+iv = np.array([p for x in per for p in x], dtype=np.uint32).reshape(-1, 2)
+part = oracle.run(off, iv, lengths[gids].astype(np.uint64), 4, 0.4)
+parts = [None] * world
+d.all_gather_object(parts, (gids, part))
+if rank == 0:
+    want = oracle.run(ref.offsets, ref.intervals, ref.lengths.astype(np.uint64), 4, 0.4)
+    R = len(ref.lengths)
+    seen = np.zeros(R, np.int64)
+    ok = True
+    for g, (boff, breg, rtype) in parts:
+        seen[g] += 1
+        for l, r in enumerate(g):
+            a = breg[int(boff[l]):int(boff[l + 1])]
+            b = want[1][int(want[0][r]):int(want[0][r + 1])]
+            ok = ok and np.array_equal(a, b) and rtype[l] == want[2][r]
+    ok = ok and bool((seen == 1).all())
+    print("RESULT", "OK" if ok else "MISMATCH")
+d.destroy_process_group()
+"""
+
+
+def test_two_rank_handle_partition_gloo(tmp_path):
+    script = tmp_path / "gworker.py"
+    script.write_text(GROUP_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(tmp_path)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "RESULT OK" in outs[0][0], outs
+
+
+def test_handle_partition_is_a_partition():
+    sys.path.insert(0, ROOT)
+    import yacrd_amd
+    for world in (1, 2, 3, 8):
+        owners = [yacrd_amd.stream_device_of(h, world) for h in range(1000)]
+        assert set(owners) == set(range(world)) and all(o == h % world for h, o in enumerate(owners))
+    assert yacrd_amd.stream_device_of(0xFFFFFFFD, 8) == 0xFFFFFFFD % 8

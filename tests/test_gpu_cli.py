@@ -110,12 +110,27 @@ def test_m4_mhap_and_compressed_inputs(work, golden_dir, tmp_path):
     assert p.returncode != 0 and "xz" in p.stderr
 
 
-def test_two_engines_partitioned_path(work, golden_dir):
-    """--gpus 2 needs two devices; on a 1-GPU box the host-CSR + partition path is covered through
-    the library (tests/test_gpu_parity.py::test_partitioned...); here: the CLI refuses loudly."""
+def test_several_engines_stream_group_path(work, golden_dir, tmp_path):
+    """--gpus N streams the records to N engines by handle mod N (yacrd_stream_group); a 1-GPU box has no
+    second device, so the CLI refuses --gpus 64 loudly, and YACRD_GPUS_ON_DEVICE=0 puts all N engines on
+    device 0: same report as --gpus 1, also for gzip input (host parser) and a bigger synthetic file."""
     p = subprocess.run([BIN, "-i", str(work / "reads.paf"), "-o", str(work / "g2.yacrd"), "--gpus", "64"],
                        capture_output=True, text=True)
     assert p.returncode != 0 and "device" in p.stderr
+    env = dict(os.environ, YACRD_GPUS_ON_DEVICE="0")
+    from yacrd_amd import host
+    big = str(tmp_path / "big.paf")
+    host.synth_paf(host.SYNTH_ONT, 3000, 60000, 20250303, big)
+    for src, cov in ((str(work / "reads.paf"), "0"), (big, "4")):
+        one = str(tmp_path / "one.yacrd")
+        p = subprocess.run([BIN, "-i", src, "-o", one, "-c", cov, "-t", "4"], capture_output=True, text=True)
+        assert p.returncode == 0, p.stderr
+        for n in ("2", "3"):
+            out = str(tmp_path / ("n%s.yacrd" % n))
+            p = subprocess.run([BIN, "-i", src, "-o", out, "-c", cov, "-t", "4", "--gpus", n], env=env,
+                               capture_output=True, text=True)
+            assert p.returncode == 0, p.stderr
+            assert open(out).read() == open(one).read()
 
 
 def test_bad_usage_is_loud(work):

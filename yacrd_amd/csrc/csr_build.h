@@ -32,6 +32,7 @@ __device__ __forceinline__ u32 run_heads(u32 key, u32 &rank)
 }
 
 constexpr int kCsrThreads = 256;
+constexpr u32 kSkipRead = 0xFFFFFFFEu; // == YACRD_HANDLE_ELSEWHERE (include/yacrd_engine.h)
 
 __global__ __launch_bounds__(kCsrThreads) void csr_count_kernel(const OvlRec *__restrict__ recs, u64 n,
                                                                 const u32 *__restrict__ map,
@@ -51,10 +52,15 @@ __global__ __launch_bounds__(kCsrThreads) void csr_count_kernel(const OvlRec *__
                 a = a < n_handles ? map[a] : ~0u;
                 b = b < n_handles ? map[b] : ~0u;
             }
-            if (a >= n_reads || b >= n_reads) {
+            // kSkipRead: a read that lives on another device (read-partitioned streaming, yacrd_stream_group: a
+            // record goes to the devices of both of its reads and each keeps its own half); anything else out of
+            // range is an error
+            if ((a >= n_reads && a != kSkipRead) || (b >= n_reads && b != kSkipRead)) {
                 atomicOr(err, 1u);
                 a = b = ~0u;
             }
+            if (a == kSkipRead) a = ~0u;
+            if (b == kSkipRead) b = ~0u;
         }
         u32 rank;
         const u32 run = run_heads(a, rank);
@@ -85,7 +91,9 @@ __global__ __launch_bounds__(kCsrThreads) void csr_scatter_kernel(const OvlRec *
                 a = a < n_handles ? map[a] : ~0u;
                 b = b < n_handles ? map[b] : ~0u;
             }
-            if (a >= n_reads || b >= n_reads) a = b = ~0u; // reported by the count pass
+            if ((a >= n_reads && a != kSkipRead) || (b >= n_reads && b != kSkipRead)) a = b = ~0u; // reported by the count pass
+            if (a == kSkipRead) a = ~0u;
+            if (b == kSkipRead) b = ~0u;
         }
         u32 rank;
         const u32 run = run_heads(a, rank);

@@ -5,7 +5,7 @@
 //   yacrd -i <overlaps.paf|.m4|.mhap|report.yacrd> -o <report.yacrd> [-t N] [-c COV] [-n RATIO]
 //         [--read-buffer-size N] [-d PREFIX] [--ondisk-buffer-size N]
 //         [scrubb|filter|extract|split -i <in> -o <out>]
-// Additive flags only: --gpus N (read-partitioned over N GPUs, default 1).
+// Additive flags only: --gpus N (reads partitioned over N GPUs by id handle, default 1).
 // The bad-region computation and the read classification run on the GPU through
 // include/yacrd_engine.h; there is no CPU fallback — without a gfx950 device this exits non-zero.
 #include <cerrno>
@@ -128,8 +128,10 @@ int main(int argc, char **argv)
 
     // ---- engines (one per GPU)
     std::vector<yacrd_engine *> engines;
+    // YACRD_GPUS_ON_DEVICE=<d>: every engine on device d (how the N > 1 path is tested on a one-GPU box)
+    const char *same_dev = std::getenv("YACRD_GPUS_ON_DEVICE");
     for (unsigned long long g = 0; g < gpus; g++) {
-        yacrd_engine_cfg cfg = {(int32_t)g, YACRD_F_DEFAULT};
+        yacrd_engine_cfg cfg = {same_dev && *same_dev ? (int32_t)std::atoi(same_dev) : (int32_t)g, YACRD_F_DEFAULT};
         yacrd_engine *e = nullptr;
         if (yacrd_engine_create(&cfg, &e) != YACRD_OK) die(yacrd_last_error());
         engines.push_back(e);
@@ -175,31 +177,25 @@ int main(int argc, char **argv)
             view.name_off = dev_reads.name_off;
             view.names = dev_reads.names;
             view.lengths = dev_reads.lengths;
-        } else if (engines.size() == 1) {
-            // one GPU: the parser's records cross PCIe from pinned buffers while it is still
-            // parsing, the CSR is built in HBM (yacrd_stream_*), then the engine runs on it
-            yacrd_stream *st = nullptr;
-            if (yacrd_stream_open(engines[0], 0, 0, &st) != YACRD_OK) die(yacrd_last_error());
+        } else {
+            // The parser's records cross PCIe from pinned buffers while it is still parsing — routed by
+            // handle mod N to the GPUs of their two reads (yacrd_stream_group_*; with one GPU the sink is the
+            // stream's own) — every GPU builds the CSR of its reads in HBM and runs on it, no collective
+            // (reads are independent, src/stack.rs:61); results come back in first-appearance order.
+            yacrd_stream_group *grp = nullptr;
+            if (yacrd_stream_group_open(engines.data(), (uint32_t)engines.size(), 0, 0, &grp) != YACRD_OK)
+                die(yacrd_last_error());
             yacrd_rec_sink sink;
-            yacrd_stream_sink(st, &sink);
+            yacrd_stream_group_sink(grp, &sink);
             if (yacrd_ingest_stream(input.c_str(), 0, (int)threads, &sink, &csr)) die(yacrd_host_last_error());
             yacrd_csr_get(csr, &view);
             const uint32_t *map = nullptr;
             uint64_t n_handles = 0;
             if (yacrd_csr_handle_map(csr, &map, &n_handles)) die(yacrd_host_last_error());
-            if (yacrd_stream_finish(st, map, n_handles, view.lengths, view.n_reads, cov32, not_coverage,
-                                    &res) != YACRD_OK)
+            if (yacrd_stream_group_finish(grp, map, n_handles, view.lengths, view.n_reads, cov32, not_coverage,
+                                          &res) != YACRD_OK)
                 die(yacrd_last_error());
-            yacrd_stream_close(st);
-        } else {
-            // several GPUs: host CSR, contiguous read ranges balanced by interval count, one
-            // engine per GPU, no collective (reads are independent, src/stack.rs:61)
-            if (yacrd_csr_from_file(input.c_str(), 0, (int)threads, &csr)) die(yacrd_host_last_error());
-            yacrd_csr_get(csr, &view);
-            if (yacrd_engines_run_partitioned(engines.data(), (uint32_t)engines.size(), view.offsets,
-                                              view.intervals, view.lengths, view.n_reads, cov32,
-                                              not_coverage, &res) != YACRD_OK)
-                die(yacrd_last_error());
+            yacrd_stream_group_close(grp);
         }
         bp.n_reads = view.n_reads;
         bp.name_off = view.name_off;

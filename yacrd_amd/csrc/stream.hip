@@ -15,6 +15,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -97,7 +100,7 @@ namespace yke {
 // Overlap records in HBM -> the engine's input CSR (in_off, in_iv; in_len holds the lengths already): count,
 // scan, scatter (csr_build.h).  `map` (or null) translates the records' handles to read ids.  Blocking.
 int csr_from_records(yacrd_engine *e, const RecSlab *slabs, size_t n_slabs, const u32 *d_map, u64 n_handles, u64 n_reads,
-                     DevBuf &cnt, DevBuf &part, DevBuf &err, hipEvent_t done)
+                     DevBuf &cnt, DevBuf &part, DevBuf &err, hipEvent_t done, u64 *n_intervals)
 {
     u64 n = 0;
     for (size_t i = 0; i < n_slabs; i++) n += slabs[i].n;
@@ -135,10 +138,13 @@ int csr_from_records(yacrd_engine *e, const RecSlab *slabs, size_t n_slabs, cons
                                cnt.as<u32>(), e->in_iv.as<uint2>());
     if (done) HIP_TRY(hipEventRecord(done, e->stream));
     u32 h_err = 0;
+    u64 h_total = 0; // (fewer than two per record when reads live elsewhere: kSkipRead)
     HIP_TRY(hipMemcpyAsync(&h_err, err.p, sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(&h_total, e->in_off.as<u64>() + n_reads, sizeof(u64), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipGetLastError());
     if (h_err) return fail(YACRD_EINVAL, "a record names a read outside handle_map / n_reads");
+    if (n_intervals) *n_intervals = h_total;
     return YACRD_OK;
 }
 // exclusive prefix sums u32[n] -> u64[n + 1] on the engine's stream (asynchronous)
@@ -355,17 +361,306 @@ int yacrd_stream_finish(yacrd_stream *s, const uint32_t *handle_map, uint64_t n_
     std::vector<RecSlab> rs;
     for (auto &sl : s->slabs)
         if (sl.used) rs.push_back(RecSlab{sl.buf.as<yk::OvlRec>(), sl.used});
-    rc = csr_from_records(e, rs.data(), rs.size(), d_map, n_handles, n_reads, s->cnt, s->part, s->err, s->evb1);
+    u64 n_iv_here = n_iv;
+    rc = csr_from_records(e, rs.data(), rs.size(), d_map, n_handles, n_reads, s->cnt, s->part, s->err, s->evb1, &n_iv_here);
     if (rc) return rc;
     s->stats.build_ms = ev_ms(s->evb0, s->evb1);
     const double t0 = now_ms();
-    rc = run_on_device(e, e->in_off.as<u64>(), e->in_iv.as<uint2>(), e->in_len.as<u32>(), n_reads, n_iv,
+    rc = run_on_device(e, e->in_off.as<u64>(), e->in_iv.as<uint2>(), e->in_len.as<u32>(), n_reads, n_iv_here,
                        coverage, not_coverage);
     if (rc) return rc;
     s->stats.run_ms = (float)(now_ms() - t0);
     rc = fetch_result(e, out);
     s->stats.d2h_ms = e->timing.d2h_ms;
     return rc;
+}
+
+// ---- the group: one stream per device, records routed by handle mod N while the parser runs ----------
+struct yacrd_stream_group {
+    std::vector<yacrd_stream *> st;
+    uint64_t chunk = 0; // records per staging buffer (what a parser thread fills)
+    uint64_t piece = 0; // records per routed piece (what leaves for a device in one copy)
+    // What a parser thread fills is a plain host buffer (a lane's staging); commit sorts its records into the
+    // lane's per-device pieces, and a full piece goes through a pinned buffer of that device's stream — held
+    // only for the memcpy, never between calls: any number of parser threads works with any number of buffers.
+    struct Lane {
+        yacrd_ovl_rec *staging = nullptr;
+        bool held = false;
+        std::vector<yacrd_ovl_rec *> out; // per device: piece records
+        std::vector<uint64_t> fill;
+        ~Lane()
+        {
+            std::free(staging);
+            for (yacrd_ovl_rec *p : out) std::free(p);
+        }
+    };
+    std::mutex mu;
+    std::vector<std::unique_ptr<Lane>> lanes;
+    std::vector<uint64_t> owned; // reads per device in the last finish
+};
+
+namespace {
+
+int group_acquire(void *ctx, yacrd_ovl_rec **buf, uint64_t *cap)
+{
+    yacrd_stream_group *g = (yacrd_stream_group *)ctx;
+    if (!g || !buf) return fail(YACRD_EINVAL, "null argument");
+    *buf = nullptr;
+    std::lock_guard<std::mutex> lock(g->mu);
+    yacrd_stream_group::Lane *lane = nullptr;
+    for (auto &l : g->lanes)
+        if (!l->held) {
+            lane = l.get();
+            break;
+        }
+    if (!lane) {
+        std::unique_ptr<yacrd_stream_group::Lane> fresh(new (std::nothrow) yacrd_stream_group::Lane());
+        if (!fresh) return fail(YACRD_ENOMEM, "host allocation failed");
+        fresh->staging = (yacrd_ovl_rec *)std::malloc((size_t)g->chunk * sizeof(yacrd_ovl_rec));
+        if (!fresh->staging) return fail(YACRD_ENOMEM, "host allocation failed");
+        fresh->out.assign(g->st.size(), nullptr);
+        fresh->fill.assign(g->st.size(), 0);
+        for (size_t d = 0; d < g->st.size(); d++) {
+            fresh->out[d] = (yacrd_ovl_rec *)std::malloc((size_t)g->piece * sizeof(yacrd_ovl_rec));
+            if (!fresh->out[d]) return fail(YACRD_ENOMEM, "host allocation failed");
+        }
+        lane = fresh.get();
+        g->lanes.push_back(std::move(fresh));
+    }
+    lane->held = true;
+    *buf = lane->staging;
+    if (cap) *cap = g->chunk;
+    return YACRD_OK;
+}
+
+// a lane's piece for device d leaves: pinned buffer, memcpy, commit (the DMA starts)
+int lane_send(yacrd_stream_group *g, yacrd_stream_group::Lane *lane, uint32_t d)
+{
+    const uint64_t n = lane->fill[d];
+    if (!n) return YACRD_OK;
+    lane->fill[d] = 0;
+    yacrd_ovl_rec *pin = nullptr;
+    uint64_t cap = 0;
+    int rc = yacrd_stream_acquire(g->st[d], &pin, &cap);
+    if (rc) return rc;
+    std::memcpy(pin, lane->out[d], (size_t)n * sizeof(yacrd_ovl_rec)); // (piece <= the stream's chunk)
+    return yacrd_stream_commit(g->st[d], pin, n);
+}
+
+int group_commit(void *ctx, yacrd_ovl_rec *buf, uint64_t n)
+{
+    yacrd_stream_group *g = (yacrd_stream_group *)ctx;
+    if (!g || !buf) return fail(YACRD_EINVAL, "null argument");
+    yacrd_stream_group::Lane *lane = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g->mu);
+        for (auto &l : g->lanes)
+            if (l->staging == buf && l->held) lane = l.get();
+    }
+    if (!lane) return fail(YACRD_EINVAL, "not a held buffer of this stream group");
+    const uint32_t N = (uint32_t)g->st.size();
+    int rc = n > g->chunk ? fail(YACRD_EINVAL, "more records than the buffer holds") : YACRD_OK;
+    const uint64_t piece = g->piece;
+    for (uint64_t i = 0; i < n && !rc; i++) {
+        const yacrd_ovl_rec &r = buf[i];
+        const uint32_t da = r.a % N, db = r.b % N; // == yacrd_stream_device_of
+        lane->out[da][lane->fill[da]++] = r;
+        if (lane->fill[da] == piece) rc = lane_send(g, lane, da);
+        if (db != da && !rc) {
+            lane->out[db][lane->fill[db]++] = r;
+            if (lane->fill[db] == piece) rc = lane_send(g, lane, db);
+        }
+    }
+    std::lock_guard<std::mutex> lock(g->mu);
+    lane->held = false;
+    return rc;
+}
+
+// every lane's pieces leave for their devices, or are dropped (g->mu held; no lane may be held)
+int group_flush_locked(yacrd_stream_group *g, bool keep)
+{
+    int rc = YACRD_OK;
+    for (auto &l : g->lanes) {
+        if (l->held) return fail(YACRD_EINVAL, "a buffer is still held by a parser");
+        for (size_t d = 0; d < g->st.size(); d++) {
+            if (keep) {
+                const int r1 = lane_send(g, l.get(), (uint32_t)d);
+                if (r1 && !rc) rc = r1;
+            }
+            l->fill[d] = 0;
+        }
+    }
+    return rc;
+}
+
+} // namespace
+
+uint32_t yacrd_stream_device_of(uint32_t handle, uint32_t n_devices)
+{
+    return n_devices ? handle % n_devices : 0u;
+}
+
+int yacrd_stream_group_open(yacrd_engine *const *engines, uint32_t n_engines, uint64_t chunk_records,
+                            uint32_t n_buffers, yacrd_stream_group **out)
+{
+    if (!engines || n_engines == 0 || !out) return fail(YACRD_EINVAL, "bad argument");
+    *out = nullptr;
+    for (uint32_t d = 0; d < n_engines; d++)
+        if (!engines[d]) return fail(YACRD_EINVAL, "null engine");
+    yacrd_stream_group *g = new (std::nothrow) yacrd_stream_group();
+    if (!g) return fail(YACRD_ENOMEM, "host allocation failed");
+    if (chunk_records == 0) chunk_records = 131072;
+    g->chunk = chunk_records;
+    g->piece = std::min<uint64_t>(chunk_records, 32768); // 768 KiB per copy: PCIe is near its peak from 256 KiB on
+    g->owned.assign(n_engines, 0);
+    for (uint32_t d = 0; d < n_engines; d++) {
+        yacrd_stream *s = nullptr;
+        const int rc = yacrd_stream_open(engines[d], chunk_records, n_buffers, &s);
+        if (rc) {
+            yacrd_stream_group_close(g);
+            return rc;
+        }
+        g->st.push_back(s);
+    }
+    *out = g;
+    return YACRD_OK;
+}
+
+int yacrd_stream_group_sink(yacrd_stream_group *g, yacrd_rec_sink *sink)
+{
+    if (!g || !sink) return fail(YACRD_EINVAL, "null argument");
+    if (g->st.size() == 1) return yacrd_stream_sink(g->st[0], sink); // nothing to route
+    sink->ctx = g;
+    sink->acquire = group_acquire;
+    sink->commit = group_commit;
+    return YACRD_OK;
+}
+
+int yacrd_stream_group_reset(yacrd_stream_group *g)
+{
+    if (!g) return fail(YACRD_EINVAL, "null argument");
+    std::lock_guard<std::mutex> lock(g->mu);
+    int rc = group_flush_locked(g, false);
+    for (yacrd_stream *s : g->st) {
+        const int r1 = yacrd_stream_reset(s);
+        if (r1 && !rc) rc = r1;
+    }
+    return rc;
+}
+
+int yacrd_stream_group_finish(yacrd_stream_group *g, const uint32_t *handle_map, uint64_t n_handles,
+                              const uint32_t *lengths, uint64_t n_reads, uint32_t coverage,
+                              double not_coverage, yacrd_result *out)
+{
+    if (!g || !out) return fail(YACRD_EINVAL, "null argument");
+    const uint32_t N = (uint32_t)g->st.size();
+    if (N == 1) {
+        g->owned[0] = n_reads;
+        return yacrd_stream_finish(g->st[0], handle_map, n_handles, lengths, n_reads, coverage, not_coverage, out);
+    }
+    std::memset(out, 0, sizeof(*out));
+    if (n_reads && !lengths) return fail(YACRD_EINVAL, "null lengths");
+    if (n_reads >= 0xFFFFFFFEull) return fail(YACRD_EINVAL, "n_reads must be < 2^32 - 2");
+    std::lock_guard<std::mutex> lock(g->mu);
+    // whatever happens below, no device keeps records of this file
+    struct ResetOnExit {
+        yacrd_stream_group *g;
+        bool armed = true;
+        ~ResetOnExit()
+        {
+            if (!armed) return;
+            (void)group_flush_locked(g, false);
+            for (yacrd_stream *s : g->st) (void)yacrd_stream_reset(s);
+        }
+    } reset_on_exit{g};
+    int rc = group_flush_locked(g, true);
+    if (rc) return rc;
+
+    // read id -> handle (the identity without a map)
+    if (!handle_map) n_handles = n_reads;
+    std::vector<uint32_t> inv((size_t)n_reads, 0xFFFFFFFFu);
+    for (uint64_t h = 0; h < n_handles; h++) {
+        const uint32_t r = handle_map ? handle_map[h] : (uint32_t)h;
+        if (r == 0xFFFFFFFFu) continue; // (a handle no record uses)
+        if (r >= n_reads || inv[r] != 0xFFFFFFFFu) return fail(YACRD_EINVAL, "handle_map is not one-to-one onto the reads");
+        inv[r] = (uint32_t)h;
+    }
+    for (uint64_t r = 0; r < n_reads; r++)
+        if (inv[r] == 0xFFFFFFFFu) return fail(YACRD_EINVAL, "handle_map misses a read");
+
+    std::vector<yacrd_result> parts(N);
+    std::vector<int> codes(N, YACRD_OK);
+    std::vector<std::string> errs(N);
+    auto work = [&](uint32_t d) {
+        std::vector<uint32_t> local((size_t)n_handles, YACRD_HANDLE_ELSEWHERE), len_d;
+        len_d.reserve((size_t)(n_reads / N + 1024));
+        for (uint64_t r = 0; r < n_reads; r++) {
+            const uint32_t h = inv[r];
+            if (h % N != d) continue;
+            local[h] = (uint32_t)len_d.size();
+            len_d.push_back(lengths[r]);
+        }
+        g->owned[d] = len_d.size();
+        codes[d] = yacrd_stream_finish(g->st[d], local.data(), n_handles, len_d.data(), len_d.size(), coverage,
+                                       not_coverage, &parts[d]);
+        if (codes[d]) errs[d] = yke::err_slot();
+    };
+    {
+        std::vector<std::thread> th;
+        for (uint32_t d = 1; d < N; d++) th.emplace_back(work, d);
+        work(0);
+        for (auto &t : th) t.join();
+    }
+    reset_on_exit.armed = false; // (every stream's finish has emptied it)
+    for (uint32_t d = 0; d < N; d++)
+        if (codes[d]) {
+            const int code = codes[d];
+            const std::string msg = "device " + std::to_string(d) + ": " + errs[d];
+            for (auto &r : parts) yacrd_result_free(&r);
+            return fail(code, msg);
+        }
+    // merge: first-appearance order again
+    uint64_t G = 0;
+    for (auto &r : parts) G += r.n_regions;
+    out->bad_offsets = (uint64_t *)std::malloc((size_t)(n_reads + 1) * sizeof(uint64_t));
+    out->bad_regions = (uint32_t *)std::malloc((size_t)(2 * G + 2) * sizeof(uint32_t));
+    out->read_type = (uint8_t *)std::malloc((size_t)n_reads + 1);
+    if (!out->bad_offsets || !out->bad_regions || !out->read_type) {
+        for (auto &r : parts) yacrd_result_free(&r);
+        yacrd_result_free(out);
+        return fail(YACRD_ENOMEM, "host allocation failed");
+    }
+    std::vector<uint64_t> next(N, 0);
+    uint64_t g0 = 0;
+    for (uint64_t r = 0; r < n_reads; r++) {
+        const uint32_t d = inv[r] % N;
+        const uint64_t l = next[d]++;
+        const uint64_t b0 = parts[d].bad_offsets[l], b1 = parts[d].bad_offsets[l + 1];
+        out->bad_offsets[r] = g0;
+        if (b1 > b0) std::memcpy(out->bad_regions + 2 * g0, parts[d].bad_regions + 2 * b0, (size_t)(b1 - b0) * 2 * sizeof(uint32_t));
+        g0 += b1 - b0;
+        out->read_type[r] = parts[d].read_type[l];
+    }
+    out->bad_offsets[n_reads] = g0;
+    out->n_reads = n_reads;
+    out->n_regions = g0;
+    for (auto &r : parts) yacrd_result_free(&r);
+    return YACRD_OK;
+}
+
+int yacrd_stream_group_last_stats(const yacrd_stream_group *g, uint32_t index, yacrd_stream_stats *st,
+                                  uint64_t *n_reads_owned)
+{
+    if (!g || index >= g->st.size()) return fail(YACRD_EINVAL, "bad argument");
+    if (n_reads_owned) *n_reads_owned = g->owned[index];
+    return st ? yacrd_stream_last_stats(g->st[index], st) : YACRD_OK;
+}
+
+void yacrd_stream_group_close(yacrd_stream_group *g)
+{
+    if (!g) return;
+    for (yacrd_stream *s : g->st) yacrd_stream_close(s);
+    delete g;
 }
 
 int yacrd_stream_last_stats(const yacrd_stream *s, yacrd_stream_stats *st)

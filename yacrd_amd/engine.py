@@ -42,6 +42,8 @@ EXPORTED_SYMBOLS = [
     "yacrd_stream_open", "yacrd_stream_sink", "yacrd_stream_acquire", "yacrd_stream_commit",
     "yacrd_stream_finish", "yacrd_stream_last_stats", "yacrd_stream_reset", "yacrd_stream_close",
     "yacrd_engine_ingest_paf", "yacrd_reads_free",
+    "yacrd_stream_device_of", "yacrd_stream_group_open", "yacrd_stream_group_sink", "yacrd_stream_group_finish",
+    "yacrd_stream_group_last_stats", "yacrd_stream_group_reset", "yacrd_stream_group_close",
 ]
 
 
@@ -256,6 +258,17 @@ def load_library():
     lib.yacrd_stream_last_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(_StreamStats)]
     lib.yacrd_stream_close.argtypes = [ctypes.c_void_p]
     lib.yacrd_stream_close.restype = None
+    lib.yacrd_stream_device_of.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+    lib.yacrd_stream_device_of.restype = ctypes.c_uint32
+    lib.yacrd_stream_group_open.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.c_uint64,
+                                            ctypes.c_uint32, ctypes.POINTER(ctypes.c_void_p)]
+    lib.yacrd_stream_group_sink.argtypes = [ctypes.c_void_p, ctypes.POINTER(RecSink)]
+    lib.yacrd_stream_group_finish.argtypes = lib.yacrd_stream_finish.argtypes
+    lib.yacrd_stream_group_last_stats.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.POINTER(_StreamStats),
+                                                  ctypes.POINTER(ctypes.c_uint64)]
+    lib.yacrd_stream_group_reset.argtypes = [ctypes.c_void_p]
+    lib.yacrd_stream_group_close.argtypes = [ctypes.c_void_p]
+    lib.yacrd_stream_group_close.restype = None
     _lib = lib
     return lib
 
@@ -558,6 +571,92 @@ class Stream:
     def close(self):
         if self._h:
             self._lib.yacrd_stream_close(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+HANDLE_ELSEWHERE = 0xFFFFFFFE
+
+
+def stream_device_of(handle, n_devices):
+    """The device a read belongs to in a StreamGroup (yacrd_stream_device_of: handle mod N).  Loads the
+    library only: no GPU needed."""
+    return int(load_library().yacrd_stream_device_of(int(handle), int(n_devices)))
+
+
+class StreamGroup:
+    """yacrd_stream_group: one yacrd_stream per engine; the sink routes every record to the device(s) of its two
+    reads while the parser runs, finish() builds one CSR per device, runs them side by side and merges the
+    results into first-appearance order."""
+
+    def __init__(self, engines, chunk_records=0, n_buffers=0):
+        self._lib = load_library()
+        self._engines = list(engines)
+        arr = (ctypes.c_void_p * len(self._engines))(*[e._h for e in self._engines])
+        self._h = ctypes.c_void_p()
+        _check(self._lib, self._lib.yacrd_stream_group_open(arr, len(self._engines), chunk_records, n_buffers,
+                                                            ctypes.byref(self._h)))
+        self._sink = None
+
+    def sink(self):
+        s = RecSink()
+        _check(self._lib, self._lib.yacrd_stream_group_sink(self._h, ctypes.byref(s)))
+        return s
+
+    def push(self, recs):
+        """Copy an OVL_REC_DTYPE array through the group's sink (tests; the parser fills buffers in place)."""
+        recs = np.ascontiguousarray(recs, dtype=OVL_REC_DTYPE)
+        if self._sink is None:
+            self._sink = self.sink()
+        sink = self._sink
+        at = 0
+        while at < len(recs):
+            buf = ctypes.POINTER(OvlRec)()
+            cap = ctypes.c_uint64()
+            rc = sink.acquire(sink.ctx, ctypes.byref(buf), ctypes.byref(cap))
+            _check(self._lib, rc)
+            n = min(int(cap.value), len(recs) - at)
+            ctypes.memmove(buf, recs[at:at + n].ctypes.data, n * OVL_REC_DTYPE.itemsize)
+            _check(self._lib, sink.commit(sink.ctx, buf, n))
+            at += n
+
+    def finish(self, handle_map, lengths, coverage, not_coverage):
+        lengths = np.ascontiguousarray(lengths, dtype=np.uint32)
+        if handle_map is not None:
+            handle_map = np.ascontiguousarray(handle_map, dtype=np.uint32)
+        res = _Result()
+        _check(self._lib, self._lib.yacrd_stream_group_finish(
+            self._h, _ptr(handle_map, ctypes.c_uint32) if handle_map is not None and handle_map.size else None,
+            0 if handle_map is None else handle_map.shape[0],
+            _ptr(lengths, ctypes.c_uint32) if lengths.size else None, lengths.shape[0],
+            min(int(coverage), 0xFFFFFFFF), float(not_coverage), ctypes.byref(res)))
+        return _take(self._lib, res)
+
+    def reset(self):
+        _check(self._lib, self._lib.yacrd_stream_group_reset(self._h))
+
+    def stats(self, index):
+        st = _StreamStats()
+        owned = ctypes.c_uint64()
+        _check(self._lib, self._lib.yacrd_stream_group_last_stats(self._h, index, ctypes.byref(st), ctypes.byref(owned)))
+        d = {n: getattr(st, n) for n, _ in _StreamStats._fields_}
+        d["reads_owned"] = int(owned.value)
+        return d
+
+    def close(self):
+        if self._h:
+            self._lib.yacrd_stream_group_close(self._h)
             self._h = ctypes.c_void_p()
 
     def __del__(self):

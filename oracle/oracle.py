@@ -5,6 +5,7 @@ Reference citations are paths relative to the reference root (natir/yacrd @ 2024
 """
 import ctypes
 import os
+import re
 import subprocess
 
 import numpy as np
@@ -186,7 +187,23 @@ def csv_int(f, bits):
     return v
 
 
-def _ingest(lines, delim, cols):
+def csv_char(f):
+    """serde `char` (PafRecord._strand, M4Record._strand_a/_strand_b, src/io.rs:29,41,45): exactly one scalar."""
+    if len(f) != 1:
+        raise ValueError("not a single character: %r" % f)
+
+
+_F64 = re.compile(r"[+-]?(\d+\.?\d*([eE][+-]?\d+)?|\.\d+([eE][+-]?\d+)?|inf|infinity|nan)\Z", re.IGNORECASE)
+
+
+def csv_f64(f):
+    """Rust's f64::from_str (M4Record._error, src/io.rs:39): sign, digits, point, exponent, or inf / infinity /
+    nan in any case — no hex floats, no blanks."""
+    if not _F64.match(f):
+        raise ValueError("not a float: %r" % f)
+
+
+def _ingest(lines, delim, cols, chars=(), f64s=(), u64s=()):
     ia, la, ba, ea, ib, lb, bb, eb = cols
     reads = {}  # id -> [list of (s,e), length]; dict keeps first-appearance order
 
@@ -200,6 +217,13 @@ def _ingest(lines, delim, cols):
     text = lines if isinstance(lines, str) else "".join(
         l if l.endswith(("\n", "\r")) else l + "\n" for l in lines)
     for f in csv_records(text, delim):
+        # the fields the reference deserialises and then drops fail the record all the same (mod.rs:93-97 / :125-129)
+        for i in chars:
+            csv_char(f[i])
+        for i in f64s:
+            csv_f64(f[i])
+        for i in u64s:
+            csv_int(f[i], 64)
         add(f[ia], (csv_int(f[ba], 32), csv_int(f[ea], 32)), csv_int(f[la], 64))  # mod.rs:108 / :140
         add(f[ib], (csv_int(f[bb], 32), csv_int(f[eb], 32)), csv_int(f[lb], 64))  # mod.rs:109 / :141
     return reads
@@ -207,12 +231,12 @@ def _ingest(lines, delim, cols):
 
 def parse_paf(lines):
     """PafRecord columns, src/io.rs:23-34."""
-    return _ingest(lines, "\t", (0, 1, 2, 3, 5, 6, 7, 8))
+    return _ingest(lines, "\t", (0, 1, 2, 3, 5, 6, 7, 8), chars=(4,))
 
 
 def parse_m4(lines):
     """M4Record columns, src/io.rs:36-50: a b err shared sa ba ea la sb bb eb lb."""
-    return _ingest(lines, " ", (0, 7, 5, 6, 1, 11, 9, 10))
+    return _ingest(lines, " ", (0, 7, 5, 6, 1, 11, 9, 10), chars=(4, 8), f64s=(2,), u64s=(3,))
 
 
 def to_csr(reads):

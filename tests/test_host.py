@@ -95,6 +95,40 @@ def test_ingest_rules():
     assert host.csr_from_memory("", host.FMT_PAF, 1).n_reads == 0
 
 
+def test_unused_typed_fields_agree_with_the_oracle():
+    """The fields the reference deserialises and drops (PafRecord._strand: char; M4Record._error: f64,
+    _shared_min: u64, _strand_a/_strand_b: char — src/io.rs:23-50) still fail the record when they do not parse
+    (mod.rs:93-97 / :125-129): host parser and oracle accept and reject the same lines."""
+    def both(text, fmt, parse):
+        try:
+            want = oracle.to_csr(parse(text))
+        except (ValueError, IndexError):
+            want = None
+        try:
+            got = host.csr_from_memory(text, fmt, 1)
+        except host.HostError:
+            got = None
+        assert (want is None) == (got is None), text
+        if want is not None:
+            assert got.names == want[0] and got.intervals.tolist() == want[2].tolist()
+        return want is not None
+
+    paf = "a\t100\t1\t50\t%s\tb\t200\t2\t60\n"
+    for strand, ok in (("+", True), ("-", True), ("*", True), ("\u00e9", True), ("", False), ("++", False), ("+-", False)):
+        assert both(paf % strand, host.FMT_PAF, oracle.parse_paf) == ok, strand
+    m4 = "a b %s %s %s 1 50 100 %s 2 60 200\n"
+    for err, shared, sa, sb, ok in (("0.1", "42", "0", "1", True), ("1e-3", "0x2a", "+", "-", True),
+                                    (".5", "+7", "0", "0", True), ("1.", "7", "0", "0", True),
+                                    ("inf", "7", "0", "0", True), ("NaN", "7", "0", "0", True),
+                                    ("-infinity", "7", "0", "0", True), ("0x1p3", "7", "0", "0", False),
+                                    ("e5", "7", "0", "0", False), (".", "7", "0", "0", False),
+                                    ("1.5", "-7", "0", "0", False), ("1.5", "7.0", "0", "0", False),
+                                    ("1.5", "18446744073709551616", "0", "0", False),
+                                    ("1.5", "7", "00", "0", False), ("1.5", "7", "0", "01", False),
+                                    ("abc", "7", "0", "0", False)):
+        assert both(m4 % (err, shared, sa, sb), host.FMT_M4, oracle.parse_m4) == ok, (err, shared, sa, sb)
+
+
 def test_ingest_gzip_and_format_sniffing(golden_dir, tmp_path):
     import gzip, shutil
     src = os.path.join(golden_dir, "reads.paf")

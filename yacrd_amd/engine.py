@@ -116,8 +116,11 @@ CLASS_KERNELS = {  # the HIP kernel behind each class, as rocprofv3 prints it
     "R8": "sweep_group_kernel<16, 8, 0>", "R16": "sweep_group_kernel<16, 16, 0>",
     "H16": "sweep_group_kernel<32, 16, 0>", "W2": "sweep_group_kernel<64, 2, 0>",
     "W4": "sweep_group_kernel<64, 4, 0>", "W8": "sweep_group_kernel<64, 8, 0>",
-    "W16": "sweep_group_kernel<64, 16, 0>", "M1": "sweep_lds_kernel<256, 8192>",
-    "M2": "sweep_lds_kernel<1024, 32768>", "BIG": "big_* kernels (sweep_big.h)",
+    "W16": "sweep_group_kernel<64, 16, 0>",
+    # the workgroup / device-wide classes are timed as a PHASE: the screen and, for what it leaves, the fallback
+    "M1": "screen_wg_kernel (+ sweep_lds_kernel<256, 8192> for its fallback list)",
+    "M2": "screen_wg_kernel (+ sweep_lds_kernel<256, 8192> / <1024, 32768> for its fallback list)",
+    "BIG": "bs_setup / bs_minmax / bs_hist / bs_verdict (screen_big.h)",
 }
 
 

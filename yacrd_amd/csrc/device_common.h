@@ -87,7 +87,8 @@ struct SweepArgs {
     u32 cov;
     u32 prefilter;       // 1: drop events in bins deeper than cov before the sort (sweep_wave.h); 2: and count
     uint2 *stage;        // per-read slot of n+2 regions at off[r] + 2r
-    u32 *counts;         // [R] regions per read
+    u32 *counts;         // [R] regions per read; kDeferredMark / kClosedForm: see below
+    uint2 *closed;       // [R] (a, b) of the reads whose counts[] says kClosedForm
     u32 *rej_list;       // reads this sweep cannot take (degenerate interval): append here
     u32 *rej_count;
     u32 *over_list;      // sweep_lds_kernel: reads with more events than its LDS holds even after the
@@ -95,6 +96,12 @@ struct SweepArgs {
     Counters *ctr;
 };
 constexpr u32 kDeferredMark = 0xFFFFFFFFu; // in counts[r]: "deferred", not a region count (<= intervals + 2)
+// in counts[r]: the read's regions are (0, a) if a != 0 and (b, len) if b != len, with (a, b) = closed[r].  The
+// register classes' screen answers this way instead of through the read's stage slot: the slots lie ~1.6 KB apart,
+// and two scattered 8-byte stores per read here + two scattered loads in the follow-on kernel cost 0.16 ms of
+// a 0.97 ms step on a 2 M-read input whose reads all have their two end regions (bench.py --jitter 30); closed[] is
+// written and read in (nearly) read order.
+constexpr u32 kClosedForm = 0xFFFFFFFEu;
 
 __device__ __forceinline__ u32 lane_id() { return threadIdx.x & 63u; }
 

@@ -360,6 +360,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     }
     HIP_TRY(e->stage.reserve((size_t)(n_iv + 2 * n_reads64) * sizeof(uint2)));
     HIP_TRY(e->counts.reserve((size_t)n_reads * sizeof(u32)));
+    HIP_TRY(e->closed.reserve((size_t)n_reads * sizeof(uint2)));
     HIP_TRY(e->read_type.reserve((size_t)n_reads));
     if (e->bad_regions.cap < (size_t)(4 * n_reads64 + 1024) * sizeof(uint2))
         HIP_TRY(e->bad_regions.reserve((size_t)(4 * n_reads64 + 1024) * sizeof(uint2)));
@@ -440,6 +441,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     sa.prefilter = (e->flags & YACRD_F_NO_PREFILTER) ? 0u : (e->flags & YACRD_F_COUNT_PREFILTERED) ? 2u : 1u;
     sa.stage = e->stage.as<uint2>();
     sa.counts = e->counts.as<u32>();
+    sa.closed = e->closed.as<uint2>();
     sa.ctr = ctr;
     sa.over_list = over_med;
     sa.over_count = &ctr->over_med;

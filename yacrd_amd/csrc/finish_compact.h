@@ -128,6 +128,14 @@ __global__ __launch_bounds__(kScanBlock, YK_FINISH_OCC) void finish_compact_kern
     u32 g = in ? a.counts[r] : 0u;
     if (g == kDeferredMark) g = 0u; // (a marked read of more than 256 intervals cannot exist)
     const u64 off_r = in ? a.off[r] : 0;
+    const u32 L = in ? a.len[r] : 0u;
+    // the screen's closed form (device_common.h: kClosedForm): regions (0, a) and (b, len), whichever is not empty
+    const bool closed = g == kClosedForm;
+    uint2 ab = make_uint2(0u, L);
+    if (closed) {
+        ab = a.closed[r];
+        g = (ab.x != 0u ? 1u : 0u) + (ab.y != L ? 1u : 0u);
+    }
 
     // ---- phase B: scan, compaction, classification
     u32 tot;
@@ -169,16 +177,22 @@ __global__ __launch_bounds__(kScanBlock, YK_FINISH_OCC) void finish_compact_kern
         c.bad_offsets[r] = dst;
         if (r == c.n_reads - 1) c.bad_offsets[c.n_reads] = dst + g;
 
-        const uint2 *slot = a.stage + (off_r + 2 * (u64)r);
-        const u32 L = a.len[r];
         u32 bad = 0;
         bool middle = false;
         const bool fits = dst + g <= c.region_cap;
-        for (u32 k = 0; k < g; k++) {
-            const uint2 v = slot[k];
-            if (fits) c.bad_regions[dst + k] = v;
-            bad += v.y - v.x;
-            middle |= (v.x != 0u) & (v.y != L);
+        if (closed) { // (neither region lies in the middle: the first begins at 0, the second ends at len)
+            u32 k = 0;
+            if (ab.x != 0u && fits) c.bad_regions[dst + k++] = make_uint2(0u, ab.x);
+            if (ab.y != L && fits) c.bad_regions[dst + k] = make_uint2(ab.y, L);
+            bad = ab.x + (L - ab.y);
+        } else {
+            const uint2 *slot = a.stage + (off_r + 2 * (u64)r);
+            for (u32 k = 0; k < g; k++) {
+                const uint2 v = slot[k];
+                if (fits) c.bad_regions[dst + k] = v;
+                bad += v.y - v.x;
+                middle |= (v.x != 0u) & (v.y != L);
+            }
         }
         if (!fits) atomicOr(&ctr->region_overflow, 1u);
         c.read_type[r] = (uint8_t)classify(bad, middle, L, c.not_cov);

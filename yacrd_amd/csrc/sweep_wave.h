@@ -803,15 +803,14 @@ __device__ __forceinline__ void screen_block(const SweepArgs &a, u32 block)
         const bool healthy = healthy_screen<LANES, 1>(v[t], real0, real1, len[t], c, pmin, pmax, hr) && !girr;
         if (lig == (u32)(LANES - 1) && active[t]) { // the group's last lane has the verdict
             if (healthy || (!girr && (i32)n[t] <= c)) {
-                uint2 *slot = a.stage + (o[t] + 2 * (u64)r[t]);
-                u32 g = 0;
-                if ((i32)n[t] <= c) { // never more than c intervals open: the whole read is bad
-                    if (len[t] != 0) slot[g++] = make_uint2(0u, len[t]);
+                // never more than c intervals open: the whole read is bad = (0, a) with a = len
+                const u32 ra = (i32)n[t] <= c ? len[t] : hr.a, rb = (i32)n[t] <= c ? len[t] : hr.b;
+                if (ra != 0 || rb != len[t]) {
+                    a.closed[r[t]] = make_uint2(ra, rb);
+                    a.counts[r[t]] = kClosedForm;
                 } else {
-                    if (hr.a != 0) slot[g++] = make_uint2(0u, hr.a);
-                    if (hr.b != len[t]) slot[g++] = make_uint2(hr.b, len[t]);
+                    a.counts[r[t]] = 0;
                 }
-                a.counts[r[t]] = g;
                 if (a.prefilter == 2) atomicAdd(&a.ctr->prefiltered, 1u);
             } else {
                 a.counts[r[t]] = kDeferredMark;

@@ -185,6 +185,31 @@ def test_paths_agree_with_each_other(engine, engine_general, engine_lds):
 
 
 # ---- edge cases -------------------------------------------------------------------------------
+def test_region_buffer_outgrown_and_counters_handed_over():
+    """bad_regions starts at 4 R + 1024 entries; reads with hundreds of gaps each outgrow it: the follow-on kernel's
+    last slab hands the counters over with the overflow flag derived from the total (finish_compact.h), the host
+    grows the buffer and redoes the follow-on kernel only.  A fresh engine per case (buffers only grow)."""
+    for n_reads, per_read, cov in ((50, 400, 0), (1500, 120, 0), (3000, 9, 0), (40, 3000, 1)):
+        rng = np.random.default_rng(n_reads)
+        offs, ivs, lens = [0], [], []
+        for _ in range(n_reads):
+            starts = np.sort(rng.choice(np.arange(0, 40 * per_read, 20), size=per_read, replace=False))
+            iv = np.stack([starts, starts + rng.integers(1, 10, size=per_read)], axis=1)  # disjoint: a gap after each
+            if cov:
+                iv = np.repeat(iv, 2, axis=0)  # depth 2 > c = 1 inside every interval
+            ivs.append(iv)
+            offs.append(offs[-1] + len(iv))
+            lens.append(40 * per_read + 50)
+        off = np.array(offs, np.uint64)
+        iv = np.concatenate(ivs).astype(np.uint32)
+        ln = np.array(lens, np.uint32)
+        want = oracle.run(off, iv, ln.astype(np.uint64), cov, 0.4, n_threads=2)
+        assert int(want[0][-1]) > 4 * n_reads + 1024  # the case does outgrow the first allocation
+        with yacrd_amd.Engine() as e:
+            assert_same(e.run(off, iv, ln, cov, 0.4), want, "first run %d x %d" % (n_reads, per_read))
+            assert_same(e.run(off, iv, ln, cov, 0.4), want, "second run")
+
+
 def test_empty_batch(engine):
     got = engine.run(np.zeros(1, np.uint64), np.zeros((0, 2), np.uint32), np.zeros(0, np.uint32),
                      0, 0.8)

@@ -80,12 +80,18 @@ int launch_compact(yacrd_engine *e, const yk::SweepArgs &sa, u32 n_reads, double
     ca.bad_regions = e->bad_regions.as<uint2>();
     ca.region_cap = (u64)(e->bad_regions.cap / sizeof(uint2));
     ca.read_type = e->read_type.as<uint8_t>();
+#ifdef YK_NO_HANDOVER
+    ca.host_ctr = nullptr;
     hipLaunchKernelGGL(yk::finish_compact_kernel, dim3(nb), dim3(yk::kScanBlock), 0, e->stream, ca);
-    // (Handing the counters over from the kernel's last workgroup — a ticket per workgroup, the block copied
-    // to the pinned page by whoever draws the last one — was tried twice: with system-scope stores in round 2
-    // (kernel + 8 us) and with plain stores behind a release / acquire ticket in round 3: no gain on a
-    // 100 k-read batch, 140 -> 200 us on 2 M reads (1 953 same-address tickets).  The 4 us copy stays.)
     HIP_TRY(hipMemcpyAsync(e->h_ctr, ctr, sizeof(yk::Counters), hipMemcpyDeviceToHost, e->stream));
+#else
+    // The counter block goes home from inside the kernel (its last slab: finish_compact.h): no copy command —
+    // a 4 us dispatch of its own — behind it.  (Rounds 2-3 tried this with a ticket per workgroup to find the
+    // last one to FINISH: 1 953 same-address tickets on 2 M reads cost more than the copy.  The slab that ends
+    // the batch needs no ticket: its look-back has seen everyone else's aggregate.)
+    ca.host_ctr = e->h_ctr;
+    hipLaunchKernelGGL(yk::finish_compact_kernel, dim3(nb), dim3(yk::kScanBlock), 0, e->stream, ca);
+#endif
     return YACRD_OK;
 }
 

@@ -25,6 +25,7 @@ struct CompactArgs2 {
     uint2 *bad_regions;
     u64 region_cap;
     uint8_t *read_type;   // [R]
+    Counters *host_ctr;   // pinned host copy of the counter block, written by the slab that ends the batch (or null)
 };
 
 constexpr int kFinishWaves = kScanBlock / 64;
@@ -119,8 +120,13 @@ __global__ __launch_bounds__(kScanBlock, YK_FINISH_OCC) void finish_compact_kern
 #endif
         __syncthreads(); // (global stores of this workgroup's wavefronts are visible to each other after it)
         if (threadIdx.x == 0) {
-            atomicAdd(&ctr->deferred, s_n);
-            atomicAdd((unsigned long long *)&ctr->deferred_iv, s_iv);
+            // returning atomics, waited for: they are performed before this slab publishes its aggregate below, so the
+            // slab that ends the batch — whose look-back has seen every aggregate — reads final counters.  (Issued
+            // before the sorts and waited for after them they cost three registers across the sort: spills, +10 us
+            // on 2 M reads.)
+            const u32 t0 = atomicAdd(&ctr->deferred, s_n);
+            const unsigned long long t1 = atomicAdd((unsigned long long *)&ctr->deferred_iv, s_iv);
+            asm volatile("" ::"v"(t0), "v"(t1));
         }
     }
     const u32 r = bid * kScanBlock + threadIdx.x;
@@ -169,6 +175,22 @@ __global__ __launch_bounds__(kScanBlock, YK_FINISH_OCC) void finish_compact_kern
             __hip_atomic_store(&c.scan_state[bid], kPre | (base + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_base = base;
             if ((u64)(bid + 1) * kScanBlock >= c.n_reads) ctr->total_regions = base + tot;
+        }
+        // The counters go home from here: the slab that ends the batch has seen every other slab's aggregate, hence
+        // every slab is past its phase A (the only writer of counters besides the totals set right here), and the
+        // overflow flag follows from the total.  One wavefront, 512 bytes, no copy command behind the kernel.
+        if (c.host_ctr && (u64)(bid + 1) * kScanBlock >= c.n_reads) {
+            const u64 total = (u64)__shfl((long long)(base + tot), 0, 64);
+            const u32 *src = reinterpret_cast<const u32 *>(ctr);
+            u32 *dst = reinterpret_cast<u32 *>(c.host_ctr);
+            constexpr u32 kWords = (u32)(sizeof(Counters) / 4);
+            for (u32 i = lane; i < kWords; i += 64u) {
+                u32 w = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (i == (u32)(offsetof(Counters, total_regions) / 4)) w = (u32)total;
+                if (i == (u32)(offsetof(Counters, total_regions) / 4) + 1u) w = (u32)(total >> 32);
+                if (i == (u32)(offsetof(Counters, region_overflow) / 4)) w = total > c.region_cap ? 1u : 0u;
+                dst[i] = w;
+            }
         }
     }
     __syncthreads();

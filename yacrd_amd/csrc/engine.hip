@@ -1099,13 +1099,14 @@ void yacrd_engine_destroy(yacrd_engine *e)
         }
     }
     DevBuf *bufs[] = {&e->in_off, &e->in_iv, &e->in_len, &e->lists, &e->ctrl2[0], &e->ctrl2[1], &e->stage,
-                      &e->counts, &e->gen_sizes, &e->gen_scratch_off,
+                      &e->counts, &e->closed, &e->gen_sizes, &e->gen_scratch_off,
                       &e->gen_scratch, &e->big_tab, &e->big_keys, &e->big_redo, &e->bt_tab, &e->bt_hist, &e->bt_cur, &e->bt_keys, &e->bs_seg, &e->bs_chunk, &e->bs_hist,
                       &e->bad_offsets, &e->bad_regions, &e->read_type};
     for (DevBuf *b : bufs) b->release();
     if (e->h_ctr) (void)hipHostFree(e->h_ctr);
     if (e->h_out) (void)hipHostFree(e->h_out);
     if (e->paf_arena) (void)hipHostFree(e->paf_arena);
+    if (e->paf_scratch && e->paf_scratch_free) e->paf_scratch_free(e->paf_scratch);
     for (int b = 0; b < yacrd_engine::kBounce; b++) {
         if (e->bounce[b]) (void)hipHostFree(e->bounce[b]);
         if (e->bounce_ev[b]) (void)hipEventDestroy(e->bounce_ev[b]);

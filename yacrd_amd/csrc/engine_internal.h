@@ -161,6 +161,8 @@ struct yacrd_engine {
     // pinned buffers the PAF text passes through on its way to HBM (gpu_paf.hip), grow-only
     void *paf_arena = nullptr;
     size_t paf_arena_cap = 0;
+    void *paf_scratch = nullptr;                 // gpu_paf.hip's device buffers (its type), kept between calls
+    void (*paf_scratch_free)(void *) = nullptr;
 };
 
 

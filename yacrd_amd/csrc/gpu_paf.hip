@@ -9,7 +9,8 @@
 // The host parser (host/paf_csr.cc) is bound by its id table: two hash lookups per line, cache misses the CPUs
 // cannot hide (133 M overlaps/s on 16 CPUs).  Here the host only MOVES the text: threads pread fixed chunks of
 // the file into pinned buffers, every chunk crosses PCIe at once (hipMemcpyAsync) into a mirror of the file in
-// HBM.  Then, on the device:
+// HBM; the calling thread hands every 128 MiB of landed text to the scan + parse kernels (the engine's stream waits
+// for the chunks' copy events, the host for nothing).  On the device:
 //   scan     newlines counted (the number of records to expect), '"' / lone CR looked for
 //   parse    32 KiB of text staged in LDS per workgroup; a thread takes the lines that START in its 128 bytes: nine
 //            fields checked as the host's fast path checks them, both ids hashed and looked up in an open-addressing table whose slots name the text
@@ -34,6 +35,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -54,6 +56,9 @@ struct GpArgs {
     unsigned long long *n_recs;
     u32 *status;        // bit 0: the text needs the host parser; bit 1: the id table is full
     unsigned long long *n_lines; // newline-terminated lines + an unterminated last one
+    // the part of the text one launch works on (the parse runs segment by segment while later chunks still cross PCIe)
+    u64 begin, end;     // scan: bytes [begin, end); parse: the tiles from begin / kGpTile on (its grid = their number)
+    u64 avail;          // bytes [0, avail) of the mirror have landed (== n for the last segment)
 };
 
 constexpr int kGpT = 256; // threads per workgroup
@@ -64,15 +69,16 @@ __global__ __launch_bounds__(kGpT) void gp_scan_kernel(GpArgs a)
 {
     const u64 stride = (u64)gridDim.x * kGpT * 16u;
     u32 lines = 0, special = 0;
-    for (u64 base = ((u64)blockIdx.x * kGpT + threadIdx.x) * 16u; base < a.n; base += stride) {
-        // 16 bytes per thread and step (the mirror is padded: reads beyond n see zeros)
+    for (u64 base = a.begin + ((u64)blockIdx.x * kGpT + threadIdx.x) * 16u; base < a.end; base += stride) {
+        // 16 bytes per thread and step (segments begin on chunk boundaries; the mirror is padded: reads beyond n see
+        // zeros, reads beyond an inner segment's end see the next chunk, which has landed)
         const uint4 v = *reinterpret_cast<const uint4 *>(a.text + base);
         const u32 w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int k = 0; k < 16; k++) {
             const u64 i = base + (u64)k;
             const u32 c = (w[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
-            if (i < a.n) {
+            if (i < a.end) {
                 lines += c == '\n' ? 1u : 0u;
                 special |= c == '"' ? 1u : 0u;
                 if (c == '\r') { // fine only as the first half of CRLF
@@ -89,7 +95,7 @@ __global__ __launch_bounds__(kGpT) void gp_scan_kernel(GpArgs a)
         if (lines) atomicAdd(a.n_lines, (unsigned long long)lines);
         if (special) atomicOr(a.status, kNeedHost);
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0 && a.n && a.text[a.n - 1] != '\n') atomicAdd(a.n_lines, 1ull);
+    if (a.end == a.n && blockIdx.x == 0 && threadIdx.x == 0 && a.n && a.text[a.n - 1] != '\n') atomicAdd(a.n_lines, 1ull);
 }
 
 // ---- pass 2: parse ---------------------------------------------------------------------------------------------
@@ -168,12 +174,16 @@ __device__ __forceinline__ u32 gp_intern(const GpArgs &a, const GpText &t, u64 p
 __global__ __launch_bounds__(kGpT) void gp_parse_kernel(GpArgs a)
 {
     __shared__ __attribute__((aligned(16))) unsigned char win[kGpTile + kGpOver];
-    const u64 tile0 = (u64)blockIdx.x * (u64)kGpTile;
+    const u64 tile0 = a.begin + (u64)blockIdx.x * (u64)kGpTile; // (a.begin is a multiple of the tile size)
     if (tile0 >= a.n) return;
+    // Bytes at and beyond `n` are not looked at: the text's end for the last segment, what has landed so far for the
+    // others (their lines end long before it; one that does not is the host parser's: flagged below).
+    const u64 n = a.avail;
     {
         // the window, 16 bytes per thread and step (the mirror is padded by 64 zero bytes and the last step is clipped
-        // to whole 16-byte pieces inside it)
-        const u64 want = min((u64)(kGpTile + kGpOver), ((a.n + 63) & ~(u64)15) - tile0);
+        // to whole 16-byte pieces inside it; an inner segment's `avail` is a chunk boundary)
+        const u64 lim = a.avail == a.n ? ((a.n + 63) & ~(u64)15) : a.avail;
+        const u64 want = min((u64)(kGpTile + kGpOver), lim - tile0);
         for (u64 i = (u64)threadIdx.x * 16u; i < want; i += (u64)kGpT * 16u)
             *reinterpret_cast<uint4 *>(win + i) = *reinterpret_cast<const uint4 *>(a.text + tile0 + i);
     }
@@ -182,8 +192,7 @@ __global__ __launch_bounds__(kGpT) void gp_parse_kernel(GpArgs a)
     t.lds = win;
     t.glob = a.text;
     t.t0 = tile0;
-    t.t1 = min(a.n, tile0 + (u64)(kGpTile + kGpOver));
-    const u64 n = a.n;
+    t.t1 = min(n, tile0 + (u64)(kGpTile + kGpOver));
     const u64 lo = tile0 + (u64)threadIdx.x * 128u;
     if (lo >= n) return;
     const u64 hi = min(n, lo + 128u);
@@ -250,6 +259,7 @@ __global__ __launch_bounds__(kGpT) void gp_parse_kernel(GpArgs a)
             eb = gp_uint(t, q, n, 0xFFFFFFFFull, true, ok);
             ok = ok && la <= 0xFFFFFFFFull && lb <= 0xFFFFFFFFull; // (the engine's limit; the host parser says so)
             if (!ok) status |= kNeedHost;
+            if (q >= n && n < a.n) status |= kNeedHost; // (a record that reaches into text still on its way: megabytes long)
             next = q; // the rest of the line holds nothing for the record: its newline is looked for below
         }
         u32 s1 = 0, s2 = 0;
@@ -351,7 +361,7 @@ double now_ms()
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-struct Scratch { // device buffers of one call, released on every exit
+struct Scratch { // the call's device buffers; they stay with the engine (grow-only) and go when it is destroyed
     DevBuf text, claim, first_pos, recs, ctl, keys, keys2, slots, slots2, tmp, map, name_len, name_at, name_off,
         names, cnt, part, err;
     ~Scratch()
@@ -393,18 +403,79 @@ int yacrd_engine_ingest_paf(yacrd_engine *e, const char *path, int n_threads, ui
     if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) return fail(YACRD_EFALLBACK, "not a regular file: the host parser reads it");
     const u64 n = (u64)st.st_size;
     DeviceGuard guard(e->device);
-    Scratch S;
+    // (allocating and freeing ~0.8 GB of HBM per call cost 1.5 ms of a 15 ms run)
+    if (!e->paf_scratch) {
+        e->paf_scratch = new (std::nothrow) Scratch();
+        e->paf_scratch_free = [](void *p) { delete static_cast<Scratch *>(p); };
+        if (!e->paf_scratch) return fail(YACRD_ENOMEM, "host allocation failed");
+    }
+    Scratch &S = *static_cast<Scratch *>(e->paf_scratch);
     const double t_start = now_ms();
 
-    // ---- the text: pread chunks -> pinned buffers -> HBM, all chunks in flight at once
+    // ---- what does not depend on the text's content: the mirror, the id table, the control words
     HIP_TRY(S.text.reserve((size_t)n + 64));
     HIP_TRY(hipMemsetAsync(S.text.as<char>() + n, 0, 64, e->stream)); // (the scan reads 16 bytes at a time)
+    u64 cap = (u64)1 << 20;
+    while (cap < n / 64 && cap < ((u64)1 << 31)) cap <<= 1; // ids are a small fraction of the lines; a full table = fallback
+    HIP_TRY(S.claim.reserve((size_t)cap * sizeof(u64)));
+    HIP_TRY(S.first_pos.reserve((size_t)cap * sizeof(u64)));
+    HIP_TRY(S.ctl.reserve(64));
+    HIP_TRY(hipMemsetAsync(S.ctl.p, 0, 64, e->stream));
+    HIP_TRY(hipMemsetAsync(S.claim.p, 0, (size_t)cap * sizeof(u64), e->stream));
+    HIP_TRY(hipMemsetAsync(S.first_pos.p, 0xFF, (size_t)cap * sizeof(u64), e->stream));
+    // Room for the records: the number of lines is only known when the last byte has been scanned, and the parse
+    // does not wait for that — so from the line density of the file's first MiB plus a quarter (never more than
+    // one record per 17 bytes); a parse that outgrows it is repeated with the exact number below.
+    u64 rec_cap = n / 17 + 2;
+    {
+        const size_t sample = (size_t)std::min<u64>(n, (u64)1 << 20);
+        std::vector<char> head(sample + 1);
+        size_t got = 0;
+        while (got < sample) {
+            const ssize_t k = ::pread(fd, head.data() + got, sample - got, (off_t)got);
+            if (k < 0 && errno == EINTR) continue;
+            if (k <= 0) return fail(YACRD_EINVAL, "read error in the overlap file");
+            got += (size_t)k;
+        }
+        u64 nl = 0;
+        for (const char *q = head.data(), *end = q + sample; (q = (const char *)std::memchr(q, '\n', (size_t)(end - q))) != nullptr; q++) nl++;
+        if (nl) rec_cap = std::min<u64>(rec_cap, (u64)((double)n / (double)sample * (double)nl * 1.25) + 4096);
+    }
+    HIP_TRY(S.recs.reserve((size_t)rec_cap * sizeof(yk::OvlRec)));
+    yk::GpArgs ga{};
+    ga.text = S.text.as<unsigned char>();
+    ga.n = n;
+    ga.n_lines = S.ctl.as<unsigned long long>();
+    ga.n_recs = S.ctl.as<unsigned long long>() + 1;
+    ga.status = reinterpret_cast<u32 *>(S.ctl.as<unsigned long long>() + 2);
+    u32 *d_nreads = reinterpret_cast<u32 *>(S.ctl.as<unsigned long long>() + 3);
+    ga.claim = S.claim.as<u64>();
+    ga.first_pos = S.first_pos.as<u64>();
+    ga.mask = (u32)(cap - 1);
+    ga.recs = S.recs.as<yk::OvlRec>();
+    ga.rec_cap = rec_cap;
+    if ((n + yk::kGpTile - 1) / yk::kGpTile >= 0x7FFFFFFFull) return fail(YACRD_EFALLBACK, "file too large for the device parser");
+    // scan + parse of the bytes [begin, end) on the engine's stream (begin on a tile boundary)
+    auto launch_segment = [&](u64 begin, u64 end, u64 avail) {
+        ga.begin = begin, ga.end = end, ga.avail = avail;
+        const u32 scan_grid = (u32)std::min<u64>(((end - begin) / (yk::kGpT * 16u)) + 1, (u64)e->num_cu * 16);
+        hipLaunchKernelGGL(yk::gp_scan_kernel, dim3(scan_grid), dim3(yk::kGpT), 0, e->stream, ga);
+        const u64 tiles = (end - begin + yk::kGpTile - 1) / yk::kGpTile;
+        if (tiles) hipLaunchKernelGGL(yk::gp_parse_kernel, dim3((u32)tiles), dim3(yk::kGpT), 0, e->stream, ga);
+    };
+
+    // ---- the text: pread chunks -> pinned buffers -> HBM, all chunks in flight at once; THIS thread hands every
+    // segment of kSeg chunks to the scan + parse kernels as soon as it (and the chunk behind it: a tile's overhang,
+    // the byte after a CR) has landed — the engine's stream waits for the chunks' copy events, the host for nothing
     {
         // (the pinned arena stays with the engine: pinning 100 MB costs more than moving 367 MB through it)
-        constexpr size_t kChunk = (size_t)4 << 20;
+        // (128 MiB per scan + parse launch.  The two kernels take 0.9 ms for 367 MB, so what the overlap buys is small;
+        // segments of 16 / 32 MiB got in the way of the copy threads: tools/paf_matrix.py, profiles/r03/paf_matrix.log)
+        constexpr size_t kChunk = (size_t)4 << 20, kSeg = 32;
+        static_assert(kChunk % yk::kGpTile == 0, "segments begin on tile boundaries");
         const size_t n_chunks = (size_t)((n + kChunk - 1) / kChunk);
         unsigned T = n_threads > 0 ? (unsigned)n_threads : 6u; // (more threads only get in each other's way: 367 MB in 10 ms with 4-8)
-        T = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(T, 32u), n_chunks));
+        T = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min(T, 32u), std::max<size_t>(n_chunks, 1)));
         const size_t n_buf = (size_t)2 * T;
         if (e->paf_arena_cap < n_buf * kChunk) {
             if (e->paf_arena) (void)hipHostFree(e->paf_arena);
@@ -415,21 +486,23 @@ int yacrd_engine_ingest_paf(yacrd_engine *e, const char *path, int n_threads, ui
         }
         char *arena = (char *)e->paf_arena;
         std::vector<hipStream_t> copy(T, nullptr);
-        std::vector<hipEvent_t> ev(n_buf, nullptr);
+        std::vector<hipEvent_t> ev(n_chunks, nullptr); // one per chunk: recorded behind its copy
+        std::unique_ptr<std::atomic<int>[]> landed(new std::atomic<int>[n_chunks + 1]);
+        for (size_t c = 0; c <= n_chunks; c++) landed[c].store(0);
         std::atomic<size_t> next(0);
         std::atomic<int> bad(0);
         for (unsigned t = 0; t < T; t++)
             if (hipStreamCreateWithFlags(&copy[t], hipStreamNonBlocking) != hipSuccess) bad = 1;
-        for (size_t b = 0; b < n_buf; b++)
-            if (hipEventCreateWithFlags(&ev[b], hipEventDisableTiming) != hipSuccess) bad = 1;
+        for (size_t c = 0; c < n_chunks; c++)
+            if (hipEventCreateWithFlags(&ev[c], hipEventDisableTiming) != hipSuccess) bad = 1;
         auto work = [&](unsigned t) { // thread t owns buffers 2t and 2t + 1: one fills while the other flies
             if (hipSetDevice(e->device) != hipSuccess) bad = 1;
-            bool flying[2] = {false, false};
+            long prev[2] = {-1, -1}; // the chunk that last flew from each buffer
             for (int turn = 0; !bad.load(); turn ^= 1) {
                 const size_t c = next.fetch_add(1);
                 if (c >= n_chunks) break;
                 const size_t b = (size_t)2 * t + (size_t)turn;
-                if (flying[turn] && hipEventSynchronize(ev[b]) != hipSuccess) bad = 1;
+                if (prev[turn] >= 0 && hipEventSynchronize(ev[(size_t)prev[turn]]) != hipSuccess) bad = 1;
                 char *dst = arena + b * kChunk;
                 const size_t off = c * kChunk, len = (size_t)std::min<u64>(kChunk, n - off);
                 size_t got = 0;
@@ -444,20 +517,36 @@ int yacrd_engine_ingest_paf(yacrd_engine *e, const char *path, int n_threads, ui
                 }
                 if (bad.load()) break;
                 if (hipMemcpyAsync(S.text.as<char>() + off, dst, len, hipMemcpyHostToDevice, copy[t]) != hipSuccess ||
-                    hipEventRecord(ev[b], copy[t]) != hipSuccess)
+                    hipEventRecord(ev[c], copy[t]) != hipSuccess)
                     bad = 1;
-                flying[turn] = true;
+                prev[turn] = (long)c;
+                landed[c].store(1, std::memory_order_release); // (its event is recorded: the dispatcher may wait on it)
             }
             if (copy[t]) (void)hipStreamSynchronize(copy[t]);
         };
-        if (!bad.load()) {
-            std::vector<std::thread> th;
-            for (unsigned t = 1; t < T; t++) th.emplace_back(work, t);
-            work(0);
-            for (auto &x : th) x.join();
+        std::vector<std::thread> th;
+        if (!bad.load())
+            for (unsigned t = 0; t < T; t++) th.emplace_back(work, t);
+        // the dispatcher
+        size_t waited = 0;
+        for (size_t c0 = 0; c0 < n_chunks && !bad.load(); c0 += kSeg) {
+            const size_t c1 = std::min(c0 + kSeg, n_chunks), need = std::min(c1 + 1, n_chunks);
+            while (waited < need && !bad.load()) {
+                if (!landed[waited].load(std::memory_order_acquire)) {
+                    struct timespec ts = {0, 20000};
+                    nanosleep(&ts, nullptr);
+                    continue;
+                }
+                if (hipStreamWaitEvent(e->stream, ev[waited], 0) != hipSuccess) bad = 1;
+                waited++;
+            }
+            if (bad.load()) break;
+            launch_segment((u64)c0 * kChunk, std::min<u64>(n, (u64)c1 * kChunk), std::min<u64>(n, (u64)need * kChunk));
         }
-        for (hipStream_t s : copy)
-            if (s) (void)hipStreamDestroy(s);
+        for (auto &x : th) x.join();
+        for (hipStream_t s2 : copy)
+            if (s2) (void)hipStreamDestroy(s2);
+        if (bad.load()) (void)hipStreamSynchronize(e->stream); // (kernels may still wait on events about to go)
         for (hipEvent_t x : ev)
             if (x) (void)hipEventDestroy(x);
         if (bad.load() == 2) return fail(YACRD_EINVAL, "read error in the overlap file");
@@ -466,51 +555,34 @@ int yacrd_engine_ingest_paf(yacrd_engine *e, const char *path, int n_threads, ui
     }
     const double t_text = now_ms();
 
-    // ---- scan: the number of lines, anything for the host parser?
-    HIP_TRY(S.ctl.reserve(64));
-    HIP_TRY(hipMemsetAsync(S.ctl.p, 0, 64, e->stream));
-    yk::GpArgs ga{};
-    ga.text = S.text.as<unsigned char>();
-    ga.n = n;
-    ga.n_lines = S.ctl.as<unsigned long long>();
-    ga.n_recs = S.ctl.as<unsigned long long>() + 1;
-    ga.status = reinterpret_cast<u32 *>(S.ctl.as<unsigned long long>() + 2);
-    u32 *d_nreads = reinterpret_cast<u32 *>(S.ctl.as<unsigned long long>() + 3);
-    const u32 scan_grid = (u32)std::min<u64>((n / (yk::kGpT * 16u)) + 1, (u64)e->num_cu * 16);
-    hipLaunchKernelGGL(yk::gp_scan_kernel, dim3(scan_grid), dim3(yk::kGpT), 0, e->stream, ga);
+    // ---- what the scan and the parse found
     unsigned long long h_ctl[4] = {0, 0, 0, 0};
-    HIP_TRY(hipMemcpyAsync(h_ctl, S.ctl.p, sizeof(h_ctl), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    if ((u32)h_ctl[2] & yk::kNeedHost)
-        return fail(YACRD_EFALLBACK, "the text holds a '\"' or a lone CR: csv quoting / record rules are the host parser's");
-    const u64 n_lines = h_ctl[0];
-    if (n_lines >= 0x7FFFFFFFull * 2) return fail(YACRD_EFALLBACK, "too many lines for the device parser");
-
-    // ---- parse
-    u64 cap = (u64)1 << 20;
-    while (cap < n / 64 && cap < ((u64)1 << 31)) cap <<= 1; // ids are a small fraction of the lines; a full table = fallback
-    HIP_TRY(S.claim.reserve((size_t)cap * sizeof(u64)));
-    HIP_TRY(S.first_pos.reserve((size_t)cap * sizeof(u64)));
-    HIP_TRY(S.recs.reserve((size_t)(n_lines + 1) * sizeof(yk::OvlRec)));
-    HIP_TRY(hipMemsetAsync(S.claim.p, 0, (size_t)cap * sizeof(u64), e->stream));
-    HIP_TRY(hipMemsetAsync(S.first_pos.p, 0xFF, (size_t)cap * sizeof(u64), e->stream));
-    ga.claim = S.claim.as<u64>();
-    ga.first_pos = S.first_pos.as<u64>();
-    ga.mask = (u32)(cap - 1);
-    ga.recs = S.recs.as<yk::OvlRec>();
-    ga.rec_cap = n_lines + 1;
-    const u64 n_tiles = (n + yk::kGpTile - 1) / yk::kGpTile;
-    if (n_tiles >= 0x7FFFFFFFull) return fail(YACRD_EFALLBACK, "file too large for the device parser");
-    if (n) hipLaunchKernelGGL(yk::gp_parse_kernel, dim3((u32)n_tiles), dim3(yk::kGpT), 0, e->stream, ga);
     HIP_TRY(hipMemcpyAsync(h_ctl, S.ctl.p, sizeof(h_ctl), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipGetLastError());
     if ((u32)h_ctl[2] & yk::kNeedHost)
-        return fail(YACRD_EFALLBACK, "a line is not a plain PAF record (fewer than nine columns, a 0x integer, a length "
-                                     "beyond u32 ...): the host parser decides");
+        return fail(YACRD_EFALLBACK, "the text holds a '\"', a lone CR or a line that is not a plain PAF record (fewer than nine "
+                                     "columns, a 0x integer, a length beyond u32 ...): the host parser decides");
     if ((u32)h_ctl[2] & yk::kTableFull) return fail(YACRD_EFALLBACK, "more read ids than the device table holds");
-    const u64 n_recs = h_ctl[1];
+    const u64 n_lines = h_ctl[0];
+    if (n_lines >= 0x7FFFFFFFull * 2) return fail(YACRD_EFALLBACK, "too many lines for the device parser");
+    u64 n_recs = h_ctl[1];
     if (n_recs > n_lines + 1) return fail(YACRD_EINTERNAL, "device parser: more records than lines");
+    if (n_recs > rec_cap) { // the estimate fell short (line lengths far from uniform): once more, with room for every record
+        rec_cap = n_recs + 1;
+        HIP_TRY(S.recs.reserve((size_t)rec_cap * sizeof(yk::OvlRec)));
+        ga.recs = S.recs.as<yk::OvlRec>();
+        ga.rec_cap = rec_cap;
+        HIP_TRY(hipMemsetAsync(S.ctl.p, 0, 64, e->stream));
+        HIP_TRY(hipMemsetAsync(S.claim.p, 0, (size_t)cap * sizeof(u64), e->stream));
+        HIP_TRY(hipMemsetAsync(S.first_pos.p, 0xFF, (size_t)cap * sizeof(u64), e->stream));
+        launch_segment(0, n, n);
+        HIP_TRY(hipMemcpyAsync(h_ctl, S.ctl.p, sizeof(h_ctl), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipGetLastError());
+        if (((u32)h_ctl[2] & (yk::kNeedHost | yk::kTableFull)) || h_ctl[1] != n_recs)
+            return fail(YACRD_EINTERNAL, "device parser: the second parse disagrees with the first");
+    }
     // ---- the reads: occupied slots by first position
     HIP_TRY(S.keys.reserve((size_t)cap * sizeof(u64) + 64));
     HIP_TRY(S.slots.reserve((size_t)cap * sizeof(u32) + 64));

@@ -113,3 +113,36 @@ def test_long_lines_and_ids_across_tiles(engine, tmp_path):
             f.write(eol.join(out) + eol)
         assert os.path.getsize(p) > 300000
         _check(engine, p, 2, 0.4)
+
+
+def test_record_room_estimate_falls_short_and_segments(engine, tmp_path):
+    """The room for the records comes from the line density of the file's first MiB (+25 %): a file that opens
+    with long lines and goes on with short ones outgrows it, and the parse is repeated with the exact number.
+    The file is also longer than one 128 MiB scan + parse segment: lines straddle the segment boundary."""
+    rng = np.random.default_rng(77)
+    path = str(tmp_path / "skew.paf")
+    ids = ["r%05d" % i for i in range(3000)]
+    with open(path, "w") as f:
+        # ~1.3 MiB of lines carrying a 2 KB tag behind the nine columns: ~600 lines per MiB
+        pad = "x" * 2000
+        for k in range(700):
+            a, b = ids[k % 50], ids[(k * 7 + 1) % 50]
+            f.write("%s\t9000\t%d\t%d\t+\t%s\t9000\t%d\t%d\ttg:Z:%s\n" % (a, k, k + 500, b, 2 * k, 2 * k + 700, pad))
+        # then short lines: ~30 per KiB; enough of them to pass 128 MiB
+        block = []
+        for k in range(20000):
+            a, b = int(rng.integers(0, 3000)), int(rng.integers(0, 3000))
+            s1, s2 = int(rng.integers(0, 8000)), int(rng.integers(0, 8000))
+            block.append("%s\t9000\t%d\t%d\t-\t%s\t9000\t%d\t%d\n" % (ids[a], s1, s1 + int(rng.integers(1, 900)), ids[b], s2,
+                                                                  s2 + int(rng.integers(1, 900))))
+        text = "".join(block)
+        reps = (130 << 20) // len(text) + 1
+        for _ in range(reps):
+            f.write(text)
+    assert os.path.getsize(path) > (129 << 20)
+    got, names, lengths, stats = engine.ingest_paf(path, 3, 0.4)
+    c = host.csr_from_file(path, n_threads=8)
+    assert names == c.names and np.array_equal(lengths, c.lengths)
+    assert stats["n_records"] == 700 + 20000 * reps
+    want = oracle.run(c.offsets, c.intervals, c.lengths.astype(np.uint64), 3, 0.4, n_threads=8)
+    assert_same(got, want, "skewed line lengths")

@@ -114,9 +114,12 @@ enum { YACRD_SYNTH_ONT = 0, YACRD_SYNTH_SEQUEL = 1, YACRD_SYNTH_SKEWED = 2 };
 /* flags.  NO_INJECTION: no abutting / degenerate intervals.  JITTER: the N(0, sigma) offset of a
  * dovetail end is REFLECTED into the read instead of clamped onto 0 / len (SURVEY.md §8d's clamp puts
  * 15 % of all starts on exactly 0 and 15 % of all ends on exactly len; a real overlapper's chain ends
- * are spread over a few dozen positions).  Bits 8..15: sigma of that offset in positions (0 = 30). */
+ * are spread over a few dozen positions).  Bits 8..15: sigma of that offset in positions (0 = 30).
+ * Bits 16..23: per cent of the reads that are chimeras — a junction no overlap crosses — instead of
+ * SURVEY.md §8d's 2 (0 = 2): the reads yacrd looks for, i.e. the ones the healthy-read screen defers. */
 enum { YACRD_SYNTH_F_NO_INJECTION = 1u, YACRD_SYNTH_F_JITTER = 2u };
 #define YACRD_SYNTH_F_SIGMA(s) (((uint32_t)(s) & 0xFFu) << 8)
+#define YACRD_SYNTH_F_CHIMERA_PCT(p) (((uint32_t)(p) & 0xFFu) << 16)
 
 typedef struct {
     uint32_t profile;       /* YACRD_SYNTH_* */

@@ -492,6 +492,25 @@ def test_deferral_rate_swings_between_batches():
         e.close()
 
 
+def test_build_choice_follows_the_share_of_bad_reads():
+    """Default flags, batches big enough for the screening build (>= 4 M intervals in R16 + H16): with the
+    generator's 2 % chimeras every batch goes through the screen; with 40 % (YACRD_SYNTH_F_CHIMERA_PCT) more than a
+    quarter of a screened batch comes back deferred and the engine takes the sorting build for the next 15 batches,
+    then probes the screen again (engine.hip: nodefer_left / kProbeEvery).  Bit-exact either way."""
+    from yacrd_amd import host
+    for pct, want_screened in ((0, 18), (40, 2)):
+        off, iv, ln = host.synth_csr(host.SYNTH_ONT, 60000, 3000000, 31 + pct, host.synth_f_chimera_pct(pct))
+        want = oracle.run(off, iv, ln.astype(np.uint64), 4, 0.4, n_threads=8)
+        with yacrd_amd.Engine() as e:
+            e.timing_total(reset=True)
+            for i in range(18):
+                got = e.run(off, iv, ln, 4, 0.4)
+                if i in (0, 1, 2, 16, 17):
+                    assert_same(got, want, "%d %% chimeras, batch %d" % (pct, i))
+            t, runs = e.timing_total()
+            assert runs == 18 and t["screened"] == want_screened, (pct, t["screened"])
+
+
 def test_device_batches_pipeline():
     """yacrd_engines_run_device_batches: a list of device-resident batches over 1-3 engines, every
     batch fetched in its callback and compared with the oracle; a callback can stop the loop."""

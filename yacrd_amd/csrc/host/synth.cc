@@ -102,6 +102,8 @@ struct Gen {
         junction.assign(R, 0);
         win0.assign(R, 0);
         win1.assign(R, 0);
+        const uint32_t pct = (c.flags >> 16) & 0xFFu; // YACRD_SYNTH_F_CHIMERA_PCT
+        const double chimera = pct ? std::min(pct, 97u) / 100.0 : 0.02;
         parallel_ranges(R, synth_threads(), [&](unsigned, uint64_t r0, uint64_t r1) {
             for (uint64_t r = r0; r < r1; r++) {
                 Rng rng = stream_rng(c.seed, 1, r);
@@ -117,10 +119,10 @@ struct Gen {
                 }
                 len[r] = (uint32_t)L;
                 const double u = rng.uniform();
-                if (u < 0.02) {
+                if (u < chimera) {
                     junction[r] = (uint32_t)((0.2 + 0.6 * rng.uniform()) * L);
                     if (junction[r] == 0) junction[r] = 1;
-                } else if (u < 0.05) {
+                } else if (u < chimera + 0.03) {
                     const uint32_t w = std::max<uint32_t>(len[r] / 5, 2);
                     win0[r] = (uint32_t)rng.below(len[r] - w + 1);
                     win1[r] = win0[r] + w;

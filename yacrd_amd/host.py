@@ -13,6 +13,11 @@ SYNTH_ONT, SYNTH_SEQUEL, SYNTH_SKEWED = 0, 1, 2
 SYNTH_F_NO_INJECTION, SYNTH_F_JITTER = 1, 2
 
 
+def synth_f_chimera_pct(p):
+    """YACRD_SYNTH_F_CHIMERA_PCT: per cent of the reads that are chimeras (default 2)."""
+    return (int(p) & 0xFF) << 16
+
+
 def synth_f_sigma(s):
     """sigma (positions) of the dovetail ends' offset, 1..255 (default 30)"""
     return (int(s) & 0xFF) << 8

@@ -99,6 +99,9 @@ def roofline_of(yacrd_amd, t, n_launches, R, G, key, note):
         deferred = int(t.get("deferred_reads", 0))
         c_iv -= int(t.get("deferred_intervals", 0))
         c_reads -= deferred
+    if cname in ("M1", "M2", "BIG"):
+        note += ("; kernel_ms brackets the class's whole PHASE (the screen and, for the reads it leaves, the fallback kernels one "
+                 "after the other), `traffic` is the screen kernel's alone: profiles/r03_kernel_stats_configs3.csv has the kernels")
     b_dom = 8 * c_iv + 21 * c_reads + 16 + 8 * (G * c_reads // max(R, 1))
     ach = b_dom / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     tr = traffic_entry(key) if key else None

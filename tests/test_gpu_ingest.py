@@ -146,3 +146,81 @@ def test_record_room_estimate_falls_short_and_segments(engine, tmp_path):
     assert stats["n_records"] == 700 + 20000 * reps
     want = oracle.run(c.offsets, c.intervals, c.lengths.astype(np.uint64), 3, 0.4, n_threads=8)
     assert_same(got, want, "skewed line lengths")
+
+
+def _random_paf(rng, n_lines, anomaly):
+    """Random PAF text: plain records in the shapes the fast path takes (optional '+' signs, trailing columns, CRLF,
+    empty lines, ids of 1..40 bytes incl. non-ASCII, a multi-byte strand); `anomaly` adds ONE thing that is either the
+    host parser's business or an error in the reference."""
+    ids = ["r%d" % i for i in range(int(rng.integers(1, 12)))] + ["ü%d" % i for i in range(2)] + ["x" * int(rng.integers(1, 40))]
+    lens = {k: int(rng.integers(1, 5000)) for k in ids}
+    eol = "\r\n" if rng.random() < 0.3 else "\n"
+    lines = []
+    for _ in range(n_lines):
+        a, b = ids[int(rng.integers(len(ids)))], ids[int(rng.integers(len(ids)))]
+        f = [a, str(lens[a]), str(int(rng.integers(0, 6000))), str(int(rng.integers(0, 6000))), str(rng.choice(["+", "-", "*", "é"])),
+             b, str(lens[b] if rng.random() < 0.8 else int(rng.integers(1, 9999))), str(int(rng.integers(0, 6000))), str(int(rng.integers(0, 6000)))]
+        for k in (1, 2, 3, 6, 7, 8):
+            if rng.random() < 0.1:
+                f[k] = "+" + f[k]
+        if rng.random() < 0.4:
+            f += ["%d" % int(rng.integers(0, 300)), "tp:A:P", "cm:i:%d" % int(rng.integers(0, 99))][: int(rng.integers(1, 4))]
+        lines.append("\t".join(f))
+        if rng.random() < 0.05:
+            lines.append("")
+    if anomaly and lines:
+        k = int(rng.integers(len(lines)))
+        parts = lines[k].split("\t") if lines[k] else ["a", "1", "0", "1", "+", "b", "1", "0", "1"]
+        kind = anomaly
+        if kind == 1:
+            parts[0] = '"' + parts[0] + '"'               # quoted id: same record for the csv crate
+        elif kind == 2:
+            parts[2] = "0x1f"                               # hex integer
+        elif kind == 3:
+            parts = parts[:8]                               # too few columns: an error
+        elif kind == 4:
+            parts[4] = "+-"                                 # strand of two characters: an error
+        elif kind == 5:
+            parts[3] = "4294967296"                         # u32 overflow: an error
+        elif kind == 6:
+            parts[8] = parts[8] + "\rtail"                  # a lone CR splits the record
+        elif kind == 7:
+            parts[7] = "-3"                                 # negative: an error
+        elif kind == 8:
+            parts[1] = ""                                   # empty length: an error
+        lines[k] = "\t".join(parts)
+    text = eol.join(lines)
+    if lines and rng.random() < 0.7:
+        text += eol
+    return text
+
+
+def test_random_text_against_the_oracle_ingest(engine, tmp_path):
+    """Differential fuzz of the device parser: on every random text it either hands the file to the host parser
+    (NeedsHostParser) or returns exactly what the oracle's ingest + sweep return; plain texts must NOT fall back."""
+    rng = np.random.default_rng(20250305)
+    taken = fell_back = 0
+    for case in range(400):
+        anomaly = 0 if case % 2 == 0 else int(rng.integers(1, 9))
+        text = _random_paf(rng, int(rng.integers(0, 120)), anomaly)
+        p = str(tmp_path / "f.paf")
+        with open(p, "w", newline="", encoding="utf-8") as f:
+            f.write(text)
+        try:
+            reads = oracle.parse_paf(text)
+            want = oracle.to_csr(reads)
+        except (ValueError, IndexError):
+            want = None
+        cov = int(rng.integers(0, 4))
+        try:
+            got, names, lengths, stats = engine.ingest_paf(p, cov, 0.4)
+        except yacrd_amd.NeedsHostParser:
+            fell_back += 1
+            assert anomaly != 0, "a plain text went to the host parser:\n%r" % text
+            continue
+        taken += 1
+        assert want is not None, "the device parser accepted what the reference rejects:\n%r" % text
+        w_names, off, iv, ln = want
+        assert names == list(w_names) and np.array_equal(lengths.astype(np.uint64), ln), text
+        assert_same(got, oracle.run(off, iv, ln, cov, 0.4, n_threads=2), "case %d" % case)
+    assert taken >= 200 and fell_back >= 100, (taken, fell_back)

@@ -549,7 +549,51 @@ def end_to_end(ya, host, eng, prof, R, O, cov, nc):
                 bt = dt if bt is None else min(bt, dt)
             rates[str(th)] = O / bt
         out["host_csr_ingest_overlaps_per_sec_by_threads"] = rates
+        os.remove(paf)
+        out["at_scale"] = guarded(end_to_end_at_scale, ya, host, eng, d)
         return out
+    finally:
+        if os.path.exists(paf):
+            os.remove(paf)
+
+
+def end_to_end_at_scale(ya, host, eng, d, R=600_000, O=60_000_000):
+    """The same two routes on 4.5 GB of text (configs[2]'s profile at 600 k reads / 60 M overlaps: byte offsets pass
+    2^32; 367 MB is over before the copy threads are up to speed).  tools/e2e_large.py runs configs[2] (15 GB) and the
+    north star's configs[4] (37 GB) the same way: profiles/r03_e2e_large.log."""
+    st = os.statvfs(d)
+    need = 80 * O  # ~75 bytes per line
+    if st.f_bavail * st.f_frsize < 2 * need:
+        return {"skipped": "less than %.0f GB free on %s" % (2 * need / 1e9, d)}
+    paf = os.path.join(d, "yacrd_bench_scale_%d.paf" % os.getpid())
+    el = ya.load_library()
+    try:
+        host.synth_paf(host.SYNTH_SEQUEL, R, O, 20250306, paf)
+        size = os.path.getsize(paf)
+        best = None
+        for rep in range(3):
+            res, rd, stt = ya.engine._Result(), ya.engine._Reads(), ya.engine._IngestStats()
+            t0 = time.perf_counter()
+            rc = el.yacrd_engine_ingest_paf(eng._h, paf.encode(), 6, 3, 0.4, ctypes.byref(res), ctypes.byref(rd), ctypes.byref(stt))
+            dt = time.perf_counter() - t0
+            if rc != 0:
+                raise RuntimeError("device parser: %d %s" % (rc, el.yacrd_last_error().decode()))
+            sig = (int(rd.n_reads), int(res.n_regions), int(np.ctypeslib.as_array(res.read_type, shape=(int(res.n_reads),)).sum()))
+            el.yacrd_result_free(ctypes.byref(res))
+            el.yacrd_reads_free(ctypes.byref(rd))
+            if best is None or dt < best["seconds"]:
+                best = {"seconds": dt, **{k: getattr(stt, k) for k in ("text_ms", "parse_ms", "build_ms", "run_ms", "d2h_ms")}}
+        with ya.StreamGroup([eng]) as grp:
+            t0 = time.perf_counter()
+            c = host.ingest_stream(paf, grp.sink(), n_threads=0)
+            ref = grp.finish(c.handle_map, c.lengths, 3, 0.4)
+            dt_host = time.perf_counter() - t0
+        same = sig == (len(c.lengths), int(ref.bad_offsets[-1]), int(ref.read_type.sum()))
+        return {"workload": "SEQUEL profile, %d reads / %d overlaps as PAF text" % (R, O), "paf_bytes": size,
+                "device_parser": {"overlaps_per_sec": O / best["seconds"], "reads_per_sec": R / best["seconds"],
+                                  "text_GBps": size / best["seconds"] / 1e9, **best},
+                "host_parser_streamed": {"overlaps_per_sec": O / dt_host, "seconds": dt_host},
+                "same_reads_regions_types": same}
     finally:
         if os.path.exists(paf):
             os.remove(paf)

@@ -23,7 +23,7 @@ try:
         for rep in range(3):  # the C call alone (the Python wrapper's name decoding is not the library's time)
             res, rd, stt = yacrd_amd.engine._Result(), yacrd_amd.engine._Reads(), yacrd_amd.engine._IngestStats()
             t0 = time.perf_counter()
-            rc = el.yacrd_engine_ingest_paf(e._h, paf.encode(), 6, 3, 0.4, ctypes.byref(res), ctypes.byref(rd), ctypes.byref(stt))
+            rc = el.yacrd_engine_ingest_paf(e._h, paf.encode(), int(os.environ.get("YACRD_E2E_THREADS", "6")), 3, 0.4, ctypes.byref(res), ctypes.byref(rd), ctypes.byref(stt))
             dt = time.perf_counter() - t0
             assert rc == 0, rc
             el.yacrd_result_free(ctypes.byref(res)); el.yacrd_reads_free(ctypes.byref(rd))

@@ -364,11 +364,23 @@ double now_ms()
 struct Scratch { // the call's device buffers; they stay with the engine (grow-only) and go when it is destroyed
     DevBuf text, claim, first_pos, recs, ctl, keys, keys2, slots, slots2, tmp, map, name_len, name_at, name_off,
         names, cnt, part, err;
-    ~Scratch()
+    size_t bytes()
     {
-        DevBuf *all[] = {&text, &claim, &first_pos, &recs, &ctl, &keys, &keys2, &slots, &slots2, &tmp, &map, &name_len,
-                         &name_at, &name_off, &names, &cnt, &part, &err};
-        for (DevBuf *b : all) b->release();
+        size_t n = 0;
+        for (DevBuf *b : all()) n += b->cap;
+        return n;
+    }
+    void release()
+    {
+        for (DevBuf *b : all()) b->release();
+    }
+    ~Scratch() { release(); }
+
+private:
+    std::vector<DevBuf *> all()
+    {
+        return {&text, &claim, &first_pos, &recs, &ctl, &keys, &keys2, &slots, &slots2, &tmp, &map, &name_len,
+                &name_at, &name_off, &names, &cnt, &part, &err};
     }
 };
 
@@ -667,6 +679,8 @@ int yacrd_engine_ingest_paf(yacrd_engine *e, const char *path, int n_threads, ui
     };
     rc = body();
     if (rc) yacrd_reads_free(reads);
+    // small files (repeated calls: a service, the bench) keep their buffers; a file of gigabytes gives its HBM back
+    if (S.bytes() > ((size_t)4 << 30)) S.release();
     return rc;
 }
 

@@ -20,13 +20,15 @@ try:
     with yacrd_amd.Engine() as e:
         el = yacrd_amd.load_library()
         best = None
-        for rep in range(3):  # the C call alone (the Python wrapper's name decoding is not the library's time)
+        for rep in range(int(os.environ.get("YACRD_E2E_REPS", "3"))):  # the C call alone (the Python wrapper's name decoding is not the library's time)
             res, rd, stt = yacrd_amd.engine._Result(), yacrd_amd.engine._Reads(), yacrd_amd.engine._IngestStats()
             t0 = time.perf_counter()
             rc = el.yacrd_engine_ingest_paf(e._h, paf.encode(), int(os.environ.get("YACRD_E2E_THREADS", "6")), 3, 0.4, ctypes.byref(res), ctypes.byref(rd), ctypes.byref(stt))
             dt = time.perf_counter() - t0
             assert rc == 0, rc
             el.yacrd_result_free(ctypes.byref(res)); el.yacrd_reads_free(ctypes.byref(rd))
+            print("  call %d: %.3f s (text %.0f ms)" % (rep, dt, stt.text_ms), flush=True)
+            time.sleep(float(os.environ.get("YACRD_E2E_SLEEP", "0")))
             if best is None or dt < best:
                 best, st = dt, {k: getattr(stt, k) for k in ("text_ms", "parse_ms", "build_ms", "run_ms", "d2h_ms")}
         print("device parser: %.3f s = %.1f M overlaps/s, %.1f GB/s of text; phases %s" % (

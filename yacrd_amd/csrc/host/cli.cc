@@ -163,7 +163,9 @@ int main(int argc, char **argv)
         view.lengths = bp.lengths;
     } else {
         int dev_parse = YACRD_EFALLBACK;
-        if (engines.size() == 1 && paf && !m4) {
+        // YACRD_NO_DEVICE_PARSER=1: the host parser for everything (A/B, tools/e2e_cli_paf.py)
+        const char *no_dev = std::getenv("YACRD_NO_DEVICE_PARSER");
+        if (engines.size() == 1 && paf && !m4 && !(no_dev && *no_dev == '1')) {
             // one GPU, PAF text: the host only moves the file to HBM, the device parses it, numbers the reads,
             // builds the CSR and runs the engine (yacrd_engine_ingest_paf).  Whatever is not a plain PAF file
             // (compressed, quoted fields, lone CRs, 0x integers, malformed lines ...) comes back as

@@ -396,12 +396,18 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     e->ctrl_clean[cur] = 0;
     const size_t other_bytes = std::min<size_t>(e->ctrl2[other].cap, (size_t)1 << 30) & ~(size_t)3;
     if (full) HIP_TRY(hipEventRecord(e->ev[EV_START], e->stream));
-    hipLaunchKernelGGL(yk::plan_kernel, dim3((n_reads + yk::kPlanReads - 1) / yk::kPlanReads),
-                       dim3(yk::kPlanBlock), 0, e->stream, d_off, n_reads, lists, ctr,
-                       (u32)((e->flags & YACRD_F_FORCE_GENERAL) ? 1
-                             : (e->flags & (YACRD_F_WAVE_ONLY | YACRD_F_FORCE_LDS_SORT)) ? 2
-                             : (e->flags & YACRD_F_NO_HALVES) ? 3 : 0),
-                       e->ctrl2[other].as<u32>(), (u32)(other_bytes / 4));
+    {
+        const u32 plan_mode = (u32)((e->flags & YACRD_F_FORCE_GENERAL) ? 1
+                                    : (e->flags & (YACRD_F_WAVE_ONLY | YACRD_F_FORCE_LDS_SORT)) ? 2
+                                    : (e->flags & YACRD_F_NO_HALVES) ? 3 : 0);
+        if (n_reads < yk::kPlanSmallReads)
+            hipLaunchKernelGGL(yk::plan_kernel<1>, dim3((n_reads + yk::kPlanBlock - 1) / yk::kPlanBlock), dim3(yk::kPlanBlock), 0,
+                               e->stream, d_off, n_reads, lists, ctr, plan_mode, e->ctrl2[other].as<u32>(), (u32)(other_bytes / 4));
+        else
+            hipLaunchKernelGGL(yk::plan_kernel<4>, dim3((n_reads + 4 * yk::kPlanBlock - 1) / (4 * yk::kPlanBlock)),
+                               dim3(yk::kPlanBlock), 0, e->stream, d_off, n_reads, lists, ctr, plan_mode,
+                               e->ctrl2[other].as<u32>(), (u32)(other_bytes / 4));
+    }
     e->ctrl_clean[other] = other_bytes;
     if (full) HIP_TRY(hipEventRecord(e->ev[EV_PLAN], e->stream));
 

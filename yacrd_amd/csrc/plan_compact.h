@@ -8,16 +8,19 @@ namespace yk {
 // Ranks: one LDS atomic per (wavefront, class present in it) — lanes of a class are counted
 // with a ballot, their rank inside the wavefront is a popcount — then one global atomic per class
 // per workgroup.  (One LDS atomic per read serialised 1024 lanes on one address: 8 us -> 3 us.)
-constexpr int kPlanBlock = 1024, kPlanPer = 4, kPlanReads = kPlanBlock * kPlanPer; // threads, reads per thread, reads per workgroup
+constexpr int kPlanBlock = 1024; // threads; a workgroup takes PER slabs of 1024 consecutive reads (PER reads per thread)
+constexpr u32 kPlanSmallReads = 400000; // batches below this: PER = 1 // threads, reads per thread, reads per workgroup
 
 // `zero` / `zero_words`: the control block of the NEXT run (the engine alternates between two), left
 // zeroed here so that no run starts with a fill on its critical path.
-// A workgroup takes kPlanPer slabs of 1024 consecutive reads: its two global atomics (counts and
-// interval totals of the classes it met) hit the same two cache lines as every other workgroup's and
-// are performed at the memory side one after the other — 1 953 workgroups for configs[2]'s 2 M reads
-// made a 24 MB pass take 35 us; 489 take 19.  On configs[1] the kernel alone gets slower (7 -> 11 us: 25
-// workgroups), the pipelined batch faster (27.9 -> 26.0 us: fewer workgroups and atomics in the way of
-// another engine's sweep); two slabs: 28.0 us, eight: 29.7.
+// A workgroup takes PER slabs of 1024 consecutive reads: its two global atomics (counts and interval totals of
+// the classes it met) hit the same two cache lines as every other workgroup's and are performed at the memory
+// side one after the other — 1 953 workgroups for configs[2]'s 2 M reads made a 24 MB pass take 35 us; 489 take
+// 19: PER = 4 for long batches.  A batch of 100 000 reads is 98 workgroups at PER = 1 and 25 at 4 — a quarter of
+// the device's CUs busy for 9-11 us instead of 7: with the three-dispatch chain of round 3 PER = 1 gives 24.4 us
+// per pipelined batch against 26.6 and 64.5 against 68 us for one batch at a time (round 2, five dispatches,
+// measured it the other way round: 27.9 against 26.0).
+template <int PER>
 __global__ __launch_bounds__(kPlanBlock) void plan_kernel(const u64 *off, u32 n_reads, u32 *lists,
                                                           Counters *ctr, u32 mode, u32 *zero,
                                                           u32 zero_words)
@@ -32,6 +35,7 @@ __global__ __launch_bounds__(kPlanBlock) void plan_kernel(const u64 *off, u32 n_
         s_iv[threadIdx.x] = 0;
     }
     __syncthreads();
+    constexpr int kPlanPer = PER, kPlanReads = kPlanBlock * PER;
     u32 cls[kPlanPer], local[kPlanPer];
     const u64 lt = (1ull << lane_id()) - 1ull;
 #pragma unroll

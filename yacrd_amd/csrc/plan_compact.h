@@ -9,7 +9,11 @@ namespace yk {
 // with a ballot, their rank inside the wavefront is a popcount — then one global atomic per class
 // per workgroup.  (One LDS atomic per read serialised 1024 lanes on one address: 8 us -> 3 us.)
 constexpr int kPlanBlock = 1024; // threads; a workgroup takes PER slabs of 1024 consecutive reads (PER reads per thread)
-constexpr u32 kPlanSmallReads = 400000; // batches below this: PER = 1 // threads, reads per thread, reads per workgroup
+constexpr u32 kPlanSmallReads = 400000; // batches below this: PER = 1
+#ifndef YK_PLAN_SMALL_BLOCK
+#define YK_PLAN_SMALL_BLOCK 1024
+#endif
+constexpr int kPlanSmallBlock = YK_PLAN_SMALL_BLOCK; // threads per workgroup of the short batches' form
 
 // `zero` / `zero_words`: the control block of the NEXT run (the engine alternates between two), left
 // zeroed here so that no run starts with a fill on its critical path.
@@ -20,11 +24,12 @@ constexpr u32 kPlanSmallReads = 400000; // batches below this: PER = 1 // thread
 // the device's CUs busy for 9-11 us instead of 7: with the three-dispatch chain of round 3 PER = 1 gives 24.4 us
 // per pipelined batch against 26.6 and 64.5 against 68 us for one batch at a time (round 2, five dispatches,
 // measured it the other way round: 27.9 against 26.0).
-template <int PER>
-__global__ __launch_bounds__(kPlanBlock) void plan_kernel(const u64 *off, u32 n_reads, u32 *lists,
-                                                          Counters *ctr, u32 mode, u32 *zero,
-                                                          u32 zero_words)
+template <int PER, int BLK = kPlanBlock>
+__global__ __launch_bounds__(BLK) void plan_kernel(const u64 *off, u32 n_reads, u32 *lists,
+                                                   Counters *ctr, u32 mode, u32 *zero,
+                                                   u32 zero_words)
 {
+    constexpr int kPlanBlock = BLK; // (shadows the long batches' constant)
     for (u32 i = blockIdx.x * kPlanBlock + threadIdx.x; i < zero_words; i += gridDim.x * kPlanBlock)
         zero[i] = 0;
     __shared__ u32 s_cnt[CLS_COUNT];

@@ -41,6 +41,10 @@ def test_single_gpu_line_scaled():
     e = d["end_to_end"]
     assert e["overlaps"] == 100000 and e["host_parser"]["stream"]["reads_found"] == 2000 and e["overlaps_per_sec"] > 1e6
     assert e["device_parser"]["same_result_as_host_parser"] and e["device_parser"]["phases"]["reads_found"] == 2000
+    sc = e["at_scale"]
+    assert sc["same_reads_regions_types"] and sc["device_parser"]["overlaps_per_sec"] > 1e6
+    for k in ("10%", "40%"):
+        assert d["more_bad_reads"][k]["parity"].startswith("bit-exact")
     ns = d["north_star"]
     assert ns["parity"].startswith("bit-exact") and ns["reads"] == 100000 and "configs[4]" in ns["workload"]
     for k in ("configs[1]", "configs[2]"):

@@ -178,7 +178,8 @@ struct RecSlab {
     uint64_t n;
 };
 int csr_from_records(yacrd_engine *e, const RecSlab *slabs, size_t n_slabs, const u32 *d_map, u64 n_handles, u64 n_reads,
-                     DevBuf &cnt, DevBuf &part, DevBuf &err, hipEvent_t done, u64 *n_intervals = nullptr);
+                     DevBuf &cnt, DevBuf &part, DevBuf &err, hipEvent_t done, u64 *n_intervals = nullptr,
+                     bool counted = false);
 int scan_u32_to_u64(yacrd_engine *e, const u32 *in, u64 n, u64 *out, DevBuf &part);
 // host -> HBM at PCIe rate: direct DMA when `src` is pinned, otherwise through the engine's pinned
 // bounce buffers filled by a few copy threads; asynchronous on e->stream only for pinned sources

@@ -50,6 +50,7 @@ struct GpArgs {
     u64 n;              // bytes
     u64 *claim;         // [cap]: 0 = empty, else text position of the id that claimed the slot + 1
     u64 *first_pos;     // [cap]: smallest (byte offset * 2 + side) at which the slot's id was seen
+    u32 *slot_cnt;      // [cap]: intervals of the slot's id (one per record side): the CSR build's count pass, done here
     u32 mask;           // cap - 1
     OvlRec *recs;
     u64 rec_cap;
@@ -285,6 +286,12 @@ __global__ __launch_bounds__(kGpT) void gp_parse_kernel(GpArgs a)
                 atomicMin((unsigned long long *)&a.first_pos[s1], (unsigned long long)pa);
             if (pb < __hip_atomic_load(&a.first_pos[s2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
                 atomicMin((unsigned long long *)&a.first_pos[s2], (unsigned long long)pb);
+            if (s1 == s2) {
+                atomicAdd(&a.slot_cnt[s1], 2u);
+            } else {
+                atomicAdd(&a.slot_cnt[s1], 1u);
+                atomicAdd(&a.slot_cnt[s2], 1u);
+            }
             if (at < a.rec_cap) {
                 OvlRec r;
                 r.a = s1, r.b = s2, r.sa = (u32)sa, r.ea = (u32)ea, r.sb = (u32)sb, r.eb = (u32)eb;
@@ -351,11 +358,12 @@ __global__ __launch_bounds__(256) void gp_collect_kernel(const u64 *claim, const
 // id there), the extent of its name
 __global__ __launch_bounds__(256) void gp_number_kernel(const unsigned char *t, const u64 *keys, const u32 *slots,
                                                         u32 n_reads, u32 *handle_map, u32 *lengths, u32 *name_len,
-                                                        u64 *name_at)
+                                                        u64 *name_at, const u32 *slot_cnt, u32 *cnt)
 {
     const u32 g = blockIdx.x * 256u + threadIdx.x;
     if (g >= n_reads) return;
     handle_map[slots[g]] = g;
+    cnt[g] = slot_cnt[slots[g]];
     const u64 pos = keys[g];
     u64 q = pos >> 1; // the line's start
     if (pos & 1u) {   // the second id: behind five fields
@@ -393,7 +401,7 @@ double now_ms()
 }
 
 struct Scratch { // the call's device buffers; they stay with the engine (grow-only) and go when it is destroyed
-    DevBuf text, claim, first_pos, recs, ctl, keys, keys2, slots, slots2, tmp, map, name_len, name_at, name_off,
+    DevBuf text, claim, first_pos, slot_cnt, recs, ctl, keys, keys2, slots, slots2, tmp, map, name_len, name_at, name_off,
         names, cnt, part, err;
     size_t bytes()
     {
@@ -410,7 +418,7 @@ struct Scratch { // the call's device buffers; they stay with the engine (grow-o
 private:
     std::vector<DevBuf *> all()
     {
-        return {&text, &claim, &first_pos, &recs, &ctl, &keys, &keys2, &slots, &slots2, &tmp, &map, &name_len,
+        return {&text, &claim, &first_pos, &slot_cnt, &recs, &ctl, &keys, &keys2, &slots, &slots2, &tmp, &map, &name_len,
                 &name_at, &name_off, &names, &cnt, &part, &err};
     }
 };
@@ -462,10 +470,12 @@ int yacrd_engine_ingest_paf(yacrd_engine *e, const char *path, int n_threads, ui
     while (cap < n / 64 && cap < ((u64)1 << 31)) cap <<= 1; // ids are a small fraction of the lines; a full table = fallback
     HIP_TRY(S.claim.reserve((size_t)cap * sizeof(u64)));
     HIP_TRY(S.first_pos.reserve((size_t)cap * sizeof(u64)));
+    HIP_TRY(S.slot_cnt.reserve((size_t)cap * sizeof(u32)));
     HIP_TRY(S.ctl.reserve(64));
     HIP_TRY(hipMemsetAsync(S.ctl.p, 0, 64, e->stream));
     HIP_TRY(hipMemsetAsync(S.claim.p, 0, (size_t)cap * sizeof(u64), e->stream));
     HIP_TRY(hipMemsetAsync(S.first_pos.p, 0xFF, (size_t)cap * sizeof(u64), e->stream));
+    HIP_TRY(hipMemsetAsync(S.slot_cnt.p, 0, (size_t)cap * sizeof(u32), e->stream));
     // Room for the records: the number of lines is only known when the last byte has been scanned, and the parse
     // does not wait for that — so from the line density of the file's first MiB plus a quarter (never more than
     // one record per 17 bytes); a parse that outgrows it is repeated with the exact number below.
@@ -494,6 +504,7 @@ int yacrd_engine_ingest_paf(yacrd_engine *e, const char *path, int n_threads, ui
     u32 *d_nreads = reinterpret_cast<u32 *>(S.ctl.as<unsigned long long>() + 3);
     ga.claim = S.claim.as<u64>();
     ga.first_pos = S.first_pos.as<u64>();
+    ga.slot_cnt = S.slot_cnt.as<u32>();
     ga.mask = (u32)(cap - 1);
     ga.recs = S.recs.as<yk::OvlRec>();
     ga.rec_cap = rec_cap;
@@ -619,6 +630,7 @@ int yacrd_engine_ingest_paf(yacrd_engine *e, const char *path, int n_threads, ui
         HIP_TRY(hipMemsetAsync(S.ctl.p, 0, 64, e->stream));
         HIP_TRY(hipMemsetAsync(S.claim.p, 0, (size_t)cap * sizeof(u64), e->stream));
         HIP_TRY(hipMemsetAsync(S.first_pos.p, 0xFF, (size_t)cap * sizeof(u64), e->stream));
+        HIP_TRY(hipMemsetAsync(S.slot_cnt.p, 0, (size_t)cap * sizeof(u32), e->stream));
         launch_segment(0, n, n);
         HIP_TRY(hipMemcpyAsync(h_ctl, S.ctl.p, sizeof(h_ctl), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
@@ -655,11 +667,13 @@ int yacrd_engine_ingest_paf(yacrd_engine *e, const char *path, int n_threads, ui
     HIP_TRY(S.name_at.reserve((size_t)(R + 1) * sizeof(u64)));
     HIP_TRY(S.name_off.reserve((size_t)(R + 2) * sizeof(u64)));
     HIP_TRY(e->in_len.reserve((size_t)(R + 1) * sizeof(u32)));
+    HIP_TRY(S.cnt.reserve((size_t)(R + 4) * sizeof(u32)));
+    HIP_TRY(hipMemsetAsync(S.cnt.p, 0, (size_t)(R + 4) * sizeof(u32), e->stream));
     HIP_TRY(hipMemsetAsync(S.map.p, 0xFF, (size_t)cap * sizeof(u32), e->stream));
     const u32 rg = (R + 255) / 256;
     if (R)
         hipLaunchKernelGGL(yk::gp_number_kernel, dim3(rg), dim3(256), 0, e->stream, ga.text, S.keys2.as<u64>(), S.slots2.as<u32>(),
-                           R, S.map.as<u32>(), e->in_len.as<u32>(), S.name_len.as<u32>(), S.name_at.as<u64>());
+                           R, S.map.as<u32>(), e->in_len.as<u32>(), S.name_len.as<u32>(), S.name_at.as<u64>(), S.slot_cnt.as<u32>(), S.cnt.as<u32>());
     {
         const int rcs = scan_u32_to_u64(e, S.name_len.as<u32>(), (u64)R, S.name_off.as<u64>(), S.part);
         if (rcs) return rcs;
@@ -689,7 +703,7 @@ int yacrd_engine_ingest_paf(yacrd_engine *e, const char *path, int n_threads, ui
         // ---- CSR on the device (csr_build.h through stream.hip's helper), then the engine
         const u64 n_iv = 2 * n_recs;
         const RecSlab slab{S.recs.as<yk::OvlRec>(), n_recs};
-        const int rcb = csr_from_records(e, &slab, 1, S.map.as<u32>(), cap, R, S.cnt, S.part, S.err, nullptr);
+        const int rcb = csr_from_records(e, &slab, 1, S.map.as<u32>(), cap, R, S.cnt, S.part, S.err, nullptr, nullptr, true);
         if (rcb) return rcb;
         const double t_build = now_ms();
         int rc2 = run_on_device(e, e->in_off.as<u64>(), e->in_iv.as<uint2>(), e->in_len.as<u32>(), R, n_iv, coverage, not_coverage);

@@ -100,7 +100,7 @@ namespace yke {
 // Overlap records in HBM -> the engine's input CSR (in_off, in_iv; in_len holds the lengths already): count,
 // scan, scatter (csr_build.h).  `map` (or null) translates the records' handles to read ids.  Blocking.
 int csr_from_records(yacrd_engine *e, const RecSlab *slabs, size_t n_slabs, const u32 *d_map, u64 n_handles, u64 n_reads,
-                     DevBuf &cnt, DevBuf &part, DevBuf &err, hipEvent_t done, u64 *n_intervals)
+                     DevBuf &cnt, DevBuf &part, DevBuf &err, hipEvent_t done, u64 *n_intervals, bool counted)
 {
     u64 n = 0;
     for (size_t i = 0; i < n_slabs; i++) n += slabs[i].n;
@@ -111,13 +111,14 @@ int csr_from_records(yacrd_engine *e, const RecSlab *slabs, size_t n_slabs, cons
     HIP_TRY(cnt.reserve((size_t)(n_reads + 4) * sizeof(u32)));
     HIP_TRY(part.reserve((size_t)(nb + 1) * sizeof(u64)));
     HIP_TRY(err.reserve(64));
-    HIP_TRY(hipMemsetAsync(cnt.p, 0, (size_t)(n_reads + 4) * sizeof(u32), e->stream));
+    // (`counted`: cnt[] already holds every read's number of intervals — the device parser counts while it parses)
+    if (!counted) HIP_TRY(hipMemsetAsync(cnt.p, 0, (size_t)(n_reads + 4) * sizeof(u32), e->stream));
     HIP_TRY(hipMemsetAsync(err.p, 0, 64, e->stream));
     const u32 R32 = (u32)n_reads;
     auto grid_for = [&](uint64_t recs) {
         return (u32)std::min<uint64_t>((recs + yk::kCsrThreads - 1) / yk::kCsrThreads, (uint64_t)e->num_cu * 16);
     };
-    for (size_t i = 0; i < n_slabs; i++)
+    for (size_t i = 0; i < n_slabs && !counted; i++)
         if (slabs[i].n)
             hipLaunchKernelGGL(yk::csr_count_kernel, dim3(grid_for(slabs[i].n)), dim3(yk::kCsrThreads), 0, e->stream,
                                slabs[i].recs, (u64)slabs[i].n, d_map, (u64)n_handles, R32, cnt.as<u32>(), err.as<u32>());

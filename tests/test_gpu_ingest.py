@@ -195,10 +195,11 @@ def _random_paf(rng, n_lines, anomaly):
     return text
 
 
-def test_random_text_against_the_oracle_ingest(engine, tmp_path):
+@pytest.mark.parametrize("seed", [20250305, 7, 99991])
+def test_random_text_against_the_oracle_ingest(engine, tmp_path, seed):
     """Differential fuzz of the device parser: on every random text it either hands the file to the host parser
     (NeedsHostParser) or returns exactly what the oracle's ingest + sweep return; plain texts must NOT fall back."""
-    rng = np.random.default_rng(20250305)
+    rng = np.random.default_rng(seed)
     taken = fell_back = 0
     for case in range(400):
         anomaly = 0 if case % 2 == 0 else int(rng.integers(1, 9))

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/e2e_cli_paf.py [reads overlaps] — the drop-in CLI as a user runs it, cold process, PAF text in /dev/shm ->
 .yacrd report: wall time of `yacrd -i s.paf -o r.yacrd -c 3 -n 0.4 -t 0` (device parser) and of the same with
-YACRD_CLI_HOST_PARSER=1 ... (GPU box).  Reports compared line by line."""
+YACRD_NO_DEVICE_PARSER=1 (the host parser; GPU box).  Reports compared line by line."""
 import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""tools/paf_matrix.py — yacrd_engine_ingest_paf on the configs[1] PAF text: threads x segment size (YACRD_PAF_SEG chunks of
-4 MiB per scan + parse launch; 100000 = no overlap), best and median of 5 (GPU box)."""
+"""tools/paf_matrix.py — yacrd_engine_ingest_paf on the configs[1] PAF text: threads (x segment size when the library is built with a YACRD_PAF_SEG
+override: the run logged in profiles/r03/paf_matrix.log; 128 MiB is compiled in now), best and median of 5 (GPU box)."""
 import ctypes, os, sys, time, statistics
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

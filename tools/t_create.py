@@ -1,3 +1,5 @@
+#!/usr/bin/env python3
+"""tools/t_create.py — dlopen of the engine library, first and second yacrd_engine_create (HIP start-up): GPU box."""
 import time, sys, os
 t0=time.perf_counter()
 sys.path.insert(0,'/root/repo')

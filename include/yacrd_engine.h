@@ -317,6 +317,12 @@ typedef struct {
 } yacrd_ingest_stats;
 int yacrd_engine_ingest_paf(yacrd_engine *e, const char *path, int n_threads, uint32_t coverage, double not_coverage,
                             yacrd_result *out, yacrd_reads *reads, yacrd_ingest_stats *stats /* may be NULL */);
+/* The same for either overlap format — format: 0 = by file name like util::get_file_type (src/util.rs:39-55), 1 = PAF,
+ * 2 = M4 / MHAP (Reads2Ovl::init_m4, src/reads2ovl/mod.rs:115-145; M4Record, src/io.rs:36-50: twelve space-separated
+ * columns; an error rate not written as plain decimal digits is the host parser's: YACRD_EFALLBACK). */
+int yacrd_engine_ingest_overlaps(yacrd_engine *e, const char *path, int format, int n_threads, uint32_t coverage,
+                                 double not_coverage, yacrd_result *out, yacrd_reads *reads,
+                                 yacrd_ingest_stats *stats /* may be NULL */);
 void yacrd_reads_free(yacrd_reads *r);
 
 /* Copy the last device result to host (allocates like yacrd_engine_run). */

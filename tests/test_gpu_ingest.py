@@ -225,3 +225,134 @@ def test_random_text_against_the_oracle_ingest(engine, tmp_path, seed):
         assert names == list(w_names) and np.array_equal(lengths.astype(np.uint64), ln), text
         assert_same(got, oracle.run(off, iv, ln, cov, 0.4, n_threads=2), "case %d" % case)
     assert taken >= 200 and fell_back >= 100, (taken, fell_back)
+
+
+# ---- M4 / MHAP (Reads2Ovl::init_m4, src/reads2ovl/mod.rs:115-145; M4Record, src/io.rs:36-50) on the device --------
+def _paf_to_m4(text, err="0.1", shared="2"):
+    out = []
+    for l in text.split("\n"):
+        if not l:
+            out.append(l)
+            continue
+        f = l.rstrip("\r").split("\t")
+        out.append(" ".join([f[0], f[5], err, shared, "0", f[2], f[3], f[1], "1", f[7], f[8], f[6]]) + ("\r" if l.endswith("\r") else ""))
+    return "\n".join(out)
+
+
+def _check_m4(engine, path, cov, nc):
+    got, names, lengths, stats = engine.ingest_paf(path, cov, nc, fmt=2)
+    with open(path, newline="") as f:
+        reads = oracle.parse_m4(f.read())
+    w_names, off, iv, ln = oracle.to_csr(reads)
+    assert names == list(w_names) and np.array_equal(lengths.astype(np.uint64), ln)
+    assert stats["n_reads"] == len(names) and stats["n_records"] * 2 == int(off[-1])
+    assert_same(got, oracle.run(off, iv, ln, cov, nc, n_threads=4), path)
+    return got, names, lengths
+
+
+def test_m4_fixture_and_synthetic(engine, golden_dir, tmp_path):
+    with open(os.path.join(golden_dir, "reads.paf")) as f:
+        m4 = _paf_to_m4(f.read())
+    p = str(tmp_path / "reads.m4")
+    with open(p, "w", newline="") as f:
+        f.write(m4)
+    got, names, lengths = _check_m4(engine, p, 0, 0.8)
+    with open(os.path.join(golden_dir, "truth.yacrd")) as f:
+        truth = set(line.rstrip("\n") for line in f)
+    assert set(oracle.report_from_csr(names, lengths.astype(np.uint64), got.bad_offsets, got.bad_regions, got.read_type)) == truth
+    # by file name (format 0), and the same reads as the host parser finds
+    got0, names0, _, _ = engine.ingest_paf(p, 0, 0.8, fmt=0)
+    assert names0 == names and np.array_equal(got0.read_type, got.read_type)
+    paf = str(tmp_path / "s.paf")
+    host.synth_paf(host.SYNTH_ONT, 3000, 60000, 12, paf)
+    with open(paf) as f:
+        text = _paf_to_m4(f.read(), err="1.5e-2", shared="+17")
+    p2 = str(tmp_path / "s.mhap")
+    with open(p2, "w", newline="") as f:
+        f.write(text)
+    _, names2, lengths2 = _check_m4(engine, p2, 4, 0.4)
+    c = host.csr_from_file(p2, n_threads=3)
+    assert c.names == names2 and np.array_equal(c.lengths, lengths2)
+
+
+@pytest.mark.parametrize("err,taken", [("0.1", True), ("12", True), ("-0.5", True), ("+3.25E+2", True), ("1e5", True),
+                                       ("inf", False), ("NaN", False), (".5", False), ("1.", False), ("0x1p3", False), ("", False)])
+def test_m4_error_rate_shapes(engine, tmp_path, err, taken):
+    """The device takes the plain decimal forms of M4's f64 column; whatever else Rust's f64::from_str may accept (or
+    reject) is the host parser's: never a wrong answer."""
+    text = "a b %s 42 0 1 50 100 1 2 60 200\nb c %s 7 + 3 70 200 - 4 80 300 extra cols\n" % (err, err)
+    p = str(tmp_path / "e.m4")
+    with open(p, "w", newline="") as f:
+        f.write(text)
+    if taken:
+        _check_m4(engine, p, 0, 0.8)
+    else:
+        with pytest.raises(yacrd_amd.NeedsHostParser):
+            engine.ingest_paf(p, 0, 0.8, fmt=2)
+
+
+@pytest.mark.parametrize("text", [
+    "a b 0.1 2 0 1 50 100 1 2 60\n",                # eleven columns
+    "a b 0.1 2 00 1 50 100 1 2 60 200\n",           # strand of two characters
+    "a b 0.1 2 0 1 50 100 1 2 60 4294967296\n",     # a length beyond the engine
+    "a b 0.1 -2 0 1 50 100 1 2 60 200\n",           # _shared_min is a u64
+    "a  b 0.1 2 0 1 50 100 1 2 60 200\n",           # two spaces: an empty field
+    '"a" b 0.1 2 0 1 50 100 1 2 60 200\n',          # a quoted field
+])
+def test_m4_inputs_for_the_host_parser(engine, tmp_path, text):
+    p = str(tmp_path / "h.m4")
+    with open(p, "w", newline="") as f:
+        f.write(text)
+    with pytest.raises(yacrd_amd.NeedsHostParser):
+        engine.ingest_paf(p, 0, 0.8, fmt=2)
+
+
+def test_m4_random_text_against_the_oracle_ingest(engine, tmp_path):
+    rng = np.random.default_rng(4242)
+    taken = fell_back = 0
+    for case in range(300):
+        anomaly = 0 if case % 2 == 0 else int(rng.integers(1, 9))
+        text = _paf_to_m4(_random_paf(rng, int(rng.integers(0, 100)), 0).replace("\r\n", "\n"),
+                          err=str(rng.choice(["0.25", "3", "1e-3", "+7.5"])), shared=str(int(rng.integers(0, 1000))))
+        lines = text.split("\n")
+        if anomaly and any(lines):
+            k = int(rng.choice([i for i, l in enumerate(lines) if l]))
+            f = lines[k].split(" ")
+            if anomaly == 1:
+                f[0] = '"' + f[0] + '"'
+            elif anomaly == 2:
+                f[5] = "0x1f"
+            elif anomaly == 3:
+                f = f[:11]
+            elif anomaly == 4:
+                f[8] = "+-"
+            elif anomaly == 5:
+                f[6] = "4294967296"
+            elif anomaly == 6:
+                f[2] = "inf"
+            elif anomaly == 7:
+                f[3] = "-3"
+            else:
+                f[9] = ""
+            lines[k] = " ".join(f)
+            text = "\n".join(lines)
+        p = str(tmp_path / "f.m4")
+        with open(p, "w", newline="", encoding="utf-8") as fh:
+            fh.write(text)
+        try:
+            want = oracle.to_csr(oracle.parse_m4(text))
+        except (ValueError, IndexError):
+            want = None
+        cov = int(rng.integers(0, 4))
+        try:
+            got, names, lengths, stats = engine.ingest_paf(p, cov, 0.4, fmt=2)
+        except yacrd_amd.NeedsHostParser:
+            fell_back += 1
+            assert anomaly != 0, "a plain text went to the host parser:\n%r" % text
+            continue
+        taken += 1
+        assert want is not None, "the device parser accepted what the reference rejects:\n%r" % text
+        w_names, off, iv, ln = want
+        assert names == list(w_names) and np.array_equal(lengths.astype(np.uint64), ln), text
+        assert_same(got, oracle.run(off, iv, ln, cov, 0.4, n_threads=2), "case %d" % case)
+    assert taken >= 150 and fell_back >= 60, (taken, fell_back)

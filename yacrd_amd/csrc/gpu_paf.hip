@@ -36,6 +36,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -60,6 +61,7 @@ struct GpArgs {
     // the part of the text one launch works on (the parse runs segment by segment while later chunks still cross PCIe)
     u64 begin, end;     // scan: bytes [begin, end); parse: the tiles from begin / kGpTile on (its grid = their number)
     u64 avail;          // bytes [0, avail) of the mirror have landed (== n for the last segment)
+    u32 delim;          // the field delimiter: '\t' (PAF) or ' ' (M4: src/reads2ovl/mod.rs:116-117)
 };
 
 constexpr int kGpT = 256; // threads per workgroup
@@ -121,9 +123,9 @@ __device__ __forceinline__ u64 gp_hash(const GpText &t, u64 p, u32 n)
     h *= 0xbf58476d1ce4e5b9ull;
     return h ^ (h >> 32);
 }
-// decimal u64 with an optional '+', at least one digit, then a tab (or, for the last field, the line's end);
+// decimal u64 with an optional '+', at least one digit, then the delimiter (or, for the last field, the line's end);
 // clears `ok` when the field is anything else.  `le` = the text's end: a line ends at '\n' (or "\r\n").
-__device__ __forceinline__ u64 gp_uint(const GpText &t, u64 &q, u64 n, u64 limit, bool last, bool &ok)
+__device__ __forceinline__ u64 gp_uint(const GpText &t, u64 &q, u64 n, u64 limit, bool last, bool &ok, u32 dl)
 {
     u64 i = q;
     u32 c = i < n ? t[i] : '\n';
@@ -142,7 +144,7 @@ __device__ __forceinline__ u64 gp_uint(const GpText &t, u64 &q, u64 n, u64 limit
         c = i < n ? t[i] : '\n';
     }
     good = good && i != b && v <= limit;
-    if (c == '\t') {
+    if (c == dl) {
         i++;
     } else { // the line's end: '\n', or '\r' in front of one (a lone CR never gets here: the scan refused it)
         good = good && last && (c == '\n' || c == '\r');
@@ -163,17 +165,21 @@ __device__ __forceinline__ u32 gp_intern(const GpArgs &a, const GpText &t, u64 p
             if (old == 0) return s;
             w = old;
         }
-        const u64 c = w - 1; // the claimant's id starts there and ends at a tab (or it would not have been parsed)
+        const u64 c = w - 1; // the claimant's id starts there and ends at a delimiter (or it would not have been parsed)
         if (c == p) return s;
-        bool same = g[c + n] == '\t';
+        bool same = g[c + n] == a.delim;
         for (u32 i = 0; same && i < n; i++) same = g[c + i] == t[p + i];
         if (same) return s;
     }
     return ~0u;
 }
 
+// M4 = false: PafRecord (src/io.rs:23-34: a la sa ea strand b lb sb eb ...); true: M4Record (src/io.rs:36-50:
+// a b error shared strand_a sa ea la strand_b sb eb lb ...), space-separated.
+template <bool M4>
 __global__ __launch_bounds__(kGpT) void gp_parse_kernel(GpArgs a)
 {
+    const u32 dl = a.delim;
     __shared__ __attribute__((aligned(16))) unsigned char win[kGpTile + kGpOver];
     const u64 tile0 = a.begin + (u64)blockIdx.x * (u64)kGpTile; // (a.begin is a multiple of the tile size)
     if (tile0 >= a.n) return;
@@ -221,43 +227,85 @@ __global__ __launch_bounds__(kGpT) void gp_parse_kernel(GpArgs a)
         } else {
             ok = true;
             u64 q = p;
-            u32 c = c0;
-            while (c != '\t' && c != '\n') { // id_a
+            // an id: up to the delimiter (an id that runs into the line's end makes the record too short)
+            auto take_id = [&](u64 &start, u32 &len) {
+                start = q;
+                u32 c = q < n ? t[q] : '\n';
+                while (c != dl && c != '\n') {
+                    q++;
+                    c = q < n ? t[q] : '\n';
+                }
+                ok = ok && c == dl;
+                len = (u32)(q - start);
                 q++;
-                c = q < n ? t[q] : '\n';
-            }
-            ok = c == '\t';
-            na = (u32)(q - ia);
-            q++;
-            la = gp_uint(t, q, n, ~0ull, false, ok);
-            sa = gp_uint(t, q, n, 0xFFFFFFFFull, false, ok);
-            ea = gp_uint(t, q, n, 0xFFFFFFFFull, false, ok);
-            if (ok) { // strand: exactly one UTF-8 scalar (serde char), judged by its lead byte like the host
+            };
+            // a strand: exactly one UTF-8 scalar (serde char), judged by its lead byte like the host
+            auto take_char = [&]() {
                 u64 tb = q;
-                c = tb < n ? t[tb] : '\n';
+                u32 c = tb < n ? t[tb] : '\n';
                 const u32 lead = c;
-                while (c != '\t' && c != '\n') {
+                while (c != dl && c != '\n') {
                     tb++;
                     c = tb < n ? t[tb] : '\n';
                 }
                 const u32 want = lead < 0x80u ? 1u : (lead >> 5) == 6u ? 2u : (lead >> 4) == 14u ? 3u : (lead >> 3) == 30u ? 4u : 0u;
-                ok = c == '\t' && want != 0u && tb - q == (u64)want;
+                ok = ok && c == dl && want != 0u && tb - q == (u64)want;
                 q = tb + 1;
-            }
-            ib = q;
-            if (ok) {
-                c = q < n ? t[q] : '\n';
-                while (c != '\t' && c != '\n') {
+            };
+            // M4's error rate: the plain decimal forms only — [+-] digits [. digits] [e [+-] digits] with a digit on
+            // both sides of the point — whatever else Rust's f64::from_str takes (inf, nan, ".5", "1.") is the host's
+            auto take_f64 = [&]() {
+                u32 c = q < n ? t[q] : '\n';
+                auto step = [&]() {
                     q++;
                     c = q < n ? t[q] : '\n';
+                };
+                auto digits = [&]() {
+                    u32 k = 0;
+                    while (c - '0' <= 9u) {
+                        k++;
+                        step();
+                    }
+                    return k;
+                };
+                if (c == '+' || c == '-') step();
+                bool good = digits() != 0u;
+                if (c == '.') {
+                    step();
+                    good = good && digits() != 0u;
                 }
-                ok = c == '\t';
-                nb = (u32)(q - ib);
+                if (c == 'e' || c == 'E') {
+                    step();
+                    if (c == '+' || c == '-') step();
+                    good = good && digits() != 0u;
+                }
+                ok = ok && good && c == dl;
                 q++;
+            };
+            if constexpr (!M4) {
+                take_id(ia, na);
+                la = gp_uint(t, q, n, ~0ull, false, ok, dl);
+                sa = gp_uint(t, q, n, 0xFFFFFFFFull, false, ok, dl);
+                ea = gp_uint(t, q, n, 0xFFFFFFFFull, false, ok, dl);
+                if (ok) take_char();
+                if (ok) take_id(ib, nb);
+                lb = gp_uint(t, q, n, ~0ull, false, ok, dl);
+                sb = gp_uint(t, q, n, 0xFFFFFFFFull, false, ok, dl);
+                eb = gp_uint(t, q, n, 0xFFFFFFFFull, true, ok, dl);
+            } else {
+                take_id(ia, na);
+                if (ok) take_id(ib, nb);
+                if (ok) take_f64();
+                (void)gp_uint(t, q, n, ~0ull, false, ok, dl); // _shared_min: u64
+                if (ok) take_char();
+                sa = gp_uint(t, q, n, 0xFFFFFFFFull, false, ok, dl);
+                ea = gp_uint(t, q, n, 0xFFFFFFFFull, false, ok, dl);
+                la = gp_uint(t, q, n, ~0ull, false, ok, dl);
+                if (ok) take_char();
+                sb = gp_uint(t, q, n, 0xFFFFFFFFull, false, ok, dl);
+                eb = gp_uint(t, q, n, 0xFFFFFFFFull, false, ok, dl);
+                lb = gp_uint(t, q, n, ~0ull, true, ok, dl);
             }
-            lb = gp_uint(t, q, n, ~0ull, false, ok);
-            sb = gp_uint(t, q, n, 0xFFFFFFFFull, false, ok);
-            eb = gp_uint(t, q, n, 0xFFFFFFFFull, true, ok);
             ok = ok && la <= 0xFFFFFFFFull && lb <= 0xFFFFFFFFull; // (the engine's limit; the host parser says so)
             if (!ok) status |= kNeedHost;
             if (q >= n && n < a.n) status |= kNeedHost; // (a record that reaches into text still on its way: megabytes long)
@@ -354,29 +402,33 @@ __global__ __launch_bounds__(256) void gp_collect_kernel(const u64 *claim, const
     }
     flush();
 }
-// read g (first-appearance order) = the id first seen at keys[g]: its slot -> g, its length (the field after the
-// id there), the extent of its name
+// read g (first-appearance order) = the id first seen at keys[g]: its slot -> g, its length (PAF: the field after
+// the id; M4: the 8th / 12th field of the line), the extent of its name, its number of intervals
 __global__ __launch_bounds__(256) void gp_number_kernel(const unsigned char *t, const u64 *keys, const u32 *slots,
                                                         u32 n_reads, u32 *handle_map, u32 *lengths, u32 *name_len,
-                                                        u64 *name_at, const u32 *slot_cnt, u32 *cnt)
+                                                        u64 *name_at, const u32 *slot_cnt, u32 *cnt, u32 delim)
 {
     const u32 g = blockIdx.x * 256u + threadIdx.x;
     if (g >= n_reads) return;
     handle_map[slots[g]] = g;
     cnt[g] = slot_cnt[slots[g]];
     const u64 pos = keys[g];
+    const bool m4 = delim == ' ', second = (pos & 1u) != 0;
+    const int id_field = m4 ? (second ? 1 : 0) : (second ? 5 : 0), len_field = m4 ? (second ? 11 : 7) : (second ? 6 : 1);
     u64 q = pos >> 1; // the line's start
-    if (pos & 1u) {   // the second id: behind five fields
-        for (int f = 0; f < 5; f++) {
-            while (t[q] != '\t') q++;
-            q++;
-        }
+    for (int f = 0; f < id_field; f++) {
+        while (t[q] != delim) q++;
+        q++;
     }
     const u64 id0 = q;
-    while (t[q] != '\t') q++;
+    while (t[q] != delim) q++;
     name_at[g] = id0;
     name_len[g] = (u32)(q - id0);
     q++;
+    for (int f = id_field + 1; f < len_field; f++) {
+        while (t[q] != delim) q++;
+        q++;
+    }
     if (t[q] == '+') q++;
     u64 v = 0;
     while ((u32)t[q] - '0' <= 9u) v = v * 10u + ((u32)t[q++] - '0');
@@ -439,7 +491,21 @@ void yacrd_reads_free(yacrd_reads *r)
 int yacrd_engine_ingest_paf(yacrd_engine *e, const char *path, int n_threads, uint32_t coverage, double not_coverage,
                             yacrd_result *out, yacrd_reads *reads, yacrd_ingest_stats *stats)
 {
+    return yacrd_engine_ingest_overlaps(e, path, 1, n_threads, coverage, not_coverage, out, reads, stats);
+}
+
+int yacrd_engine_ingest_overlaps(yacrd_engine *e, const char *path, int format, int n_threads, uint32_t coverage,
+                                 double not_coverage, yacrd_result *out, yacrd_reads *reads, yacrd_ingest_stats *stats)
+{
     if (!e || !path || !out || !reads) return fail(YACRD_EINVAL, "null argument");
+    if (format == 0) { // by file name, like util::get_file_type (src/util.rs:39-55)
+        const std::string name(path);
+        auto has = [&](const char *x) { return name.find(x) != std::string::npos; };
+        format = (has(".m4") || has(".mhap")) ? 2 : has(".paf") ? 1 : 0;
+        if (format == 0) return fail(YACRD_EINVAL, std::string("cannot tell the overlap format of ") + path);
+    }
+    if (format != 1 && format != 2) return fail(YACRD_EINVAL, "format: 0 = by name, 1 = PAF, 2 = M4");
+    const bool m4 = format == 2;
     std::memset(out, 0, sizeof(*out));
     std::memset(reads, 0, sizeof(*reads));
     if (stats) std::memset(stats, 0, sizeof(*stats));
@@ -508,6 +574,7 @@ int yacrd_engine_ingest_paf(yacrd_engine *e, const char *path, int n_threads, ui
     ga.mask = (u32)(cap - 1);
     ga.recs = S.recs.as<yk::OvlRec>();
     ga.rec_cap = rec_cap;
+    ga.delim = m4 ? (u32)' ' : (u32)'\t';
     if ((n + yk::kGpTile - 1) / yk::kGpTile >= 0x7FFFFFFFull) return fail(YACRD_EFALLBACK, "file too large for the device parser");
     // scan + parse of the bytes [begin, end) on the engine's stream (begin on a tile boundary)
     auto launch_segment = [&](u64 begin, u64 end, u64 avail) {
@@ -515,7 +582,8 @@ int yacrd_engine_ingest_paf(yacrd_engine *e, const char *path, int n_threads, ui
         const u32 scan_grid = (u32)std::min<u64>(((end - begin) / (yk::kGpT * 16u)) + 1, (u64)e->num_cu * 16);
         hipLaunchKernelGGL(yk::gp_scan_kernel, dim3(scan_grid), dim3(yk::kGpT), 0, e->stream, ga);
         const u64 tiles = (end - begin + yk::kGpTile - 1) / yk::kGpTile;
-        if (tiles) hipLaunchKernelGGL(yk::gp_parse_kernel, dim3((u32)tiles), dim3(yk::kGpT), 0, e->stream, ga);
+        if (tiles && m4) hipLaunchKernelGGL(yk::gp_parse_kernel<true>, dim3((u32)tiles), dim3(yk::kGpT), 0, e->stream, ga);
+        else if (tiles) hipLaunchKernelGGL(yk::gp_parse_kernel<false>, dim3((u32)tiles), dim3(yk::kGpT), 0, e->stream, ga);
     };
 
     // ---- the text: pread chunks -> pinned buffers -> HBM, all chunks in flight at once; THIS thread hands every
@@ -615,8 +683,9 @@ int yacrd_engine_ingest_paf(yacrd_engine *e, const char *path, int n_threads, ui
     HIP_TRY(hipStreamSynchronize(e->stream));
     HIP_TRY(hipGetLastError());
     if ((u32)h_ctl[2] & yk::kNeedHost)
-        return fail(YACRD_EFALLBACK, "the text holds a '\"', a lone CR or a line that is not a plain PAF record (fewer than nine "
-                                     "columns, a 0x integer, a length beyond u32 ...): the host parser decides");
+        return fail(YACRD_EFALLBACK, "the text holds a '\"', a lone CR or a line that is not a plain PAF / M4 record (too few "
+                                     "columns, a 0x integer, a length beyond u32, an error rate written as inf or .5 ...): the "
+                                     "host parser decides");
     if ((u32)h_ctl[2] & yk::kTableFull) return fail(YACRD_EFALLBACK, "more read ids than the device table holds");
     const u64 n_lines = h_ctl[0];
     if (n_lines >= 0x7FFFFFFFull * 2) return fail(YACRD_EFALLBACK, "too many lines for the device parser");
@@ -673,7 +742,7 @@ int yacrd_engine_ingest_paf(yacrd_engine *e, const char *path, int n_threads, ui
     const u32 rg = (R + 255) / 256;
     if (R)
         hipLaunchKernelGGL(yk::gp_number_kernel, dim3(rg), dim3(256), 0, e->stream, ga.text, S.keys2.as<u64>(), S.slots2.as<u32>(),
-                           R, S.map.as<u32>(), e->in_len.as<u32>(), S.name_len.as<u32>(), S.name_at.as<u64>(), S.slot_cnt.as<u32>(), S.cnt.as<u32>());
+                           R, S.map.as<u32>(), e->in_len.as<u32>(), S.name_len.as<u32>(), S.name_at.as<u64>(), S.slot_cnt.as<u32>(), S.cnt.as<u32>(), ga.delim);
     {
         const int rcs = scan_u32_to_u64(e, S.name_len.as<u32>(), (u64)R, S.name_off.as<u64>(), S.part);
         if (rcs) return rcs;

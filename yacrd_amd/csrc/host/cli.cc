@@ -165,13 +165,14 @@ int main(int argc, char **argv)
         int dev_parse = YACRD_EFALLBACK;
         // YACRD_NO_DEVICE_PARSER=1: the host parser for everything (A/B, tools/e2e_cli_paf.py)
         const char *no_dev = std::getenv("YACRD_NO_DEVICE_PARSER");
-        if (engines.size() == 1 && paf && !m4 && !(no_dev && *no_dev == '1')) {
-            // one GPU, PAF text: the host only moves the file to HBM, the device parses it, numbers the reads,
-            // builds the CSR and runs the engine (yacrd_engine_ingest_paf).  Whatever is not a plain PAF file
-            // (compressed, quoted fields, lone CRs, 0x integers, malformed lines ...) comes back as
+        if (engines.size() == 1 && (paf || m4) && !(no_dev && *no_dev == '1')) {
+            // one GPU, PAF or M4 text: the host only moves the file to HBM, the device parses it, numbers the reads,
+            // builds the CSR and runs the engine (yacrd_engine_ingest_overlaps).  Whatever is not a plain file of
+            // plain records (compressed, quoted fields, lone CRs, 0x integers, malformed lines ...) comes back as
             // YACRD_EFALLBACK and takes the host parser below, which knows the whole syntax and the messages.
-            dev_parse = yacrd_engine_ingest_paf(engines[0], input.c_str(), (int)std::min<unsigned long long>(threads, 8),
-                                                cov32, not_coverage, &res, &dev_reads, nullptr);
+            dev_parse = yacrd_engine_ingest_overlaps(engines[0], input.c_str(), m4 ? 2 : 1,
+                                                     (int)std::min<unsigned long long>(threads, 8), cov32, not_coverage,
+                                                     &res, &dev_reads, nullptr);
             if (dev_parse != YACRD_OK && dev_parse != YACRD_EFALLBACK) die(yacrd_last_error());
         }
         if (dev_parse == YACRD_OK) {

@@ -41,7 +41,7 @@ EXPORTED_SYMBOLS = [
     "yacrd_engine_submit", "yacrd_engine_collect", "yacrd_pinned_alloc", "yacrd_pinned_free",
     "yacrd_stream_open", "yacrd_stream_sink", "yacrd_stream_acquire", "yacrd_stream_commit",
     "yacrd_stream_finish", "yacrd_stream_last_stats", "yacrd_stream_reset", "yacrd_stream_close",
-    "yacrd_engine_ingest_paf", "yacrd_reads_free",
+    "yacrd_engine_ingest_paf", "yacrd_engine_ingest_overlaps", "yacrd_reads_free",
     "yacrd_stream_device_of", "yacrd_stream_group_open", "yacrd_stream_group_sink", "yacrd_stream_group_finish",
     "yacrd_stream_group_last_stats", "yacrd_stream_group_reset", "yacrd_stream_group_close",
 ]
@@ -228,6 +228,9 @@ def load_library():
     lib.yacrd_engine_fetch.argtypes = [ctypes.c_void_p, ctypes.POINTER(_Result)]
     lib.yacrd_engine_ingest_paf.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_uint32, ctypes.c_double,
                                             ctypes.POINTER(_Result), ctypes.POINTER(_Reads), ctypes.POINTER(_IngestStats)]
+    lib.yacrd_engine_ingest_overlaps.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint32,
+                                                 ctypes.c_double, ctypes.POINTER(_Result), ctypes.POINTER(_Reads),
+                                                 ctypes.POINTER(_IngestStats)]
     lib.yacrd_reads_free.argtypes = [ctypes.POINTER(_Reads)]
     lib.yacrd_reads_free.restype = None
     lib.yacrd_stream_reset.argtypes = [ctypes.c_void_p]
@@ -405,12 +408,13 @@ class Engine:
         _check(self._lib, self._lib.yacrd_engine_wait(self._h, ctypes.byref(out)))
         return out
 
-    def ingest_paf(self, path, coverage, not_coverage, n_threads=0):
-        """yacrd_engine_ingest_paf: PAF text -> (Result, names, lengths, stats) with the parse on the GPU; raises
-        NeedsHostParser when the input is not for the device parser."""
+    def ingest_paf(self, path, coverage, not_coverage, n_threads=0, fmt=1):
+        """yacrd_engine_ingest_overlaps (fmt 1 = PAF, 2 = M4, 0 = by file name): overlap text -> (Result, names,
+        lengths, stats) with the parse on the GPU; raises NeedsHostParser when the input is not for the device parser."""
         res, rd, st = _Result(), _Reads(), _IngestStats()
-        rc = self._lib.yacrd_engine_ingest_paf(self._h, os.fsencode(path), int(n_threads), min(int(coverage), 0xFFFFFFFF),
-                                               float(not_coverage), ctypes.byref(res), ctypes.byref(rd), ctypes.byref(st))
+        rc = self._lib.yacrd_engine_ingest_overlaps(self._h, os.fsencode(path), int(fmt), int(n_threads),
+                                                    min(int(coverage), 0xFFFFFFFF), float(not_coverage), ctypes.byref(res),
+                                                    ctypes.byref(rd), ctypes.byref(st))
         if rc == E_FALLBACK:
             raise NeedsHostParser(self._lib.yacrd_last_error().decode())
         _check(self._lib, rc)

@@ -195,7 +195,10 @@ def _random_paf(rng, n_lines, anomaly):
     return text
 
 
-@pytest.mark.parametrize("seed", [20250305, 7, 99991])
+_SEEDS = [20250305, 7, 99991] + [int(x) for x in os.environ.get("YACRD_PAF_FUZZ_SEEDS", "").split(",") if x]  # (soak runs: more seeds)
+
+
+@pytest.mark.parametrize("seed", _SEEDS)
 def test_random_text_against_the_oracle_ingest(engine, tmp_path, seed):
     """Differential fuzz of the device parser: on every random text it either hands the file to the host parser
     (NeedsHostParser) or returns exactly what the oracle's ingest + sweep return; plain texts must NOT fall back."""

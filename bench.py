@@ -265,7 +265,7 @@ def resident_block(cx, label, profile, R, O, cov, nc, seed, jitter, steps, warmu
 
 def small_batches_block(cx, jitter=0, chimeras=0):
     """configs[1]: rounds 1-2's headline.  Batches of 100 k reads pipelined over `--engines` engines on one GPU
-    from one host thread (yacrd_engine_submit_device / _wait): the plan / follow-on kernels, the counter copy, the
+    from one host thread (yacrd_engine_submit_device / _wait): the plan / follow-on kernels, the
     launch gaps and the host's turn of one batch hide behind the sweep of another.  Weak scaling when N > 1 (every
     rank its own batch)."""
     ya, host, torch, args = cx.ya, cx.host, cx.torch, cx.args

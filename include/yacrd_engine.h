@@ -161,7 +161,7 @@ int yacrd_engine_run_device(yacrd_engine *e, const void *d_offsets, const void *
 /* yacrd_engine_run_device in two halves, so that one host thread can keep batches in flight on
  * several engines of a device (submit on engine A, submit on engine B, wait on A, submit on A ...):
  * the plan / follow-on kernels and the launch gaps of one batch hide behind the
- * sweep of another; the engines take turns with the dominant sweep launch.  submit enqueues the
+ * sweep of another.  submit enqueues the
  * whole run when the previous run on this engine had the same shape (its class counts size the
  * launches; wait validates them and, in the rare case they do not hold, runs the batch again the
  * synchronous way) and otherwise simply runs it to the end.  The inputs must stay valid until

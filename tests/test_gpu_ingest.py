@@ -146,6 +146,12 @@ def test_record_room_estimate_falls_short_and_segments(engine, tmp_path):
     assert stats["n_records"] == 700 + 20000 * reps
     want = oracle.run(c.offsets, c.intervals, c.lengths.astype(np.uint64), 3, 0.4, n_threads=8)
     assert_same(got, want, "skewed line lengths")
+    # the parser keeps its buffers between calls; trim gives them back, and the next call allocates again
+    engine.trim()
+    again, names2, _, _ = engine.ingest_paf(path, 3, 0.4)
+    assert names2 == names
+    assert_same(again, want, "after yacrd_engine_trim")
+    engine.trim()
 
 
 def _random_paf(rng, n_lines, anomaly):

@@ -16,6 +16,11 @@ t0 = time.perf_counter()
 host.synth_paf(host.SYNTH_SEQUEL, R, O, 20250306, paf)
 size = os.path.getsize(paf)
 print("generated %.2f GB in %.1f s" % (size / 1e9, time.perf_counter() - t0), flush=True)
+if os.environ.get("YACRD_E2E_PREREAD"):  # is a process's slow first call the file's first read?
+    t0 = time.perf_counter()
+    os.system("cat %s > /dev/null" % paf)
+    print("pre-read with cat: %.2f s" % (time.perf_counter() - t0), flush=True)
+time.sleep(3)  # (the generator's burst on all CPUs: let the cgroup quota recover)
 try:
     with yacrd_amd.Engine() as e:
         el = yacrd_amd.load_library()

@@ -65,6 +65,12 @@ struct GpArgs {
 };
 
 constexpr int kGpT = 256; // threads per workgroup
+
+// pinned host memory -> the mirror, by a kernel (see the host side: used when the mirror is a fresh allocation)
+__global__ __launch_bounds__(256) void gp_blit_kernel(uint4 *__restrict__ dst, const uint4 *__restrict__ src, u64 n16)
+{
+    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < n16; i += (u64)gridDim.x * 256u) dst[i] = src[i];
+}
 constexpr u32 kNeedHost = 1u, kTableFull = 2u;
 
 // ---- pass 1: how many lines, and is there anything the fast path must not see ------------------------------
@@ -479,6 +485,15 @@ private:
 
 extern "C" {
 
+int yacrd_engine_trim(yacrd_engine *e)
+{
+    if (!e) return fail(YACRD_EINVAL, "engine is null");
+    if (e->pending.active || e->host_pending) return fail(YACRD_EINVAL, "the engine has a submitted batch pending");
+    DeviceGuard guard(e->device);
+    if (e->paf_scratch) static_cast<Scratch *>(e->paf_scratch)->release();
+    return YACRD_OK;
+}
+
 void yacrd_reads_free(yacrd_reads *r)
 {
     if (!r) return;
@@ -530,7 +545,14 @@ int yacrd_engine_ingest_overlaps(yacrd_engine *e, const char *path, int format, 
     const double t_start = now_ms();
 
     // ---- what does not depend on the text's content: the mirror, the id table, the control words
+    const void *mirror_before = S.text.p;
     HIP_TRY(S.text.reserve((size_t)n + 64));
+    // Fresh HBM is slow to fill, whoever fills it: the text of a 37 GB file takes 0.70 s to get into a mirror that
+    // is being reused and 2.2-2.4 s (hipMemcpyAsync; 5.1 s in a process's first call) or 0.85-2.4 s (copy kernels;
+    // 2.1 s in a first call) into one that was allocated for this call — same box, same run, profiles/r03_e2e_large.log.
+    // So the buffers stay with the engine (yacrd_engine_trim gives them back), chunks go by copy kernel into a fresh
+    // mirror and by hipMemcpyAsync, 15 % faster once the memory is warm, into a reused one.
+    const bool blit = S.text.p != mirror_before;
     HIP_TRY(hipMemsetAsync(S.text.as<char>() + n, 0, 64, e->stream)); // (the scan reads 16 bytes at a time)
     u64 cap = (u64)1 << 20;
     while (cap < n / 64 && cap < ((u64)1 << 31)) cap <<= 1; // ids are a small fraction of the lines; a full table = fallback
@@ -638,8 +660,12 @@ int yacrd_engine_ingest_overlaps(yacrd_engine *e, const char *path, int format, 
                     got += (size_t)k;
                 }
                 if (bad.load()) break;
-                if (hipMemcpyAsync(S.text.as<char>() + off, dst, len, hipMemcpyHostToDevice, copy[t]) != hipSuccess ||
-                    hipEventRecord(ev[c], copy[t]) != hipSuccess)
+                if (blit) { // (the arena's buffers are 4 MiB: whole 16-byte pieces; the mirror is padded by 64 bytes)
+                    hipLaunchKernelGGL(yk::gp_blit_kernel, dim3(256), dim3(256), 0, copy[t], reinterpret_cast<uint4 *>(S.text.as<char>() + off),
+                                       reinterpret_cast<const uint4 *>(dst), (u64)((len + 15) / 16));
+                    if (hipEventRecord(ev[c], copy[t]) != hipSuccess) bad = 1;
+                } else if (hipMemcpyAsync(S.text.as<char>() + off, dst, len, hipMemcpyHostToDevice, copy[t]) != hipSuccess ||
+                           hipEventRecord(ev[c], copy[t]) != hipSuccess)
                     bad = 1;
                 prev[turn] = (long)c;
                 landed[c].store(1, std::memory_order_release); // (its event is recorded: the dispatcher may wait on it)
@@ -793,8 +819,6 @@ int yacrd_engine_ingest_overlaps(yacrd_engine *e, const char *path, int format, 
     };
     rc = body();
     if (rc) yacrd_reads_free(reads);
-    // small files (repeated calls: a service, the bench) keep their buffers; a file of gigabytes gives its HBM back
-    if (S.bytes() > ((size_t)4 << 30)) S.release();
     return rc;
 }
 

@@ -41,7 +41,7 @@ EXPORTED_SYMBOLS = [
     "yacrd_engine_submit", "yacrd_engine_collect", "yacrd_pinned_alloc", "yacrd_pinned_free",
     "yacrd_stream_open", "yacrd_stream_sink", "yacrd_stream_acquire", "yacrd_stream_commit",
     "yacrd_stream_finish", "yacrd_stream_last_stats", "yacrd_stream_reset", "yacrd_stream_close",
-    "yacrd_engine_ingest_paf", "yacrd_engine_ingest_overlaps", "yacrd_reads_free",
+    "yacrd_engine_ingest_paf", "yacrd_engine_ingest_overlaps", "yacrd_reads_free", "yacrd_engine_trim",
     "yacrd_stream_device_of", "yacrd_stream_group_open", "yacrd_stream_group_sink", "yacrd_stream_group_finish",
     "yacrd_stream_group_last_stats", "yacrd_stream_group_reset", "yacrd_stream_group_close",
 ]
@@ -231,6 +231,7 @@ def load_library():
     lib.yacrd_engine_ingest_overlaps.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint32,
                                                  ctypes.c_double, ctypes.POINTER(_Result), ctypes.POINTER(_Reads),
                                                  ctypes.POINTER(_IngestStats)]
+    lib.yacrd_engine_trim.argtypes = [ctypes.c_void_p]
     lib.yacrd_reads_free.argtypes = [ctypes.POINTER(_Reads)]
     lib.yacrd_reads_free.restype = None
     lib.yacrd_stream_reset.argtypes = [ctypes.c_void_p]
@@ -426,6 +427,10 @@ class Engine:
         stats = {n: getattr(st, n) for n, _ in _IngestStats._fields_}
         self._lib.yacrd_reads_free(ctypes.byref(rd))
         return _take(self._lib, res), names, lengths, stats
+
+    def trim(self):
+        """yacrd_engine_trim: give the device parser's buffers back."""
+        _check(self._lib, self._lib.yacrd_engine_trim(self._h))
 
     def fetch(self):
         res = _Result()

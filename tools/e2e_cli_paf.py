@@ -15,6 +15,7 @@ try:
     t0 = time.perf_counter()
     host.synth_paf(host.SYNTH_SEQUEL, R, O, 20250307, paf)
     print("generated %.2f GB in %.1f s" % (os.path.getsize(paf) / 1e9, time.perf_counter() - t0), flush=True)
+    os.system("cat %s > /dev/null" % paf)  # (a freshly written /dev/shm file is slow to read the first time: 1.2 s for 15 GB)
     time.sleep(3)  # (the generator's burst on all CPUs: let the cgroup quota recover)
     outs = []
     for label, env in (("device parser (default)", {}), ("host parser (YACRD_NO_DEVICE_PARSER=1)", {"YACRD_NO_DEVICE_PARSER": "1"})):

@@ -660,6 +660,7 @@ int yacrd_engine_ingest_overlaps(yacrd_engine *e, const char *path, int format, 
                     got += (size_t)k;
                 }
                 if (bad.load()) break;
+                if (blit && (len & 15)) std::memset(dst + len, 0, 16 - (len & 15)); // (the file's last piece: zeros, not leftovers, behind it)
                 if (blit) { // (the arena's buffers are 4 MiB: whole 16-byte pieces; the mirror is padded by 64 bytes)
                     hipLaunchKernelGGL(yk::gp_blit_kernel, dim3(256), dim3(256), 0, copy[t], reinterpret_cast<uint4 *>(S.text.as<char>() + off),
                                        reinterpret_cast<const uint4 *>(dst), (u64)((len + 15) / 16));

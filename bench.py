@@ -7,20 +7,23 @@ cut into contiguous read ranges by yacrd_partition_reads (balanced by interval c
 range r on its own GPU, and there is no data-path collective — torch.distributed is used only for the
 barrier and the max over ranks.
 
-HEADLINE (`value`, "scaling": "strong"): BASELINE.json configs[2] at full size — 2 M reads / 200 M PAF
-overlaps, Sequel-like lengths, -c 3 -n 0.4, 3.3 GB of input per pass (outside the 256 MiB Infinity
-Cache) — the same fixed input for every N.  `--weak` brings back rounds 1-2's headline (every rank a
-configs[1]-sized batch of its own, batches pipelined over three engines).
+HEADLINE (`value`, "scaling": "strong"): BASELINE.json configs[4] at full size — the north star's target
+workload: 5 M reads / 500 M PAF overlaps = 1 G intervals, Sequel-like lengths, -c 3 -n 0.4, 8 GB of input per
+pass — the same fixed input for every N (generated once per node: rank 0 writes the CSR to /dev/shm, the other
+ranks map their slices).  `--config 2` / `--config 3` put another config there; `--weak` brings back rounds
+1-2's headline (every rank a configs[1]-sized batch of its own, batches pipelined over three engines).
 
 Rank 0 prints ONE JSON line carrying `roofline` for the dominant kernel (start / stop events attached to
 every launch of the timed region, on the engine's stream) and `cpu_baseline` (the CPU oracle on this
-box's cores; N = 1 only), plus, at N = 1 (SURVEY.md §8d asks for all of them):
-  north_star      configs[4]: 5 M reads / 500 M overlaps (the north star's target workload) on one GPU
+box's cores on a sample of the headline workload; N = 1 only), plus, at N = 1 (SURVEY.md §8d asks for all of them):
+  configs2        configs[2]: 2 M reads / 200 M overlaps (rounds 2-3's headline)
+  skewed          configs[3]: 10 k ultra-long reads, 57 M intervals (workgroup / device-wide screens + fallbacks)
   small_batches   configs[1] (100 k reads / 5 M overlaps, -c 4): batches pipelined over three engines,
                   one batch at a time without class-count prediction, per-phase times
   jitter          configs[1] and configs[2] from the generator that REFLECTS the dovetail ends' offsets
                   into the read instead of clamping them onto 0 / len (no exact position holds
-                  a pile): healthy / deferred reads, kernel ms, roofline fraction, oracle parity
+                  a pile), sigma = 30, 100 and 300 positions: healthy / deferred reads, kernel ms,
+                  roofline fraction, oracle parity
   pcie_inclusive  R / (H2D + kernels + D2H): a configs[1] batch sent from pinned host memory every step
   end_to_end      overlaps/s from PAF TEXT to read types on the full configs[1] file
 """
@@ -101,7 +104,7 @@ def roofline_of(yacrd_amd, t, n_launches, R, G, key, note):
         c_reads -= deferred
     if cname in ("M1", "M2", "BIG"):
         note += ("; kernel_ms brackets the class's whole PHASE (the screen and, for the reads it leaves, the fallback kernels one "
-                 "after the other), `traffic` is the screen kernel's alone: profiles/r03_kernel_stats_configs3.csv has the kernels")
+                 "after the other), `traffic` is the screen kernel's alone: profiles/r04_kernel_stats_configs3.csv has the kernels")
     b_dom = 8 * c_iv + 21 * c_reads + 16 + 8 * (G * c_reads // max(R, 1))
     ach = b_dom / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     tr = traffic_entry(key) if key else None
@@ -172,6 +175,40 @@ def oracle_sample_parity(got, off, iv, ln, cov, nc, max_reads):
     return ok, int(len(pick))
 
 
+def shared_csr(cx, profile, R, O, seed, flags):
+    """The synthetic CSR of a fixed input, generated ONCE per node: with one rank, straight from the generator;
+    with several, rank 0 generates and writes the three arrays to /dev/shm, the others map them read-only (the
+    generator runs on every hardware thread the cgroup allows: N ranks generating the whole input side by side
+    share that quota and take N times as long — 43 s x 8 for configs[4]).  Every rank must call this."""
+    host = cx.host
+    if cx.world == 1:
+        return host.synth_csr(cx.prof(profile), R, O, seed, flags=flags)
+    d = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    tag = os.path.join(d, "yacrd_bench_csr_%s_%d_%d_%d_%d" % (os.environ.get("MASTER_PORT", "0"), R, O, seed, flags))
+    names = [tag + sfx for sfx in (".off.npy", ".iv.npy", ".len.npy")]
+    if cx.rank == 0:
+        arrs = host.synth_csr(cx.prof(profile), R, O, seed, flags=flags)
+        for nm, a in zip(names, arrs):
+            np.save(nm, a)
+        cx.dist.barrier()
+        cx.shared_files = getattr(cx, "shared_files", []) + names
+        return arrs
+    cx.dist.barrier()
+    return tuple(np.load(nm, mmap_mode="r") for nm in names)
+
+
+def drop_shared(cx):
+    """Remove what shared_csr wrote (after a barrier: every rank has copied its slice)."""
+    if cx.world > 1:
+        cx.dist.barrier()
+    for nm in getattr(cx, "shared_files", []):
+        try:
+            os.remove(nm)
+        except OSError:
+            pass
+    cx.shared_files = []
+
+
 def resident_block(cx, label, profile, R, O, cov, nc, seed, jitter, steps, warmup, parity_reads, traffic_key=None,
                    keep_host=False):
     """One fixed input for every N, read-partitioned over the ranks: generate, upload, W untimed + K timed
@@ -179,12 +216,15 @@ def resident_block(cx, label, profile, R, O, cov, nc, seed, jitter, steps, warmu
     Every rank must call this (barriers, all_gather); rank 0 gets the block, the others None."""
     ya, host, torch, ydist, dist = cx.ya, cx.host, cx.torch, cx.ydist, cx.dist
     t0 = time.perf_counter()
-    offsets, intervals, lengths = host.synth_csr(cx.prof(profile), R, O, seed, flags=cx.sflags(jitter))
+    offsets, intervals, lengths = shared_csr(cx, profile, R, O, seed, cx.sflags(jitter))
     gen_s = time.perf_counter() - t0
     I_all = int(offsets[-1])
     cuts = ya.partition_reads(offsets, cx.world)
     r0, r1 = int(cuts[cx.rank]), int(cuts[cx.rank + 1])
     off, iv, ln = ydist.local_csr(offsets, intervals, lengths, r0, r1)
+    if cx.world > 1:  # (slices of the shared maps: private copies, the files go away below)
+        off, iv, ln = np.ascontiguousarray(off), np.ascontiguousarray(iv), np.ascontiguousarray(ln)
+        drop_shared(cx)
     Rl, Il = r1 - r0, int(off[-1])
     t0 = time.perf_counter()
     d_off = torch.from_numpy(np.ascontiguousarray(off).view(np.int64)).to(cx.dev)
@@ -618,8 +658,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--config", type=int, default=2, choices=[1, 2, 3, 4],
-                    help="BASELINE.json configs[k] as the headline's fixed input (default 2: 2 M reads / 200 M overlaps)")
+    ap.add_argument("--config", type=int, default=4, choices=[1, 2, 3, 4],
+                    help="BASELINE.json configs[k] as the headline's fixed input (default 4: the north star's 5 M reads / "
+                         "500 M overlaps)")
     ap.add_argument("--weak", action="store_true",
                     help="headline = rounds 1-2's: every rank its own configs[1]-sized batch, pipelined over --engines engines")
     ap.add_argument("--jitter", type=int, default=0,
@@ -637,8 +678,9 @@ def main():
                     help="small batches: events on the dominant kernel of EVERY step (default: every 8th step of an engine "
                          "when there are more than 64 steps: the events cost ~10 us per step against a 20 us kernel)")
     ap.add_argument("--no-extras", action="store_true", help="headline only")
-    ap.add_argument("--no-north-star", action="store_true")
-    ap.add_argument("--north-star-steps", type=int, default=3)
+    ap.add_argument("--sub-steps", type=int, default=10, help="timed steps of the configs[2] / configs[3] sub-blocks")
+    ap.add_argument("--jitter-sigmas", type=str, default="30,100,300",
+                    help="sigmas of the `jitter` block (comma separated; empty = no jitter block)")
     ap.add_argument("--scale", type=float, default=1.0,
                     help="scale every config's reads and overlaps (plumbing tests only: a scaled run is not a measurement, "
                          "and the workload strings say so)")
@@ -652,6 +694,7 @@ def main():
     ya, host = cx.ya, cx.host
     rank, world = cx.rank, cx.world
     extras = world == 1 and not args.no_extras
+    backend = cx.dist.get_backend() if cx.dist is not None else None
 
     line, head, keep_small, keep_head = None, None, None, None
     if args.weak:
@@ -661,13 +704,17 @@ def main():
             args.small_warmup = args.warmup
         head, keep_small = small_batches_block(cx, args.jitter)
         scaling = "weak"
+    elif args.config == 1:
+        ap.error("configs[1] is the --weak headline (batches of 100 k reads); --config takes 2, 3 or 4")
     else:
         profile, R, O, cov, nc, seed = CONFIGS[args.config]
         R, O = args.reads or R, args.overlaps or O
         if args.coverage is not None:
             cov = args.coverage
-        head, keep_head = resident_block(cx, "configs[%d]" % args.config, profile, R, O, cov, nc, seed, args.jitter, args.steps,
-                                         args.warmup, 20000, traffic_key=None if args.jitter else "configs[%d]" % args.config,
+        label = "configs[%d]" % args.config + (" (the north star's target workload)" if args.config == 4 else "")
+        head, keep_head = resident_block(cx, label, profile, R, O, cov, nc, seed, args.jitter, args.steps,
+                                         args.warmup, 50000 if args.config == 4 else 20000,
+                                         traffic_key=None if args.jitter else "configs[%d]" % args.config,
                                          keep_host=world == 1 and not args.no_cpu_baseline)
         scaling = "strong"
     if rank == 0:
@@ -685,7 +732,8 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "config": {"workload": ("SCALED x%g (not a measurement): " % args.scale if args.scale != 1.0 else "") + head["workload"] + "; see pcie_inclusive / end_to_end for the rates that include PCIe and the parse",
-                       "parallelism": "read-partition x%d, no collective" % world},
+                       "parallelism": "read-partition x%d, no collective" % world,
+                       "torch_distributed_backend": backend if backend else "none (one process)"},
             "kernel_overlaps_per_sec": head["kernel_overlaps_per_sec"],
             "parity": head["parity"],
             "roofline": head["roofline"],
@@ -701,12 +749,38 @@ def main():
             del offsets, intervals, lengths
     if extras:
         if not args.weak:
+            for key, k in (("configs2", 2), ("skewed", 3)):
+                if k == args.config:
+                    continue
+                pk = CONFIGS[k]
+                try:
+                    line[key], _ = resident_block(cx, "configs[%d]" % k, pk[0], pk[1], pk[2], pk[3], pk[4], pk[5], 0,
+                                                  args.sub_steps, 2, 20000, traffic_key="configs[%d]" % k)
+                except Exception as ex:
+                    line[key] = {"error": repr(ex)}
             line["small_batches"], keep_small = small_batches_block(cx)
-        jit = {}
-        jit["configs[1]"], _ = small_batches_block(cx, jitter=30)
-        p2 = CONFIGS[2]
-        jit["configs[2]"], _ = resident_block(cx, "configs[2]", p2[0], p2[1], p2[2], p2[3], p2[4], p2[5], 30, 5, 2, 20000)
-        line["jitter"] = jit
+        sigmas = [int(x) for x in args.jitter_sigmas.split(",") if x.strip()]
+        if sigmas:
+            jit = {}
+            p2 = CONFIGS[2]
+            for sg in sigmas:
+                key = "" if sg == 30 else "_sigma%d" % sg
+                b1, _ = small_batches_block(cx, jitter=sg)
+                jit["configs[1]" + key] = b1
+                try:
+                    b2, _ = resident_block(cx, "configs[2]", p2[0], p2[1], p2[2], p2[3], p2[4], p2[5], sg, 5, 2, 20000)
+                except Exception as ex:
+                    b2 = {"error": repr(ex)}
+                jit["configs[2]" + key] = b2
+            # what the windows of the screen are there for, in one table: the share of the screened reads it decides
+            def share(b):
+                if not isinstance(b, dict) or "error" in b:
+                    return None
+                h = b.get("healthy_reads", b.get("healthy_reads_rank0"))
+                df = b.get("deferred_reads", b.get("deferred_reads_rank0"))
+                return None if h is None or df is None else h / max(1, h + df)
+            jit["healthy_share_of_screened_reads"] = {k: share(b) for k, b in list(jit.items())}
+            line["jitter"] = jit
         # more of the reads yacrd looks for: what the screen defers grows with them, and from a quarter on the engine
         # takes the sorting build (engine.hip: nodefer_left)
         bad = {}
@@ -726,14 +800,6 @@ def main():
             for e in engs:
                 e.close()
             keep_small = None
-        if not args.no_north_star:
-            p4 = CONFIGS[4]
-            try:
-                ns, _ = resident_block(cx, "configs[4] (the north star's target workload)", p4[0], p4[1], p4[2], p4[3], p4[4],
-                                       p4[5], 0, args.north_star_steps, 1, 50000, traffic_key="configs[4]")
-            except Exception as ex:
-                ns = {"error": repr(ex)}
-            line["north_star"] = ns
     if keep_small is not None:
         for e in keep_small[3]:
             e.close()

@@ -143,3 +143,48 @@ def test_handle_partition_is_a_partition():
         owners = [yacrd_amd.stream_device_of(h, world) for h in range(1000)]
         assert set(owners) == set(range(world)) and all(o == h % world for h, o in enumerate(owners))
     assert yacrd_amd.stream_device_of(0xFFFFFFFD, 8) == 0xFFFFFFFD % 8
+
+
+SHARED_WORKER = r"""
+import os, sys, types
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import bench, yacrd_amd
+from yacrd_amd import dist as ydist, host
+# bench.py's input for N > 1: generated once (rank 0), written to /dev/shm, mapped by the other ranks; every rank
+# slices its own contiguous read range out of it and the files are gone afterwards
+rank, local_rank, world = ydist.env_rank()
+d = ydist.init(backend="gloo")
+cx = types.SimpleNamespace(world=world, rank=rank, dist=d, host=host, prof=lambda name: host.SYNTH_SEQUEL)
+offsets, intervals, lengths = bench.shared_csr(cx, "sequel", 3000, 90000, 77, 0)
+want = host.synth_csr(host.SYNTH_SEQUEL, 3000, 90000, 77)
+same = all(np.array_equal(np.asarray(a), b) for a, b in zip((offsets, intervals, lengths), want))
+r0, r1 = ydist.shard(offsets, rank, world, yacrd_amd.partition_reads)
+off, iv, ln = (np.ascontiguousarray(x) for x in ydist.local_csr(offsets, intervals, lengths, r0, r1))
+bench.drop_shared(cx)
+left = [f for f in os.listdir("/dev/shm") if f.startswith("yacrd_bench_csr_%s_" % os.environ["MASTER_PORT"])] if os.path.isdir("/dev/shm") else []
+sizes = [None] * world
+d.all_gather_object(sizes, (r1 - r0, int(off[-1]), same, isinstance(offsets, np.memmap)))
+if rank == 0:
+    ok = (sum(s[0] for s in sizes) == 3000 and sum(s[1] for s in sizes) == 180000 and all(s[2] for s in sizes)
+          and not sizes[0][3] and all(s[3] for s in sizes[1:]) and not left)
+    print("RESULT", "OK" if ok else "MISMATCH", sizes, left)
+d.destroy_process_group()
+"""
+
+
+def test_bench_input_is_generated_once_per_node(tmp_path):
+    script = tmp_path / "sworker.py"
+    script.write_text(SHARED_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "RESULT OK" in outs[0][0], outs

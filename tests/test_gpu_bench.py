@@ -21,19 +21,20 @@ def _last_json(text):
 
 def test_single_gpu_line_scaled():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2",
-                        "--scale", "0.02", "--small-steps", "20", "--north-star-steps", "2"],
+                        "--scale", "0.02", "--small-steps", "20", "--sub-steps", "3"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     d = _last_json(p.stdout)
     assert d["metric"] == "reads_per_sec_classified" and d["n_gpus"] == 1 and d["scaling"] == "strong"
-    assert "configs[2]" in d["config"]["workload"] and d["config"]["workload"].startswith("SCALED")
+    assert "configs[4]" in d["config"]["workload"] and d["config"]["workload"].startswith("SCALED")
+    assert d["headline"]["reads"] == 100000 and d["config"]["torch_distributed_backend"].startswith("none")
     assert d["steps"] == 4 and d["warmup"] == 2
     assert d["parity"].startswith("bit-exact")
     r = d["roofline"]
     assert r["bound"] == "hbm" and 0 < r["frac"] < 1 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-9
     assert r["timed_launches"] == r["launches"] == 4  # every launch of the timed region carries its events
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
-    for k in ("pcie_inclusive", "end_to_end", "small_batches", "north_star"):
+    for k in ("pcie_inclusive", "end_to_end", "small_batches", "configs2", "skewed"):
         assert "error" not in d[k], d[k]
     sb = d["small_batches"]
     assert sb["parity"].startswith("bit-exact") and sb["roofline"]["timed_launches"] == 20
@@ -45,11 +46,14 @@ def test_single_gpu_line_scaled():
     assert sc["same_reads_regions_types"] and sc["device_parser"]["overlaps_per_sec"] > 1e6
     for k in ("10%", "40%"):
         assert d["more_bad_reads"][k]["parity"].startswith("bit-exact")
-    ns = d["north_star"]
-    assert ns["parity"].startswith("bit-exact") and ns["reads"] == 100000 and "configs[4]" in ns["workload"]
-    for k in ("configs[1]", "configs[2]"):
+    c2, sk = d["configs2"], d["skewed"]
+    assert c2["parity"].startswith("bit-exact") and c2["reads"] == 40000 and "configs[2]" in c2["workload"]
+    assert sk["parity"].startswith("bit-exact") and sk["reads"] == 200 and "SKEWED" in sk["workload"]
+    assert sk["roofline"]["size_class"] in ("M1", "M2", "BIG")
+    for k in ("configs[1]", "configs[2]", "configs[1]_sigma100", "configs[2]_sigma100", "configs[1]_sigma300", "configs[2]_sigma300"):
         j = d["jitter"][k]
         assert j["parity"].startswith("bit-exact") and "reflected" in j["workload"].lower()
+        assert 0.0 <= d["jitter"]["healthy_share_of_screened_reads"][k] <= 1.0
 
 
 @pytest.mark.parametrize("weak", [False, True])
@@ -72,7 +76,8 @@ def test_two_ranks_on_one_device(weak):
         return
     # the engine ran under both ranks, each on its own read range, and matched the oracle there
     h = d["headline"]
-    assert d["scaling"] == "strong" and "configs[2]" in d["config"]["workload"] and len(h["per_rank"]) == 2
-    assert sum(r["reads"] for r in h["per_rank"]) == 60000
-    assert sum(r["intervals"] for r in h["per_rank"]) == 12000000
+    assert d["scaling"] == "strong" and "configs[4]" in d["config"]["workload"] and len(h["per_rank"]) == 2
+    assert d["config"]["torch_distributed_backend"] == "gloo"
+    assert sum(r["reads"] for r in h["per_rank"]) == 150000
+    assert sum(r["intervals"] for r in h["per_rank"]) == 30000000
     assert h["interval_imbalance_max_over_min"] < 1.05

@@ -25,8 +25,10 @@ def init(backend=None, device=None):
         try:
             dist.init_process_group("nccl", device_id=device)
             return dist
-        except Exception:
-            pass
+        except Exception as ex:  # said out loud; callers report dist.get_backend() (bench.py: config.torch_distributed_backend)
+            import sys
+            print("yacrd_amd.dist: nccl (RCCL) process group failed (%r): falling back to gloo for the barrier / max over ranks" % (ex,),
+                  file=sys.stderr, flush=True)
     dist.init_process_group("gloo")
     return dist
 

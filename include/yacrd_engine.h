@@ -245,7 +245,10 @@ int yacrd_stream_acquire(yacrd_stream *s, yacrd_ovl_rec **buf, uint64_t *capacit
 int yacrd_stream_commit(yacrd_stream *s, yacrd_ovl_rec *buf, uint64_t n_records);
 /* All records are in.  handle_map[n_handles] (or NULL), lengths[n_reads]: builds the CSR in HBM,
  * runs the engine (blocking) and returns the host result like yacrd_engine_run.  The stream is
- * empty again afterwards — on success AND on every error return — and can take the next file. */
+ * empty again afterwards — on success AND on every error return — and can take the next file; the two
+ * exceptions are calls that are refused before anything is touched (YACRD_EINVAL: a batch pending on the
+ * engine, a buffer a parser still holds): fix the cause, then yacrd_stream_reset (the group's finish
+ * clears every device when any of its streams failed). */
 int yacrd_stream_finish(yacrd_stream *s, const uint32_t *handle_map, uint64_t n_handles,
                         const uint32_t *lengths, uint64_t n_reads, uint32_t coverage,
                         double not_coverage, yacrd_result *out);

@@ -53,7 +53,8 @@ def test_single_gpu_line_scaled():
     for k in ("configs[1]", "configs[2]", "configs[1]_sigma100", "configs[2]_sigma100", "configs[1]_sigma300", "configs[2]_sigma300"):
         j = d["jitter"][k]
         assert j["parity"].startswith("bit-exact") and "reflected" in j["workload"].lower()
-        assert 0.0 <= d["jitter"]["healthy_share_of_screened_reads"][k] <= 1.0
+        share = d["jitter"]["healthy_share_of_screened_reads"][k]  # (None: a scaled batch too short for the screening build)
+        assert share is None or 0.0 <= share <= 1.0
 
 
 @pytest.mark.parametrize("weak", [False, True])

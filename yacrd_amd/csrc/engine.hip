@@ -60,7 +60,18 @@ namespace {
 
 // finish the deferred reads + scan + compact + classify: one kernel (finish_compact.h), then the totals
 // come home.  `sa` carries the run's inputs, stage / counts and the small classes' rejection list.
-int launch_compact(yacrd_engine *e, const yk::SweepArgs &sa, u32 n_reads, double not_cov)
+// Batches of this many reads and more take the follow-on step as two kernels (finish_compact.h: deferred_sweep_kernel
+// + scan_compact_kernel); YACRD_SPLIT_MIN_READS overrides (A/B: 0 = always, a huge number = never).
+static uint64_t split_min_reads()
+{
+    static const uint64_t v = [] {
+        const char *e = std::getenv("YACRD_SPLIT_MIN_READS");
+        return e ? std::strtoull(e, nullptr, 10) : (uint64_t)yk::kPlanSmallReads;
+    }();
+    return v;
+}
+
+int launch_compact(yacrd_engine *e, const yk::SweepArgs &sa, u32 n_reads, double not_cov, bool screened)
 {
     const u32 nb = (n_reads + yk::kScanBlock - 1) / yk::kScanBlock;
     yk::Counters *ctr = e->ctrl2[e->ctrl_cur].as<yk::Counters>();
@@ -80,6 +91,13 @@ int launch_compact(yacrd_engine *e, const yk::SweepArgs &sa, u32 n_reads, double
     ca.bad_regions = e->bad_regions.as<uint2>();
     ca.region_cap = (u64)(e->bad_regions.cap / sizeof(uint2));
     ca.read_type = e->read_type.as<uint8_t>();
+    if ((uint64_t)n_reads >= split_min_reads()) {
+        ca.host_ctr = e->h_ctr;
+        if (screened)
+            hipLaunchKernelGGL(yk::deferred_sweep_kernel, dim3(nb), dim3(yk::kDeferThreads), 0, e->stream, ca.sweep, n_reads);
+        hipLaunchKernelGGL(yk::scan_compact_kernel, dim3(nb), dim3(yk::kScanThreads), 0, e->stream, ca);
+        return YACRD_OK;
+    }
 #ifdef YK_NO_HANDOVER
     ca.host_ctr = nullptr;
     hipLaunchKernelGGL(yk::finish_compact_kernel, dim3(nb), dim3(yk::kScanBlock), 0, e->stream, ca);
@@ -690,7 +708,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     if (full) HIP_TRY(hipEventRecord(e->ev[EV_GEN], e->stream));
 
     // ---- follow-on kernel: scan + compact + classify
-    rc = launch_compact(e, sa, n_reads, not_cov);
+    rc = launch_compact(e, sa, n_reads, not_cov, screened);
     if (rc) return rc;
     if (full) HIP_TRY(hipEventRecord(e->ev[EV_COMPACT], e->stream));
     if (defer && predicted) { // yacrd_engine_submit_device: the caller waits later (finish_pending)
@@ -795,7 +813,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         // reset the scan state, the ticket and the overflow flag (keep the class counters)
         HIP_TRY(hipMemsetAsync(&ctr->region_overflow, 0, 3 * sizeof(u32), e->stream));
         HIP_TRY(hipMemsetAsync(ctr + 1, 0, (size_t)nb * sizeof(u64), e->stream));
-        rc = launch_compact(e, sa, n_reads, not_cov);
+        rc = launch_compact(e, sa, n_reads, not_cov, screened);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(e->ev[EV_X1], e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));

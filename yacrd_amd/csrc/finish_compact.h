@@ -151,12 +151,12 @@ __global__ __launch_bounds__(kScanBlock, YK_FINISH_OCC) void finish_compact_kern
         u64 base = 0;
         if (bid > 0) {
             if (lane == 0)
-                __hip_atomic_store(&c.scan_state[bid], kAgg | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&c.scan_state[bid], kAgg | tot, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); // (release: this slab's counter atomics of phase A happen before whoever sees the aggregate)
             for (i32 hi = (i32)bid - 1;; hi -= 64) {
                 const i32 idx = hi - (i32)lane; // lane 0 looks at the nearest predecessor
                 u64 v, pre;
                 for (;;) { // until the window holds no empty entry before its nearest prefix
-                    v = idx >= 0 ? __hip_atomic_load(&c.scan_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                    v = idx >= 0 ? __hip_atomic_load(&c.scan_state[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
                                  : kPre; // before the first workgroup: prefix 0
                     pre = __builtin_amdgcn_ballot_w64((v >> 62) == 2);
                     const u64 before = pre ? ((pre & (0 - pre)) - 1ull) : ~0ull; // lanes nearer than it
@@ -172,7 +172,7 @@ __global__ __launch_bounds__(kScanBlock, YK_FINISH_OCC) void finish_compact_kern
             }
         }
         if (lane == 0) {
-            __hip_atomic_store(&c.scan_state[bid], kPre | (base + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&c.scan_state[bid], kPre | (base + tot), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
             s_base = base;
             if ((u64)(bid + 1) * kScanBlock >= c.n_reads) ctr->total_regions = base + tot;
         }
@@ -218,6 +218,258 @@ __global__ __launch_bounds__(kScanBlock, YK_FINISH_OCC) void finish_compact_kern
         }
         if (!fits) atomicOr(&ctr->region_overflow, 1u);
         c.read_type[r] = (uint8_t)classify(bad, middle, L, c.not_cov);
+    }
+}
+
+
+// ==== the follow-on step as TWO kernels (round 4): long batches ========================================
+// finish_compact_kernel above does both phases in 1024-thread workgroups at a 64-register budget: its 64-lane
+// sorts spill (40 bytes of scratch per thread — all 2 M threads of configs[2] write 12 of them: the 97 MB
+// WRITE_SIZE / 199 MB FETCH_SIZE of round 3's PMC against ~20 / 124 MB of data), they sort one read per wavefront
+// without the bin filter (~1000 instructions per read, 48 M VALU for 47 600 reads: the sorting build of the
+// fused launch does the same read in less than half), and its scan holds two workgroups per CU.
+// For batches of kPlanSmallReads reads and more the engine launches instead:
+//   deferred_sweep_kernel   256 threads per slab of 1024 reads: the slab's marked reads are listed in LDS by
+//                           size, then swept four (<= 128 intervals, 16-lane rows) or two (<= 256, half
+//                           wavefronts) at a time by sweep_group_read — the sorting build's code: bin filter
+//                           in front of the register sort, 96 registers, no scratch;
+//   scan_compact_kernel     256 threads x 4 consecutive reads: 16-byte loads of counts / lengths / closed forms,
+//                           decoupled look-back over 1024-read aggregates (every workgroup of a 2 M-read batch is
+//                           resident at once), 16-byte stores of bad_offsets, one 4-byte store of four read types.
+// Short batches keep the one-dispatch form (a dispatch more costs what the phases gain there).
+constexpr int kDeferSlab = 1024, kDeferThreads = 256;
+
+__global__ __launch_bounds__(kDeferThreads, 5) void deferred_sweep_kernel(SweepArgs a, u32 n_reads)
+{
+    __shared__ u32 s_list[kDeferSlab]; // indices inside the slab: half-wavefront reads from the front, row reads from the back
+    __shared__ u32 s_n32, s_n16;
+    __shared__ unsigned long long s_iv;
+    if (threadIdx.x == 0) s_n32 = 0, s_n16 = 0, s_iv = 0;
+    __syncthreads();
+    const u32 lane = lane_id();
+    const u32 slab0 = blockIdx.x * (u32)kDeferSlab;
+    constexpr int PER = kDeferSlab / kDeferThreads;
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const u32 i = (u32)k * kDeferThreads + threadIdx.x, r = slab0 + i;
+        const bool marked = r < n_reads && a.counts[r] == kDeferredMark;
+        const u64 mm = __builtin_amdgcn_ballot_w64(marked);
+        if (mm == 0) continue; // (uniform in the wavefront)
+        any = true;
+        u32 n = 0;
+        if (marked) n = (u32)(a.off[r + 1] - a.off[r]);
+        const bool half = marked && n > 128u; // (a marked read has at most 256 intervals)
+        const u64 mh = __builtin_amdgcn_ballot_w64(half), mr = mm & ~mh;
+        u32 bh = 0, br = 0;
+        if (lane == (u32)__builtin_ctzll(mm)) {
+            if (mh) bh = atomicAdd(&s_n32, (u32)__builtin_popcountll(mh));
+            if (mr) br = atomicAdd(&s_n16, (u32)__builtin_popcountll(mr));
+        }
+        bh = (u32)__builtin_amdgcn_readlane((int)bh, (int)__builtin_ctzll(mm));
+        br = (u32)__builtin_amdgcn_readlane((int)br, (int)__builtin_ctzll(mm));
+        const u64 below = (1ull << lane) - 1ull;
+        if (half) s_list[bh + (u32)__builtin_popcountll(mh & below)] = i;
+        else if (marked) s_list[(u32)kDeferSlab - 1u - (br + (u32)__builtin_popcountll(mr & below))] = i;
+        u64 iv = n; // intervals of the marked reads, for the roofline's exact byte count
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) iv += __shfl_xor(iv, d, 64);
+        if (lane == 0) atomicAdd(&s_iv, (unsigned long long)iv);
+    }
+    (void)any;
+    __syncthreads();
+    const u32 n32 = s_n32, n16 = s_n16;
+    if (n32 + n16 == 0) return; // uniform in the workgroup
+    if (threadIdx.x == 0) {
+        atomicAdd(&a.ctr->deferred, n32 + n16);
+        atomicAdd((unsigned long long *)&a.ctr->deferred_iv, s_iv);
+    }
+    const LaneConst lc = make_lane_const(lane);
+    constexpr u32 kWaves = kDeferThreads / 64;
+    const u32 wave = threadIdx.x >> 6;
+    // two reads per wavefront and turn (32-lane halves)
+    for (u32 i0 = wave * 2u; i0 < n32; i0 += kWaves * 2u) { // (uniform in the wavefront)
+        const u32 idx = i0 + (lane >> 5);
+        const bool active = idx < n32;
+        u32 r = 0, n = 0, len = 0;
+        u64 o = 0;
+        if (active) {
+            r = slab0 + s_list[idx];
+            o = a.off[r];
+            n = (u32)(a.off[r + 1] - o);
+            len = a.len[r];
+        }
+        sweep_group_read<32, 16, 0, (int)kWaves>(a.iv + o, n, len, a.cov, active, r, a, lc);
+    }
+    // four per wavefront and turn (16-lane rows)
+    for (u32 i0 = wave * 4u; i0 < n16; i0 += kWaves * 4u) {
+        const u32 idx = i0 + (lane >> 4);
+        const bool active = idx < n16;
+        u32 r = 0, n = 0, len = 0;
+        u64 o = 0;
+        if (active) {
+            r = slab0 + s_list[(u32)kDeferSlab - 1u - idx];
+            o = a.off[r];
+            n = (u32)(a.off[r + 1] - o);
+            len = a.len[r];
+        }
+        sweep_group_read<16, 16, 0, (int)kWaves>(a.iv + o, n, len, a.cov, active, r, a, lc);
+    }
+}
+
+constexpr int kScanThreads = 256, kScanPer = 4, kScanReads = kScanThreads * kScanPer;
+static_assert(kScanReads == kScanBlock, "the control block holds one scan word per 1024 reads");
+
+__global__ __launch_bounds__(kScanThreads) void scan_compact_kernel(CompactArgs2 c)
+{
+    __shared__ u32 sc[kScanThreads / 64];
+    __shared__ u32 s_bid;
+    __shared__ u64 s_base;
+    const SweepArgs &a = c.sweep;
+    Counters *ctr = a.ctr;
+    if (threadIdx.x == 0) s_bid = atomicAdd(&ctr->scan_ticket, 1u);
+    __syncthreads();
+    const u32 bid = s_bid, lane = lane_id();
+    const u64 r0 = (u64)bid * kScanReads + threadIdx.x * (u32)kScanPer; // (u64: the last slab of a batch of nearly 2^32 reads)
+    u32 g[kScanPer], L[kScanPer];
+    uint2 ab[kScanPer];
+    bool closed[kScanPer];
+    // 16-byte loads where the four reads exist (counts / closed are the engine's own buffers; the lengths are the
+    // caller's: their alignment is looked at)
+    const bool vec = r0 + kScanPer <= c.n_reads && (reinterpret_cast<uintptr_t>(a.len) & 15u) == 0;
+    if (vec) {
+        const uint4 g4 = *reinterpret_cast<const uint4 *>(a.counts + r0);
+        const uint4 l4 = *reinterpret_cast<const uint4 *>(a.len + r0);
+        g[0] = g4.x, g[1] = g4.y, g[2] = g4.z, g[3] = g4.w;
+        L[0] = l4.x, L[1] = l4.y, L[2] = l4.z, L[3] = l4.w;
+    } else {
+#pragma unroll
+        for (int k = 0; k < kScanPer; k++) {
+            const bool in = r0 + k < c.n_reads;
+            g[k] = in ? a.counts[r0 + k] : 0u;
+            L[k] = in ? a.len[r0 + k] : 0u;
+        }
+    }
+    bool any_closed = false;
+#pragma unroll
+    for (int k = 0; k < kScanPer; k++) {
+        if (g[k] == kDeferredMark) g[k] = 0u; // (cannot be left: the deferred sweep ran before)
+        closed[k] = g[k] == kClosedForm;
+        any_closed |= closed[k];
+        ab[k] = make_uint2(0u, L[k]);
+    }
+    if (any_closed) { // the screen's closed form (device_common.h: kClosedForm)
+        if (vec) {
+            const uint4 c0 = *reinterpret_cast<const uint4 *>(a.closed + r0), c1 = *reinterpret_cast<const uint4 *>(a.closed + r0 + 2);
+            const uint2 t[4] = {make_uint2(c0.x, c0.y), make_uint2(c0.z, c0.w), make_uint2(c1.x, c1.y), make_uint2(c1.z, c1.w)};
+#pragma unroll
+            for (int k = 0; k < kScanPer; k++)
+                if (closed[k]) ab[k] = t[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < kScanPer; k++)
+                if (closed[k]) ab[k] = a.closed[r0 + k];
+        }
+    }
+    u32 mine = 0;
+#pragma unroll
+    for (int k = 0; k < kScanPer; k++) {
+        if (closed[k]) g[k] = (ab[k].x != 0u ? 1u : 0u) + (ab[k].y != L[k] ? 1u : 0u);
+        mine += g[k];
+    }
+    u32 tot;
+    u32 local = block_excl_add<kScanThreads>(mine, sc, tot);
+    if (threadIdx.x < 64) { // decoupled look-back, 64 predecessors per round trip (as in finish_compact_kernel)
+        constexpr u64 kAgg = 1ull << 62, kPre = 2ull << 62, kVal = (1ull << 62) - 1;
+        u64 base = 0;
+        if (bid > 0) {
+            if (lane == 0) __hip_atomic_store(&c.scan_state[bid], kAgg | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (i32 hi = (i32)bid - 1;; hi -= 64) {
+                const i32 idx = hi - (i32)lane;
+                u64 v, pre;
+                for (;;) {
+                    v = idx >= 0 ? __hip_atomic_load(&c.scan_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kPre;
+                    pre = __builtin_amdgcn_ballot_w64((v >> 62) == 2);
+                    const u64 before = pre ? ((pre & (0 - pre)) - 1ull) : ~0ull;
+                    if ((__builtin_amdgcn_ballot_w64((v >> 62) == 0) & before) == 0) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                const u32 first_pre = pre ? (u32)__builtin_ctzll(pre) : 64u;
+                u64 part = lane <= first_pre ? (v & kVal) : 0;
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
+                base += part;
+                if (pre) break;
+            }
+        }
+        if (lane == 0) {
+            __hip_atomic_store(&c.scan_state[bid], kPre | (base + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_base = base;
+            if ((u64)(bid + 1) * kScanReads >= c.n_reads) ctr->total_regions = base + tot;
+        }
+        // the counters go home from the slab that ends the batch (every other writer of counters is a kernel that
+        // finished before this one started)
+        if (c.host_ctr && (u64)(bid + 1) * kScanReads >= c.n_reads) {
+            const u64 total = (u64)__shfl((long long)(base + tot), 0, 64);
+            const u32 *src = reinterpret_cast<const u32 *>(ctr);
+            u32 *dst = reinterpret_cast<u32 *>(c.host_ctr);
+            constexpr u32 kWords = (u32)(sizeof(Counters) / 4);
+            for (u32 i = lane; i < kWords; i += 64u) {
+                u32 w = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (i == (u32)(offsetof(Counters, total_regions) / 4)) w = (u32)total;
+                if (i == (u32)(offsetof(Counters, total_regions) / 4) + 1u) w = (u32)(total >> 32);
+                if (i == (u32)(offsetof(Counters, region_overflow) / 4)) w = total > c.region_cap ? 1u : 0u;
+                dst[i] = w;
+            }
+        }
+    }
+    __syncthreads();
+    if (r0 >= c.n_reads) return;
+    u64 dst = s_base + local;
+    u64 offs[kScanPer];
+    u32 types = 0;
+    bool overflow = false;
+#pragma unroll
+    for (int k = 0; k < kScanPer; k++) {
+        offs[k] = dst;
+        const u64 r = r0 + k;
+        if (r < c.n_reads) {
+            u32 bad = 0;
+            bool middle = false;
+            const bool fits = dst + g[k] <= c.region_cap;
+            if (closed[k]) { // (neither region lies in the middle: the first begins at 0, the second ends at len)
+                u32 j = 0;
+                if (ab[k].x != 0u && fits) c.bad_regions[dst + j++] = make_uint2(0u, ab[k].x);
+                if (ab[k].y != L[k] && fits) c.bad_regions[dst + j] = make_uint2(ab[k].y, L[k]);
+                bad = ab[k].x + (L[k] - ab[k].y);
+            } else if (g[k]) {
+                const uint2 *slot = a.stage + (a.off[r] + 2 * r);
+                for (u32 j = 0; j < g[k]; j++) {
+                    const uint2 v = slot[j];
+                    if (fits) c.bad_regions[dst + j] = v;
+                    bad += v.y - v.x;
+                    middle |= (v.x != 0u) & (v.y != L[k]);
+                }
+            }
+            overflow |= !fits;
+            types |= classify(bad, middle, L[k], c.not_cov) << (8 * k);
+            if (r == c.n_reads - 1) c.bad_offsets[c.n_reads] = dst + g[k];
+        }
+        dst += g[k];
+    }
+    if (overflow) atomicOr(&ctr->region_overflow, 1u);
+    if (r0 + kScanPer <= c.n_reads) {
+        ulonglong2 *bo = reinterpret_cast<ulonglong2 *>(c.bad_offsets + r0); // (engine-owned: 256-byte aligned, r0 % 4 == 0)
+        bo[0] = make_ulonglong2(offs[0], offs[1]);
+        bo[1] = make_ulonglong2(offs[2], offs[3]);
+        *reinterpret_cast<u32 *>(c.read_type + r0) = types;
+    } else {
+#pragma unroll
+        for (int k = 0; k < kScanPer; k++)
+            if (r0 + k < c.n_reads) {
+                c.bad_offsets[r0 + k] = offs[k];
+                c.read_type[r0 + k] = (uint8_t)(types >> (8 * k));
+            }
     }
 }
 

@@ -164,7 +164,11 @@ __device__ __forceinline__ u32 gp_intern(const GpArgs &a, const GpText &t, u64 p
 {
     const unsigned char *g = a.text;
     u32 s = (u32)h & a.mask;
-    for (u32 probes = 0; probes <= a.mask; probes++, s = (s + 1u) & a.mask) {
+    // (a bounded walk: a table that is nearly full — more distinct ids than it was sized for, e.g. a read-to-reference
+    // PAF with a new query id on every line — would otherwise cost every later lookup a walk over all of it before
+    // the file is handed to the host parser anyway)
+    const u32 max_probes = min(a.mask, 1024u);
+    for (u32 probes = 0; probes <= max_probes; probes++, s = (s + 1u) & a.mask) {
         u64 w = __hip_atomic_load(&a.claim[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (w == 0) {
             const u64 old = atomicCAS((unsigned long long *)&a.claim[s], 0ull, (unsigned long long)(p + 1));
@@ -173,7 +177,7 @@ __device__ __forceinline__ u32 gp_intern(const GpArgs &a, const GpText &t, u64 p
         }
         const u64 c = w - 1; // the claimant's id starts there and ends at a delimiter (or it would not have been parsed)
         if (c == p) return s;
-        bool same = g[c + n] == a.delim;
+        bool same = c + n < a.avail && g[c + n] == a.delim; // (a shorter id near the end of what has landed: not this one)
         for (u32 i = 0; same && i < n; i++) same = g[c + i] == t[p + i];
         if (same) return s;
     }
@@ -543,6 +547,18 @@ int yacrd_engine_ingest_overlaps(yacrd_engine *e, const char *path, int format, 
     }
     Scratch &S = *static_cast<Scratch *>(e->paf_scratch);
     const double t_start = now_ms();
+    {
+        // The parse on the device wants the text, a 24-byte record per line, the id table, the CSR and the region
+        // slots in HBM at once: ~2.6 x the file (measured: 37.2 GB of text -> 96 GB).  An input beyond that goes to
+        // the host parser, whose streamed records need ~0.5 x: answered here, before anything is allocated.
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const double have = (double)free_b + (double)S.text.cap + (double)S.recs.cap + (double)e->stage.cap +
+                                (double)e->in_iv.cap;
+            if (2.6 * (double)n + (double)((size_t)256 << 20) > have)
+                return fail(YACRD_EFALLBACK, "the file is too large to be parsed in this device's free memory: the host parser streams it");
+        }
+    }
 
     // ---- what does not depend on the text's content: the mirror, the id table, the control words
     const void *mirror_before = S.text.p;

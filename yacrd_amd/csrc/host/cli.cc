@@ -8,6 +8,7 @@
 // Additive flags only: --gpus N (reads partitioned over N GPUs by id handle, default 1).
 // The bad-region computation and the read classification run on the GPU through
 // include/yacrd_engine.h; there is no CPU fallback — without a gfx950 device this exits non-zero.
+#include <algorithm>
 #include <cerrno>
 #include <cstdio>
 #include <cstdlib>
@@ -170,9 +171,18 @@ int main(int argc, char **argv)
             // builds the CSR and runs the engine (yacrd_engine_ingest_overlaps).  Whatever is not a plain file of
             // plain records (compressed, quoted fields, lone CRs, 0x integers, malformed lines ...) comes back as
             // YACRD_EFALLBACK and takes the host parser below, which knows the whole syntax and the messages.
-            dev_parse = yacrd_engine_ingest_overlaps(engines[0], input.c_str(), m4 ? 2 : 1,
-                                                     (int)std::min<unsigned long long>(threads, 8), cov32, not_coverage,
+            // The threads that move the file into pinned memory are not the reference's rayon pool: their number does
+            // not follow -t (default 1 = 8 GB/s of a 56 GB/s link); the engine's own default (6) unless
+            // YACRD_COPY_THREADS says otherwise.
+            const char *ct = std::getenv("YACRD_COPY_THREADS");
+            const int copy_threads = ct && *ct ? std::max(0, std::atoi(ct)) : 0;
+            dev_parse = yacrd_engine_ingest_overlaps(engines[0], input.c_str(), m4 ? 2 : 1, copy_threads, cov32, not_coverage,
                                                      &res, &dev_reads, nullptr);
+            if (dev_parse == YACRD_ENOMEM) { // HBM ran out on the way (the parse wants ~2.6 x the file): the streamed host parse needs a fifth
+                std::fprintf(stderr, "[INFO] device parser: %s; falling back to the host parser\n", yacrd_last_error());
+                (void)yacrd_engine_trim(engines[0]);
+                dev_parse = YACRD_EFALLBACK;
+            }
             if (dev_parse != YACRD_OK && dev_parse != YACRD_EFALLBACK) die(yacrd_last_error());
         }
         if (dev_parse == YACRD_OK) {

@@ -331,6 +331,19 @@ int yacrd_stream_finish(yacrd_stream *s, const uint32_t *handle_map, uint64_t n_
     std::lock_guard<std::mutex> g(s->mu);
     for (uint32_t b = 0; b < s->n_buffers; b++)
         if (s->state[b] == BUF_HELD) return fail(YACRD_EINVAL, "a buffer is still held by a parser");
+    // Whatever happens from here on, the stream is empty afterwards: records of a failed finish must not mix
+    // with the next file's (their handles come from another id table).  (The two misuse returns above — a batch
+    // pending on the engine, a buffer a parser still holds — touch nothing: yacrd_stream_reset after fixing them.)
+    struct ResetOnExit {
+        yacrd_stream *s;
+        ~ResetOnExit()
+        {
+            (void)hipStreamSynchronize(s->copy); // (copies in flight land in slabs about to be reused)
+            for (uint32_t b = 0; b < s->n_buffers; b++)
+                if (s->state[b] == BUF_FLYING) retire(s, b);
+            stream_reset_locked(s);
+        }
+    } reset_on_exit{s};
     HIP_TRY(hipStreamSynchronize(s->copy)); // every record is in HBM
     for (uint32_t b = 0; b < s->n_buffers; b++)
         if (s->state[b] == BUF_FLYING) retire(s, b);
@@ -339,13 +352,6 @@ int yacrd_stream_finish(yacrd_stream *s, const uint32_t *handle_map, uint64_t n_
     s->stats.n_records = n;
     s->stats.h2d_bytes = n * sizeof(yacrd_ovl_rec);
     s->stats.h2d_busy_ms = (float)s->busy_ms;
-
-    // Whatever happens below, the stream is empty afterwards: records of a failed finish must not mix
-    // with the next file's (their handles come from another id table).
-    struct ResetOnExit {
-        yacrd_stream *s;
-        ~ResetOnExit() { stream_reset_locked(s); }
-    } reset_on_exit{s};
     if (n && n_reads == 0) return fail(YACRD_EINVAL, "records without reads");
 
     HIP_TRY(e->in_len.reserve((size_t)(n_reads + 1) * sizeof(u32)));
@@ -612,7 +618,11 @@ int yacrd_stream_group_finish(yacrd_stream_group *g, const uint32_t *handle_map,
         work(0);
         for (auto &t : th) t.join();
     }
-    reset_on_exit.armed = false; // (every stream's finish has emptied it)
+    // (a finish that got as far as its records has emptied its stream; one that failed before that — the engine had a
+    // batch pending, a copy failed — has not: then the group's reset stays armed and clears every device)
+    bool any_failed = false;
+    for (uint32_t d = 0; d < N; d++) any_failed |= codes[d] != YACRD_OK;
+    reset_on_exit.armed = any_failed;
     for (uint32_t d = 0; d < N; d++)
         if (codes[d]) {
             const int code = codes[d];

@@ -101,6 +101,10 @@ enum { YACRD_OP_SCRUBB = 0, YACRD_OP_FILTER = 1, YACRD_OP_EXTRACT = 2, YACRD_OP_
 /* editor::{scrubbing,filter,extract,split} (src/editor/ scrubbing.rs, filter.rs, extract.rs, split.rs): FASTA/FASTQ for all four, PAF/M4
  * for filter and extract; gzip in -> gzip out.  Reads unknown to `bp` are NotBad with no region. */
 int yacrd_edit_file(int op, const char *in_path, const char *out_path, const yacrd_badparts_view *bp);
+/* The same with a thread count (0 = every usable CPU, what yacrd_edit_file passes; YACRD_EDIT_THREADS overrides):
+ * plain FASTA / FASTQ files are cut at record boundaries and edited chunk-parallel, output byte-identical to one
+ * thread's; compressed files and overlap files take the one-thread loop. */
+int yacrd_edit_file_mt(int op, const char *in_path, const char *out_path, const yacrd_badparts_view *bp, int n_threads);
 
 /* FromReport (src/stack.rs:176-257): a .yacrd report back into the BadPart table.  read_type is
  * left NULL: classify with yacrd_engine_classify() and the -n of the current invocation. */
@@ -117,8 +121,8 @@ enum { YACRD_SYNTH_ONT = 0, YACRD_SYNTH_SEQUEL = 1, YACRD_SYNTH_SKEWED = 2 };
  * are spread over a few dozen positions).  Bits 8..15: sigma of that offset in positions (0 = 30).
  * Bits 16..23: per cent of the reads that are chimeras — a junction no overlap crosses — instead of
  * SURVEY.md §8d's 2 (0 = 2): the reads yacrd looks for, i.e. the ones the healthy-read screen defers. */
-enum { YACRD_SYNTH_F_NO_INJECTION = 1u, YACRD_SYNTH_F_JITTER = 2u };
-#define YACRD_SYNTH_F_SIGMA(s) (((uint32_t)(s) & 0xFFu) << 8)
+enum { YACRD_SYNTH_F_NO_INJECTION = 1u, YACRD_SYNTH_F_JITTER = 2u, YACRD_SYNTH_F_SIGMA_X4 = 4u /* the sigma field counts 4 positions */ };
+#define YACRD_SYNTH_F_SIGMA(s) ((s) > 255 ? (YACRD_SYNTH_F_SIGMA_X4 | ((((uint32_t)(s) / 4u) & 0xFFu) << 8)) : (((uint32_t)(s) & 0xFFu) << 8))
 #define YACRD_SYNTH_F_CHIMERA_PCT(p) (((uint32_t)(p) & 0xFFu) << 16)
 
 typedef struct {

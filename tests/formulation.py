@@ -502,6 +502,80 @@ def window_screen_regions(intervals, length, cov, nb, W):
     return ([(0, a)] if a != 0 else []) + ([(bb, length)] if bb != length else [])
 
 
+def slid_window_screen_regions(intervals, length, cov, nb, W, max_slides):
+    """window_screen_regions with windows that SLIDE (round 4): when the first W positions hold fewer than cov + 1
+    starts (or the last W fewer than cov + 1 ends) — dovetail ends spread wider than the window — the screen is
+    repeated with that window moved on by W, the events it has passed carried as a count: P starts in front of the
+    head window, Q ends behind the tail window.  Nothing else changes: in event order the read is
+    [P passed starts][head window][coarse blocks, re-based at the head window][tail window][Q passed ends], the passed
+    starts precede every end (smallest end >= pmin + h0 + W is required), the passed ends follow every start
+    (largest start <= pmax - t0 - W), so a coarse-counted start still has at least
+    (P + window starts) + (coarse starts before its block) - (ends through its block) intervals open, a is where
+    P + the window's running count reaches cov + 1 and b likewise from the top.  max_slides = 0 is
+    window_screen_regions.  Returns (regions, slides used) or None."""
+    n = len(intervals)
+    if n == 0:
+        return ([(0, length)] if length != 0 else []), 0
+    if any(not (0 <= s < e <= length) for s, e in intervals) or length >= 2**30 - 1:
+        return None
+    if n <= cov:
+        return [(0, length)], 0
+    if n < 2:
+        return None
+    sh = bin_shift(length, nb)
+    pmin = min(s for s, e in intervals)
+    pmax = max(e for s, e in intervals)
+    emin = min(e for s, e in intervals)
+    smax = max(s for s, e in intervals)
+    h0 = t0 = 0
+    for slide in range(max_slides + 1):
+        if emin - pmin < h0 + W or pmax - smax < t0 + W or (pmax - pmin) - h0 - t0 < 2 * W:
+            return None
+        lo, hi = pmin + h0, pmax - t0
+        P = sum(1 for s, e in intervals if s < lo)
+        Q = sum(1 for s, e in intervals if e > hi)
+        assert P <= cov and Q <= cov
+        S, E = [0] * (nb + 1), [0] * (nb + 1)
+        FH, FT = [0] * W, [0] * W
+        for s, e in intervals:
+            if s >= lo:
+                if s - lo < W:
+                    FH[s - lo] += 1
+                else:
+                    S[min((s - lo) >> sh, nb)] += 1
+            if e <= hi:
+                if hi - e < W:
+                    FT[hi - e] += 1
+                else:
+                    E[min((e - lo) >> sh, nb)] += 1
+        F, G = P + sum(FH), Q + sum(FT)
+        if F < cov + 1 or G < cov + 1:
+            if slide == max_slides:
+                return None
+            h0 += W if F < cov + 1 else 0
+            t0 += W if G < cov + 1 else 0
+            continue
+        D = F
+        for b in range(nb + 1):
+            if S[b] > 0 and not (D - E[b] > cov):
+                return None
+            D += S[b] - E[b]
+        acc, a = P, None
+        for i in range(W):
+            acc += FH[i]
+            if acc >= cov + 1:
+                a = lo + i
+                break
+        acc, bb = Q, None
+        for i in range(W):
+            acc += FT[i]
+            if acc >= cov + 1:
+                bb = hi - i
+                break
+        return ([(0, a)] if a != 0 else []) + ([(bb, length)] if bb != length else []), slide
+    return None
+
+
 def unified_screen_regions(intervals, length, cov, nb, W):
     """screen_wg.h / screen_big.h: the order-statistics screen with ONE position map for starts and ends,
         idx(x) = min(dx, W) + (dx >> sh) + max(dx - T, 0),   dx = x - pmin,  T = (pmax - pmin) - W,  2^sh >= W:

@@ -146,3 +146,88 @@ def test_report_reader(tmp_path, golden_dir):
     # round trip of the golden report
     names, lengths, bo, br = host.report_read(os.path.join(golden_dir, "truth.yacrd"))
     assert len(names) == 230 and int(bo[-1]) == 462
+
+
+# ---- the chunk-parallel editors (round 4): byte-identical to the one-thread loop -----------------------------
+def _synthetic_case(tmp_path, n_reads=300, n_ovl=9000):
+    paf = str(tmp_path / "s.paf")
+    fq = str(tmp_path / "s.fastq")
+    host.synth_paf(host.SYNTH_ONT, n_reads, n_ovl, 4242, paf)
+    host.synth_fastq(host.SYNTH_ONT, n_reads, n_ovl, 4242, 7, fq)
+    with open(paf) as f:
+        table = table_from_reads(oracle.parse_paf(f), 4, 0.4)
+    return fq, table
+
+
+@pytest.mark.parametrize("op", ["scrubb", "filter", "extract", "split"])
+def test_parallel_editors_equal_one_thread(tmp_path, monkeypatch, op):
+    fq, table = _synthetic_case(tmp_path)
+    one = str(tmp_path / "one.fastq")
+    host.edit_file(OPS[op], fq, one, *table, n_threads=1)
+    want = open(one, "rb").read()
+    assert len(want) > 100000
+    for chunk in ("100", "4096", "65536"):
+        monkeypatch.setenv("YACRD_EDIT_CHUNK", chunk)
+        for th in (2, 5):
+            out = str(tmp_path / ("par_%s_%d.fastq" % (chunk, th)))
+            host.edit_file(OPS[op], fq, out, *table, n_threads=th)
+            assert open(out, "rb").read() == want, (op, chunk, th)
+    # FASTA (multi-line sequences): the same records, wrapped at 60 columns
+    fa = str(tmp_path / "s.fasta")
+    with open(fq) as f, open(fa, "w") as o:
+        lines = f.read().split("\n")
+        for i in range(0, len(lines) - 3, 4):
+            o.write(">" + lines[i][1:] + "\n")
+            for k in range(0, len(lines[i + 1]), 60):
+                o.write(lines[i + 1][k:k + 60] + "\n")
+    monkeypatch.delenv("YACRD_EDIT_CHUNK")
+    host.edit_file(OPS[op], fa, one + ".fa", *table, n_threads=1)
+    monkeypatch.setenv("YACRD_EDIT_CHUNK", "1000")
+    host.edit_file(OPS[op], fa, one + ".par.fa", *table, n_threads=4)
+    assert open(one + ".fa", "rb").read() == open(one + ".par.fa", "rb").read()
+
+
+def test_parallel_editors_tricky_fastq(tmp_path, monkeypatch):
+    """Quality lines that begin with '@' or '+', CRLF terminators, blank lines between records, a last record
+    without a newline: the chunk boundaries never split a record, the output is the one-thread loop's."""
+    rng = np.random.default_rng(5)
+    recs = []
+    for i in range(400):
+        n = int(rng.integers(1, 90))
+        seq = "".join(rng.choice(list("ACGT"), n))
+        qual = "".join(rng.choice(list("@+?I#"), n))
+        if i % 3 == 0:
+            qual = "@" + qual[1:]
+        if i % 7 == 0:
+            qual = "+" + qual[1:]
+        nl = "\r\n" if i % 5 == 0 else "\n"
+        recs.append("@r%d d%d%s%s%s+%s%s%s" % (i, i, nl, seq, nl, nl, qual, nl) + ("\n" if i % 11 == 0 else ""))
+    data = "".join(recs).rstrip("\n")
+    src = str(tmp_path / "t.fastq")
+    open(src, "w", newline="").write(data)
+    reads = {"r%d" % i: [[(0, 3), (5, 9)], 40] for i in range(0, 400, 2)}
+    table = table_from_reads(reads, 0, 0.8)
+    one = str(tmp_path / "one.fastq")
+    host.edit_file(host.OP_SCRUBB, src, one, *table, n_threads=1)
+    for chunk in ("64", "333", "5000"):
+        monkeypatch.setenv("YACRD_EDIT_CHUNK", chunk)
+        out = str(tmp_path / ("p%s.fastq" % chunk))
+        host.edit_file(host.OP_SCRUBB, src, out, *table, n_threads=3)
+        assert open(out, "rb").read() == open(one, "rb").read(), chunk
+
+
+def test_parallel_editors_malformed_record_is_the_one_thread_error(tmp_path, monkeypatch):
+    good = "".join("@r%d\nACGTACGT\n+\n????????\n" % i for i in range(500))
+    bad = good + "@broken\nACGT\n+\n??\n" + good  # sequence / quality lengths differ
+    src = str(tmp_path / "b.fastq")
+    open(src, "w").write(bad)
+    table = table_from_reads({"r1": [[(0, 3)], 8]}, 0, 0.8)
+    outs = []
+    for th, chunk in ((1, None), (4, "700")):
+        if chunk:
+            monkeypatch.setenv("YACRD_EDIT_CHUNK", chunk)
+        out = str(tmp_path / ("o%d.fastq" % th))
+        with pytest.raises(host.HostError) as ei:
+            host.edit_file(host.OP_FILTER, src, out, *table, n_threads=th)
+        outs.append(str(ei.value))
+    assert outs[0] == outs[1] and "fastq format failed" in outs[0]

@@ -191,6 +191,64 @@ def test_window_screen_matches_oracle():
     assert n_fired > n_total // 5
 
 
+def test_slid_window_screen_matches_oracle():
+    """Round 4: the same screen with windows that slide on by W when the order statistic lies beyond them
+    (dovetail ends spread by sigma = 100 .. 300 positions): wherever it decides — after any number of slides — it
+    equals the oracle; what it decides without a slide it decides the same way with slides allowed; and it decides
+    MORE reads."""
+    from formulation import slid_window_screen_regions, window_screen_regions
+    rng = np.random.default_rng(777)
+    fired = {0: 0, 4: 0}
+    slid = 0
+    for it in range(1500):
+        L = int(rng.integers(2, 400)) if it % 3 == 0 else int(rng.integers(400, 50000))
+        n = int(rng.integers(1, 30)) if it % 4 == 0 else int(rng.integers(30, 300))
+        jitter = (0.0, 5.0, 30.0, 100.0, 300.0)[it % 5]
+        iv = _pile_read(rng, n, L, jitter)
+        if it % 6 == 1:
+            iv = [(s, min(max(e, s + 200), L)) for s, e in iv if s + 200 <= L] or iv
+        if it % 11 == 0:
+            g = max(1, L // 8)
+            iv = [(min((s // g) * g, L - 1), min(max((e // g) * g, (s // g) * g + 1), L)) for s, e in iv]
+            iv = [(s, max(e, s + 1)) for s, e in iv]
+        if it % 7 == 3:
+            w0, w1 = L // 3, max(L // 3 + 2, 2 * L // 3)
+            iv = [(min(max(s, w0), w1 - 1), min(max(e, min(max(s, w0), w1 - 1) + 1), w1)) for s, e in iv]
+        for cov in (0, 1, 4, 9, 50):
+            want = oracle.compute_bad_part(iv, L, cov)
+            for nb, W in ((16, 32), (32, 32), (16, 8), (4, 2)):
+                base = window_screen_regions(iv, L, cov, nb, W)
+                # (the coarse blocks are counted from the window here and from position 0 there: now and then one of
+                # the two partitions decides a read the other leaves to the sort; both equal the oracle where they decide)
+                zero = slid_window_screen_regions(iv, L, cov, nb, W, 0)
+                assert zero is None or (zero[0] == want and zero[1] == 0), (iv, L, cov, nb, W)
+                got = slid_window_screen_regions(iv, L, cov, nb, W, 4)
+                if base is not None:
+                    assert base == want
+                    fired[0] += 1
+                if zero is not None:
+                    assert got is not None and got == zero
+                if got is not None:
+                    assert got[0] == want, (iv, L, cov, nb, W, got)
+                    fired[4] += 1
+                    slid += got[1] > 0
+    assert fired[4] > fired[0] and slid > 100, (fired, slid)
+
+
+def test_slid_window_screen_tiny_exhaustive():
+    import itertools
+    from formulation import slid_window_screen_regions
+    for L in range(1, 8):
+        pairs = [(s, e) for s in range(L + 1) for e in range(s + 1, L + 1)]
+        for k in range(1, 4):
+            for iv in itertools.combinations_with_replacement(pairs, k):
+                for cov in range(0, 3):
+                    want = oracle.compute_bad_part(list(iv), L, cov)
+                    for nb, W in ((2, 1), (4, 1), (4, 2)):
+                        got = slid_window_screen_regions(list(iv), L, cov, nb, W, 3)
+                        assert got is None or got[0] == want, (iv, L, cov, nb, W, got)
+
+
 def test_window_screen_tiny_exhaustive():
     import itertools
     from formulation import window_screen_regions

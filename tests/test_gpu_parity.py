@@ -382,8 +382,11 @@ def test_screen_on_jittered_profiles(prof, cov):
     BASELINE's thresholds (it finished 2 % of them when it needed c + 1 starts on ONE position)."""
     from yacrd_amd import host
     R, O = (6000, 300000) if prof == 0 else (3000, 300000)
+    # Round 4 (VERDICT r3 item 4): sigma = 100 and 300 — the (c+1)-th smallest start lies beyond the screen's
+    # 32-position window for a fifth / most of the ONT-depth reads; the windows slide (sweep_wave.h: kScreenSlides) and
+    # the screen still decides >= 90 % of them.
     for sflags in (host.SYNTH_F_JITTER, host.SYNTH_F_JITTER | host.synth_f_sigma(8),
-                   host.SYNTH_F_JITTER | host.synth_f_sigma(100)):
+                   host.SYNTH_F_JITTER | host.synth_f_sigma(100), host.SYNTH_F_JITTER | host.synth_f_sigma(300)):
         o, iv, ln = host.synth_csr(prof, R, O, 77 + cov, flags=sflags)
         want = oracle.run(o, iv, ln.astype(np.uint64), cov, 0.4, n_threads=4)
         n = np.diff(o.astype(np.int64))
@@ -393,8 +396,8 @@ def test_screen_on_jittered_profiles(prof, cov):
             with yacrd_amd.Engine(flags=flags | yacrd_amd.F_COUNT_PREFILTERED) as e:
                 assert_same(e.run(o, iv, ln, cov, 0.4), want, "profile %d synth flags %d flags %d" % (prof, sflags, flags))
                 t = e.timing()
-                if flags == yacrd_amd.F_ALWAYS_DEFER and sflags == host.SYNTH_F_JITTER and cov in (3, 4):
-                    assert t["deferred_reads"] <= in_classes // 10, (t["deferred_reads"], in_classes)
+                if flags & yacrd_amd.F_ALWAYS_DEFER and sflags != (host.SYNTH_F_JITTER | host.synth_f_sigma(8)) and cov in (3, 4):
+                    assert t["deferred_reads"] <= in_classes // 10, (sflags, flags, t["deferred_reads"], in_classes)
                     assert t["prefiltered_reads"] >= in_classes * 9 // 10
 
 

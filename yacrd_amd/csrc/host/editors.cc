@@ -17,9 +17,16 @@
 
 #include "codec.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -54,7 +61,8 @@ const char *type_name(FileType t)
 // ---- input: plain, gzip, bzip2 or xz, sniffed from magic bytes like niffler (src/util.rs:57-70) --
 struct Reader {
     yh::InStream in;
-    std::vector<char> buf;
+    std::vector<char> own;
+    const char *buf = nullptr; // the bytes line() / peek() look at: `own` (a stream's window) or a range of a mapped file
     size_t pos = 0, end = 0;
     bool eof = false;
     bool failed = false; // read / decompression error (message in the error slot): callers check
@@ -62,14 +70,23 @@ struct Reader {
     int open(const char *path)
     {
         if (in.open(path)) return 1;
-        buf.resize(1 << 20);
+        own.resize(1 << 20);
+        buf = own.data();
         return 0;
+    }
+    // a range of memory as the whole input (the multi-threaded editors: one chunk of a mapped file)
+    void open_memory(const char *p, size_t n)
+    {
+        buf = p;
+        pos = 0;
+        end = n;
+        eof = true; // nothing behind it
     }
     yh::Compression compression() const { return in.format(); }
     bool fill()
     {
         if (eof) return false;
-        const long n = in.read(buf.data(), buf.size());
+        const long n = in.read(own.data(), own.size());
         if (n <= 0) {
             eof = true;
             failed = n < 0; // a truncated or corrupt stream is an error, not the end of the file
@@ -87,11 +104,11 @@ struct Reader {
         for (;;) {
             if (pos == end && !fill()) break;
             any = true;
-            const char *p = buf.data() + pos;
+            const char *p = buf + pos;
             const char *nl = (const char *)std::memchr(p, '\n', end - pos);
             if (nl) {
                 out.append(p, (size_t)(nl - p));
-                pos = (size_t)(nl - buf.data()) + 1;
+                pos = (size_t)(nl - buf) + 1;
                 return true;
             }
             out.append(p, end - pos);
@@ -111,22 +128,28 @@ struct Writer {
     yh::OutStream os;
     std::vector<char> buf;
     bool failed = false;
+    bool to_memory = false; // everything stays in `buf` (the multi-threaded editors: one chunk's output)
     int open(const char *path, yh::Compression fmt)
     {
         if (os.open(path, fmt)) return 1;
         buf.reserve(1 << 20);
         return 0;
     }
+    void open_memory(size_t expect)
+    {
+        to_memory = true;
+        buf.reserve(expect);
+    }
     void flush()
     {
-        if (buf.empty()) return;
+        if (buf.empty() || to_memory) return;
         failed |= !os.write(buf.data(), buf.size());
         buf.clear();
     }
     void put(const char *p, size_t n)
     {
         buf.insert(buf.end(), p, p + n);
-        if (buf.size() > (1u << 20) - 4096) flush();
+        if (!to_memory && buf.size() > (1u << 20) - 4096) flush();
     }
     void put(const std::string &s) { put(s.data(), s.size()); }
     void put(char c) { put(&c, 1); }
@@ -139,29 +162,75 @@ struct Writer {
 };
 
 // ---- BadPart lookups ---------------------------------------------------------------------------
+// Name -> read index.  Open addressing over read indices (the names stay where the view has them: no copies), built
+// by every usable CPU with one CAS per read: a std::unordered_map<std::string, u32> of configs[4]'s 5 M reads took
+// longer to build than the GPU needs for the whole detection.  Equal names: the smallest index wins (what
+// emplace() in read order did).
 struct BadParts {
     const yacrd_badparts_view *v;
-    std::unordered_map<std::string, uint32_t> index;
-    explicit BadParts(const yacrd_badparts_view *view) : v(view)
+    std::vector<std::atomic<uint32_t>> slots;
+    uint64_t mask = 0;
+    static constexpr uint32_t kEmpty = 0xFFFFFFFFu;
+    bool same(uint32_t r, const char *p, size_t n) const
     {
-        index.reserve((size_t)v->n_reads * 2 + 16);
-        for (uint64_t r = 0; r < v->n_reads; r++)
-            index.emplace(std::string(v->names + v->name_off[r],
-                                      (size_t)(v->name_off[r + 1] - v->name_off[r])),
-                          (uint32_t)r);
+        const uint64_t a = v->name_off[r], b = v->name_off[r + 1];
+        return b - a == n && std::memcmp(v->names + a, p, n) == 0;
+    }
+    explicit BadParts(const yacrd_badparts_view *view, unsigned n_threads = 0) : v(view)
+    {
+        uint64_t cap = 16;
+        while (cap < 2 * v->n_reads + 16) cap <<= 1;
+        slots = std::vector<std::atomic<uint32_t>>(cap);
+        mask = cap - 1;
+        const unsigned T = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(n_threads ? n_threads : yh::usable_cpus(), v->n_reads / 65536 + 1));
+        auto work = [&](unsigned t) {
+            for (uint64_t i = (cap * t) / T, e = (cap * (t + 1)) / T; i < e; i++) slots[i].store(kEmpty, std::memory_order_relaxed);
+        };
+        auto fill = [&](unsigned t) {
+            const uint64_t r0 = v->n_reads * t / T, r1 = v->n_reads * (t + 1) / T;
+            for (uint64_t r = r0; r < r1; r++) {
+                const char *p = v->names + v->name_off[r];
+                const size_t n = (size_t)(v->name_off[r + 1] - v->name_off[r]);
+                for (uint64_t s = yh::hash_bytes(p, n) & mask;; s = (s + 1) & mask) {
+                    uint32_t cur = slots[s].load(std::memory_order_acquire);
+                    if (cur == kEmpty && slots[s].compare_exchange_strong(cur, (uint32_t)r, std::memory_order_acq_rel)) break;
+                    // (cur now holds the slot's owner)
+                    if (same(cur, p, n)) { // a duplicate name: keep the smaller index
+                        while (cur > (uint32_t)r && !slots[s].compare_exchange_weak(cur, (uint32_t)r, std::memory_order_acq_rel)) {
+                        }
+                        break;
+                    }
+                }
+            }
+        };
+        auto run = [&](auto &&fn) {
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < T; t++) th.emplace_back(fn, t);
+            fn(0u);
+            for (auto &x : th) x.join();
+        };
+        run(work);
+        run(fill);
     }
     // get_bad_part + type: unknown id -> (empty, 0, NotBad)
     void get(const std::string &id, const uint32_t *&reg, size_t &n, uint32_t &len, int &type) const
     {
-        auto it = index.find(id);
-        if (it == index.end()) {
+        uint32_t r = kEmpty;
+        for (uint64_t s = yh::hash_bytes(id.data(), id.size()) & mask;; s = (s + 1) & mask) {
+            const uint32_t cur = slots[s].load(std::memory_order_relaxed);
+            if (cur == kEmpty) break;
+            if (same(cur, id.data(), id.size())) {
+                r = cur;
+                break;
+            }
+        }
+        if (r == kEmpty) {
             reg = nullptr;
             n = 0;
             len = 0;
             type = 0;
             return;
         }
-        const uint32_t r = it->second;
         reg = v->bad_regions + 2 * v->bad_offsets[r];
         n = (size_t)(v->bad_offsets[r + 1] - v->bad_offsets[r]);
         len = v->lengths[r];
@@ -362,6 +431,126 @@ int edit_sequences(int op, bool fastq, Reader &in, Writer &out, const BadParts &
     return 0;
 }
 
+// ---- the same over a plain (uncompressed) file with every usable CPU ------------------------------------------
+// The reference's editors are one thread reading records and writing them back (scrubbing.rs:156-236 and its three
+// siblings): ~3 GB/s in this restatement, which at configs[4]'s 5 M-read FASTQ is 30 times the detection's wall
+// clock.  Records are independent and their order is the input's, so the file is mapped, cut into chunks at record
+// boundaries, every chunk goes through the SAME record loop as above (a Reader over the chunk's bytes, a Writer into
+// memory) on its own thread, and the outputs land with pwrite at offsets that follow from the sizes of the chunks
+// before — byte-identical to the one-thread output.  A boundary is a line that starts a record: '>' for FASTA; for
+// FASTQ an '@' line whose line after next starts with '+' and whose fourth line is a header again (a quality line
+// may begin with '@', a sequence line never begins with '+').  Anything unexpected — a chunk that fails to parse, a
+// boundary that cannot be found — and the whole file is done again by the one-thread loop, which owns the reference's
+// error behaviour.
+size_t edit_chunk()
+{ // bytes per chunk (YACRD_EDIT_CHUNK overrides: the tests cut small files into many chunks)
+    if (const char *e = std::getenv("YACRD_EDIT_CHUNK"))
+        if (*e) return (size_t)std::max(64ll, std::atoll(e));
+    return (size_t)16 << 20;
+}
+
+size_t next_line(const char *base, size_t size, size_t p)
+{
+    if (p >= size) return size;
+    const char *nl = (const char *)std::memchr(base + p, '\n', size - p);
+    return nl ? (size_t)(nl - base) + 1 : size;
+}
+// first record start at or after `from` (npos = none found where one should be)
+size_t record_start(const char *base, size_t size, size_t from, bool fastq)
+{
+    size_t p = from == 0 ? 0 : next_line(base, size, from - 1);
+    for (int tries = 0; p < size; tries++) {
+        if (!fastq) {
+            if (base[p] == '>') return p;
+        } else {
+            if (tries > 16) return std::string::npos;
+            if (base[p] == '@') {
+                const size_t l2 = next_line(base, size, next_line(base, size, p));
+                if (l2 < size && base[l2] == '+') {
+                    const size_t l4 = next_line(base, size, next_line(base, size, l2));
+                    if (l4 >= size || base[l4] == '@' || base[l4] == '\n' || base[l4] == '\r') return p;
+                }
+            }
+        }
+        p = next_line(base, size, p);
+    }
+    return size;
+}
+
+// 0 = done; 1 = failed with a message; -1 = not taken (the caller runs the one-thread loop)
+int edit_sequences_parallel(int op, bool fastq, const char *in_path, const char *out_path, const BadParts &bp, unsigned T)
+{
+    const int fd = ::open(in_path, O_RDONLY);
+    if (fd < 0) return -1;
+    struct stat st;
+    const size_t kEditChunk = edit_chunk();
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || (size_t)st.st_size < 2 * kEditChunk) {
+        ::close(fd);
+        return -1;
+    }
+    const size_t size = (size_t)st.st_size;
+    const char *base = (const char *)mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    ::close(fd);
+    if (base == MAP_FAILED) return -1;
+    struct Unmap {
+        const char *p;
+        size_t n;
+        ~Unmap() { munmap((void *)p, n); }
+    } unmap{base, size};
+    (void)madvise((void *)base, size, MADV_SEQUENTIAL);
+    std::vector<size_t> cut{0};
+    for (size_t at = kEditChunk; at < size; at += kEditChunk) {
+        const size_t b = record_start(base, size, at, fastq);
+        if (b == std::string::npos) return -1;
+        if (b >= size) break;
+        if (b > cut.back()) cut.push_back(b);
+    }
+    cut.push_back(size);
+    const size_t n_chunks = cut.size() - 1;
+    if (n_chunks < 2) return -1;
+    const int ofd = ::open(out_path, O_WRONLY | O_CREAT | O_TRUNC, 0666);
+    if (ofd < 0) return yh::fail(std::string("cannot create ") + out_path);
+    std::vector<std::atomic<long long>> off(n_chunks + 1);
+    for (auto &o : off) o.store(-1);
+    off[0].store(0);
+    std::atomic<size_t> next(0);
+    std::atomic<int> state(0); // 1 = a chunk did not parse (retry on one thread), 2 = write error
+    auto work = [&]() {
+        for (;;) {
+            const size_t i = next.fetch_add(1);
+            if (i >= n_chunks) break;
+            Reader in;
+            in.open_memory(base + cut[i], cut[i + 1] - cut[i]);
+            Writer out;
+            out.open_memory(cut[i + 1] - cut[i] + (cut[i + 1] - cut[i]) / 16 + 4096);
+            const bool skip = state.load() != 0;
+            if (!skip && edit_sequences(op, fastq, in, out, bp) != 0) state.store(1);
+            long long at;
+            while ((at = off[i].load(std::memory_order_acquire)) < 0) std::this_thread::yield();
+            const size_t n = (skip || state.load()) ? 0 : out.buf.size();
+            off[i + 1].store(at + (long long)n, std::memory_order_release);
+            for (size_t done = 0; done < n;) {
+                const ssize_t k = ::pwrite(ofd, out.buf.data() + done, n - done, (off_t)(at + (long long)done));
+                if (k < 0 && errno == EINTR) continue;
+                if (k <= 0) {
+                    state.store(2);
+                    break;
+                }
+                done += (size_t)k;
+            }
+        }
+    };
+    T = (unsigned)std::max<size_t>(1, std::min<size_t>(T, n_chunks));
+    std::vector<std::thread> th;
+    for (unsigned t = 1; t < T; t++) th.emplace_back(work);
+    work();
+    for (auto &x : th) x.join();
+    const int rc = ::close(ofd);
+    if (state.load() == 1) return -1; // (the one-thread loop truncates the output and words the error)
+    if (state.load() == 2 || rc != 0) return yh::fail("Error during writing of the output file");
+    return 0;
+}
+
 // filter / extract on overlap files: filter.rs:140-228, extract.rs:144-232 (csv reader, not flexible)
 int edit_overlaps(int op, bool paf, Reader &in, Writer &out, const BadParts &bp)
 {
@@ -528,6 +717,11 @@ void yacrd_report_free(yacrd_report *r) { delete r; }
 
 int yacrd_edit_file(int op, const char *in_path, const char *out_path, const yacrd_badparts_view *bp)
 {
+    return yacrd_edit_file_mt(op, in_path, out_path, bp, 0);
+}
+
+int yacrd_edit_file_mt(int op, const char *in_path, const char *out_path, const yacrd_badparts_view *bp, int n_threads)
+{
     if (op < 0 || op > 3 || !in_path || !out_path || !bp) return yh::fail("bad argument");
     if (bp->n_reads && (!bp->read_type || !bp->bad_offsets || !bp->lengths || !bp->name_off))
         return yh::fail("bad parts table is incomplete (read_type comes from the engine)");
@@ -538,11 +732,19 @@ int yacrd_edit_file(int op, const char *in_path, const char *out_path, const yac
     if (!(seq || (ovl && (op == OP_FILTER || op == OP_EXTRACT))))
         return yh::fail(std::string("Can't run ") + op_name(op) + " on " + type_name(ft) +
                         " file " + in_path);
+    unsigned T = n_threads > 0 ? (unsigned)n_threads : yh::usable_cpus();
+    if (const char *e = std::getenv("YACRD_EDIT_THREADS"))
+        if (*e) T = (unsigned)std::max(1, std::atoi(e));
+    T = std::min(T, 64u);
     Reader in;
     if (in.open(in_path)) return 1;
+    const BadParts table(bp, T);
+    if (seq && T > 1 && in.compression() == yh::COMP_NONE) { // plain sequence files: every usable CPU
+        const int rcp = edit_sequences_parallel(op, ft == FT_FASTQ, in_path, out_path, table, T);
+        if (rcp >= 0) return rcp;
+    }
     Writer out;
     if (out.open(out_path, in.compression())) return 1;
-    const BadParts table(bp);
     const int rc = seq ? edit_sequences(op, ft == FT_FASTQ, in, out, table)
                        : edit_overlaps(op, ft == FT_PAF, in, out, table);
     if (rc) return rc;

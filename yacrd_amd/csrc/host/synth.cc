@@ -157,7 +157,7 @@ struct Gen {
             // the dovetail ends then sit on exactly 0 / len), or — YACRD_SYNTH_F_JITTER — reflected into
             // the read, so that the ends are spread over a few dozen positions like the chain ends of a
             // real overlapper and no exact position holds a pile
-            const unsigned sig = (cfg.flags >> 8) & 0xFFu;
+            const unsigned sig = ((cfg.flags >> 8) & 0xFFu) * ((cfg.flags & YACRD_SYNTH_F_SIGMA_X4) ? 4u : 1u);
             int64_t jit = (int64_t)std::llround((sig ? (double)sig : 30.0) * rng.normal());
             const bool start_side = (rng.next() & 1) != 0;
             if (cfg.flags & YACRD_SYNTH_F_JITTER) jit = start_side ? std::llabs(jit) : -std::llabs(jit);

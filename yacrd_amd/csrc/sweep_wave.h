@@ -433,7 +433,23 @@ __device__ __forceinline__ bool group_any(u64 ballot)
 
 struct HealthyRead {
     u32 a, b; // the (c+1)-th smallest start, the (c+1)-th largest end
+    i32 F, G; // starts counted up to the end of the head window, ends from the start of the tail window on
 };
+// Windows that slide (round 4; tests/formulation.py::slid_window_screen_regions is the emulation, fuzzed against the
+// oracle).  The (c+1)-th smallest start of a read whose dovetail overlaps end within sigma positions of each other
+// lies ~0.2 sigma (ONT depth, -c 4) .. 0.1 sigma (Sequel depth) behind the smallest one: inside W = 32 positions for
+// SURVEY.md 8d's sigma = 30, beyond them for a fifth of configs[1]'s reads at sigma = 100 and for most at 300 (what
+// minimap2's chain ends look like: VERDICT r3).  A wider table costs every read (W = 64: 9 KB of LDS per wavefront
+// instead of 5, occupancy 5 -> 4 by LDS alone: 0.61 -> 0.78 ms on configs[2], profiles/r04/a_ab_window64.log), so
+// instead a read whose window came up short is screened AGAIN with that window moved on by W, what the window has
+// passed carried as a count: P starts in front of the head window, Q ends behind the tail window.  In event order
+// the read is [P][head window][coarse blocks][tail window][Q] as long as no end lies at or before the head window's
+// last position and no start at or behind the tail window's first: checked per slide on the read's smallest end
+// and largest start.  Only wavefronts that hold such a read take the extra passes.
+#ifndef YK_SCREEN_SLIDES
+#define YK_SCREEN_SLIDES 4
+#endif
+constexpr int kScreenSlides = YK_SCREEN_SLIDES;
 
 // The screen works on the raw positions (no event keys are made): v[j] = two intervals (x, y) and
 // (z, w) of this lane, real0[j] / real1[j] = whether those slots belong to the read (the others hold
@@ -453,9 +469,11 @@ struct HealthyRead {
 // errs on the safe side, and no start lives in those blocks anyway.
 // Counters hold starts in bits 0..9 and ends in bits 10..19 (a read of these classes has <= 256
 // intervals), which leaves the upper bits of the coarse bins' scan for the two window indices.
-template <int LANES, int WPB>
+// SLID: pmin / pmax are the head window's first and the tail window's last position (the read's smallest start +
+// h0, its largest end - t0), events outside [pmin, pmax] are not counted, P / Q stand for them.
+template <int LANES, int WPB, bool SLID = false>
 __device__ __forceinline__ bool healthy_screen(const uint4 (&v)[4], const bool (&real0)[4], const bool (&real1)[4],
-                                               u32 len, i32 c, u32 pmin, u32 pmax, HealthyRead &hr)
+                                               u32 len, i32 c, u32 pmin, u32 pmax, HealthyRead &hr, u32 P = 0, u32 Q = 0)
 {
     constexpr int NB = LANES, W = kScreenWindow, NBIN = 2 * W + NB, GROUPS = 64 / LANES, PER = W / LANES,
                   ZPER = NBIN / LANES;
@@ -486,7 +504,10 @@ __device__ __forceinline__ bool healthy_screen(const uint4 (&v)[4], const bool (
         const u32 ds = s - pmin, dx = e - pmin;
         const u32 is = min(ds, (u32)W) + (ds >> sh);
         const u32 ie = (dx >> sh) + __builtin_elementwise_sub_sat(dx, T) + (u32)W;
-        if (real) {
+        if constexpr (SLID) { // (what the windows have passed is not counted: P and Q stand for it)
+            if (real && s >= pmin) atomicAdd(reinterpret_cast<u32 *>(tb + ((is << 4) + cp)), one);
+            if (real && e <= pmax) atomicAdd(reinterpret_cast<u32 *>(tb + ((ie << 4) + cp)), one_end);
+        } else if (real) {
             atomicAdd(reinterpret_cast<u32 *>(tb + ((is << 4) + cp)), one);
             atomicAdd(reinterpret_cast<u32 *>(tb + ((ie << 4) + cp)), one_end);
         }
@@ -517,7 +538,8 @@ __device__ __forceinline__ bool healthy_screen(const uint4 (&v)[4], const bool (
     u32 reached = 0;
     {
         const u32 k1 = (u32)min(c + 1, 0x1FF);
-        u32 run = fincl - fw + (512u - k1) * (1u | kEnd); // counts in front of this lane's bins, biased
+        // counts in front of this lane's bins, biased (SLID: P <= c starts and Q <= c ends are already in)
+        u32 run = fincl - fw + (SLID ? ((512u - k1 + P) | ((512u - k1 + Q) << 10)) : (512u - k1) * (1u | kEnd));
 #pragma unroll
         for (int q = 0; q < PER; q++) {
             run += f[q];
@@ -535,7 +557,8 @@ __device__ __forceinline__ bool healthy_screen(const uint4 (&v)[4], const bool (
     const i32 x = (i32)(ex & kField) - (i32)((wincl >> 10) & kField); // starts before - ends through this block
     const u32 xm = gscan_min<LANES>((w & kField) != 0u ? (u32)(x + 0x10000) : 0xFFFFFFFFu);
     // (meaningful in the group's last lane from here on)
-    const i32 F = (i32)(fincl & kField), G = (i32)(fincl >> 10);
+    const i32 F = (i32)(fincl & kField) + (SLID ? (i32)P : 0), G = (i32)(fincl >> 10) + (SLID ? (i32)Q : 0);
+    hr.F = F, hr.G = G;
     hr.a = pmin + ((wincl >> 20) & 63u); // (a window that never reaches c + 1 overflows these fields: F > c
     hr.b = pmax - (wincl >> 26);         // or G > c fails then)
     const bool deep = xm == 0xFFFFFFFFu || (i32)(xm - 0x10000u) + F > c;
@@ -800,7 +823,49 @@ __device__ __forceinline__ void screen_block(const SweepArgs &a, u32 block)
             real1[j] = i0 < n_eff;
         }
         HealthyRead hr;
-        const bool healthy = healthy_screen<LANES, 1>(v[t], real0, real1, len[t], c, pmin, pmax, hr) && !girr;
+        bool healthy = healthy_screen<LANES, 1>(v[t], real0, real1, len[t], c, pmin, pmax, hr) && !girr;
+        if constexpr (kScreenSlides > 0) {
+            // a window that came up short of c + 1 (verdict in the group's last lane): slide it (see kScreenSlides).
+            // st = need | F << 1 | G << 11 of the last screen (counts clipped to their ten bits)
+            auto state_of = [&](bool nd, const HealthyRead &h) {
+                return (nd ? 1u : 0u) | ((u32)min(max(h.F, 0), 1023) << 1) | ((u32)min(max(h.G, 0), 1023) << 11);
+            };
+            u32 st = state_of(!healthy && !girr && (i32)n[t] > c && (hr.F <= c || hr.G <= c), hr);
+            if (__builtin_amdgcn_ballot_w64((st & 1u) != 0 && lig == (u32)(LANES - 1)) != 0) { // (uniform in the wavefront; rare)
+                u32 emin = v[t][0].y, smax2 = v[t][0].x; // (re-derived here: kept from above they cost the common path registers)
+#pragma unroll
+                for (int j = 0; j < K / 4; j++) {
+                    emin = min(emin, min(v[t][j].y, v[t][j].w));
+                    smax2 = max(smax2, max(v[t][j].x, v[t][j].z));
+                }
+                // room in front of the smallest end / behind the largest start, in positions from pmin / pmax
+                const u32 room_h = (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)gscan_min<LANES>(emin)) - pmin;
+                const u32 room_t = pmax - (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)gscan_max<LANES>(smax2));
+                u32 ht = 0, PQ = 0; // h0 | t0 << 16 (positions), P | Q << 16 (counts)
+#pragma unroll 1
+                for (int slide = 0; slide < kScreenSlides; slide++) {
+                    const u32 g = (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)st); // the last lane's verdict and counts, to its group
+                    const bool gneed = (g & 1u) != 0;
+                    const u32 gF = (g >> 1) & 1023u, gG = g >> 11;
+                    if (gneed && (i32)gF <= c) ht += (u32)kScreenWindow, PQ = (PQ & 0xFFFF0000u) | gF;
+                    if (gneed && (i32)gG <= c) ht += (u32)kScreenWindow << 16, PQ = (PQ & 0xFFFFu) | (gG << 16);
+                    const u32 h0 = ht & 0xFFFFu, t0 = ht >> 16;
+                    // no end at or before the head window's last position, no start at or behind the tail window's
+                    // first, and the two windows apart
+                    const bool go = gneed && room_h >= h0 + (u32)kScreenWindow && room_t >= t0 + (u32)kScreenWindow &&
+                                    pmax - pmin >= h0 + t0 + 2u * (u32)kScreenWindow;
+                    if (__builtin_amdgcn_ballot_w64(go) == 0) break; // (uniform)
+                    bool r0[K / 4], r1[K / 4];
+#pragma unroll
+                    for (int j = 0; j < K / 4; j++) r0[j] = real0[j] && go, r1[j] = real1[j] && go;
+                    wave_lds_sync(); // (the table is zeroed again)
+                    HealthyRead h2;
+                    const bool ok2 = healthy_screen<LANES, 1, true>(v[t], r0, r1, len[t], c, pmin + h0, pmax - t0, h2, PQ & 0xFFFFu, PQ >> 16);
+                    st = go ? state_of(!ok2 && (h2.F <= c || h2.G <= c), h2) : 0u; // (meaningful in the group's last lane)
+                    if (go) healthy = ok2, hr.a = h2.a, hr.b = h2.b;
+                }
+            }
+        }
         if (lig == (u32)(LANES - 1) && active[t]) { // the group's last lane has the verdict
             if (healthy || (!girr && (i32)n[t] <= c)) {
                 // never more than c intervals open: the whole read is bad = (0, a) with a = len

@@ -10,7 +10,7 @@ _LIB = os.path.join(_HERE, "lib", "libyacrd_host.so")
 
 SYNTH_ONT, SYNTH_SEQUEL, SYNTH_SKEWED = 0, 1, 2
 # yacrd_synth_cfg.flags (include/yacrd_host.h)
-SYNTH_F_NO_INJECTION, SYNTH_F_JITTER = 1, 2
+SYNTH_F_NO_INJECTION, SYNTH_F_JITTER, SYNTH_F_SIGMA_X4 = 1, 2, 4
 
 
 def synth_f_chimera_pct(p):
@@ -19,14 +19,18 @@ def synth_f_chimera_pct(p):
 
 
 def synth_f_sigma(s):
-    """sigma (positions) of the dovetail ends' offset, 1..255 (default 30)"""
-    return (int(s) & 0xFF) << 8
+    """sigma (positions) of the dovetail ends' offset (default 30): 1..255 exactly, up to 1020 in steps of 4
+    (YACRD_SYNTH_F_SIGMA_X4)"""
+    s = int(s)
+    if not 0 <= s <= 1020:
+        raise ValueError("sigma must be within 0..1020")
+    return (SYNTH_F_SIGMA_X4 | ((s // 4) << 8)) if s > 255 else (s << 8)
 FMT_AUTO, FMT_PAF, FMT_M4 = 0, 1, 2
 
 EXPORTED_SYMBOLS = [
     "yacrd_host_last_error", "yacrd_csr_from_file", "yacrd_csr_from_memory", "yacrd_csr_get",
     "yacrd_csr_find", "yacrd_csr_free", "yacrd_report_write", "yacrd_synth_csr", "yacrd_synth_paf",
-    "yacrd_edit_file", "yacrd_report_read", "yacrd_report_get", "yacrd_report_free",
+    "yacrd_edit_file", "yacrd_edit_file_mt", "yacrd_report_read", "yacrd_report_get", "yacrd_report_free",
     "yacrd_synth_fastq", "yacrd_ingest_stream", "yacrd_ingest_stream_memory", "yacrd_csr_handle_map",
 ]
 
@@ -108,6 +112,8 @@ def load_library():
         lib.yacrd_synth_fastq.argtypes = [ctypes.POINTER(_SynthCfg), ctypes.c_uint64, ctypes.c_char_p]
         lib.yacrd_edit_file.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p,
                                         ctypes.POINTER(_BadParts)]
+        lib.yacrd_edit_file_mt.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p,
+                                           ctypes.POINTER(_BadParts), ctypes.c_int]
         lib.yacrd_report_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
         lib.yacrd_report_get.argtypes = [ctypes.c_void_p, ctypes.POINTER(_BadParts)]
         lib.yacrd_report_free.argtypes = [ctypes.c_void_p]
@@ -242,9 +248,9 @@ def synth_fastq(profile, n_reads, n_overlaps, seed, extra_reads, path, flags=0):
     _check(lib, lib.yacrd_synth_fastq(ctypes.byref(cfg), extra_reads, path.encode()))
 
 
-def edit_file(op, in_path, out_path, names, lengths, bad_offsets, bad_regions, read_type):
+def edit_file(op, in_path, out_path, names, lengths, bad_offsets, bad_regions, read_type, n_threads=0):
     """editor::{scrubbing,filter,extract,split} over the BadPart table (names, lengths, region CSR,
-    engine read types)."""
+    engine read types).  n_threads: 0 = every usable CPU (plain FASTA / FASTQ are edited chunk-parallel)."""
     lib = load_library()
     blob = b"".join(n.encode() for n in names)
     name_off = np.zeros(len(names) + 1, dtype=np.uint64)
@@ -260,7 +266,7 @@ def edit_file(op, in_path, out_path, names, lengths, bad_offsets, bad_regions, r
                      bo.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)),
                      br.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
                      rt.ctypes.data_as(ctypes.POINTER(ctypes.c_uint8)))
-    _check(lib, lib.yacrd_edit_file(op, in_path.encode(), out_path.encode(), ctypes.byref(view)))
+    _check(lib, lib.yacrd_edit_file_mt(op, in_path.encode(), out_path.encode(), ctypes.byref(view), n_threads))
 
 
 def report_read(path):

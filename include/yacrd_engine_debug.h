@@ -40,5 +40,8 @@
  * launch's size (default: two from 40 M intervals on, i.e. inputs outside the Infinity Cache); tests, A/B */
 #define YACRD_F_SCREEN_ITEMS_1 262144u
 #define YACRD_F_SCREEN_ITEMS_2 524288u
+/* the workgroup classes (513 .. 16 384 intervals) run the screen and its fallback as separate launches (round 3's
+ * chain) instead of the persistent screen_wg_fused_kernel; A/B, tests */
+#define YACRD_F_NO_FUSED_SCREEN 1048576u
 
 #endif

@@ -412,11 +412,36 @@ def test_workgroup_screen_edges(cov):
     intervals = np.array([p for iv, _ in reads for p in iv], dtype=np.uint32)
     lengths = np.array([L for _, L in reads], dtype=np.uint32)
     want = oracle.run(offsets, intervals, lengths.astype(np.uint64), cov, 0.4, n_threads=8)
-    for flags in (0, yacrd_amd.F_NO_PREFILTER):
+    for flags in (0, yacrd_amd.F_NO_PREFILTER, yacrd_amd.F_NO_FUSED_SCREEN):
         with yacrd_amd.Engine(flags=flags | yacrd_amd.F_COUNT_PREFILTERED) as e:
             assert_same(e.run(offsets, intervals, lengths, cov, 0.4), want, "cov %d flags %d" % (cov, flags))
-            if flags == 0 and cov <= 11:
+            if flags != yacrd_amd.F_NO_PREFILTER and cov <= 11:
                 assert e.timing()["prefiltered_reads"] > len(reads) // 10  # the screen fires
+
+
+@pytest.mark.parametrize("cov", [0, 3, 30])
+def test_workgroup_fallback_queue(cov):
+    """Round 4: the workgroup classes' screen and its fallback in ONE persistent launch (screen_wg.h:
+    screen_wg_fused_kernel) — what the screen cannot decide goes through a queue in global memory to whichever
+    workgroup has finished screening.  Batches where most reads fail the screen (sparse / abutting / duplicate
+    pile-ups, degenerate intervals: the rejection list), more reads than the grid has workgroups, repeated runs on one
+    engine (the second is launched on the first's class counts), the three-launch chain beside it."""
+    rng = np.random.default_rng(808 + cov)
+    sizes = np.concatenate([rng.integers(513, 3000, size=1500), rng.integers(4097, 16385, size=60), [513, 4096, 4097, 8192, 8193, 16384]])
+    csr = make_csr(5150 + cov, sizes, ("sparse", "regular", "abutting", "dups", "zero_len", "degenerate", "beyond"),
+                   len_lo=20000, len_hi=600000, mode_block=7)
+    want = oracle.run(csr[0], csr[1], csr[2].astype(np.uint64), cov, 0.4, n_threads=8)
+    for flags in (0, yacrd_amd.F_NO_FUSED_SCREEN):
+        with yacrd_amd.Engine(flags=flags) as e:
+            for rep in range(3):
+                assert_same(e.run(*csr, cov, 0.4), want, "fallback queue: cov %d flags %d run %d" % (cov, flags, rep))
+    # skewed profile (configs[3] shape, reduced): screen + queue + the device-wide screen beside it
+    from yacrd_amd import host
+    o, iv, ln = host.synth_csr(host.SYNTH_SKEWED, 400, 1200000, 31 + cov)
+    w2 = oracle.run(o, iv, ln.astype(np.uint64), cov, 0.4, n_threads=8)
+    with yacrd_amd.Engine() as e:
+        for rep in range(2):
+            assert_same(e.run(o, iv, ln, cov, 0.4), w2, "skewed, run %d" % rep)
 
 
 @pytest.mark.parametrize("cov", [0, 4, 600])

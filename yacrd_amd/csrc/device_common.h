@@ -66,6 +66,8 @@ struct Counters {
     u32 over_med;            // M2 reads whose filtered keys do not fit the 256-thread kernel's LDS
     u32 fb_med[2];           // M1 / M2 reads the workgroup screen (screen_wg.h) left to the trimming filter + sort
     u32 fb_big;              // BIG reads the device-wide screen (screen_big.h) left to sweep_big_trim.h / sweep_big.h
+    u32 fbq_head[2];         // screen_wg_fused_kernel's queue of M1 / M2 reads (fb_med[] is its tail): slots claimed,
+    u32 fbq_done[2];         // workgroups that have finished screening
     u32 bs_chunks;           // chunks of the device-wide screen (written by its setup kernel)
     u64 total_regions;       // G, written by the last scan workgroup
     // reads the screen deferred and finish_compact_kernel sorted, and their intervals: one atomic each per

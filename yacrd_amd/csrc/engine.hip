@@ -95,7 +95,7 @@ int launch_compact(yacrd_engine *e, const yk::SweepArgs &sa, u32 n_reads, double
         ca.host_ctr = e->h_ctr;
         if (screened)
             hipLaunchKernelGGL(yk::deferred_sweep_kernel, dim3(nb), dim3(yk::kDeferThreads), 0, e->stream, ca.sweep, n_reads);
-        hipLaunchKernelGGL(yk::scan_compact_kernel, dim3(nb), dim3(yk::kScanThreads), 0, e->stream, ca);
+        hipLaunchKernelGGL(yk::scan_compact_kernel, dim3((n_reads + yk::kScanReads - 1) / yk::kScanReads), dim3(yk::kScanThreads), 0, e->stream, ca);
         return YACRD_OK;
     }
 #ifdef YK_NO_HANDOVER
@@ -611,6 +611,41 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
             HIP_TRY(before_class(cls));
             sa.list = list_of(cls);
             sa.list_n = &ctr->n[cls];
+            if (sa.prefilter && !(e->flags & YACRD_F_NO_FUSED_SCREEN) && e->screen_fused_wgs_per_cu > 0) {
+                // the screen and the fallback of what it leaves in ONE persistent launch (screen_wg.h): the grid must be
+                // resident as a whole (workgroups wait for each other's queue entries)
+                if (again) { // (a second pass over the class: the queue starts over)
+                    HIP_TRY(hipMemsetAsync(&ctr->fb_med[k], 0, sizeof(u32), e->stream));
+                    HIP_TRY(hipMemsetAsync(&ctr->fbq_head[k], 0, sizeof(u32), e->stream));
+                    HIP_TRY(hipMemsetAsync(&ctr->fbq_done[k], 0, sizeof(u32), e->stream));
+                    HIP_TRY(hipMemsetAsync(fb_med[k], 0xFF, (size_t)set.n[cls] * sizeof(u32), e->stream));
+                }
+                yk::ScreenFusedArgs fa;
+                fa.sweep = sa;
+                fa.sweep.over_list = over_med;
+                fa.sweep.over_count = &ctr->over_med;
+                fa.sweep.rej_list = k == 0 ? rej_med : rej_big;
+                fa.sweep.rej_count = k == 0 ? &ctr->rej_med : &ctr->rej_big;
+                fa.q = fb_med[k];
+                fa.tail = &ctr->fb_med[k];
+                fa.head = &ctr->fbq_head[k];
+                fa.done = &ctr->fbq_done[k];
+                const u32 gs = (u32)std::min<uint64_t>(set.n[cls], (uint64_t)e->num_cu * (uint64_t)e->screen_fused_wgs_per_cu);
+                hipLaunchKernelGGL(yk::screen_wg_fused_kernel, dim3(gs), dim3(yk::kWsT), 0, e->stream, fa);
+                if (k == 1) { // what does not fit the in-kernel fallback's 16 384 events even filtered (usually nothing)
+                    sa.list = over_med;
+                    sa.list_n = &ctr->over_med;
+                    sa.rej_list = rej_big;
+                    sa.rej_count = &ctr->rej_big;
+                    sa.over_list = over_med; // (cannot happen: 32 768 events hold every M2 read)
+                    sa.over_count = &ctr->over_med;
+                    const u32 grid = (u32)std::min<uint64_t>(set.n[cls], (uint64_t)e->num_cu);
+                    hipLaunchKernelGGL((yk::sweep_lds_kernel<1024, (int)yk::kMedium2Events>), dim3(grid), dim3(1024), 0,
+                                       e->stream, sa);
+                }
+                HIP_TRY(mark_class(cls));
+                continue;
+            }
             if (sa.prefilter) {
                 if (again) HIP_TRY(hipMemsetAsync(&ctr->fb_med[k], 0, sizeof(u32), e->stream)); // (its entries are done)
                 sa.over_list = fb_med[k];
@@ -1084,6 +1119,12 @@ int yacrd_engine_create(const yacrd_engine_cfg *cfg, yacrd_engine **out)
     e->device = dev;
     e->flags = cfg ? cfg->flags : 0;
     e->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    {
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yk::screen_wg_fused_kernel, yk::kWsT, 0) == hipSuccess && per_cu > 0)
+            e->screen_fused_wgs_per_cu = std::min(per_cu, 4);
+        (void)hipGetLastError();
+    }
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
     for (int i = 0; i < EV_COUNT && err == hipSuccess; i++) err = hipEventCreate(&e->ev[i]);
     for (int i = 0; i < 24 && err == hipSuccess; i++) err = hipEventCreate(&e->ev_cls[i]);

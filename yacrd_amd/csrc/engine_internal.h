@@ -121,6 +121,7 @@ struct yacrd_engine {
     hipEvent_t ev_cls[24] = {}; // brackets around class kernels
     hipEvent_t ev_done = nullptr; // hipEventBlockingSync: the final wait of YACRD_F_BLOCKING_WAIT
     int num_cu = 256;
+    int screen_fused_wgs_per_cu = 0; // workgroups of screen_wg_fused_kernel a CU holds at once (its grid must be resident as a whole)
 
     // inputs staged by yacrd_engine_run
     yke::DevBuf in_off, in_iv, in_len;

@@ -151,12 +151,17 @@ __global__ __launch_bounds__(kScanBlock, YK_FINISH_OCC) void finish_compact_kern
         u64 base = 0;
         if (bid > 0) {
             if (lane == 0)
-                __hip_atomic_store(&c.scan_state[bid], kAgg | tot, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); // (release: this slab's counter atomics of phase A happen before whoever sees the aggregate)
+                // (Relaxed on purpose.  The hand-over of the counters below relies on this slab's two counter atomics being
+                // performed before this store: they are returning atomics issued by this very lane and waited for, i.e.
+                // done at the memory side.  Spelled as release here + acquire in the look-back — ADVICE r3 — the
+                // compiler emits an L2 write-back / invalidate per store / poll: the kernel went from 0.150 to 0.344 ms
+                // on configs[2], profiles/r04/b_ab_split_follow_on.log.)
+                __hip_atomic_store(&c.scan_state[bid], kAgg | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             for (i32 hi = (i32)bid - 1;; hi -= 64) {
                 const i32 idx = hi - (i32)lane; // lane 0 looks at the nearest predecessor
                 u64 v, pre;
                 for (;;) { // until the window holds no empty entry before its nearest prefix
-                    v = idx >= 0 ? __hip_atomic_load(&c.scan_state[idx], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT)
+                    v = idx >= 0 ? __hip_atomic_load(&c.scan_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
                                  : kPre; // before the first workgroup: prefix 0
                     pre = __builtin_amdgcn_ballot_w64((v >> 62) == 2);
                     const u64 before = pre ? ((pre & (0 - pre)) - 1ull) : ~0ull; // lanes nearer than it
@@ -172,7 +177,7 @@ __global__ __launch_bounds__(kScanBlock, YK_FINISH_OCC) void finish_compact_kern
             }
         }
         if (lane == 0) {
-            __hip_atomic_store(&c.scan_state[bid], kPre | (base + tot), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&c.scan_state[bid], kPre | (base + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s_base = base;
             if ((u64)(bid + 1) * kScanBlock >= c.n_reads) ctr->total_regions = base + tot;
         }
@@ -223,102 +228,88 @@ __global__ __launch_bounds__(kScanBlock, YK_FINISH_OCC) void finish_compact_kern
 
 
 // ==== the follow-on step as TWO kernels (round 4): long batches ========================================
-// finish_compact_kernel above does both phases in 1024-thread workgroups at a 64-register budget: its 64-lane
-// sorts spill (40 bytes of scratch per thread — all 2 M threads of configs[2] write 12 of them: the 97 MB
-// WRITE_SIZE / 199 MB FETCH_SIZE of round 3's PMC against ~20 / 124 MB of data), they sort one read per wavefront
-// without the bin filter (~1000 instructions per read, 48 M VALU for 47 600 reads: the sorting build of the
-// fused launch does the same read in less than half), and its scan holds two workgroups per CU.
+// finish_compact_kernel above does both phases in 1024-thread workgroups at a 64-register budget.  On long batches
+// (configs[2]: 0.150 ms, configs[4]: 0.36 ms = a fifth of the step) that costs twice: its sorts spill (40 bytes of
+// scratch per thread — all 2 M threads of configs[2] write 12 of them: the 97 MB WRITE_SIZE / 199 MB FETCH_SIZE
+// of round 3's PMC against ~20 / 124 MB of data), and a slab's ~24 marked reads keep 16 wavefronts busy for one
+// turn and 8 for a second while the slab's scan waits (the sorts are ~600 dependent instructions per read: 29 M of
+// them for configs[2]'s 47 600 reads = 47 us of VALU time when every SIMD issues; the kernel needed ~100).
 // For batches of kPlanSmallReads reads and more the engine launches instead:
-//   deferred_sweep_kernel   256 threads per slab of 1024 reads: the slab's marked reads are listed in LDS by
-//                           size, then swept four (<= 128 intervals, 16-lane rows) or two (<= 256, half
-//                           wavefronts) at a time by sweep_group_read — the sorting build's code: bin filter
-//                           in front of the register sort, 96 registers, no scratch;
-//   scan_compact_kernel     256 threads x 4 consecutive reads: 16-byte loads of counts / lengths / closed forms,
-//                           decoupled look-back over 1024-read aggregates (every workgroup of a 2 M-read batch is
-//                           resident at once), 16-byte stores of bad_offsets, one 4-byte store of four read types.
-// Short batches keep the one-dispatch form (a dispatch more costs what the phases gain there).
+//   deferred_sweep_kernel   256 threads per slab of 1024 reads: the slab's marked reads are listed in LDS, the long
+//                           ones first, and sorted one per wavefront and turn — the same 64-lane sorts, but four
+//                           wavefronts take six turns each instead of sixteen taking one and a half, eight
+//                           workgroups share a CU, and nothing else waits for them;
+//   scan_compact_kernel     1024 threads x 4 consecutive reads: 16-byte loads of counts / lengths / closed forms,
+//                           decoupled look-back over 4096-read aggregates (a quarter of the tickets and of the
+//                           look-back chain), 16-byte stores of bad_offsets, one 4-byte store of four read types;
+//                           no scratch.
+// Short batches keep the one-dispatch form: a dispatch more costs more than the phases gain there (configs[1], one
+// batch at a time: 69.5 us against 93 us, profiles/r04/b_ab_split_follow_on.log).
+// (First attempt, same log: the marked reads through the sorting build's code — sweep_group_read<32 | 16, 16>, two or
+// four reads per wavefront behind the bin filter — 0.190 ms for configs[2]'s 47 600 reads: per read that code is
+// no cheaper than the 64-lane sort, and pairs / quadruples fill badly from a list of two dozen.)
 constexpr int kDeferSlab = 1024, kDeferThreads = 256;
 
-__global__ __launch_bounds__(kDeferThreads, 5) void deferred_sweep_kernel(SweepArgs a, u32 n_reads)
+#ifndef YK_DEFER_SWEEP_OCC
+#define YK_DEFER_SWEEP_OCC 8 // wavefronts per SIMD the register budget allows (A/B: profiles/r04)
+#endif
+__global__ __launch_bounds__(kDeferThreads, YK_DEFER_SWEEP_OCC) void deferred_sweep_kernel(SweepArgs a, u32 n_reads)
 {
-    __shared__ u32 s_list[kDeferSlab]; // indices inside the slab: half-wavefront reads from the front, row reads from the back
-    __shared__ u32 s_n32, s_n16;
+    __shared__ u32 s_list[kDeferSlab]; // index inside the slab | intervals << 16: the long reads from the front, the others from the back
+    __shared__ u32 s_n8, s_n4;
     __shared__ unsigned long long s_iv;
-    if (threadIdx.x == 0) s_n32 = 0, s_n16 = 0, s_iv = 0;
+    if (threadIdx.x == 0) s_n8 = 0, s_n4 = 0, s_iv = 0;
     __syncthreads();
     const u32 lane = lane_id();
     const u32 slab0 = blockIdx.x * (u32)kDeferSlab;
     constexpr int PER = kDeferSlab / kDeferThreads;
-    bool any = false;
 #pragma unroll
     for (int k = 0; k < PER; k++) {
         const u32 i = (u32)k * kDeferThreads + threadIdx.x, r = slab0 + i;
         const bool marked = r < n_reads && a.counts[r] == kDeferredMark;
         const u64 mm = __builtin_amdgcn_ballot_w64(marked);
         if (mm == 0) continue; // (uniform in the wavefront)
-        any = true;
         u32 n = 0;
         if (marked) n = (u32)(a.off[r + 1] - a.off[r]);
-        const bool half = marked && n > 128u; // (a marked read has at most 256 intervals)
-        const u64 mh = __builtin_amdgcn_ballot_w64(half), mr = mm & ~mh;
-        u32 bh = 0, br = 0;
+        const bool big = marked && n > 128u; // (a marked read has at most 256 intervals)
+        const u64 mb = __builtin_amdgcn_ballot_w64(big), ms = mm & ~mb;
+        u32 bb = 0, bs = 0;
         if (lane == (u32)__builtin_ctzll(mm)) {
-            if (mh) bh = atomicAdd(&s_n32, (u32)__builtin_popcountll(mh));
-            if (mr) br = atomicAdd(&s_n16, (u32)__builtin_popcountll(mr));
+            if (mb) bb = atomicAdd(&s_n8, (u32)__builtin_popcountll(mb));
+            if (ms) bs = atomicAdd(&s_n4, (u32)__builtin_popcountll(ms));
         }
-        bh = (u32)__builtin_amdgcn_readlane((int)bh, (int)__builtin_ctzll(mm));
-        br = (u32)__builtin_amdgcn_readlane((int)br, (int)__builtin_ctzll(mm));
+        bb = (u32)__builtin_amdgcn_readlane((int)bb, (int)__builtin_ctzll(mm));
+        bs = (u32)__builtin_amdgcn_readlane((int)bs, (int)__builtin_ctzll(mm));
         const u64 below = (1ull << lane) - 1ull;
-        if (half) s_list[bh + (u32)__builtin_popcountll(mh & below)] = i;
-        else if (marked) s_list[(u32)kDeferSlab - 1u - (br + (u32)__builtin_popcountll(mr & below))] = i;
+        if (big) s_list[bb + (u32)__builtin_popcountll(mb & below)] = i | (n << 16);
+        else if (marked) s_list[(u32)kDeferSlab - 1u - (bs + (u32)__builtin_popcountll(ms & below))] = i | (n << 16);
         u64 iv = n; // intervals of the marked reads, for the roofline's exact byte count
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) iv += __shfl_xor(iv, d, 64);
         if (lane == 0) atomicAdd(&s_iv, (unsigned long long)iv);
     }
-    (void)any;
     __syncthreads();
-    const u32 n32 = s_n32, n16 = s_n16;
-    if (n32 + n16 == 0) return; // uniform in the workgroup
+    const u32 n8 = s_n8, n4 = s_n4, n_marked = n8 + n4;
+    if (n_marked == 0) return; // uniform in the workgroup
     if (threadIdx.x == 0) {
-        atomicAdd(&a.ctr->deferred, n32 + n16);
+        atomicAdd(&a.ctr->deferred, n_marked);
         atomicAdd((unsigned long long *)&a.ctr->deferred_iv, s_iv);
     }
-    const LaneConst lc = make_lane_const(lane);
     constexpr u32 kWaves = kDeferThreads / 64;
-    const u32 wave = threadIdx.x >> 6;
-    // two reads per wavefront and turn (32-lane halves)
-    for (u32 i0 = wave * 2u; i0 < n32; i0 += kWaves * 2u) { // (uniform in the wavefront)
-        const u32 idx = i0 + (lane >> 5);
-        const bool active = idx < n32;
-        u32 r = 0, n = 0, len = 0;
-        u64 o = 0;
-        if (active) {
-            r = slab0 + s_list[idx];
-            o = a.off[r];
-            n = (u32)(a.off[r + 1] - o);
-            len = a.len[r];
-        }
-        sweep_group_read<32, 16, 0, (int)kWaves>(a.iv + o, n, len, a.cov, active, r, a, lc);
-    }
-    // four per wavefront and turn (16-lane rows)
-    for (u32 i0 = wave * 4u; i0 < n16; i0 += kWaves * 4u) {
-        const u32 idx = i0 + (lane >> 4);
-        const bool active = idx < n16;
-        u32 r = 0, n = 0, len = 0;
-        u64 o = 0;
-        if (active) {
-            r = slab0 + s_list[(u32)kDeferSlab - 1u - idx];
-            o = a.off[r];
-            n = (u32)(a.off[r + 1] - o);
-            len = a.len[r];
-        }
-        sweep_group_read<16, 16, 0, (int)kWaves>(a.iv + o, n, len, a.cov, active, r, a, lc);
+    // one read per wavefront and turn, the long ones (8 keys per lane) first: list position p < n8 is s_list[p],
+    // p >= n8 is the (p - n8)-th entry from the back
+    for (u32 p = threadIdx.x >> 6; p < n_marked; p += kWaves) { // (uniform in the wavefront)
+        const u32 e = p < n8 ? s_list[p] : s_list[(u32)kDeferSlab - 1u - (p - n8)];
+        const u32 rr = slab0 + (e & 0xFFFFu), n = e >> 16;
+        const u64 o = a.off[rr];
+        const u32 len = a.len[rr];
+        if (n > 128u) finish_item<8>(a.off, a.iv, a.len, a.stage, a.counts, a.rej_list, a.rej_count, a.ctr, a.cov, rr, o, n, len);
+        else finish_item<4>(a.off, a.iv, a.len, a.stage, a.counts, a.rej_list, a.rej_count, a.ctr, a.cov, rr, o, n, len);
     }
 }
 
-constexpr int kScanThreads = 256, kScanPer = 4, kScanReads = kScanThreads * kScanPer;
-static_assert(kScanReads == kScanBlock, "the control block holds one scan word per 1024 reads");
+constexpr int kScanThreads = 1024, kScanPer = 4, kScanReads = kScanThreads * kScanPer;
+static_assert(kScanReads % kScanBlock == 0, "the control block holds one scan word per 1024 reads: more than this kernel's workgroups use");
 
 __global__ __launch_bounds__(kScanThreads) void scan_compact_kernel(CompactArgs2 c)
 {

@@ -10,6 +10,7 @@
 // include/yacrd_engine.h; there is no CPU fallback — without a gfx950 device this exits non-zero.
 #include <algorithm>
 #include <cerrno>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -127,6 +128,15 @@ int main(int argc, char **argv)
         std::fprintf(stderr, "[INFO] --ondisk is accepted for compatibility; overlaps are kept in "
                              "host memory and HBM (same results, reference tests/run.rs:120-160)\n");
 
+    // YACRD_CLI_TIMING=1: wall clock of every stage on stderr (tools/e2e_scrubb_full.py)
+    const bool timing = std::getenv("YACRD_CLI_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto stage = [&](const char *what) {
+        const auto now = std::chrono::steady_clock::now();
+        if (timing) std::fprintf(stderr, "[timing] %s %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+        t_last = now;
+    };
+
     // ---- engines (one per GPU)
     std::vector<yacrd_engine *> engines;
     // YACRD_GPUS_ON_DEVICE=<d>: every engine on device d (how the N > 1 path is tested on a one-GPU box)
@@ -138,6 +148,7 @@ int main(int argc, char **argv)
         engines.push_back(e);
     }
     const uint32_t cov32 = coverage > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)coverage;
+    stage("engine_create");
 
     yacrd_csr *csr = nullptr;
     yacrd_report *rep = nullptr;
@@ -219,9 +230,11 @@ int main(int argc, char **argv)
         bp.read_type = res.read_type;
     }
 
+    stage("detect");
     // src/main.rs:62-84: the report, one line per read
     if (yacrd_report_write(output.c_str(), &view, bp.bad_offsets, bp.bad_regions, bp.read_type))
         die(yacrd_host_last_error());
+    stage("report");
 
     // src/main.rs:86-118: optional post operation
     if (!sub.empty()) {
@@ -229,6 +242,7 @@ int main(int argc, char **argv)
                                        : sub == "filter" ? YACRD_OP_FILTER
                                                          : sub == "extract" ? YACRD_OP_EXTRACT : YACRD_OP_SPLIT;
         if (yacrd_edit_file(op, sub_in.c_str(), sub_out.c_str(), &bp)) die(yacrd_host_last_error());
+        stage("edit");
     }
 
     yacrd_result_free(&res);

@@ -369,38 +369,63 @@ int yacrd_synth_fastq(const yacrd_synth_cfg *cfg, uint64_t extra_reads, const ch
     if (check_cfg(cfg)) return 1;
     FILE *f = std::fopen(path, "wb");
     if (!f) return yh::fail(std::string("cannot open ") + path);
-    std::vector<char> buf(1 << 20);
-    std::setvbuf(f, buf.data(), _IOFBF, buf.size());
     const Gen g(*cfg); // same lengths as the overlaps
-    Rng rng(cfg->seed ^ 0x5eedf00dull);
-    std::string seq, qual;
     const uint64_t total = cfg->n_reads + extra_reads;
-    uint64_t next_extra = extra_reads ? total / extra_reads / 2 : total; // spread the extras
-    uint64_t emitted_extra = 0, r = 0;
-    for (uint64_t i = 0; i < total; i++) {
-        const bool extra = emitted_extra < extra_reads && (i == next_extra || r >= cfg->n_reads);
-        uint32_t len;
-        if (extra) {
-            len = 200 + (uint32_t)rng.below(3000);
-            next_extra += total / extra_reads;
-        } else {
-            len = g.len[r];
+    // which records are the extras (reads no overlap mentions), spread over the file: decided in one cheap pass, so
+    // that the records themselves — every one with a generator of its own, seeded by its position — can be
+    // formatted on every thread (configs[4]'s FASTQ is ~100 GB: minutes from one thread and one stream)
+    std::vector<uint64_t> id(total); // read index, or extra index | 1 << 63
+    {
+        uint64_t next_extra = extra_reads ? total / extra_reads / 2 : total, emitted_extra = 0, r = 0;
+        for (uint64_t i = 0; i < total; i++) {
+            const bool extra = emitted_extra < extra_reads && (i == next_extra || r >= cfg->n_reads);
+            if (extra) {
+                id[i] = emitted_extra++ | (1ull << 63);
+                next_extra += total / extra_reads;
+            } else {
+                id[i] = r++;
+            }
         }
-        seq.resize(len);
-        for (uint32_t k = 0; k < len; k += 32) { // 2 bits per base
-            uint64_t w = rng.next();
-            const uint32_t m = std::min<uint32_t>(32, len - k);
-            for (uint32_t j = 0; j < m; j++, w >>= 2) seq[k + j] = "ACGT"[w & 3];
-        }
-        qual.assign(len, '?');
-        if (extra) std::fprintf(f, "@x%09llu no overlap len=%u\n", (unsigned long long)emitted_extra++, len);
-        else std::fprintf(f, "@r%09llu synthetic len=%u\n", (unsigned long long)r++, len);
-        std::fwrite(seq.data(), 1, len, f);
-        std::fwrite("\n+\n", 1, 3, f);
-        std::fwrite(qual.data(), 1, len, f);
-        std::fputc('\n', f);
     }
-    if (std::fclose(f) != 0) return yh::fail("write error");
+    const unsigned T = synth_threads();
+    const uint64_t kRound = (uint64_t)T * 256; // records formatted per round
+    std::vector<std::vector<char>> out(T);
+    bool ok = true;
+    for (uint64_t base = 0; base < total && ok; base += kRound) {
+        const uint64_t n = std::min(kRound, total - base);
+        parallel_ranges(n, T, [&](unsigned t, uint64_t i0, uint64_t i1) {
+            std::vector<char> &o = out[t];
+            o.clear();
+            char head[96];
+            for (uint64_t i = base + i0; i < base + i1; i++) {
+                Rng rng = stream_rng(cfg->seed ^ 0x5eedf00dull, 7, i);
+                const bool extra = (id[i] >> 63) != 0;
+                const uint64_t k = id[i] & ~(1ull << 63);
+                const uint32_t len = extra ? 200 + (uint32_t)rng.below(3000) : g.len[k];
+                const int hn = extra ? std::snprintf(head, sizeof(head), "@x%09llu no overlap len=%u\n", (unsigned long long)k, len)
+                                     : std::snprintf(head, sizeof(head), "@r%09llu synthetic len=%u\n", (unsigned long long)k, len);
+                const size_t at = o.size();
+                o.resize(at + (size_t)hn + 2 * (size_t)len + 4);
+                char *p = o.data() + at;
+                std::memcpy(p, head, (size_t)hn);
+                p += hn;
+                for (uint32_t q = 0; q < len; q += 32) { // 2 bits per base
+                    uint64_t w = rng.next();
+                    const uint32_t m = std::min<uint32_t>(32, len - q);
+                    for (uint32_t jj = 0; jj < m; jj++, w >>= 2) p[q + jj] = "ACGT"[w & 3];
+                }
+                p += len;
+                std::memcpy(p, "\n+\n", 3);
+                p += 3;
+                std::memset(p, '?', len);
+                p[len] = '\n';
+            }
+        });
+        const unsigned used = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(T, n));
+        for (unsigned t = 0; t < used && ok; t++)
+            ok = out[t].empty() || std::fwrite(out[t].data(), 1, out[t].size(), f) == out[t].size();
+    }
+    if (std::fclose(f) != 0 || !ok) return yh::fail("write error");
     return 0;
 }
 

@@ -98,7 +98,14 @@ __global__ __launch_bounds__(BLK) void plan_kernel(const u64 *off, u32 n_reads, 
 #pragma unroll
     for (int k = 0; k < kPlanPer; k++) {
         const u32 r = blockIdx.x * (u32)kPlanReads + (u32)k * kPlanBlock + threadIdx.x;
-        if (cls[k] != CLS_COUNT) lists[(u64)cls[k] * n_reads + s_base[cls[k]] + local[k]] = r;
+        if (cls[k] != CLS_COUNT) {
+            const u64 pos = s_base[cls[k]] + local[k];
+            lists[(u64)cls[k] * n_reads + pos] = r;
+            // the workgroup classes' fallback queue (screen_wg.h) starts out empty in every slot one of the class's
+            // reads could take: list CLS_COUNT + 4 (M1) / + 5 (M2) of the engine's table
+            if (cls[k] == CLS_MED1 || cls[k] == CLS_MED2)
+                lists[(u64)(CLS_COUNT + 4 + (cls[k] - CLS_MED1)) * n_reads + pos] = 0xFFFFFFFFu;
+        }
     }
 }
 

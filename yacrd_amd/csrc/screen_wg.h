@@ -29,6 +29,7 @@
 // decide (8 % of configs[3]'s reads) goes to a fallback list for those kernels.
 #pragma once
 #include "device_common.h"
+#include "sweep_lds.h"
 #include "sweep_wave.h"
 
 namespace yk {
@@ -39,148 +40,225 @@ constexpr int kWsW = 128;        // window positions on either side
 constexpr int kWsNB = kWsT - 2 * kWsW; // coarse blocks (a power of two)
 constexpr int kWsBins = kWsT;
 
-// SweepArgs.list / list_n: the class list; over_list / over_count: the reads the screen leaves to the sort.
-__global__ __launch_bounds__(kWsT) void screen_wg_kernel(SweepArgs a)
+// The screen of ONE read by the whole workgroup (kWsT threads): true = decided, its regions and count written.
+// tab: kWsBins * 4 words, red: NW x 4, sc: NW + 1 words of LDS; ends with a barrier.
+__device__ __forceinline__ bool screen_wg_read(const SweepArgs &a, u32 r, u32 *tab, u32 (*red)[4], u32 *sc)
 {
     constexpr int T = kWsT, R = kWsR, W = kWsW, NW = T / 64;
     constexpr u32 kEnd = 1u << 16, kField = kEnd - 1u;
-    __shared__ __attribute__((aligned(16))) u32 tab[kWsBins * 4]; // four copies of every counter (by thread & 3)
-    __shared__ u32 red[NW][4];
-    __shared__ u32 sc[NW + 1];
     const u32 tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
-    const u32 list_n = *a.list_n;
     const i32 c = (i32)min(a.cov, 0x3FFFFFFFu);
     uint4 *bins = reinterpret_cast<uint4 *>(tab);
     char *tb = reinterpret_cast<char *>(tab);
+    const u64 o = a.off[r];
+    const u32 n = (u32)(a.off[r + 1] - o);
+    const u32 len = a.len[r];
+    const uint2 *iv = a.iv + o;
+    const u32 chunks = (n + (u32)(T * R) - 1u) / (u32)(T * R);
+    bool fallback = n < 2u || len > kMaxKeyPos;
 
+    // ---- the read's smallest start, largest end, largest start and shortest interval (signed)
+    uint2 v[R];
+    u32 smin = 0xFFFFFFFFu, emax = 0, smax = 0;
+    i32 tmin = 0x7FFFFFFF;
+    if (!fallback) {
+        for (u32 ch = 0; ch < chunks; ch++) {
+            const u32 base = ch * (u32)(T * R) + tid;
+#pragma unroll
+            for (int j = 0; j < R; j++) v[j] = iv[min(base + (u32)(j * T), n - 1u)]; // (copies of the last interval beyond it)
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                smin = min(smin, v[j].y != 0u ? v[j].x : 0xFFFFFFFFu); // ((0, 0) intervals are inert: left out)
+                smax = max(smax, v[j].x);
+                emax = max(emax, v[j].y);
+                tmin = min(tmin, (i32)(v[j].y - v[j].x));
+            }
+        }
+    }
+    smin = wave_min(smin);
+    smax = wave_max(smax);
+    emax = wave_max(emax);
+    const u32 tkey = wave_min((u32)tmin ^ 0x80000000u); // (signed order as unsigned order)
+    if (lane == 0) red[wv][0] = smin, red[wv][1] = smax, red[wv][2] = emax, red[wv][3] = tkey;
+    // the table starts out zero: 4 * kWsBins words
+    for (u32 i = tid; i < (u32)kWsBins; i += T) bins[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    u32 pmin = 0xFFFFFFFFu, pmax = 0, qmax = 0, tn = 0xFFFFFFFFu;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        pmin = min(pmin, red[w][0]);
+        qmax = max(qmax, red[w][1]);
+        pmax = max(pmax, red[w][2]);
+        tn = min(tn, red[w][3]);
+    }
+    const i32 shortest = (i32)(tn ^ 0x80000000u);
+    // not plain (a start > its end, a position beyond the read or the key range), or a covered span too
+    // short for two windows: the sort's.  (Zero-length intervals are taken: where more than c intervals are
+    // open on both sides of one it changes nothing, and the tests below put it nowhere else.)
+    fallback = fallback || pmax > len || qmax > kMaxKeyPos || shortest < 0 || pmax - pmin < (u32)(2 * W);
+
+    bool healthy = false;
+    u32 ra = 0, rb = 0;
+    if (!fallback) { // (uniform)
+        const i32 bits = 32 - (i32)__builtin_clz(len | 1u) - ilog2c(kWsNB) + (len != 0 ? 0 : -1);
+        const u32 sh = (u32)max(bits, ilog2c(W));
+        const u32 span = pmax - pmin, Tt = span - (u32)W;
+        const u32 cp = (tid & 3u) * 4u;
+        // ---- count: one map for starts and ends
+        for (u32 ch = 0; ch < chunks; ch++) {
+            const u32 base = ch * (u32)(T * R) + tid;
+            if (chunks > 1u) {
+#pragma unroll
+                for (int j = 0; j < R; j++) v[j] = iv[min(base + (u32)(j * T), n - 1u)];
+            }
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                const u32 ds = v[j].x - pmin, dx = v[j].y - pmin;
+                const u32 is = min(ds, (u32)W) + (ds >> sh) + __builtin_elementwise_sub_sat(ds, Tt);
+                const u32 ie = min(dx, (u32)W) + (dx >> sh) + __builtin_elementwise_sub_sat(dx, Tt);
+                if (base + (u32)(j * T) < n && v[j].y != 0u) {
+                    atomicAdd(reinterpret_cast<u32 *>(tb + ((is << 4) + cp)), 1u);
+                    atomicAdd(reinterpret_cast<u32 *>(tb + ((ie << 4) + cp)), kEnd);
+                }
+            }
+        }
+        __syncthreads();
+        // ---- this thread's bin, in event order: starts | ends << 16
+        const uint4 c4 = bins[tid];
+        const u32 w = c4.x + c4.y + c4.z + c4.w;
+        // ---- windows: thread d < W looks at window position d: the starts at pmin + d (its own bin) and the
+        // ends at pmax - d
+        u32 f = 0;
+        if (tid < (u32)W) {
+            const u32 dx = span - tid;
+            const u32 it = min((u32)W + (dx >> sh) + (dx - Tt), (u32)(kWsBins - 1));
+            const uint4 t4 = bins[it];
+            f = (w & kField) | ((t4.x + t4.y + t4.z + t4.w) & (kField << 16));
+        }
+        u32 ftot;
+        const u32 fex = block_excl_add<T>(f, sc, ftot);
+        const i32 F = (i32)(ftot & kField), G = (i32)(ftot >> 16);
+        // positions whose running count has not reached c + 1 yet: their number is a - pmin / pmax - b;
+        // an end at a head position at or before a spoils the closed form
+        const u32 k1 = (u32)min(c + 1, 0x7FFF);
+        const u32 run = fex + f;
+        u32 notyet = 0;
+        bool spoiled = false;
+        if (tid < (u32)W) {
+            notyet = ((run & kField) < k1 ? 1u : 0u) | ((run >> 16) < k1 ? kEnd : 0u);
+            spoiled = (w >> 16) != 0u && (fex & kField) < k1;
+        }
+        u32 ntot;
+        block_excl_add<T>(notyet, sc, ntot);
+        // ---- depth: a bin that holds a start beyond the first c + 1 needs more than c intervals open after
+        // all of its own ends
+        u32 wtot;
+        const u32 wex = block_excl_add<T>(w, sc, wtot);
+        const i32 cs_ex = (i32)(wex & kField), ce_in = (i32)((wex >> 16) + (w >> 16));
+        const bool shallow = (w & kField) != 0u && cs_ex >= (i32)k1 && !(cs_ex - ce_in > c);
+        const u32 any_bad = block_or<T>((shallow || spoiled) ? 1u : 0u, sc);
+        healthy = any_bad == 0u && F > c && G > c;
+        ra = pmin + (ntot & kField);
+        rb = pmax - (ntot >> 16);
+    } else {
+        __syncthreads(); // (red[] / the table are reused by the next read)
+    }
+    if (tid == 0 && healthy) {
+        uint2 *slot = a.stage + (o + 2 * (u64)r);
+        u32 g = 0;
+        if (ra != 0) slot[g++] = make_uint2(0u, ra);
+        if (rb != len) slot[g++] = make_uint2(rb, len);
+        a.counts[r] = g;
+        if (a.prefilter == 2) atomicAdd(&a.ctr->prefiltered, 1u);
+    }
+    __syncthreads();
+    return healthy;
+}
+
+// SweepArgs.list / list_n: the class list; over_list / over_count: the reads the screen leaves to the sort.
+__global__ __launch_bounds__(kWsT) void screen_wg_kernel(SweepArgs a)
+{
+    constexpr int NW = kWsT / 64;
+    __shared__ __attribute__((aligned(16))) u32 tab[kWsBins * 4]; // four copies of every counter (by thread & 3)
+    __shared__ u32 red[NW][4];
+    __shared__ u32 sc[NW + 1];
+    const u32 list_n = *a.list_n;
     for (u32 b = blockIdx.x; b < list_n; b += gridDim.x) { // (uniform)
         const u32 r = a.list[b];
-        const u64 o = a.off[r];
-        const u32 n = (u32)(a.off[r + 1] - o);
-        const u32 len = a.len[r];
-        const uint2 *iv = a.iv + o;
-        const u32 chunks = (n + (u32)(T * R) - 1u) / (u32)(T * R);
-        bool fallback = n < 2u || len > kMaxKeyPos;
+        if (!screen_wg_read(a, r, tab, red, sc) && threadIdx.x == 0) a.over_list[atomicAdd(a.over_count, 1u)] = r;
+    }
+}
 
-        // ---- the read's smallest start, largest end, largest start and shortest interval (signed)
-        uint2 v[R];
-        u32 smin = 0xFFFFFFFFu, emax = 0, smax = 0;
-        i32 tmin = 0x7FFFFFFF;
-        if (!fallback) {
-            for (u32 ch = 0; ch < chunks; ch++) {
-                const u32 base = ch * (u32)(T * R) + tid;
+// ---- the screen and its fallback in ONE launch (round 4) ---------------------------------------------------------
+// Round 3 ran three kernels one after the other for a workgroup class: the screen, sweep_lds_kernel<256, 8192> over
+// the reads it left, sweep_lds_kernel<1024, 32768> over what did not fit there.  On configs[3] the two fallback
+// kernels took 61 + 65 us for 4 % of the bytes: each is one latency chain per read (two passes over the intervals,
+// the trimming plan, the sort, four sweep passes) with most of the device idle, and the second cannot start before
+// the first has ended.  Here a persistent grid does both: a workgroup screens its share of the class list (static
+// stride), appends what it cannot decide to a queue in global memory, and when its share is done takes reads off
+// that queue — its own and everybody else's — through sweep_lds_read<512, 16384> until every workgroup has finished
+// screening and the queue is empty: the fallback reads are sorted WHILE other workgroups still screen, spread over
+// every workgroup that has nothing else to do.  What does not fit 16 384 events even after the filter goes to
+// over_list for the 1024-thread kernel (launched behind this one; usually nothing).
+// Queue: q[] starts out as kQueueEmpty in every slot a read of the class could take (the plan kernel writes the
+// marker where it writes the class list), tail = slots handed out, head = slots claimed, done = workgroups that
+// finished screening.  A claimed slot beyond tail is waited for until it is filled or `done` says it never will be.
+constexpr u32 kQueueEmpty = 0xFFFFFFFFu;
+constexpr int kWsFbCap = 16384; // events the in-kernel fallback sorts (64 KB of LDS; two workgroups per CU by registers anyway)
+struct ScreenFusedArgs {
+    SweepArgs sweep;  // list / list_n: the class; over_list / over_count: beyond kWsFbCap; rej_*: degenerate reads
+    u32 *q;           // the queue's slots
+    u32 *tail, *head, *done;
+};
+__global__ __launch_bounds__(kWsT, 4) void screen_wg_fused_kernel(ScreenFusedArgs f)
+{
+    constexpr int NW = kWsT / 64;
+    __shared__ __attribute__((aligned(16))) u32 tab[kWsBins * 4];
+    __shared__ u32 red[NW][4];
+    __shared__ u32 sc[NW + 1];
+    __shared__ u32 keys[kWsFbCap];
+    __shared__ u32 s_next;
+    const SweepArgs &a = f.sweep;
+    const u32 tid = threadIdx.x;
+    const u32 list_n = *a.list_n;
+    for (u32 b = blockIdx.x; b < list_n; b += gridDim.x) { // (uniform)
+        const u32 r = a.list[b];
+        if (!screen_wg_read(a, r, tab, red, sc) && tid == 0)
+            __hip_atomic_store(&f.q[atomicAdd(f.tail, 1u)], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) {
+        __threadfence(); // this workgroup's appends before its "done"
+        atomicAdd(f.done, 1u);
+    }
+    LaneConst lc;
 #pragma unroll
-                for (int j = 0; j < R; j++) v[j] = iv[min(base + (u32)(j * T), n - 1u)]; // (copies of the last interval beyond it)
-#pragma unroll
-                for (int j = 0; j < R; j++) {
-                    smin = min(smin, v[j].y != 0u ? v[j].x : 0xFFFFFFFFu); // ((0, 0) intervals are inert: left out)
-                    smax = max(smax, v[j].x);
-                    emax = max(emax, v[j].y);
-                    tmin = min(tmin, (i32)(v[j].y - v[j].x));
-                }
-            }
-        }
-        smin = wave_min(smin);
-        smax = wave_max(smax);
-        emax = wave_max(emax);
-        const u32 tkey = wave_min((u32)tmin ^ 0x80000000u); // (signed order as unsigned order)
-        if (lane == 0) red[wv][0] = smin, red[wv][1] = smax, red[wv][2] = emax, red[wv][3] = tkey;
-        // the table starts out zero: 4 * kWsBins words
-        for (u32 i = tid; i < (u32)kWsBins; i += T) bins[i] = make_uint4(0u, 0u, 0u, 0u);
-        __syncthreads();
-        u32 pmin = 0xFFFFFFFFu, pmax = 0, qmax = 0, tn = 0xFFFFFFFFu;
-#pragma unroll
-        for (int w = 0; w < NW; w++) {
-            pmin = min(pmin, red[w][0]);
-            qmax = max(qmax, red[w][1]);
-            pmax = max(pmax, red[w][2]);
-            tn = min(tn, red[w][3]);
-        }
-        const i32 shortest = (i32)(tn ^ 0x80000000u);
-        // not plain (a start > its end, a position beyond the read or the key range), or a covered span too
-        // short for two windows: the sort's.  (Zero-length intervals are taken: where more than c intervals are
-        // open on both sides of one it changes nothing, and the tests below put it nowhere else.)
-        fallback = fallback || pmax > len || qmax > kMaxKeyPos || shortest < 0 || pmax - pmin < (u32)(2 * W);
-
-        bool healthy = false;
-        u32 ra = 0, rb = 0;
-        if (!fallback) { // (uniform)
-            const i32 bits = 32 - (i32)__builtin_clz(len | 1u) - ilog2c(kWsNB) + (len != 0 ? 0 : -1);
-            const u32 sh = (u32)max(bits, ilog2c(W));
-            const u32 span = pmax - pmin, Tt = span - (u32)W;
-            const u32 cp = (tid & 3u) * 4u;
-            // ---- count: one map for starts and ends
-            for (u32 ch = 0; ch < chunks; ch++) {
-                const u32 base = ch * (u32)(T * R) + tid;
-                if (chunks > 1u) {
-#pragma unroll
-                    for (int j = 0; j < R; j++) v[j] = iv[min(base + (u32)(j * T), n - 1u)];
-                }
-#pragma unroll
-                for (int j = 0; j < R; j++) {
-                    const u32 ds = v[j].x - pmin, dx = v[j].y - pmin;
-                    const u32 is = min(ds, (u32)W) + (ds >> sh) + __builtin_elementwise_sub_sat(ds, Tt);
-                    const u32 ie = min(dx, (u32)W) + (dx >> sh) + __builtin_elementwise_sub_sat(dx, Tt);
-                    if (base + (u32)(j * T) < n && v[j].y != 0u) {
-                        atomicAdd(reinterpret_cast<u32 *>(tb + ((is << 4) + cp)), 1u);
-                        atomicAdd(reinterpret_cast<u32 *>(tb + ((ie << 4) + cp)), kEnd);
-                    }
-                }
-            }
-            __syncthreads();
-            // ---- this thread's bin, in event order: starts | ends << 16
-            const uint4 c4 = bins[tid];
-            const u32 w = c4.x + c4.y + c4.z + c4.w;
-            // ---- windows: thread d < W looks at window position d: the starts at pmin + d (its own bin) and the
-            // ends at pmax - d
-            u32 f = 0;
-            if (tid < (u32)W) {
-                const u32 dx = span - tid;
-                const u32 it = min((u32)W + (dx >> sh) + (dx - Tt), (u32)(kWsBins - 1));
-                const uint4 t4 = bins[it];
-                f = (w & kField) | ((t4.x + t4.y + t4.z + t4.w) & (kField << 16));
-            }
-            u32 ftot;
-            const u32 fex = block_excl_add<T>(f, sc, ftot);
-            const i32 F = (i32)(ftot & kField), G = (i32)(ftot >> 16);
-            // positions whose running count has not reached c + 1 yet: their number is a - pmin / pmax - b;
-            // an end at a head position at or before a spoils the closed form
-            const u32 k1 = (u32)min(c + 1, 0x7FFF);
-            const u32 run = fex + f;
-            u32 notyet = 0;
-            bool spoiled = false;
-            if (tid < (u32)W) {
-                notyet = ((run & kField) < k1 ? 1u : 0u) | ((run >> 16) < k1 ? kEnd : 0u);
-                spoiled = (w >> 16) != 0u && (fex & kField) < k1;
-            }
-            u32 ntot;
-            block_excl_add<T>(notyet, sc, ntot);
-            // ---- depth: a bin that holds a start beyond the first c + 1 needs more than c intervals open after
-            // all of its own ends
-            u32 wtot;
-            const u32 wex = block_excl_add<T>(w, sc, wtot);
-            const i32 cs_ex = (i32)(wex & kField), ce_in = (i32)((wex >> 16) + (w >> 16));
-            const bool shallow = (w & kField) != 0u && cs_ex >= (i32)k1 && !(cs_ex - ce_in > c);
-            const u32 any_bad = block_or<T>((shallow || spoiled) ? 1u : 0u, sc);
-            healthy = any_bad == 0u && F > c && G > c;
-            ra = pmin + (ntot & kField);
-            rb = pmax - (ntot >> 16);
-        } else {
-            __syncthreads(); // (red[] / the table are reused by the next read)
-        }
+    for (int i = 0; i < 6; i++) lc.k[i] = (tid & (1u << i)) ? 0xFFFFFFFFu : 0u;
+    lc.k[6] = 0;
+    lc.addr32 = ((tid & 63u) ^ 32u) << 2;
+    for (;;) {
         if (tid == 0) {
-            if (healthy) {
-                uint2 *slot = a.stage + (o + 2 * (u64)r);
-                u32 g = 0;
-                if (ra != 0) slot[g++] = make_uint2(0u, ra);
-                if (rb != len) slot[g++] = make_uint2(rb, len);
-                a.counts[r] = g;
-                if (a.prefilter == 2) atomicAdd(&a.ctr->prefiltered, 1u);
-            } else {
-                a.over_list[atomicAdd(a.over_count, 1u)] = r;
+            const u32 idx = atomicAdd(f.head, 1u);
+            u32 r = kQueueEmpty;
+            for (;;) {
+                if (idx < __hip_atomic_load(f.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    while ((r = __hip_atomic_load(&f.q[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == kQueueEmpty)
+                        __builtin_amdgcn_s_sleep(2);
+                    break;
+                }
+                if (__hip_atomic_load(f.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x) {
+                    // every workgroup has screened its share: the tail is final
+                    if (idx < __hip_atomic_load(f.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
             }
+            s_next = r;
         }
         __syncthreads();
+        const u32 r = s_next;
+        if (r == kQueueEmpty) break; // (uniform)
+        sweep_lds_read<kWsT, kWsFbCap>(a, r, keys, sc, lc);
+        __syncthreads(); // keys / sc / s_next reused
     }
 }
 

@@ -418,6 +418,144 @@ __device__ __forceinline__ void lds_sort_and_sweep(u32 *keys, u32 *sc, u32 m_sor
         counts[r] = finish_read(slot, g_closed, mf_t ? (mf_t ^ 2u) : 0u, ml_t, min_ge, len);
 }
 
+// One read through the workgroup path: T threads, `keys` = CAP words of LDS (CAP = max events, a power of two,
+// CAP % T == 0), `sc` = T / 64 + 1 words.  Every thread of the workgroup calls it with the same r; the caller
+// synchronises before the arrays are used again.  A read with more events than the array holds even after the
+// pre-filter is appended to a.over_list; one with a degenerate interval to a.rej_list.
+template <int T, int CAP>
+__device__ __forceinline__ void sweep_lds_read(const SweepArgs &a, u32 r, u32 *keys, u32 *sc, const LaneConst &lc)
+{
+    const u32 tid = threadIdx.x;
+    const u64 o = a.off[r];
+    const u32 n = (u32)(a.off[r + 1] - o);
+    const u32 len = a.len[r];
+    uint2 *slot = a.stage + (o + 2 * (u64)r);
+
+    if (n == 0) { // only reachable through add_length (stack.rs: no loop, tail empty)
+        if (tid == 0) {
+            u32 g = 0;
+            if (len != 0) slot[g++] = make_uint2(0, len);
+            a.counts[r] = g;
+        }
+        return;
+    }
+
+    const u32 m = 2 * n;
+    // A read with more events than the LDS array holds is still taken when the pre-filter
+    // leaves at most CAP / 2 of them (configs[3]'s reads of ~5 600 intervals keep ~30 %: they
+    // fit a 256-thread workgroup, five of which share a CU, instead of owning a whole CU as a
+    // 1024-thread one); otherwise it goes to over_list for the kernel with the larger array.
+    const bool over = m > (u32)CAP;
+
+    // ---- first pass over the intervals (coalesced 8 B/lane loads): degenerate ones, the
+    // largest start key, and the pre-filter's histogram (into the tail of the empty key array)
+    using F = LdsTrim<T, CAP>;
+    const typename F::Geo geo = F::geo(len);
+    u32 *tab = F::tab(keys);
+    const bool try_filter = T >= 256 && a.prefilter != 0 && len <= kMaxKeyPos;
+    if (over && !try_filter) { // uniform
+        if (tid == 0) a.over_list[atomicAdd(a.over_count, 1u)] = r;
+        return;
+    }
+    if (try_filter) {
+        reinterpret_cast<uint4 *>(tab)[2 * tid] = make_uint4(0u, 0u, 0u, 0u);
+        reinterpret_cast<uint4 *>(tab)[2 * tid + 1] = make_uint4(0u, 0u, 0u, 0u);
+        reinterpret_cast<uint2 *>(F::ztab(keys))[tid] = make_uint2(0u, 0u);
+        __syncthreads();
+    }
+    u32 bad = 0, max_start = 0, nz = 0; // bad bit 1: an end beyond the read (no pre-filter)
+    const uint2 *iv = a.iv + o;
+    // (four loads in flight per thread: one memory latency per 4 T intervals instead of per T)
+    for (u32 i0 = tid; i0 < n; i0 += 4 * T) {
+        uint2 v4[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) v4[j] = iv[min(i0 + (u32)j * T, n - 1u)];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (i0 + (u32)j * T >= n) break;
+            u32 ks, ke;
+            const uint2 v = v4[j];
+            make_event_keys(v, ks, ke, bad, nz);
+            bad |= v.y > len ? 2u : 0u;
+            max_start = max(max_start, ks);
+            if (try_filter && v.x <= v.y && v.y <= len) { // (anything else switches the filter off below)
+                const u32 is = F::idx(geo, ks);
+                if (v.x == v.y && F::uniform(geo, is)) atomicAdd(F::ztab(keys) + is, 1u);
+                else {
+                    atomicAdd(tab + is * 4u + (tid & 3u), 1u);
+                    atomicAdd(tab + F::idx(geo, ke) * 4u + (tid & 3u), 0x10000u);
+                }
+            }
+        }
+    }
+    bad = block_or<T>(bad, sc);
+    const bool beyond = (bad & 2u) != 0;
+    bad &= 1u;
+    u32 nz_total;
+    block_excl_add<T>(nz, sc, nz_total);
+    if (bad) { // degenerate interval: exact general path takes the read
+        if (tid == 0) {
+            a.rej_list[atomicAdd(a.rej_count, 1u)] = r;
+            a.counts[r] = 0; // keeps the compaction well defined until the exact path ran
+        }
+        __syncthreads();
+        return;
+    }
+    max_start = block_max<T>(max_start, sc);
+
+    // ---- second pass: the event keys go to LDS — the survivors of the pre-filter to the
+    // slots they are handed, or all of them
+    u32 m_sort = 0, syn_start = 0; // events to sort and sweep
+    if (try_filter && !beyond)
+        m_sort = lds_trim_plan<T, CAP>(keys, len, a.cov, sc, syn_start);
+    if (!m_sort && over) { // uniform: too much survives
+        if (tid == 0) a.over_list[atomicAdd(a.over_count, 1u)] = r;
+        __syncthreads();
+        return;
+    }
+    if (m_sort) {
+        u32 ms = syn_start;
+        // A cursor whose quota is used up never gets one back, so it is looked at before it is
+        // asked (a plain read: lanes reading one address are a broadcast): of a pile of hundreds of
+        // equal keys only the first few still do the atomic.
+        auto take = [&](u32 *cur) -> u32 {
+            return (i32)*reinterpret_cast<volatile u32 *>(cur) >= 0x10000 ? atomicAdd(cur, F::kTakeOne) : 0u;
+        };
+        for (u32 i0 = tid; i0 < n; i0 += 4 * T) {
+            uint2 v4[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) v4[j] = iv[min(i0 + (u32)j * T, n - 1u)];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                if (i0 + (u32)j * T >= n) break;
+                const uint2 v = v4[j];
+                u32 ks, ke, b2 = 0, z2 = 0;
+                make_event_keys(v, ks, ke, b2, z2);
+                const u32 is = F::idx(geo, ks), ie = F::idx(geo, ke);
+                const u32 ps = take(tab + is * 4u + (F::uniform(geo, is) ? (z2 ? 2u : 1u) : (tid & 3u)));
+                const u32 pe = take(tab + ie * 4u + (F::uniform(geo, ie) ? (z2 ? 2u : 0u) : (tid & 3u)));
+                if ((i32)ps >= 0x10000) { // quota left: kept, at the slot in the low half
+                    keys[ps & 0xFFFFu] = ks;
+                    ms = max(ms, ks);
+                }
+                if ((i32)pe >= 0x10000) keys[pe & 0xFFFFu] = ke;
+            }
+        }
+        max_start = block_max<T>(ms, sc);
+    } else {
+        m_sort = m;
+        __syncthreads(); // the counters are dead, the keys may overwrite them
+        for (u32 i = tid; i < n; i += T) {
+            u32 ks, ke, b2 = 0, z2 = 0;
+            make_event_keys(iv[i], ks, ke, b2, z2);
+            keys[2 * i] = ks;
+            keys[2 * i + 1] = ke;
+        }
+    }
+    lds_sort_and_sweep<T>(keys, sc, m_sort, len, a.cov, max_start, nz_total, lc, slot, a.counts, r,
+                          a.rej_list, a.rej_count);
+}
+
 // T threads per read, CAP = max events (power of two, CAP % T == 0).
 template <int T, int CAP>
 __global__ __launch_bounds__(T) void sweep_lds_kernel(SweepArgs a)
@@ -434,135 +572,7 @@ __global__ __launch_bounds__(T) void sweep_lds_kernel(SweepArgs a)
     lc.addr32 = ((tid & 63u) ^ 32u) << 2;
 
     for (u32 b = blockIdx.x; b < list_n; b += gridDim.x) {
-        const u32 r = a.list[b];
-        const u64 o = a.off[r];
-        const u32 n = (u32)(a.off[r + 1] - o);
-        const u32 len = a.len[r];
-        uint2 *slot = a.stage + (o + 2 * (u64)r);
-
-        if (n == 0) { // only reachable through add_length (stack.rs: no loop, tail empty)
-            if (tid == 0) {
-                u32 g = 0;
-                if (len != 0) slot[g++] = make_uint2(0, len);
-                a.counts[r] = g;
-            }
-            continue;
-        }
-
-        const u32 m = 2 * n;
-        // A read with more events than the LDS array holds is still taken when the pre-filter
-        // leaves at most CAP / 2 of them (configs[3]'s reads of ~5 600 intervals keep ~30 %: they
-        // fit a 256-thread workgroup, five of which share a CU, instead of owning a whole CU as a
-        // 1024-thread one); otherwise it goes to over_list for the kernel with the larger array.
-        const bool over = m > (u32)CAP;
-
-        // ---- first pass over the intervals (coalesced 8 B/lane loads): degenerate ones, the
-        // largest start key, and the pre-filter's histogram (into the tail of the empty key array)
-        using F = LdsTrim<T, CAP>;
-        const typename F::Geo geo = F::geo(len);
-        u32 *tab = F::tab(keys);
-        const bool try_filter = T >= 256 && a.prefilter != 0 && len <= kMaxKeyPos;
-        if (over && !try_filter) { // uniform
-            if (tid == 0) a.over_list[atomicAdd(a.over_count, 1u)] = r;
-            continue;
-        }
-        if (try_filter) {
-            reinterpret_cast<uint4 *>(tab)[2 * tid] = make_uint4(0u, 0u, 0u, 0u);
-            reinterpret_cast<uint4 *>(tab)[2 * tid + 1] = make_uint4(0u, 0u, 0u, 0u);
-            reinterpret_cast<uint2 *>(F::ztab(keys))[tid] = make_uint2(0u, 0u);
-            __syncthreads();
-        }
-        u32 bad = 0, max_start = 0, nz = 0; // bad bit 1: an end beyond the read (no pre-filter)
-        const uint2 *iv = a.iv + o;
-        // (four loads in flight per thread: one memory latency per 4 T intervals instead of per T)
-        for (u32 i0 = tid; i0 < n; i0 += 4 * T) {
-            uint2 v4[4];
-#pragma unroll
-            for (int j = 0; j < 4; j++) v4[j] = iv[min(i0 + (u32)j * T, n - 1u)];
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                if (i0 + (u32)j * T >= n) break;
-                u32 ks, ke;
-                const uint2 v = v4[j];
-                make_event_keys(v, ks, ke, bad, nz);
-                bad |= v.y > len ? 2u : 0u;
-                max_start = max(max_start, ks);
-                if (try_filter && v.x <= v.y && v.y <= len) { // (anything else switches the filter off below)
-                    const u32 is = F::idx(geo, ks);
-                    if (v.x == v.y && F::uniform(geo, is)) atomicAdd(F::ztab(keys) + is, 1u);
-                    else {
-                        atomicAdd(tab + is * 4u + (tid & 3u), 1u);
-                        atomicAdd(tab + F::idx(geo, ke) * 4u + (tid & 3u), 0x10000u);
-                    }
-                }
-            }
-        }
-        bad = block_or<T>(bad, sc);
-        const bool beyond = (bad & 2u) != 0;
-        bad &= 1u;
-        u32 nz_total;
-        block_excl_add<T>(nz, sc, nz_total);
-        if (bad) { // degenerate interval: exact general path takes the read
-            if (tid == 0) {
-                a.rej_list[atomicAdd(a.rej_count, 1u)] = r;
-                a.counts[r] = 0; // keeps the compaction well defined until the exact path ran
-            }
-            __syncthreads();
-            continue;
-        }
-        max_start = block_max<T>(max_start, sc);
-
-        // ---- second pass: the event keys go to LDS — the survivors of the pre-filter to the
-        // slots they are handed, or all of them
-        u32 m_sort = 0, syn_start = 0; // events to sort and sweep
-        if (try_filter && !beyond)
-            m_sort = lds_trim_plan<T, CAP>(keys, len, a.cov, sc, syn_start);
-        if (!m_sort && over) { // uniform: too much survives
-            if (tid == 0) a.over_list[atomicAdd(a.over_count, 1u)] = r;
-            __syncthreads();
-            continue;
-        }
-        if (m_sort) {
-            u32 ms = syn_start;
-            // A cursor whose quota is used up never gets one back, so it is looked at before it is
-            // asked (a plain read: lanes reading one address are a broadcast): of a pile of hundreds of
-            // equal keys only the first few still do the atomic.
-            auto take = [&](u32 *cur) -> u32 {
-                return (i32)*reinterpret_cast<volatile u32 *>(cur) >= 0x10000 ? atomicAdd(cur, F::kTakeOne) : 0u;
-            };
-            for (u32 i0 = tid; i0 < n; i0 += 4 * T) {
-                uint2 v4[4];
-#pragma unroll
-                for (int j = 0; j < 4; j++) v4[j] = iv[min(i0 + (u32)j * T, n - 1u)];
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    if (i0 + (u32)j * T >= n) break;
-                    const uint2 v = v4[j];
-                    u32 ks, ke, b2 = 0, z2 = 0;
-                    make_event_keys(v, ks, ke, b2, z2);
-                    const u32 is = F::idx(geo, ks), ie = F::idx(geo, ke);
-                    const u32 ps = take(tab + is * 4u + (F::uniform(geo, is) ? (z2 ? 2u : 1u) : (tid & 3u)));
-                    const u32 pe = take(tab + ie * 4u + (F::uniform(geo, ie) ? (z2 ? 2u : 0u) : (tid & 3u)));
-                    if ((i32)ps >= 0x10000) { // quota left: kept, at the slot in the low half
-                        keys[ps & 0xFFFFu] = ks;
-                        ms = max(ms, ks);
-                    }
-                    if ((i32)pe >= 0x10000) keys[pe & 0xFFFFu] = ke;
-                }
-            }
-            max_start = block_max<T>(ms, sc);
-        } else {
-            m_sort = m;
-            __syncthreads(); // the counters are dead, the keys may overwrite them
-            for (u32 i = tid; i < n; i += T) {
-                u32 ks, ke, b2 = 0, z2 = 0;
-                make_event_keys(iv[i], ks, ke, b2, z2);
-                keys[2 * i] = ks;
-                keys[2 * i + 1] = ke;
-            }
-        }
-        lds_sort_and_sweep<T>(keys, sc, m_sort, len, a.cov, max_start, nz_total, lc, slot, a.counts, r,
-                              a.rej_list, a.rej_count);
+        sweep_lds_read<T, CAP>(a, a.list[b], keys, sc, lc);
         __syncthreads(); // keys / sc reused by the next read
     }
 }

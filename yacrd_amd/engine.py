@@ -31,6 +31,7 @@ F_SWEEP_TURNS = 16384
 F_TIMING_SAMPLED = 32768
 F_SCREEN_ITEMS_1 = 262144
 F_SCREEN_ITEMS_2 = 524288
+F_NO_FUSED_SCREEN = 1048576
 
 # every symbol include/yacrd_engine.h declares
 EXPORTED_SYMBOLS = [

@@ -326,6 +326,13 @@ int yacrd_engine_ingest_paf(yacrd_engine *e, const char *path, int n_threads, ui
 int yacrd_engine_ingest_overlaps(yacrd_engine *e, const char *path, int format, int n_threads, uint32_t coverage,
                                  double not_coverage, yacrd_result *out, yacrd_reads *reads,
                                  yacrd_ingest_stats *stats /* may be NULL */);
+/* The same over text that already lies in host memory (format: 1 = PAF, 2 = M4) — what a compressed overlap file is
+ * once libyacrd_host has inflated it (yacrd_text_from_file: the reference reads .gz / .bz2 / .xz through niffler like
+ * any other file, src/util.rs:57-70).  yacrd_engine_ingest_overlaps itself answers YACRD_EFALLBACK for a file that
+ * begins with a gzip / bzip2 / xz magic.  `text` needs no padding; it may be pageable. */
+int yacrd_engine_ingest_overlaps_mem(yacrd_engine *e, const char *text, uint64_t n_bytes, int format, int n_threads,
+                                     uint32_t coverage, double not_coverage, yacrd_result *out, yacrd_reads *reads,
+                                     yacrd_ingest_stats *stats /* may be NULL */);
 void yacrd_reads_free(yacrd_reads *r);
 /* The device parser keeps its buffers between calls (the text's mirror, the id table, the records: about twice the
  * file's size; a call into warm buffers is 2-3 times faster than one that has to allocate them): this gives them back. */

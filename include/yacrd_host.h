@@ -113,6 +113,21 @@ int yacrd_report_read(const char *path, yacrd_report **out);
 int yacrd_report_get(const yacrd_report *r, yacrd_badparts_view *v);
 void yacrd_report_free(yacrd_report *r);
 
+/* ---- a compressed overlap file as text in memory (for yacrd_engine_ingest_overlaps_mem: the parse on the GPU) ----
+ * gzip / bzip2 / xz, sniffed from the magic bytes like the reference's niffler reader (src/util.rs:57-70).  Returns
+ * 0 = `out` holds the text (free with yacrd_text_free), 2 = the file is not compressed (or not a regular file): read
+ * it where it lies, 1 = error (truncated / corrupt stream, like the reference's readers).  BGZF files (bgzip) are
+ * inflated member-parallel on n_threads threads (0 = every usable CPU); any other stream is one thread's work. */
+typedef struct {
+    char *data;        /* n bytes of text (+ at least 64 readable bytes behind them) */
+    uint64_t n, cap;   /* cap: size of the mapping behind `data` */
+    uint64_t members;  /* BGZF members inflated in parallel (1 = one stream) */
+    uint32_t threads;  /* threads that inflated */
+    int32_t compression; /* 1 gzip, 2 bzip2, 3 xz */
+} yacrd_text;
+int yacrd_text_from_file(const char *path, int n_threads, yacrd_text *out);
+void yacrd_text_free(yacrd_text *t);
+
 /* ---- synthetic workloads ------------------------------------------------------ */
 enum { YACRD_SYNTH_ONT = 0, YACRD_SYNTH_SEQUEL = 1, YACRD_SYNTH_SKEWED = 2 };
 /* flags.  NO_INJECTION: no abutting / degenerate intervals.  JITTER: the N(0, sigma) offset of a

@@ -103,6 +103,10 @@ def test_m4_mhap_and_compressed_inputs(work, golden_dir, tmp_path):
             "scrubb", "-i", str(tmp_path / ("r.fastq." + ext)), "-o", str(out))
         assert set(lines(tmp_path / (ext + ".yacrd"))) == truth, ext
         assert mod.open(out, "rb").read() == want, ext
+    # (round 4: a compressed overlap file is inflated on the host and parsed on the device)
+    p = subprocess.run([BIN, "-i", str(tmp_path / "x.paf.gz"), "-o", str(tmp_path / "t.yacrd")], capture_output=True, text=True,
+                       env=dict(os.environ, YACRD_CLI_TIMING="1"))
+    assert p.returncode == 0 and "[timing] inflate" in p.stderr and set(lines(tmp_path / "t.yacrd")) == truth
     blob = open(tmp_path / "x.paf.xz", "rb").read()
     open(tmp_path / "cut.paf.xz", "wb").write(blob[:len(blob) // 2])
     p = subprocess.run([BIN, "-i", str(tmp_path / "cut.paf.xz"), "-o", str(tmp_path / "cut.yacrd")],

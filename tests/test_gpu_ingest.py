@@ -365,3 +365,36 @@ def test_m4_random_text_against_the_oracle_ingest(engine, tmp_path):
         assert names == list(w_names) and np.array_equal(lengths.astype(np.uint64), ln), text
         assert_same(got, oracle.run(off, iv, ln, cov, 0.4, n_threads=2), "case %d" % case)
     assert taken >= 150 and fell_back >= 60, (taken, fell_back)
+
+
+def test_compressed_files_take_the_device_parser(engine, tmp_path):
+    """Round 4: a gzip / bzip2 / xz / BGZF overlap file is inflated by libyacrd_host
+    (yacrd_text_from_file; the reference sniffs every input like this, src/util.rs:57-70) and parsed ON THE DEVICE from
+    memory (yacrd_engine_ingest_overlaps_mem): reads, lengths, regions and types of the plain file; the file variant
+    refuses a compressed file (YACRD_EFALLBACK) instead of scanning its bytes as text."""
+    import bz2
+    import gzip
+    import lzma
+    from test_host import _bgzf
+    paf = str(tmp_path / "s.paf")
+    host.synth_paf(host.SYNTH_ONT, 5000, 150000, 91, paf)
+    want, names, lengths, _ = _check(engine, paf, 4, 0.4)
+    text = open(paf, "rb").read()
+    for name, blob in (("a.paf.gz", gzip.compress(text, 1)), ("b.paf.bz2", bz2.compress(text)), ("c.paf.xz", lzma.compress(text, preset=1)),
+                       ("d.paf.gz", _bgzf(text, 60000))):
+        p = str(tmp_path / name)
+        open(p, "wb").write(blob)
+        with pytest.raises(yacrd_amd.NeedsHostParser):
+            engine.ingest_paf(p, 4, 0.4)
+        with host.text_from_file(p) as t:
+            assert t.n_bytes == len(text)
+            got, n2, l2, st = engine.ingest_text((t.address, t.n_bytes), 4, 0.4)
+        assert n2 == names and np.array_equal(l2, lengths) and st["text_bytes"] == len(text)
+        assert_same(got, (want.bad_offsets, want.bad_regions, want.read_type), name)
+    # bytes in, M4 from memory, the empty text
+    got, n2, l2, _ = engine.ingest_text(text, 4, 0.4)
+    assert n2 == names
+    got, n2, l2, _ = engine.ingest_text(b"", 0, 0.8)
+    assert n2 == [] and len(got.read_type) == 0
+    got, n2, l2, _ = engine.ingest_text(b"1 2 0.1 2 0 100 450 1000 0 550 900 1000\n", 0, 0.8, fmt=2)
+    assert n2 == ["1", "2"] and l2.tolist() == [1000, 1000]

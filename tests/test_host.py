@@ -211,3 +211,60 @@ def test_ingest_is_identical_for_every_thread_count(tmp_path):
         assert np.array_equal(c.lengths, np.asarray(ln).astype(np.uint32))
         assert np.array_equal(c.offsets, off)
         assert np.array_equal(c.intervals.reshape(-1, 2), iv), th
+
+
+# ---- compressed overlap files as text in memory (yacrd_text_from_file; round 4) -------------------------------
+def _bgzf(data, block=40000):
+    """BGZF (bgzip): gzip members with a "BC" extra subfield holding the member's size - 1, at most 64 KiB each,
+    and the empty end-of-file member."""
+    import struct
+    import zlib
+    out = []
+    for i in list(range(0, len(data), block)) + [None]:
+        chunk = b"" if i is None else data[i:i + block]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = co.compress(chunk) + co.flush()
+        bsize = 12 + 6 + len(body) + 8
+        out.append(b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\0\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize - 1)
+                   + body + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+    return b"".join(out)
+
+
+def test_text_from_file_codecs(tmp_path):
+    import bz2
+    import gzip
+    import lzma
+    rng = np.random.default_rng(9)
+    text = b"".join(b"r%07d\t%d\t%d\t%d\t+\tr%07d\t9000\t10\t900\t800\t800\t255\n" % (i, 5000 + i % 7, i % 100, 1000 + i % 100, (i * 7) % 5000)
+                    for i in range(60000)) + bytes(rng.integers(65, 90, 1000, dtype=np.uint8))
+    plain = tmp_path / "a.paf"
+    plain.write_bytes(text)
+    assert host.text_from_file(str(plain)) is None  # not compressed: read where it lies
+    cases = {"one.paf.gz": gzip.compress(text, 1), "two.paf.gz": gzip.compress(text[:100000]) + gzip.compress(text[100000:]),
+             "b.paf.bz2": bz2.compress(text), "x.paf.xz": lzma.compress(text), "bg.paf.gz": _bgzf(text)}
+    for name, blob in cases.items():
+        p = tmp_path / name
+        p.write_bytes(blob)
+        for th in (1, 4):
+            with host.text_from_file(str(p), n_threads=th) as t:
+                assert t.bytes() == text, name
+                if name == "bg.paf.gz":
+                    assert t.members == len(text) // 40000 + 2 and (th == 1 or t.threads >= 1)
+                else:
+                    assert t.members == 1
+    # truncated / corrupt streams are errors, like the reference's readers
+    for name in ("one.paf.gz", "bg.paf.gz", "b.paf.bz2", "x.paf.xz"):
+        blob = cases[name]
+        bad = tmp_path / ("bad_" + name)
+        bad.write_bytes(blob[: len(blob) * 2 // 3])
+        with pytest.raises(host.HostError):
+            host.text_from_file(str(bad))
+    flipped = bytearray(cases["bg.paf.gz"])
+    flipped[len(flipped) // 2] ^= 0x55
+    (tmp_path / "flip.paf.gz").write_bytes(bytes(flipped))
+    with pytest.raises(host.HostError):
+        host.text_from_file(str(tmp_path / "flip.paf.gz"))
+    empty = tmp_path / "e.paf.gz"
+    empty.write_bytes(gzip.compress(b""))
+    with host.text_from_file(str(empty)) as t:
+        assert t.n_bytes == 0

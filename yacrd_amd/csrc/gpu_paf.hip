@@ -513,18 +513,56 @@ int yacrd_engine_ingest_paf(yacrd_engine *e, const char *path, int n_threads, ui
     return yacrd_engine_ingest_overlaps(e, path, 1, n_threads, coverage, not_coverage, out, reads, stats);
 }
 
-int yacrd_engine_ingest_overlaps(yacrd_engine *e, const char *path, int format, int n_threads, uint32_t coverage,
-                                 double not_coverage, yacrd_result *out, yacrd_reads *reads, yacrd_ingest_stats *stats)
+} // extern "C"
+
+namespace {
+// where the text comes from: a file (pread) or memory (a compressed file the host has inflated)
+struct TextSource {
+    int fd = -1;
+    const char *mem = nullptr;
+    // `len` bytes at `off` into dst; false = read error
+    bool fetch(char *dst, size_t len, u64 off) const
+    {
+        if (mem) {
+            std::memcpy(dst, mem + off, len);
+            return true;
+        }
+        size_t got = 0;
+        while (got < len) {
+            const ssize_t k = ::pread(fd, dst + got, len - got, (off_t)(off + got));
+            if (k < 0 && errno == EINTR) continue;
+            if (k <= 0) return false;
+            got += (size_t)k;
+        }
+        return true;
+    }
+};
+int ingest_text(yacrd_engine *e, const TextSource &src, u64 n, bool m4, int n_threads, uint32_t coverage, double not_coverage,
+                yacrd_result *out, yacrd_reads *reads, yacrd_ingest_stats *stats);
+} // namespace
+
+extern "C" {
+
+static int ingest_format(const char *path, int format, bool &m4)
 {
-    if (!e || !path || !out || !reads) return fail(YACRD_EINVAL, "null argument");
     if (format == 0) { // by file name, like util::get_file_type (src/util.rs:39-55)
+        if (!path) return fail(YACRD_EINVAL, "format 0 (by name) needs a file name");
         const std::string name(path);
         auto has = [&](const char *x) { return name.find(x) != std::string::npos; };
         format = (has(".m4") || has(".mhap")) ? 2 : has(".paf") ? 1 : 0;
         if (format == 0) return fail(YACRD_EINVAL, std::string("cannot tell the overlap format of ") + path);
     }
     if (format != 1 && format != 2) return fail(YACRD_EINVAL, "format: 0 = by name, 1 = PAF, 2 = M4");
-    const bool m4 = format == 2;
+    m4 = format == 2;
+    return YACRD_OK;
+}
+
+int yacrd_engine_ingest_overlaps(yacrd_engine *e, const char *path, int format, int n_threads, uint32_t coverage,
+                                 double not_coverage, yacrd_result *out, yacrd_reads *reads, yacrd_ingest_stats *stats)
+{
+    if (!e || !path || !out || !reads) return fail(YACRD_EINVAL, "null argument");
+    bool m4 = false;
+    if (const int rcf = ingest_format(path, format, m4)) return rcf;
     std::memset(out, 0, sizeof(*out));
     std::memset(reads, 0, sizeof(*reads));
     if (stats) std::memset(stats, 0, sizeof(*stats));
@@ -537,7 +575,42 @@ int yacrd_engine_ingest_overlaps(yacrd_engine *e, const char *path, int format, 
     } fdg{fd};
     struct stat st;
     if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) return fail(YACRD_EFALLBACK, "not a regular file: the host parser reads it");
-    const u64 n = (u64)st.st_size;
+    {
+        // gzip / bzip2 / xz (the magic bytes niffler looks at, src/util.rs:57-70): not text — the caller inflates the file
+        // (yacrd_text_from_file, libyacrd_host) and hands the text to yacrd_engine_ingest_overlaps_mem, or takes the host parser
+        unsigned char mg[6] = {0};
+        const ssize_t k = ::pread(fd, mg, sizeof mg, 0);
+        if (k >= 2 && ((mg[0] == 0x1f && mg[1] == 0x8b) || (k >= 3 && mg[0] == 'B' && mg[1] == 'Z' && mg[2] == 'h') ||
+                       (k >= 6 && mg[0] == 0xFD && std::memcmp(mg + 1, "7zXZ", 4) == 0 && mg[5] == 0)))
+            return fail(YACRD_EFALLBACK, "a compressed file: inflate it (yacrd_text_from_file + yacrd_engine_ingest_overlaps_mem) or take the host parser");
+    }
+    TextSource src;
+    src.fd = fd;
+    return ingest_text(e, src, (u64)st.st_size, m4, n_threads, coverage, not_coverage, out, reads, stats);
+}
+
+int yacrd_engine_ingest_overlaps_mem(yacrd_engine *e, const char *text, uint64_t n, int format, int n_threads, uint32_t coverage,
+                                     double not_coverage, yacrd_result *out, yacrd_reads *reads, yacrd_ingest_stats *stats)
+{
+    if (!e || (!text && n) || !out || !reads) return fail(YACRD_EINVAL, "null argument");
+    bool m4 = false;
+    if (const int rcf = ingest_format(nullptr, format, m4)) return rcf;
+    std::memset(out, 0, sizeof(*out));
+    std::memset(reads, 0, sizeof(*reads));
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if (e->pending.active || e->host_pending) return fail(YACRD_EINVAL, "the engine has a submitted batch pending");
+    TextSource src;
+    src.mem = text ? text : "";
+    return ingest_text(e, src, n, m4, n_threads, coverage, not_coverage, out, reads, stats);
+}
+
+} // extern "C"
+
+namespace {
+
+int ingest_text(yacrd_engine *e, const TextSource &src, u64 n, bool m4, int n_threads, uint32_t coverage, double not_coverage,
+                yacrd_result *out, yacrd_reads *reads, yacrd_ingest_stats *stats)
+{
     DeviceGuard guard(e->device);
     // (allocating and freeing ~0.8 GB of HBM per call cost 1.5 ms of a 15 ms run)
     if (!e->paf_scratch) {
@@ -587,13 +660,7 @@ int yacrd_engine_ingest_overlaps(yacrd_engine *e, const char *path, int format, 
     {
         const size_t sample = (size_t)std::min<u64>(n, (u64)1 << 20);
         std::vector<char> head(sample + 1);
-        size_t got = 0;
-        while (got < sample) {
-            const ssize_t k = ::pread(fd, head.data() + got, sample - got, (off_t)got);
-            if (k < 0 && errno == EINTR) continue;
-            if (k <= 0) return fail(YACRD_EINVAL, "read error in the overlap file");
-            got += (size_t)k;
-        }
+        if (!src.fetch(head.data(), sample, 0)) return fail(YACRD_EINVAL, "read error in the overlap file");
         u64 nl = 0;
         for (const char *q = head.data(), *end = q + sample; (q = (const char *)std::memchr(q, '\n', (size_t)(end - q))) != nullptr; q++) nl++;
         if (nl) rec_cap = std::min<u64>(rec_cap, (u64)((double)n / (double)sample * (double)nl * 1.25) + 4096);
@@ -665,16 +732,7 @@ int yacrd_engine_ingest_overlaps(yacrd_engine *e, const char *path, int format, 
                 if (prev[turn] >= 0 && hipEventSynchronize(ev[(size_t)prev[turn]]) != hipSuccess) bad = 1;
                 char *dst = arena + b * kChunk;
                 const size_t off = c * kChunk, len = (size_t)std::min<u64>(kChunk, n - off);
-                size_t got = 0;
-                while (got < len) {
-                    const ssize_t k = ::pread(fd, dst + got, len - got, (off_t)(off + got));
-                    if (k < 0 && errno == EINTR) continue;
-                    if (k <= 0) {
-                        bad = 2;
-                        break;
-                    }
-                    got += (size_t)k;
-                }
+                if (!src.fetch(dst, len, (u64)off)) bad = 2;
                 if (bad.load()) break;
                 if (blit && (len & 15)) std::memset(dst + len, 0, 16 - (len & 15)); // (the file's last piece: zeros, not leftovers, behind it)
                 if (blit) { // (the arena's buffers are 4 MiB: whole 16-byte pieces; the mirror is padded by 64 bytes)
@@ -839,4 +897,4 @@ int yacrd_engine_ingest_overlaps(yacrd_engine *e, const char *path, int format, 
     return rc;
 }
 
-} // extern "C"
+} // namespace

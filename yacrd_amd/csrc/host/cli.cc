@@ -157,6 +157,7 @@ int main(int argc, char **argv)
     yacrd_badparts_view bp{};
     yacrd_csr_view view{};
     yacrd_reads dev_reads{};
+    yacrd_text text{}; // a compressed input, inflated (empty otherwise); lives as long as what was parsed from it
 
     // src/main.rs:43-60: a .yacrd input bypasses detection (FromReport), anything else is overlaps
     const bool m4 = has(input, ".m4") || has(input, ".mhap"), paf = has(input, ".paf");
@@ -187,8 +188,17 @@ int main(int argc, char **argv)
             // YACRD_COPY_THREADS says otherwise.
             const char *ct = std::getenv("YACRD_COPY_THREADS");
             const int copy_threads = ct && *ct ? std::max(0, std::atoi(ct)) : 0;
-            dev_parse = yacrd_engine_ingest_overlaps(engines[0], input.c_str(), m4 ? 2 : 1, copy_threads, cov32, not_coverage,
-                                                     &res, &dev_reads, nullptr);
+            // a gzip / bzip2 / xz file (src/util.rs:57-70 sniffs every input): inflated into memory first — BGZF members on
+            // every usable CPU, any other stream on one thread, which then is the wall clock whichever parser follows
+            const int rct = yacrd_text_from_file(input.c_str(), threads == 1 ? 0 : (int)threads, &text);
+            if (rct == 1) die(yacrd_host_last_error());
+            stage("inflate");
+            if (rct == 0)
+                dev_parse = yacrd_engine_ingest_overlaps_mem(engines[0], text.data, text.n, m4 ? 2 : 1, copy_threads, cov32,
+                                                             not_coverage, &res, &dev_reads, nullptr);
+            else
+                dev_parse = yacrd_engine_ingest_overlaps(engines[0], input.c_str(), m4 ? 2 : 1, copy_threads, cov32, not_coverage,
+                                                         &res, &dev_reads, nullptr);
             if (dev_parse == YACRD_ENOMEM) { // HBM ran out on the way (the parse wants ~2.6 x the file): the streamed host parse needs a fifth
                 std::fprintf(stderr, "[INFO] device parser: %s; falling back to the host parser\n", yacrd_last_error());
                 (void)yacrd_engine_trim(engines[0]);
@@ -211,7 +221,10 @@ int main(int argc, char **argv)
                 die(yacrd_last_error());
             yacrd_rec_sink sink;
             yacrd_stream_group_sink(grp, &sink);
-            if (yacrd_ingest_stream(input.c_str(), 0, (int)threads, &sink, &csr)) die(yacrd_host_last_error());
+            // (a compressed input the device parser handed over is parsed from the text already inflated)
+            if (text.data ? yacrd_ingest_stream_memory(text.data, (size_t)text.n, m4 ? 2 : 1, (int)threads, &sink, &csr)
+                          : yacrd_ingest_stream(input.c_str(), 0, (int)threads, &sink, &csr))
+                die(yacrd_host_last_error());
             yacrd_csr_get(csr, &view);
             const uint32_t *map = nullptr;
             uint64_t n_handles = 0;
@@ -247,6 +260,7 @@ int main(int argc, char **argv)
 
     yacrd_result_free(&res);
     yacrd_reads_free(&dev_reads);
+    yacrd_text_free(&text);
     if (csr) yacrd_csr_free(csr);
     if (rep) yacrd_report_free(rep);
     for (yacrd_engine *e : engines) yacrd_engine_destroy(e);

@@ -383,3 +383,201 @@ int OutStream::close()
 }
 
 } // namespace yh
+
+// ---- a whole compressed file into memory (yacrd_text_*: the text the device parser takes) ---------------------------
+// The reference reads compressed overlap files through niffler like any other (src/util.rs:57-70); the device
+// parser wants the TEXT in one piece.  A gzip / bzip2 / xz stream is one thread's work whatever reads it (a deflate
+// stream cannot be entered in the middle): ~0.3-0.5 GB/s of text, which then is the ingest's wall clock whichever
+// parser follows.  The exception is BGZF (bgzip, htslib: the usual way bioinformatics files are gzipped when they are
+// meant to be read fast): members of at most 64 KiB that say their own size in an extra field, independent of each
+// other — found by walking the headers, inflated on every usable CPU into their final places (every member ends with its
+// uncompressed size).
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <thread>
+
+#include "../../../include/yacrd_host.h"
+
+namespace {
+
+struct Mapping { // a grow-only anonymous mapping: the text lands in one piece without a realloc copy
+    char *p = nullptr;
+    size_t cap = 0;
+    bool reserve(size_t want)
+    {
+        if (want <= cap) return true;
+        size_t ncap = std::max<size_t>(want, cap ? cap * 2 : (size_t)64 << 20);
+        ncap = (ncap + 4095) & ~(size_t)4095;
+        void *q = p ? mremap(p, cap, ncap, MREMAP_MAYMOVE)
+                    : mmap(nullptr, ncap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+        if (q == MAP_FAILED) return false;
+        p = (char *)q;
+        cap = ncap;
+        return true;
+    }
+    void release()
+    {
+        if (p) munmap(p, cap);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct BgzfMember {
+    uint64_t at, csize, out, isize; // the member in the file; its place and size in the text
+};
+// BGZF (SAM spec 4.1): gzip members with FLG.FEXTRA and a "BC" subfield holding BSIZE = member size - 1.
+// false = not BGZF from its first member to its last (the caller streams the file instead).
+bool bgzf_members(const unsigned char *f, uint64_t n, std::vector<BgzfMember> &out, uint64_t &total)
+{
+    uint64_t at = 0;
+    total = 0;
+    while (at < n) {
+        if (n - at < 18 + 8 || f[at] != 0x1f || f[at + 1] != 0x8b || f[at + 2] != 8 || !(f[at + 3] & 4)) return false;
+        const uint32_t xlen = f[at + 10] | (f[at + 11] << 8);
+        if (n - at < 12 + (uint64_t)xlen) return false;
+        uint64_t bsize = 0;
+        for (uint32_t x = 0; x + 4 <= xlen;) {
+            const unsigned char *sf = f + at + 12 + x;
+            const uint32_t slen = sf[2] | (sf[3] << 8);
+            if (sf[0] == 'B' && sf[1] == 'C' && slen == 2 && x + 6 <= xlen) bsize = (uint64_t)(sf[4] | (sf[5] << 8)) + 1;
+            x += 4 + slen;
+        }
+        if (bsize < 12 + (uint64_t)xlen + 8 || at + bsize > n) return false;
+        const unsigned char *tail = f + at + bsize - 4;
+        const uint64_t isize = (uint64_t)tail[0] | ((uint64_t)tail[1] << 8) | ((uint64_t)tail[2] << 16) | ((uint64_t)tail[3] << 24);
+        // (name / comment / header-crc fields do not occur in BGZF: the deflate data starts behind the extra field)
+        if (f[at + 3] & ~4u) return false;
+        out.push_back(BgzfMember{at, bsize, total, isize});
+        total += isize;
+        at += bsize;
+    }
+    return !out.empty();
+}
+
+} // namespace
+
+extern "C" {
+
+int yacrd_text_from_file(const char *path, int n_threads, yacrd_text *out)
+{
+    if (!path || !out) return yh::fail("null argument");
+    std::memset(out, 0, sizeof(*out));
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) return yh::fail(std::string("Can't open file ") + path + " to read");
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) {
+        ::close(fd);
+        return 2; // not a regular file: the caller streams it
+    }
+    unsigned char magic[8] = {0};
+    const ssize_t got = ::pread(fd, magic, sizeof magic, 0);
+    const yh::Compression fmt = yh::sniff_compression(magic, got > 0 ? (size_t)got : 0);
+    if (fmt == yh::COMP_NONE) {
+        ::close(fd);
+        return 2; // plain text: read it where it lies
+    }
+    out->compression = (int)fmt;
+    Mapping m;
+    const uint64_t csize = (uint64_t)st.st_size;
+    unsigned T = n_threads > 0 ? (unsigned)n_threads : yh::usable_cpus();
+    if (fmt == yh::COMP_GZIP && csize >= 28) {
+        const unsigned char *f = (const unsigned char *)mmap(nullptr, csize, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (f != MAP_FAILED) {
+            std::vector<BgzfMember> mem;
+            uint64_t total = 0;
+            if (bgzf_members(f, csize, mem, total) && m.reserve((size_t)total + 64)) {
+                std::atomic<size_t> next(0);
+                std::atomic<int> bad(0);
+                T = (unsigned)std::max<size_t>(1, std::min<size_t>(T, mem.size() / 16 + 1));
+                auto work = [&]() {
+                    z_stream zs{};
+                    if (inflateInit2(&zs, -15) != Z_OK) {
+                        bad = 1;
+                        return;
+                    }
+                    for (;;) {
+                        const size_t i0 = next.fetch_add(64);
+                        if (i0 >= mem.size() || bad.load()) break;
+                        for (size_t i = i0; i < std::min(i0 + 64, mem.size()); i++) {
+                            const BgzfMember &b = mem[i];
+                            const uint32_t xlen = f[b.at + 10] | (f[b.at + 11] << 8);
+                            inflateReset(&zs);
+                            zs.next_in = const_cast<Bytef *>(f + b.at + 12 + xlen);
+                            zs.avail_in = (uInt)(b.csize - 12 - xlen - 8);
+                            zs.next_out = (Bytef *)m.p + b.out;
+                            zs.avail_out = (uInt)b.isize;
+                            const int rc = inflate(&zs, Z_FINISH);
+                            if (rc != Z_STREAM_END || zs.avail_out != 0 || zs.avail_in != 0) {
+                                bad = 1;
+                                break;
+                            }
+                            const unsigned char *tail = f + b.at + b.csize - 8;
+                            const uint32_t want = (uint32_t)tail[0] | ((uint32_t)tail[1] << 8) | ((uint32_t)tail[2] << 16) | ((uint32_t)tail[3] << 24);
+                            if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)m.p + b.out, (uInt)b.isize) != want) {
+                                bad = 1;
+                                break;
+                            }
+                        }
+                    }
+                    inflateEnd(&zs);
+                };
+                std::vector<std::thread> th;
+                for (unsigned t = 1; t < T; t++) th.emplace_back(work);
+                work();
+                for (auto &x : th) x.join();
+                munmap((void *)f, csize);
+                ::close(fd);
+                if (bad.load()) {
+                    m.release();
+                    return yh::fail(std::string("corrupt gzip stream in ") + path);
+                }
+                out->data = m.p;
+                out->n = total;
+                out->cap = m.cap;
+                out->members = mem.size();
+                out->threads = T;
+                return 0;
+            }
+            munmap((void *)f, csize);
+            m.release();
+        }
+    }
+    ::close(fd);
+    // one stream: one thread, straight into the mapping
+    yh::InStream in;
+    if (in.open(path)) return 1;
+    uint64_t n = 0;
+    for (;;) {
+        if (!m.reserve((size_t)n + ((size_t)8 << 20) + 64)) {
+            m.release();
+            return yh::fail("out of memory while decompressing " + std::string(path));
+        }
+        const long k = in.read(m.p + n, (size_t)8 << 20);
+        if (k < 0) {
+            m.release();
+            return 1; // (message set by the decoder)
+        }
+        if (k == 0) break;
+        n += (uint64_t)k;
+    }
+    out->data = m.p;
+    out->n = n;
+    out->cap = m.cap;
+    out->members = 1;
+    out->threads = 1;
+    return 0;
+}
+
+void yacrd_text_free(yacrd_text *t)
+{
+    if (!t) return;
+    if (t->data) munmap(t->data, (size_t)t->cap);
+    std::memset(t, 0, sizeof(*t));
+}
+
+} // extern "C"

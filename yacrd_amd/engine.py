@@ -42,7 +42,7 @@ EXPORTED_SYMBOLS = [
     "yacrd_engine_submit", "yacrd_engine_collect", "yacrd_pinned_alloc", "yacrd_pinned_free",
     "yacrd_stream_open", "yacrd_stream_sink", "yacrd_stream_acquire", "yacrd_stream_commit",
     "yacrd_stream_finish", "yacrd_stream_last_stats", "yacrd_stream_reset", "yacrd_stream_close",
-    "yacrd_engine_ingest_paf", "yacrd_engine_ingest_overlaps", "yacrd_reads_free", "yacrd_engine_trim",
+    "yacrd_engine_ingest_paf", "yacrd_engine_ingest_overlaps", "yacrd_engine_ingest_overlaps_mem", "yacrd_reads_free", "yacrd_engine_trim",
     "yacrd_stream_device_of", "yacrd_stream_group_open", "yacrd_stream_group_sink", "yacrd_stream_group_finish",
     "yacrd_stream_group_last_stats", "yacrd_stream_group_reset", "yacrd_stream_group_close",
 ]
@@ -232,6 +232,9 @@ def load_library():
     lib.yacrd_engine_ingest_overlaps.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_uint32,
                                                  ctypes.c_double, ctypes.POINTER(_Result), ctypes.POINTER(_Reads),
                                                  ctypes.POINTER(_IngestStats)]
+    lib.yacrd_engine_ingest_overlaps_mem.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
+                                                     ctypes.c_uint32, ctypes.c_double, ctypes.POINTER(_Result), ctypes.POINTER(_Reads),
+                                                     ctypes.POINTER(_IngestStats)]
     lib.yacrd_engine_trim.argtypes = [ctypes.c_void_p]
     lib.yacrd_reads_free.argtypes = [ctypes.POINTER(_Reads)]
     lib.yacrd_reads_free.restype = None
@@ -417,6 +420,24 @@ class Engine:
         rc = self._lib.yacrd_engine_ingest_overlaps(self._h, os.fsencode(path), int(fmt), int(n_threads),
                                                     min(int(coverage), 0xFFFFFFFF), float(not_coverage), ctypes.byref(res),
                                                     ctypes.byref(rd), ctypes.byref(st))
+        return self._ingested(rc, res, rd, st)
+
+    def ingest_text(self, text, coverage, not_coverage, n_threads=0, fmt=1):
+        """yacrd_engine_ingest_overlaps_mem: the same over text in host memory — `text`: bytes, or (address, n_bytes) of
+        a buffer such as host.text_from_file's (a compressed overlap file, inflated)."""
+        res, rd, st = _Result(), _Reads(), _IngestStats()
+        if isinstance(text, tuple):
+            addr, n = int(text[0]), int(text[1])
+            keep = None
+        else:
+            keep = ctypes.create_string_buffer(bytes(text), len(text))
+            addr, n = ctypes.addressof(keep), len(text)
+        rc = self._lib.yacrd_engine_ingest_overlaps_mem(self._h, addr, n, int(fmt), int(n_threads), min(int(coverage), 0xFFFFFFFF),
+                                                        float(not_coverage), ctypes.byref(res), ctypes.byref(rd), ctypes.byref(st))
+        del keep
+        return self._ingested(rc, res, rd, st)
+
+    def _ingested(self, rc, res, rd, st):
         if rc == E_FALLBACK:
             raise NeedsHostParser(self._lib.yacrd_last_error().decode())
         _check(self._lib, rc)

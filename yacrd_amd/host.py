@@ -30,7 +30,7 @@ FMT_AUTO, FMT_PAF, FMT_M4 = 0, 1, 2
 EXPORTED_SYMBOLS = [
     "yacrd_host_last_error", "yacrd_csr_from_file", "yacrd_csr_from_memory", "yacrd_csr_get",
     "yacrd_csr_find", "yacrd_csr_free", "yacrd_report_write", "yacrd_synth_csr", "yacrd_synth_paf",
-    "yacrd_edit_file", "yacrd_edit_file_mt", "yacrd_report_read", "yacrd_report_get", "yacrd_report_free",
+    "yacrd_edit_file", "yacrd_edit_file_mt", "yacrd_text_from_file", "yacrd_text_free", "yacrd_report_read", "yacrd_report_get", "yacrd_report_free",
     "yacrd_synth_fastq", "yacrd_ingest_stream", "yacrd_ingest_stream_memory", "yacrd_csr_handle_map",
 ]
 
@@ -49,6 +49,45 @@ class _View(ctypes.Structure):
                 ("lengths", ctypes.POINTER(ctypes.c_uint32)),
                 ("name_off", ctypes.POINTER(ctypes.c_uint64)),
                 ("names", ctypes.POINTER(ctypes.c_char))]
+
+
+class _Text(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_void_p), ("n", ctypes.c_uint64), ("cap", ctypes.c_uint64), ("members", ctypes.c_uint64),
+                ("threads", ctypes.c_uint32), ("compression", ctypes.c_int32)]
+
+
+class Text:
+    """yacrd_text_from_file: a compressed (gzip / bzip2 / xz) file inflated into memory; .address / .n_bytes for
+    Engine.ingest_text, .bytes() for a copy; None from text_from_file when the file is not compressed."""
+
+    def __init__(self, lib, t):
+        self._lib, self._t = lib, t
+        self.address, self.n_bytes = int(t.data or 0), int(t.n)
+        self.members, self.threads, self.compression = int(t.members), int(t.threads), int(t.compression)
+
+    def bytes(self):
+        return ctypes.string_at(self.address, self.n_bytes) if self.n_bytes else b""
+
+    def close(self):
+        if self._t is not None:
+            self._lib.yacrd_text_free(ctypes.byref(self._t))
+            self._t = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+def text_from_file(path, n_threads=0):
+    lib = load_library()
+    t = _Text()
+    rc = lib.yacrd_text_from_file(os.fsencode(path), n_threads, ctypes.byref(t))
+    if rc == 2:
+        return None
+    _check(lib, rc)
+    return Text(lib, t)
 
 
 class _BadParts(ctypes.Structure):
@@ -112,6 +151,9 @@ def load_library():
         lib.yacrd_synth_fastq.argtypes = [ctypes.POINTER(_SynthCfg), ctypes.c_uint64, ctypes.c_char_p]
         lib.yacrd_edit_file.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p,
                                         ctypes.POINTER(_BadParts)]
+        lib.yacrd_text_from_file.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(_Text)]
+        lib.yacrd_text_free.argtypes = [ctypes.POINTER(_Text)]
+        lib.yacrd_text_free.restype = None
         lib.yacrd_edit_file_mt.argtypes = [ctypes.c_int, ctypes.c_char_p, ctypes.c_char_p,
                                            ctypes.POINTER(_BadParts), ctypes.c_int]
         lib.yacrd_report_read.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]

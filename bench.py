@@ -232,7 +232,7 @@ def resident_block(cx, label, profile, R, O, cov, nc, seed, jitter, steps, warmu
     d_len = torch.from_numpy(np.ascontiguousarray(ln).view(np.int32)).to(cx.dev)
     torch.cuda.synchronize()
     upload_s = time.perf_counter() - t0
-    eng = ya.Engine(device_id=cx.dev_index)  # every launch of the dominant kernel carries its events
+    eng = ya.Engine(device_id=cx.dev_index, flags=cx.args.flags)  # every launch of the dominant kernel carries its events
     ptrs = (d_off.data_ptr(), d_iv.data_ptr(), d_len.data_ptr(), Rl, Il, cov, nc)
     W, K = max(1, warmup), max(1, steps)
     for _ in range(W):
@@ -250,7 +250,7 @@ def resident_block(cx, label, profile, R, O, cov, nc, seed, jitter, steps, warmu
     G = int(res.n_regions)
     phases = None
     if cx.rank == 0:  # per-phase times: two extra passes with events around everything (never part of `value`)
-        with ya.Engine(device_id=cx.dev_index, flags=ya.F_TIMING_FULL) as fe:
+        with ya.Engine(device_id=cx.dev_index, flags=ya.F_TIMING_FULL | cx.args.flags) as fe:
             fe.run_device(*ptrs)
             fe.timing_total(reset=True)
             fe.run_device(*ptrs)
@@ -670,7 +670,7 @@ def main():
     ap.add_argument("--overlaps", type=int, default=0)
     ap.add_argument("--coverage", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--flags", type=int, default=0, help="extra YACRD_F_* engine flags for the small batches (A/B)")
+    ap.add_argument("--flags", type=int, default=0, help="extra YACRD_F_* engine flags (A/B)")
     ap.add_argument("--engines", type=int, default=3, help="engines (HIP streams) the small batches are pipelined over")
     ap.add_argument("--small-steps", type=int, default=500)
     ap.add_argument("--small-warmup", type=int, default=10)

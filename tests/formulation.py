@@ -502,7 +502,7 @@ def window_screen_regions(intervals, length, cov, nb, W):
     return ([(0, a)] if a != 0 else []) + ([(bb, length)] if bb != length else [])
 
 
-def slid_window_screen_regions(intervals, length, cov, nb, W, max_slides):
+def slid_window_screen_regions(intervals, length, cov, nb, W, max_slides, ramp_always=False):
     """window_screen_regions with windows that SLIDE (round 4): when the first W positions hold fewer than cov + 1
     starts (or the last W fewer than cov + 1 ends) — dovetail ends spread wider than the window — the screen is
     repeated with that window moved on by W, the events it has passed carried as a count: P starts in front of the
@@ -512,7 +512,9 @@ def slid_window_screen_regions(intervals, length, cov, nb, W, max_slides):
     (largest start <= pmax - t0 - W), so a coarse-counted start still has at least
     (P + window starts) + (coarse starts before its block) - (ends through its block) intervals open, a is where
     P + the window's running count reaches cov + 1 and b likewise from the top.  max_slides = 0 is
-    window_screen_regions.  Returns (regions, slides used) or None."""
+    window_screen_regions.  ramp_always: the starts between the head window and the read's smallest end count as
+    "already open" from the first pass on (the kernel's second look at a read whose window holds few starts), not
+    only after a slide.  Returns (regions, slides used) or None."""
     n = len(intervals)
     if n == 0:
         return ([(0, length)] if length != 0 else []), 0
@@ -537,10 +539,15 @@ def slid_window_screen_regions(intervals, length, cov, nb, W, max_slides):
         assert P <= cov and Q <= cov
         S, E = [0] * (nb + 1), [0] * (nb + 1)
         FH, FT = [0] * W, [0] * W
+        ramp = 0  # starts behind the head window but in front of the read's smallest end: nothing has been popped when
+        #           they arrive, the heap holds every start before them — more than cov once a has passed — so they are
+        #           never low and, like the window's starts, precede every coarse-counted start and every end
         for s, e in intervals:
             if s >= lo:
                 if s - lo < W:
                     FH[s - lo] += 1
+                elif (slide > 0 or ramp_always) and s < emin:
+                    ramp += 1
                 else:
                     S[min((s - lo) >> sh, nb)] += 1
             if e <= hi:
@@ -555,7 +562,7 @@ def slid_window_screen_regions(intervals, length, cov, nb, W, max_slides):
             h0 += W if F < cov + 1 else 0
             t0 += W if G < cov + 1 else 0
             continue
-        D = F
+        D = F + ramp
         for b in range(nb + 1):
             if S[b] > 0 and not (D - E[b] > cov):
                 return None

@@ -232,6 +232,10 @@ def test_slid_window_screen_matches_oracle():
                     assert got[0] == want, (iv, L, cov, nb, W, got)
                     fired[4] += 1
                     slid += got[1] > 0
+                ramp = slid_window_screen_regions(iv, L, cov, nb, W, 4, ramp_always=True)
+                assert ramp is None or ramp[0] == want, (iv, L, cov, nb, W, ramp)
+                if got is not None:  # (what the plain form decides the ramp form decides too: it only adds open intervals)
+                    assert ramp is not None
     assert fired[4] > fired[0] and slid > 100, (fired, slid)
 
 
@@ -245,8 +249,9 @@ def test_slid_window_screen_tiny_exhaustive():
                 for cov in range(0, 3):
                     want = oracle.compute_bad_part(list(iv), L, cov)
                     for nb, W in ((2, 1), (4, 1), (4, 2)):
-                        got = slid_window_screen_regions(list(iv), L, cov, nb, W, 3)
-                        assert got is None or got[0] == want, (iv, L, cov, nb, W, got)
+                        for ramp in (False, True):
+                            got = slid_window_screen_regions(list(iv), L, cov, nb, W, 3, ramp_always=ramp)
+                            assert got is None or got[0] == want, (iv, L, cov, nb, W, got)
 
 
 def test_window_screen_tiny_exhaustive():

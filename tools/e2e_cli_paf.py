@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/e2e_cli_paf.py [reads overlaps] — the drop-in CLI as a user runs it, cold process, PAF text in /dev/shm ->
-.yacrd report: wall time of `yacrd -i s.paf -o r.yacrd -c 3 -n 0.4 -t 0` (device parser) and of the same with
-YACRD_NO_DEVICE_PARSER=1 (the host parser; GPU box).  Reports compared line by line."""
+.yacrd report: wall time of `yacrd -i s.paf -o r.yacrd -c 3 -n 0.4` — the DEFAULT flags: no -t (round 4: the device parser's copy
+threads no longer follow -t) — and of the same with YACRD_NO_DEVICE_PARSER=1 -t 0 (the host parser on every CPU; GPU box).  Reports compared line by line."""
 import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -18,12 +18,12 @@ try:
     os.system("cat %s > /dev/null" % paf)  # (a freshly written /dev/shm file is slow to read the first time: 1.2 s for 15 GB)
     time.sleep(3)  # (the generator's burst on all CPUs: let the cgroup quota recover)
     outs = []
-    for label, env in (("device parser (default)", {}), ("host parser (YACRD_NO_DEVICE_PARSER=1)", {"YACRD_NO_DEVICE_PARSER": "1"})):
+    for label, env, extra in (("device parser (default flags)", {}, []), ("host parser (YACRD_NO_DEVICE_PARSER=1 -t 0)", {"YACRD_NO_DEVICE_PARSER": "1"}, ["-t", "0"])):
         out = os.path.join(d, "yacrd_cli_%d_%d.yacrd" % (os.getpid(), len(outs)))
         outs.append(out)
         for rep in range(2):
             t0 = time.perf_counter()
-            p = subprocess.run([exe, "-i", paf, "-o", out, "-c", "3", "-n", "0.4", "-t", "0"], env=dict(os.environ, **env),
+            p = subprocess.run([exe, "-i", paf, "-o", out, "-c", "3", "-n", "0.4"] + extra, env=dict(os.environ, **env),
                                capture_output=True, text=True)
             dt = time.perf_counter() - t0
             assert p.returncode == 0, p.stderr

@@ -251,11 +251,14 @@ __global__ __launch_bounds__(kScanBlock, YK_FINISH_OCC) void finish_compact_kern
 constexpr int kDeferSlab = 1024, kDeferThreads = 256;
 
 #ifndef YK_DEFER_SWEEP_OCC
-#define YK_DEFER_SWEEP_OCC 8 // wavefronts per SIMD the register budget allows (A/B: profiles/r04)
+#define YK_DEFER_SWEEP_OCC 6 // wavefronts per SIMD the register budget allows (8 / 6 / 5: 0.164 / 0.158 / 0.159 ms of follow-on time on configs[2], profiles/r04/c_ab_follow_on.log)
 #endif
 __global__ __launch_bounds__(kDeferThreads, YK_DEFER_SWEEP_OCC) void deferred_sweep_kernel(SweepArgs a, u32 n_reads)
 {
-    __shared__ u32 s_list[kDeferSlab]; // index inside the slab | intervals << 16: the long reads from the front, the others from the back
+    // what the thread that found the mark already knows about the read — offset, index inside the slab | intervals << 16,
+    // length — saves every turn a round trip: the long reads from the front, the others from the back
+    __shared__ u64 s_off[kDeferSlab];
+    __shared__ uint2 s_list[kDeferSlab];
     __shared__ u32 s_n8, s_n4;
     __shared__ unsigned long long s_iv;
     if (threadIdx.x == 0) s_n8 = 0, s_n4 = 0, s_iv = 0;
@@ -269,8 +272,13 @@ __global__ __launch_bounds__(kDeferThreads, YK_DEFER_SWEEP_OCC) void deferred_sw
         const bool marked = r < n_reads && a.counts[r] == kDeferredMark;
         const u64 mm = __builtin_amdgcn_ballot_w64(marked);
         if (mm == 0) continue; // (uniform in the wavefront)
-        u32 n = 0;
-        if (marked) n = (u32)(a.off[r + 1] - a.off[r]);
+        u32 n = 0, len0 = 0;
+        u64 o0 = 0;
+        if (marked) {
+            o0 = a.off[r];
+            n = (u32)(a.off[r + 1] - o0);
+            len0 = a.len[r];
+        }
         const bool big = marked && n > 128u; // (a marked read has at most 256 intervals)
         const u64 mb = __builtin_amdgcn_ballot_w64(big), ms = mm & ~mb;
         u32 bb = 0, bs = 0;
@@ -281,8 +289,12 @@ __global__ __launch_bounds__(kDeferThreads, YK_DEFER_SWEEP_OCC) void deferred_sw
         bb = (u32)__builtin_amdgcn_readlane((int)bb, (int)__builtin_ctzll(mm));
         bs = (u32)__builtin_amdgcn_readlane((int)bs, (int)__builtin_ctzll(mm));
         const u64 below = (1ull << lane) - 1ull;
-        if (big) s_list[bb + (u32)__builtin_popcountll(mb & below)] = i | (n << 16);
-        else if (marked) s_list[(u32)kDeferSlab - 1u - (bs + (u32)__builtin_popcountll(ms & below))] = i | (n << 16);
+        if (marked) {
+            const u32 at = big ? bb + (u32)__builtin_popcountll(mb & below)
+                               : (u32)kDeferSlab - 1u - (bs + (u32)__builtin_popcountll(ms & below));
+            s_list[at] = make_uint2(i | (n << 16), len0);
+            s_off[at] = o0;
+        }
         u64 iv = n; // intervals of the marked reads, for the roofline's exact byte count
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) iv += __shfl_xor(iv, d, 64);
@@ -299,10 +311,10 @@ __global__ __launch_bounds__(kDeferThreads, YK_DEFER_SWEEP_OCC) void deferred_sw
     // one read per wavefront and turn, the long ones (8 keys per lane) first: list position p < n8 is s_list[p],
     // p >= n8 is the (p - n8)-th entry from the back
     for (u32 p = threadIdx.x >> 6; p < n_marked; p += kWaves) { // (uniform in the wavefront)
-        const u32 e = p < n8 ? s_list[p] : s_list[(u32)kDeferSlab - 1u - (p - n8)];
-        const u32 rr = slab0 + (e & 0xFFFFu), n = e >> 16;
-        const u64 o = a.off[rr];
-        const u32 len = a.len[rr];
+        const u32 at = p < n8 ? p : (u32)kDeferSlab - 1u - (p - n8);
+        const uint2 e = s_list[at];
+        const u32 rr = slab0 + (e.x & 0xFFFFu), n = e.x >> 16, len = e.y;
+        const u64 o = s_off[at];
         if (n > 128u) finish_item<8>(a.off, a.iv, a.len, a.stage, a.counts, a.rej_list, a.rej_count, a.ctr, a.cov, rr, o, n, len);
         else finish_item<4>(a.off, a.iv, a.len, a.stage, a.counts, a.rej_list, a.rej_count, a.ctr, a.cov, rr, o, n, len);
     }

@@ -450,6 +450,9 @@ struct HealthyRead {
 #define YK_SCREEN_SLIDES 4
 #endif
 constexpr int kScreenSlides = YK_SCREEN_SLIDES;
+#ifndef YK_SLIDES_IN_ITEMS2
+#define YK_SLIDES_IN_ITEMS2 1 // (A/B: the two-items build of the screen without the second looks)
+#endif
 
 // The screen works on the raw positions (no event keys are made): v[j] = two intervals (x, y) and
 // (z, w) of this lane, real0[j] / real1[j] = whether those slots belong to the read (the others hold
@@ -471,9 +474,13 @@ constexpr int kScreenSlides = YK_SCREEN_SLIDES;
 // intervals), which leaves the upper bits of the coarse bins' scan for the two window indices.
 // SLID: pmin / pmax are the head window's first and the tail window's last position (the read's smallest start +
 // h0, its largest end - t0), events outside [pmin, pmax] are not counted, P / Q stand for them.
+// emin (SLID): the read's smallest end.  Starts behind the head window but in front of it — the RAMP — find nothing
+// popped yet and every earlier start still open: more than c once a has passed, so they are never low; they are
+// counted like the window's starts (open in front of every coarse-counted start), not into a coarse block.
 template <int LANES, int WPB, bool SLID = false>
 __device__ __forceinline__ bool healthy_screen(const uint4 (&v)[4], const bool (&real0)[4], const bool (&real1)[4],
-                                               u32 len, i32 c, u32 pmin, u32 pmax, HealthyRead &hr, u32 P = 0, u32 Q = 0)
+                                               u32 len, i32 c, u32 pmin, u32 pmax, HealthyRead &hr, u32 P = 0, u32 Q = 0,
+                                               u32 emin = 0)
 {
     constexpr int NB = LANES, W = kScreenWindow, NBIN = 2 * W + NB, GROUPS = 64 / LANES, PER = W / LANES,
                   ZPER = NBIN / LANES;
@@ -499,13 +506,16 @@ __device__ __forceinline__ bool healthy_screen(const uint4 (&v)[4], const bool (
     // out (counted into a bin of their own their atomics piled up on four addresses).
     const u32 cp = (lig & 3u) * 4u;
     u32 one = 1u, one_end = kEnd; // kept in registers (the compiler re-materialises them per atomic otherwise)
-    asm volatile("" : "+v"(one), "+v"(one_end));
+    if constexpr (!SLID) asm volatile("" : "+v"(one), "+v"(one_end)); // (the rare second look gives the two registers back)
+    u32 ramp = 0; // (SLID) this lane's starts between the head window and the read's smallest end
     auto count = [&](u32 s, u32 e, bool real) {
         const u32 ds = s - pmin, dx = e - pmin;
         const u32 is = min(ds, (u32)W) + (ds >> sh);
         const u32 ie = (dx >> sh) + __builtin_elementwise_sub_sat(dx, T) + (u32)W;
         if constexpr (SLID) { // (what the windows have passed is not counted: P and Q stand for it)
-            if (real && s >= pmin) atomicAdd(reinterpret_cast<u32 *>(tb + ((is << 4) + cp)), one);
+            const bool in_ramp = ds >= (u32)W && s < emin;
+            ramp += (real && s >= pmin && in_ramp) ? 1u : 0u;
+            if (real && s >= pmin && !in_ramp) atomicAdd(reinterpret_cast<u32 *>(tb + ((is << 4) + cp)), one);
             if (real && e <= pmax) atomicAdd(reinterpret_cast<u32 *>(tb + ((ie << 4) + cp)), one_end);
         } else if (real) {
             atomicAdd(reinterpret_cast<u32 *>(tb + ((is << 4) + cp)), one);
@@ -561,7 +571,9 @@ __device__ __forceinline__ bool healthy_screen(const uint4 (&v)[4], const bool (
     hr.F = F, hr.G = G;
     hr.a = pmin + ((wincl >> 20) & 63u); // (a window that never reaches c + 1 overflows these fields: F > c
     hr.b = pmax - (wincl >> 26);         // or G > c fails then)
-    const bool deep = xm == 0xFFFFFFFFu || (i32)(xm - 0x10000u) + F > c;
+    i32 open0 = F; // intervals open in front of every coarse-counted start
+    if constexpr (SLID) open0 += (i32)gscan_add<LANES>(ramp);
+    const bool deep = xm == 0xFFFFFFFFu || (i32)(xm - 0x10000u) + open0 > c;
     return deep && F > c && G > c;
 }
 
@@ -824,13 +836,15 @@ __device__ __forceinline__ void screen_block(const SweepArgs &a, u32 block)
         }
         HealthyRead hr;
         bool healthy = healthy_screen<LANES, 1>(v[t], real0, real1, len[t], c, pmin, pmax, hr) && !girr;
-        if constexpr (kScreenSlides > 0) {
+        if constexpr (kScreenSlides > 0 && (ITEMS == 1 || YK_SLIDES_IN_ITEMS2)) {
             // a window that came up short of c + 1 (verdict in the group's last lane): slide it (see kScreenSlides).
             // st = need | F << 1 | G << 11 of the last screen (counts clipped to their ten bits)
             auto state_of = [&](bool nd, const HealthyRead &h) {
                 return (nd ? 1u : 0u) | ((u32)min(max(h.F, 0), 1023) << 1) | ((u32)min(max(h.G, 0), 1023) << 11);
             };
-            u32 st = state_of(!healthy && !girr && (i32)n[t] > c && (hr.F <= c || hr.G <= c), hr);
+            // ... or one that holds so few of the read's starts (fewer than ~3 (c + 1): spread dovetails) that the depth
+            // test may have failed for want of the ramp: looked at once more where it stands, the ramp counted
+            u32 st = state_of(!healthy && !girr && (i32)n[t] > c && (hr.F <= 3 * c + 6 || hr.G <= c), hr);
             if (__builtin_amdgcn_ballot_w64((st & 1u) != 0 && lig == (u32)(LANES - 1)) != 0) { // (uniform in the wavefront; rare)
                 u32 emin = v[t][0].y, smax2 = v[t][0].x; // (re-derived here: kept from above they cost the common path registers)
 #pragma unroll
@@ -839,7 +853,8 @@ __device__ __forceinline__ void screen_block(const SweepArgs &a, u32 block)
                     smax2 = max(smax2, max(v[t][j].x, v[t][j].z));
                 }
                 // room in front of the smallest end / behind the largest start, in positions from pmin / pmax
-                const u32 room_h = (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)gscan_min<LANES>(emin)) - pmin;
+                const u32 gemin = (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)gscan_min<LANES>(emin));
+                const u32 room_h = gemin - pmin;
                 const u32 room_t = pmax - (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)gscan_max<LANES>(smax2));
                 u32 ht = 0, PQ = 0; // h0 | t0 << 16 (positions), P | Q << 16 (counts)
 #pragma unroll 1
@@ -860,7 +875,7 @@ __device__ __forceinline__ void screen_block(const SweepArgs &a, u32 block)
                     for (int j = 0; j < K / 4; j++) r0[j] = real0[j] && go, r1[j] = real1[j] && go;
                     wave_lds_sync(); // (the table is zeroed again)
                     HealthyRead h2;
-                    const bool ok2 = healthy_screen<LANES, 1, true>(v[t], r0, r1, len[t], c, pmin + h0, pmax - t0, h2, PQ & 0xFFFFu, PQ >> 16);
+                    const bool ok2 = healthy_screen<LANES, 1, true>(v[t], r0, r1, len[t], c, pmin + h0, pmax - t0, h2, PQ & 0xFFFFu, PQ >> 16, gemin);
                     st = go ? state_of(!ok2 && (h2.F <= c || h2.G <= c), h2) : 0u; // (meaningful in the group's last lane)
                     if (go) healthy = ok2, hr.a = h2.a, hr.b = h2.b;
                 }
@@ -1002,7 +1017,10 @@ __global__ __launch_bounds__(64 * kDeferWaves, kDeferOcc) void sweep_small_fused
     sweep_small_fused_body<true, kDeferWaves>(f);
 }
 // the same with two groups of list entries per wavefront in the screened classes (long launches from HBM)
-__global__ __launch_bounds__(64, kDeferOcc) void sweep_small_fused_defer2_kernel(FusedArgs f)
+#ifndef YK_DEFER2_OCC
+#define YK_DEFER2_OCC YK_DEFER_OCC
+#endif
+__global__ __launch_bounds__(64, YK_DEFER2_OCC) void sweep_small_fused_defer2_kernel(FusedArgs f)
 {
     sweep_small_fused_body<true, 1, 2>(f);
 }

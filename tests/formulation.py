@@ -502,55 +502,45 @@ def window_screen_regions(intervals, length, cov, nb, W):
     return ([(0, a)] if a != 0 else []) + ([(bb, length)] if bb != length else [])
 
 
-def slid_window_screen_regions(intervals, length, cov, nb, W, max_slides, ramp_always=False):
-    """window_screen_regions with windows that SLIDE (round 4): when the first W positions hold fewer than cov + 1
-    starts (or the last W fewer than cov + 1 ends) — dovetail ends spread wider than the window — the screen is
-    repeated with that window moved on by W, the events it has passed carried as a count: P starts in front of the
-    head window, Q ends behind the tail window.  Nothing else changes: in event order the read is
-    [P passed starts][head window][coarse blocks, re-based at the head window][tail window][Q passed ends], the passed
-    starts precede every end (smallest end >= pmin + h0 + W is required), the passed ends follow every start
-    (largest start <= pmax - t0 - W), so a coarse-counted start still has at least
-    (P + window starts) + (coarse starts before its block) - (ends through its block) intervals open, a is where
-    P + the window's running count reaches cov + 1 and b likewise from the top.  max_slides = 0 is
-    window_screen_regions.  ramp_always: the starts between the head window and the read's smallest end count as
-    "already open" from the first pass on (the kernel's second look at a read whose window holds few starts), not
-    only after a slide.  Returns (regions, slides used) or None."""
-    n = len(intervals)
-    if n == 0:
-        return ([(0, length)] if length != 0 else []), 0
-    if any(not (0 <= s < e <= length) for s, e in intervals) or length >= 2**30 - 1:
-        return None
-    if n <= cov:
-        return [(0, length)], 0
-    if n < 2:
-        return None
+def _sub_screen(intervals, length, cov, nb, W, lo0, hi0, P0, Q0, max_slides, ramp_always, s_hi=None, e_lo=None):
+    """The order-statistics screen over the events inside [lo0, hi0] of a read (starts and ends outside are not
+    counted; P0 starts in front of lo0 and Q0 ends behind hi0 are carried as counts: intervals open across the
+    border), with windows that slide by W up to max_slides times.  Returns (a, b, slides) — a: where P0 + the starts
+    counted upwards from lo0 reach cov + 1, b: where Q0 + the ends counted downwards from hi0 do — or None.
+    s_hi / e_lo: only starts below s_hi / ends from e_lo on belong to the sub-read (the halves of a read with a hole:
+    a start AT the hole's far side is the other half's, an end AT it this half's)."""
     sh = bin_shift(length, nb)
-    pmin = min(s for s, e in intervals)
-    pmax = max(e for s, e in intervals)
-    emin = min(e for s, e in intervals)
-    smax = max(s for s, e in intervals)
+    s_hi = hi0 + 1 if s_hi is None else s_hi
+    e_lo = lo0 if e_lo is None else e_lo
+    intervals = [(s if s < s_hi else 2**40, e if e >= e_lo else -1) for s, e in intervals]  # (out of every range below)
+    ends_in = [e for s, e in intervals if e >= lo0]
+    starts_in = [s for s, e in intervals if s <= hi0]
+    if not ends_in or not starts_in:
+        return None
+    emin, smax = min(ends_in), max(starts_in)
     h0 = t0 = 0
     for slide in range(max_slides + 1):
-        if emin - pmin < h0 + W or pmax - smax < t0 + W or (pmax - pmin) - h0 - t0 < 2 * W:
+        if emin - lo0 < h0 + W or hi0 - smax < t0 + W or (hi0 - lo0) - h0 - t0 < 2 * W:
             return None
-        lo, hi = pmin + h0, pmax - t0
-        P = sum(1 for s, e in intervals if s < lo)
-        Q = sum(1 for s, e in intervals if e > hi)
-        assert P <= cov and Q <= cov
+        lo, hi = lo0 + h0, hi0 - t0
+        P = P0 + sum(1 for s, e in intervals if lo0 <= s < lo)
+        Q = Q0 + sum(1 for s, e in intervals if hi < e <= hi0)
+        if P > cov or Q > cov:
+            return None
         S, E = [0] * (nb + 1), [0] * (nb + 1)
         FH, FT = [0] * W, [0] * W
-        ramp = 0  # starts behind the head window but in front of the read's smallest end: nothing has been popped when
-        #           they arrive, the heap holds every start before them — more than cov once a has passed — so they are
-        #           never low and, like the window's starts, precede every coarse-counted start and every end
+        ramp = 0  # starts behind the head window but in front of the smallest end: nothing has been popped when they
+        #           arrive, the heap holds every start before them — more than cov once a has passed — so they are never
+        #           low and, like the window's starts, precede every coarse-counted start and every end
         for s, e in intervals:
-            if s >= lo:
+            if lo <= s <= hi:
                 if s - lo < W:
                     FH[s - lo] += 1
                 elif (slide > 0 or ramp_always) and s < emin:
                     ramp += 1
                 else:
                     S[min((s - lo) >> sh, nb)] += 1
-            if e <= hi:
+            if lo <= e <= hi:
                 if hi - e < W:
                     FT[hi - e] += 1
                 else:
@@ -579,8 +569,247 @@ def slid_window_screen_regions(intervals, length, cov, nb, W, max_slides, ramp_a
             if acc >= cov + 1:
                 bb = hi - i
                 break
-        return ([(0, a)] if a != 0 else []) + ([(bb, length)] if bb != length else []), slide
+        return a, bb, slide
     return None
+
+
+def slid_window_screen_regions(intervals, length, cov, nb, W, max_slides, ramp_always=False):
+    """window_screen_regions with windows that SLIDE (round 4): when the first W positions hold fewer than cov + 1
+    starts (or the last W fewer than cov + 1 ends) — dovetail ends spread wider than the window — the screen is
+    repeated with that window moved on by W, the events it has passed carried as a count: P starts in front of the
+    head window, Q ends behind the tail window.  Nothing else changes: in event order the read is
+    [P passed starts][head window][coarse blocks, re-based at the head window][tail window][Q passed ends], the passed
+    starts precede every end (smallest end >= pmin + h0 + W is required), the passed ends follow every start
+    (largest start <= pmax - t0 - W), so a coarse-counted start still has at least
+    (P + window starts) + (coarse starts before its block) - (ends through its block) intervals open, a is where
+    P + the window's running count reaches cov + 1 and b likewise from the top.  max_slides = 0 is
+    window_screen_regions.  ramp_always: the starts between the head window and the read's smallest end count as
+    "already open" from the first pass on (the kernel's second look at a read whose window holds few starts), not
+    only after a slide.  Returns (regions, slides used) or None."""
+    n = len(intervals)
+    if n == 0:
+        return ([(0, length)] if length != 0 else []), 0
+    if any(not (0 <= s < e <= length) for s, e in intervals) or length >= 2**30 - 1:
+        return None
+    if n <= cov:
+        return [(0, length)], 0
+    if n < 2:
+        return None
+    pmin = min(s for s, e in intervals)
+    pmax = max(e for s, e in intervals)
+    r = _sub_screen(intervals, length, cov, nb, W, pmin, pmax, 0, 0, max_slides, ramp_always)
+    if r is None:
+        return None
+    a, bb, slide = r
+    return ([(0, a)] if a != 0 else []) + ([(bb, length)] if bb != length else []), slide
+
+
+def hole_screen_regions(intervals, length, cov, nb, W, max_slides, nbf=64):
+    """The OTHER closed form (round 4): a read whose coverage drops to cov or less in ONE stretch inside — what a
+    chimera looks like, the reads yacrd exists to find.  If a position sp inside the stretch has no event in
+    [sp, sp + w) and at most cov intervals across it, the read falls into the intervals that end before sp (L), those
+    that start behind it (R) and k <= cov that span it; with hiL = the largest end below sp, loR = the smallest start
+    at or above it and no event strictly between the two, the reference's sweep (src/stack.rs:61-139) does on L and
+    the k spanning intervals what it does on a healthy read whose last k intervals never end — its tail stops at
+    x = where the ends counted down from hiL, the k included, reach cov + 1 (the pops from there on leave cov or
+    fewer in the heap: not flagged, :77-79) — then finds the heap at k when R's first start arrives, opens a gap
+    (x, s) at each of R's first cov + 1 - k starts (:83-89; merged by equal begin, :119-136, to (x, y) with y where
+    the starts counted up from loR, the k included, reach cov + 1) and goes on as on a healthy read: the regions are
+    (0, a), (x, y), (b, len).  Both halves are the sub-read screen (_sub_screen) with the spanning intervals carried.
+    How loR is found (what the kernel can do without a sort): coarse blocks of 2^sh positions from the smallest
+    start; the first block, behind a block whose depth bound exceeds cov, whose bound does not; nbf sub-bins over that
+    block and the next; the first sub-bin that holds a start and whose depth bound (its own ends taken first) is <= cov;
+    its smallest start.  Everything else follows from loR: L = the intervals that end at or before it, R = those that
+    start at or behind it, the k others span it.  A wrong guess costs nothing but the closed form: k > cov, or one of
+    the two halves fails its screen.  Returns the regions or None."""
+    n = len(intervals)
+    if n < 2 or n <= cov or any(not (0 <= s < e <= length) for s, e in intervals) or length >= 2**30 - 1:
+        return None
+    sh = bin_shift(length, nb)
+    pmin = min(s for s, e in intervals)
+    pmax = max(e for s, e in intervals)
+    S, E = [0] * (nb + 2), [0] * (nb + 2)
+    for s, e in intervals:
+        S[min((s - pmin) >> sh, nb + 1)] += 1
+        E[min((e - pmin) >> sh, nb + 1)] += 1
+    seen_deep, istar, sb, eb = False, None, 0, 0
+    for i in range(nb + 2):
+        x = sb - (eb + E[i])  # starts before block i - ends through it
+        if x > cov:
+            seen_deep = True
+        elif seen_deep:
+            istar = i
+            break
+        sb += S[i]
+        eb += E[i]
+    if istar is None:
+        return None
+    B0 = pmin + (istar << sh)
+    w = max(1, (2 << sh) // nbf)
+    FS, FE = [0] * nbf, [0] * nbf
+    D0 = 0
+    for s, e in intervals:
+        if s < B0:
+            D0 += 1
+        elif (s - B0) // w < nbf:
+            FS[(s - B0) // w] += 1
+        if e < B0:
+            D0 -= 1
+        elif (e - B0) // w < nbf:
+            FE[(e - B0) // w] += 1
+    jstar, D = None, D0
+    for j in range(nbf):
+        if FS[j] > 0 and D - FE[j] <= cov:  # a start that may find cov or fewer intervals open
+            jstar = j
+            break
+        D += FS[j] - FE[j]
+    if jstar is None:
+        return None
+    loR = min(s for s, e in intervals if s >= B0 and (s - B0) // w == jstar)  # R = the intervals that start at or behind it
+    Lends = [e for s, e in intervals if e <= loR]  # (an end AT loR is popped before that start is looked at, :72-81)
+    if not Lends:
+        return None
+    hiL = max(Lends)
+    k = sum(1 for s, e in intervals if s < loR < e)
+    if k > cov:
+        return None
+    if any(hiL < s < loR for s, e in intervals):
+        return None  # a spanning interval that starts after L's last end: it would arrive at a heap already drained
+    left = _sub_screen(intervals, length, cov, nb, W, pmin, hiL, 0, k, max_slides, True, s_hi=loR)
+    if left is None:
+        return None
+    right = _sub_screen(intervals, length, cov, nb, W, loR, pmax, k, 0, max_slides, True, e_lo=loR + 1)
+    if right is None:
+        return None
+    a, x, _ = left
+    y, bb, _ = right
+    return ([(0, a)] if a != 0 else []) + [(x, y)] + ([(bb, length)] if bb != length else [])
+
+
+def hole_fast_regions(intervals, length, cov, nb, W, nbf=64):
+    """hole_screen_regions the way sweep_wave.h computes it (round 4): no second screen of the two halves — a and b,
+    the windows' counts F and G and the coarse blocks' depth bounds are the FIRST screen's (window_screen_regions: it
+    found them and failed on the depth test of some block), and what the hole adds is looked at where it lies:
+      1. istar = the first coarse block whose bound fails; only it and its successor may fail;
+      2. nbf sub-bins over those two blocks, the depth D0 in front of them (> cov required: the hole lies behind the
+         covered part) carried through them; jstar = the first sub-bin with a start whose bound (its own ends first)
+         is <= cov; loR = its smallest start;
+      3. hiL = the largest end at or before loR, k = the intervals across loR (<= cov), no start between hiL and loR;
+      4. x from W one-position bins downwards from hiL (k carried; no start of the left half inside them),
+         y from W one-position bins upwards from loR (k carried; no end inside them);
+      5. behind jstar every sub-bin that may hold a start at or behind the right half's smallest end must be deep
+         again (the starts in front of that end are the ramp: nothing popped yet).
+    Returns the regions or None."""
+    n = len(intervals)
+    if n < 2 or n <= cov or any(not (0 <= s < e <= length) for s, e in intervals) or length >= 2**30 - 1:
+        return None
+    sh = bin_shift(length, nb)
+    sh = max(sh, (W - 1).bit_length())  # blocks of at least W positions, like the kernel
+    pmin = min(s for s, e in intervals)
+    pmax = max(e for s, e in intervals)
+    if min(e - s for s, e in intervals) < W or pmax - pmin < 2 * W:
+        return None
+    span, T = pmax - pmin, pmax - pmin - W
+    NBIN = 2 * W + nb
+    FH, FT = [0] * W, [0] * W
+    CS, CE = [0] * NBIN, [0] * NBIN
+    for s, e in intervals:
+        ds, dx = s - pmin, e - pmin
+        if ds < W:
+            FH[ds] += 1
+        else:
+            CS[min(W + (ds >> sh), NBIN - 1)] += 1
+        if span - dx < W:
+            FT[span - dx] += 1
+        CE[min(W + (dx >> sh) + max(dx - T, 0), NBIN - 1)] += 1
+    F, G = sum(FH), sum(FT)
+    if F < cov + 1 or G < cov + 1:
+        return None
+    acc, a = 0, None
+    for i in range(W):
+        acc += FH[i]
+        if acc >= cov + 1:
+            a = pmin + i
+            break
+    acc, bb = 0, None
+    for i in range(W):
+        acc += FT[i]
+        if acc >= cov + 1:
+            bb = pmax - i
+            break
+    # 1. the coarse blocks' bounds (bins W .. W + nb - 1)
+    failing, sb, eb = [], 0, 0
+    for i in range(nb):
+        eb += CE[W + i]
+        if CS[W + i] > 0 and not (F + sb - eb > cov):
+            failing.append(i)
+        sb += CS[W + i]
+    if not failing or failing[0] == 0 or any(i > failing[0] + 1 for i in failing):
+        return None
+    istar = failing[0]
+    # 2. sub-bins over blocks istar, istar + 1
+    B0 = pmin + (istar << sh)
+    fsh = sh + 1 - (nbf.bit_length() - 1)
+    if fsh < 0:
+        return None
+    FS, FE = [0] * nbf, [0] * nbf
+    D0 = 0
+    for s, e in intervals:
+        if s < B0:
+            D0 += 1
+        elif (s - B0) >> fsh < nbf:
+            FS[(s - B0) >> fsh] += 1
+        if e < B0:
+            D0 -= 1
+        elif (e - B0) >> fsh < nbf:
+            FE[(e - B0) >> fsh] += 1
+    if D0 <= cov:
+        return None
+    jstar, D, Dj = None, D0, [0] * nbf
+    for j in range(nbf):
+        Dj[j] = D
+        if jstar is None and FS[j] > 0 and D - FE[j] <= cov:
+            jstar = j
+        D += FS[j] - FE[j]
+    if jstar is None:
+        return None
+    loR = min(s for s, e in intervals if s >= B0 and (s - B0) >> fsh == jstar)
+    # 3.
+    Lends = [e for s, e in intervals if e <= loR]
+    if not Lends:
+        return None
+    hiL = max(Lends)
+    k = sum(1 for s, e in intervals if s < loR < e)
+    if k > cov or any(hiL < s < loR for s, e in intervals):
+        return None
+    # 4. the two windows at the hole
+    if any(hiL - W < s < loR for s, e in intervals):  # a start of the left half inside its tail window
+        return None
+    emin_r = min([e for s, e in intervals if e > loR] or [None])
+    if emin_r is None or emin_r - loR < W:  # an end inside the right half's head window
+        return None
+    acc, x = k, None
+    for d in range(W):
+        acc += sum(1 for s, e in intervals if e == hiL - d)
+        if acc >= cov + 1:
+            x = hiL - d
+            break
+    acc, y = k, None
+    for d in range(W):
+        acc += sum(1 for s, e in intervals if s == loR + d)
+        if acc >= cov + 1:
+            y = loR + d
+            break
+    if x is None or y is None:
+        return None
+    # 5. behind the hole: the ramp (starts in front of the right half's smallest end), then deep again
+    if B0 + ((jstar + 1) << fsh) - 1 >= emin_r:  # the sub-bin of loR reaches the right half's smallest end
+        return None
+    for j in range(jstar + 1, nbf):
+        last = B0 + ((j + 1) << fsh) - 1
+        if FS[j] > 0 and last >= emin_r and not (Dj[j] - FE[j] > cov):
+            return None
+    return ([(0, a)] if a != 0 else []) + [(x, y)] + ([(bb, length)] if bb != length else [])
 
 
 def unified_screen_regions(intervals, length, cov, nb, W):

@@ -317,3 +317,101 @@ def test_unified_screen_tiny_exhaustive():
                     for nb, W in ((2, 1), (4, 1), (4, 2), (8, 3)):
                         got = unified_screen_regions(list(iv), L, cov, nb, W)
                         assert got is None or got == want, (iv, L, cov, nb, W)
+
+
+def _survey_read(rng, n, L, jitter):
+    """SURVEY.md 8d's shape: 60 % dovetails anchored within N(0, jitter) of one end (reflected into the read), 40 %
+    internal, every interval at least min(500, L / 4) long."""
+    lo = max(1, min(500, L // 4))
+    iv = []
+    for _ in range(n):
+        if rng.random() < 0.6:
+            ell = lo + int(rng.integers(0, max(1, int(0.8 * L) - lo)))
+            j = abs(int(round(jitter * rng.normal())))
+            if rng.random() < 0.5:
+                s, e = j, j + ell
+            else:
+                e = L - j
+                s = e - ell
+        else:
+            ell = lo + int(rng.integers(0, max(1, L // 2 - lo)))
+            s = int(rng.integers(0, max(1, L - ell)))
+            e = s + ell
+        s = min(max(s, 0), L - 1)
+        e = min(max(e, s + 1), L)
+        iv.append((s, e))
+    return iv
+
+
+def _chimera_read(rng, n, L, jitter, base=None):
+    """SURVEY.md 8d's chimera: a junction j; every interval that crosses it is cut back to the side holding its
+    midpoint, 10..100 positions short of j — here also with a few intervals left spanning, gaps of any width and
+    intervals ending / starting exactly at the junction."""
+    iv = (base or _pile_read)(rng, n, L, jitter)
+    j = int(rng.integers(max(1, L // 5), max(2, 4 * L // 5)))
+    span_left = int(rng.integers(0, 4)) if rng.random() < 0.5 else 0
+    out = []
+    for s, e in iv:
+        if s < j < e:
+            if span_left > 0 and rng.random() < 0.1:
+                span_left -= 1
+                out.append((s, e))
+                continue
+            gap = int(rng.integers(0, 100)) if rng.random() < 0.8 else 0
+            if (s + e) // 2 < j:
+                e = max(s + 1, j - gap)
+            else:
+                s = min(e - 1, j + gap)
+        out.append((s, e))
+    return out
+
+
+def test_hole_screen_matches_oracle():
+    """Round 4: the closed form for a read with ONE stretch of low coverage inside (formulation.hole_screen_regions):
+    wherever it decides it equals the oracle — chimeras with gaps of any width, intervals left spanning the junction,
+    spread piles, coarse grids — and it decides most of the generator's chimeras."""
+    from formulation import hole_fast_regions, hole_screen_regions, slid_window_screen_regions
+    rng = np.random.default_rng(90210)
+    fired = total = decided = decided_fast = 0
+    for it in range(2500):
+        L = int(rng.integers(50, 600)) if it % 5 == 0 else int(rng.integers(600, 60000))
+        n = int(rng.integers(2, 40)) if it % 4 == 0 else int(rng.integers(40, 256))
+        jitter = (0.0, 5.0, 30.0, 100.0)[it % 4]
+        base = _survey_read if it % 2 else _pile_read
+        iv = _chimera_read(rng, n, L, jitter, base) if it % 3 else base(rng, n, L, jitter)
+        if it % 13 == 0:
+            g = max(1, L // 16)
+            iv = [(min((s // g) * g, L - 1), min(max((e // g) * g, (s // g) * g + 1), L)) for s, e in iv]
+            iv = [(s, max(e, s + 1)) for s, e in iv]
+        for cov in (0, 1, 3, 4, 9):
+            want = oracle.compute_bad_part(iv, L, cov)
+            for nb, W in ((16, 32), (32, 32), (16, 8), (4, 4)):
+                got = hole_screen_regions(iv, L, cov, nb, W, 4)
+                assert got is None or got == want, (iv, L, cov, nb, W, got, want)
+                decided += got is not None
+                fast = hole_fast_regions(iv, L, cov, nb, W)
+                assert fast is None or fast == want, (iv, L, cov, nb, W, fast, want)
+                decided_fast += fast is not None
+                if it % 3 and it % 2 and nb >= 16 and W == 32 and cov in (3, 4) and L >= 4000 and n >= 80 and it % 13:
+                    total += 1
+                    fired += got is not None or slid_window_screen_regions(iv, L, cov, nb, W, 4, True) is not None
+    assert fired > total * 8 // 10 and decided > 3000 and decided_fast > 1500, (fired, total, decided, decided_fast)
+
+
+def test_hole_screen_tiny_exhaustive():
+    import itertools
+    from formulation import hole_fast_regions, hole_screen_regions
+    for L in range(2, 9):
+        pairs = [(s, e) for s in range(L + 1) for e in range(s + 1, L + 1)]
+        for k in range(2, 5):
+            for iv in itertools.combinations_with_replacement(pairs, k):
+                if k == 4 and (sum(a for a, b in iv) + L) % 3:
+                    continue  # (a third of the quadruples)
+                for cov in range(0, 3):
+                    want = oracle.compute_bad_part(list(iv), L, cov)
+                    for nb, W, nbf in ((4, 1, 8), (2, 1, 4), (4, 2, 64)):
+                        got = hole_screen_regions(list(iv), L, cov, nb, W, 2, nbf)
+                        assert got is None or got == want, (iv, L, cov, nb, W, got, want)
+                    for nb, W, nbf in ((4, 1, 8), (2, 1, 4), (2, 2, 8)):
+                        got = hole_fast_regions(list(iv), L, cov, nb, W, nbf)
+                        assert got is None or got == want, (iv, L, cov, nb, W, nbf, got, want)

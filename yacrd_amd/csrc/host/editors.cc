@@ -75,8 +75,10 @@ struct Reader {
         return 0;
     }
     // a range of memory as the whole input (the multi-threaded editors: one chunk of a mapped file)
+    bool memory = false;
     void open_memory(const char *p, size_t n)
     {
+        memory = true;
         buf = p;
         pos = 0;
         end = n;
@@ -215,11 +217,15 @@ struct BadParts {
     // get_bad_part + type: unknown id -> (empty, 0, NotBad)
     void get(const std::string &id, const uint32_t *&reg, size_t &n, uint32_t &len, int &type) const
     {
+        get(id.data(), id.size(), reg, n, len, type);
+    }
+    void get(const char *id, size_t id_len, const uint32_t *&reg, size_t &n, uint32_t &len, int &type) const
+    {
         uint32_t r = kEmpty;
-        for (uint64_t s = yh::hash_bytes(id.data(), id.size()) & mask;; s = (s + 1) & mask) {
+        for (uint64_t s = yh::hash_bytes(id, id_len) & mask;; s = (s + 1) & mask) {
             const uint32_t cur = slots[s].load(std::memory_order_relaxed);
             if (cur == kEmpty) break;
-            if (same(cur, id.data(), id.size())) {
+            if (same(cur, id, id_len)) {
                 r = cur;
                 break;
             }
@@ -244,21 +250,6 @@ struct SeqRecord {
     std::string name, desc, seq, qual;
 };
 
-void write_fastq(Writer &w, const std::string &name, const std::string &desc, const char *seq,
-                 const char *qual, size_t n)
-{
-    w.put('@');
-    w.put(name);
-    if (!desc.empty()) {
-        w.put(' ');
-        w.put(desc);
-    }
-    w.put('\n');
-    w.put(seq, n);
-    w.put("\n+\n", 3);
-    w.put(qual, n);
-    w.put('\n');
-}
 void write_fasta(Writer &w, const std::string &name, const std::string &desc, const char *seq,
                  size_t n)
 {
@@ -367,33 +358,98 @@ void cut_positions(int op, const uint32_t *reg, size_t n, uint32_t len, std::vec
     }
 }
 
+// A record as views (into a chunk of the mapped file, or into a SeqRecord's strings).
+struct RecView {
+    const char *name, *desc, *seq, *qual;
+    size_t name_len, desc_len, n;
+    const char *raw = nullptr; // the whole record as it stands in the input, when that IS what write_fastq would write
+    size_t raw_len = 0;
+};
+
+// The next FASTQ record of a memory range WITHOUT copying it, when it is in the canonical form the writer produces —
+// "@name[ desc]\nseq\n+\nqual\n", no CR, a bare '+' line, a description that is not empty when a blank follows the
+// name — which is what every FASTQ this tool has written, and nearly every one it reads, looks like.  false = not at
+// such a record (blank lines, CRLF, "+name" lines, the file's last line without a newline, anything malformed): the
+// caller takes next_fastq, which owns the reference's rules and errors.
+bool fast_fastq(Reader &r, RecView &v)
+{
+    if (!r.memory) return false;
+    const char *p = r.buf + r.pos, *end = r.buf + r.end;
+    if (p >= end || *p != '@') return false;
+    const char *l1 = (const char *)std::memchr(p, '\n', (size_t)(end - p));
+    if (!l1 || l1 == p + 1 || l1[-1] == '\r') return false;
+    const char *seq = l1 + 1;
+    const char *l2 = seq < end ? (const char *)std::memchr(seq, '\n', (size_t)(end - seq)) : nullptr;
+    if (!l2 || (l2 > seq && l2[-1] == '\r')) return false;
+    const char *plus = l2 + 1;
+    if (plus + 1 >= end || plus[0] != '+' || plus[1] != '\n') return false;
+    const char *qual = plus + 2;
+    const char *l4 = qual < end ? (const char *)std::memchr(qual, '\n', (size_t)(end - qual)) : nullptr;
+    if (!l4 || (l4 > qual && l4[-1] == '\r') || l4 - qual != l2 - seq) return false;
+    const char *sp = (const char *)std::memchr(p + 1, ' ', (size_t)(l1 - p - 1));
+    if (sp && sp + 1 == l1) return false; // "name " : the writer drops the blank
+    v.name = p + 1;
+    v.name_len = (size_t)((sp ? sp : l1) - (p + 1));
+    v.desc = sp ? sp + 1 : l1;
+    v.desc_len = sp ? (size_t)(l1 - sp - 1) : 0;
+    v.seq = seq;
+    v.qual = qual;
+    v.n = (size_t)(l2 - seq);
+    v.raw = p;
+    v.raw_len = (size_t)(l4 + 1 - p);
+    r.pos = (size_t)(l4 + 1 - r.buf);
+    return true;
+}
+
+void put_fastq(Writer &w, const char *name, size_t name_len, const char *suffix, size_t suffix_len, const char *desc, size_t desc_len,
+               const char *seq, const char *qual, size_t n)
+{
+    w.put('@');
+    w.put(name, name_len);
+    w.put(suffix, suffix_len);
+    if (desc_len) {
+        w.put(' ');
+        w.put(desc, desc_len);
+    }
+    w.put('\n');
+    w.put(seq, n);
+    w.put("\n+\n", 3);
+    w.put(qual, n);
+    w.put('\n');
+}
+
 int edit_sequences(int op, bool fastq, Reader &in, Writer &out, const BadParts &bp)
 {
     SeqRecord rec;
-    std::string err, key, piece;
+    std::string err;
     std::vector<uint32_t> poss;
+    char suffix[48];
     for (;;) {
-        const bool ok = fastq ? next_fastq(in, rec, err) : next_fasta(in, rec, err);
-        if (!ok) {
-            if (in.failed) return 1; // message set by the decoder
-            if (!err.empty()) return yh::fail(err);
-            break;
+        RecView v;
+        if (!(fastq && fast_fastq(in, v))) {
+            const bool ok = fastq ? next_fastq(in, rec, err) : next_fasta(in, rec, err);
+            if (!ok) {
+                if (in.failed) return 1; // message set by the decoder
+                if (!err.empty()) return yh::fail(err);
+                break;
+            }
+            v = RecView{rec.name.data(), rec.desc.data(), rec.seq.data(), rec.qual.data(), rec.name.size(), rec.desc.size(), rec.seq.size()};
         }
         // FASTQ: first whitespace token of the name (scrubbing.rs:174-179); FASTA: the name
-        key = rec.name;
+        size_t key_len = v.name_len;
         if (fastq) {
-            size_t i = 0;
-            while (i < key.size() && !is_ws(key[i])) i++;
-            key.resize(i);
+            key_len = 0;
+            while (key_len < v.name_len && !is_ws(v.name[key_len])) key_len++;
         }
         const uint32_t *reg;
         size_t n;
         uint32_t len;
         int type;
-        bp.get(key, reg, n, len, type);
+        bp.get(v.name, key_len, reg, n, len, type);
         auto copy = [&]() {
-            if (fastq) write_fastq(out, rec.name, rec.desc, rec.seq.data(), rec.qual.data(), rec.seq.size());
-            else write_fasta(out, rec.name, rec.desc, rec.seq.data(), rec.seq.size());
+            if (v.raw) out.put(v.raw, v.raw_len);
+            else if (fastq) put_fastq(out, v.name, v.name_len, "", 0, v.desc, v.desc_len, v.seq, v.qual, v.n);
+            else write_fasta(out, std::string(v.name, v.name_len), std::string(v.desc, v.desc_len), v.seq, v.n);
         };
         if (op == OP_FILTER) {
             if (type == 0) copy();
@@ -412,20 +468,20 @@ int edit_sequences(int op, bool fastq, Reader &in, Writer &out, const BadParts &
         cut_positions(op, reg, n, len, poss, first);
         for (size_t k = first; k + 1 < poss.size(); k += 2) {
             const uint32_t p0 = poss[k], p1 = poss[k + 1];
-            if (p0 > rec.seq.size() || p1 > rec.seq.size()) {
+            if (p0 > v.n || p1 > v.n) {
                 std::fprintf(stderr,
-                             "[ERROR] For read %s %s position is larger than read, it's strange check "
+                             "[ERROR] For read %.*s %s position is larger than read, it's strange check "
                              "your data. For this read, this split position and next are ignore.\n",
-                             rec.name.c_str(), op == OP_SCRUBB ? "scrubb" : "split");
+                             (int)v.name_len, v.name, op == OP_SCRUBB ? "scrubb" : "split");
                 break;
             }
             if (p0 > p1) // the reference panics on seq[p0..p1] with p0 > p1
-                return yh::fail("bad region with begin > end while cutting read " + rec.name);
-            piece = rec.name + "_" + std::to_string(p0) + "_" + std::to_string(p1);
+                return yh::fail("bad region with begin > end while cutting read " + std::string(v.name, v.name_len));
+            const int sl = std::snprintf(suffix, sizeof suffix, "_%u_%u", p0, p1);
             if (fastq)
-                write_fastq(out, piece, rec.desc, rec.seq.data() + p0, rec.qual.data() + p0, p1 - p0);
+                put_fastq(out, v.name, v.name_len, suffix, (size_t)sl, v.desc, v.desc_len, v.seq + p0, v.qual + p0, p1 - p0);
             else
-                write_fasta(out, piece, std::string(), rec.seq.data() + p0, p1 - p0);
+                write_fasta(out, std::string(v.name, v.name_len) + suffix, std::string(), v.seq + p0, p1 - p0);
         }
     }
     return 0;

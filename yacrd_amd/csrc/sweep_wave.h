@@ -451,7 +451,11 @@ struct HealthyRead {
 #endif
 constexpr int kScreenSlides = YK_SCREEN_SLIDES;
 #ifndef YK_SLIDES_IN_ITEMS2
-#define YK_SLIDES_IN_ITEMS2 1 // (A/B: the two-items build of the screen without the second looks)
+// The two-items build of the screen (long launches from HBM: sweep_small_fused_defer2_kernel) keeps the single look: with
+// two items' intervals live the second looks' registers push it over its budget (a spilled load at its very start, or
+// occupancy 5: 0.625 -> 0.66 ms on configs[2]), and the Sequel-depth reads it is quoted on gain nothing from them
+// (97.6 % decided at sigma = 100 and 300 either way: profiles/r04/d_ab_screen_slides_occupancy.log).
+#define YK_SLIDES_IN_ITEMS2 0
 #endif
 
 // The screen works on the raw positions (no event keys are made): v[j] = two intervals (x, y) and

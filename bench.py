@@ -666,6 +666,8 @@ def main():
     ap.add_argument("--jitter", type=int, default=0,
                     help="headline input from the generator that reflects the dovetail ends' offsets into the read "
                          "(YACRD_SYNTH_F_JITTER), sigma = this many positions (SURVEY.md 8d's is 30)")
+    ap.add_argument("--chimeras", type=int, default=0,
+                    help="with --weak: per cent of the reads that are chimeras (YACRD_SYNTH_F_CHIMERA_PCT; SURVEY.md 8d's is 2)")
     ap.add_argument("--reads", type=int, default=0, help="override the headline's (or, with --weak, the batch's) read count")
     ap.add_argument("--overlaps", type=int, default=0)
     ap.add_argument("--coverage", type=int, default=None)
@@ -702,7 +704,7 @@ def main():
             args.small_steps = args.steps
         if args.warmup != ap.get_default("warmup"):
             args.small_warmup = args.warmup
-        head, keep_small = small_batches_block(cx, args.jitter)
+        head, keep_small = small_batches_block(cx, args.jitter, args.chimeras)
         scaling = "weak"
     elif args.config == 1:
         ap.error("configs[1] is the --weak headline (batches of 100 k reads); --config takes 2, 3 or 4")

@@ -719,3 +719,52 @@ def test_fused_defer_build(cov):
         with yacrd_amd.Engine(flags=flags) as e:
             assert_same(e.run(*csr, cov, 0.4), want, "cases flags %d" % flags)
             assert_same(e.run(*csr, cov, 0.4), want, "cases flags %d, predicted run" % flags)
+
+
+@pytest.mark.parametrize("prof,cov", [(0, 4), (1, 3), (1, 0), (0, 9)])
+def test_hole_closed_form_on_chimeras(prof, cov):
+    """Round 4: a read with ONE stretch of low coverage inside — a chimera — gets its three regions in closed form
+    from the screen (sweep_wave.h: hole_form; tests/formulation.py::hole_fast_regions is the emulation).  30 % chimeras,
+    clamped and spread piles, both builds of the screen: bit-exact, and most chimeras no longer reach the sort."""
+    from yacrd_amd import host
+    R, O = (6000, 300000) if prof == 0 else (3000, 300000)
+    for sflags in (host.synth_f_chimera_pct(30), host.SYNTH_F_JITTER | host.synth_f_chimera_pct(30),
+                   host.SYNTH_F_JITTER | host.synth_f_sigma(100) | host.synth_f_chimera_pct(30)):
+        o, iv, ln = host.synth_csr(prof, R, O, 123 + cov, flags=sflags)
+        want = oracle.run(o, iv, ln.astype(np.uint64), cov, 0.4, n_threads=4)
+        chimeric = int((want[2] == 1).sum())
+        for flags in (yacrd_amd.F_ALWAYS_DEFER, yacrd_amd.F_ALWAYS_DEFER | yacrd_amd.F_SCREEN_ITEMS_2, 0):
+            with yacrd_amd.Engine(flags=flags) as e:
+                for rep in range(2):
+                    assert_same(e.run(o, iv, ln, cov, 0.4), want, "profile %d cov %d synth flags %d flags %d run %d" % (prof, cov, sflags, flags, rep))
+                t = e.timing()
+                if flags and cov in (3, 4) and not (sflags & (0xFF << 8)):
+                    assert chimeric > R // 5 and t["deferred_reads"] < chimeric // 2, (t["deferred_reads"], chimeric)
+
+
+def test_hole_closed_form_fuzz():
+    """The emulation's fuzz (tests/test_formulation.py::test_hole_screen_matches_oracle) on the kernel itself: chimeras with
+    gaps of any width, intervals left spanning the junction, piles spread or not, coarse grids, five thresholds."""
+    from test_formulation import _chimera_read, _pile_read, _survey_read
+    rng = np.random.default_rng(4711)
+    reads = []
+    for it in range(4000):
+        L = int(rng.integers(100, 900)) if it % 7 == 0 else int(rng.integers(900, 60000))
+        n = int(rng.integers(65, 257))
+        jitter = (0.0, 5.0, 30.0, 100.0)[it % 4]
+        base = _survey_read if it % 2 else _pile_read
+        iv = _chimera_read(rng, n, L, jitter, base) if it % 3 else base(rng, n, L, jitter)
+        if it % 13 == 0:
+            g = max(1, L // 16)
+            iv = [(min((s // g) * g, L - 1), min(max((e // g) * g, (s // g) * g + 1), L)) for s, e in iv]
+            iv = [(s, max(e, s + 1)) for s, e in iv]
+        reads.append((iv, L))
+    offsets = np.zeros(len(reads) + 1, np.uint64)
+    offsets[1:] = np.cumsum([len(iv) for iv, _ in reads])
+    intervals = np.array([p for iv, _ in reads for p in iv], dtype=np.uint32)
+    lengths = np.array([L for _, L in reads], dtype=np.uint32)
+    for cov in (0, 1, 3, 4, 9):
+        want = oracle.run(offsets, intervals, lengths.astype(np.uint64), cov, 0.4, n_threads=8)
+        for flags in (yacrd_amd.F_ALWAYS_DEFER, yacrd_amd.F_ALWAYS_DEFER | yacrd_amd.F_SCREEN_ITEMS_2):
+            with yacrd_amd.Engine(flags=flags) as e:
+                assert_same(e.run(offsets, intervals, lengths, cov, 0.4), want, "hole fuzz cov %d flags %d" % (cov, flags))

@@ -450,6 +450,9 @@ struct HealthyRead {
 #define YK_SCREEN_SLIDES 4
 #endif
 constexpr int kScreenSlides = YK_SCREEN_SLIDES;
+#ifndef YK_HOLE_FORM
+#define YK_HOLE_FORM 1 // the closed form for a read with one stretch of low coverage inside (hole_form below)
+#endif
 #ifndef YK_SLIDES_IN_ITEMS2
 // The two-items build of the screen (long launches from HBM: sweep_small_fused_defer2_kernel) keeps the single look: with
 // two items' intervals live the second looks' registers push it over its budget (a spilled load at its very start, or
@@ -753,6 +756,234 @@ __device__ __forceinline__ void sweep_group_read(const uint2 *__restrict__ iv, u
     sweep_group_keys<LANES, K, XM>(x, 2 * n, len, c, active, r, badmask, zmask, zl_check, a, lc);
 }
 
+// ---- the OTHER closed form: a read with one stretch of low coverage inside (round 4) ---------------------------------
+// tests/formulation.py::hole_fast_regions is the emulation (hole_screen_regions the derivation), both fuzzed against
+// the oracle.  A chimera — the read yacrd exists to find — is two healthy reads back to back: the intervals that end at
+// or before loR, the first start that finds c or fewer intervals open behind the covered part (L), those that start at
+// or behind it (R), and k <= c that span it.  The reference's sweep (src/stack.rs:61-139) stops flagging ends on the
+// left where the ends counted down from hiL = L's largest end, the k included, reach c + 1 (x: the pops from there on
+// leave c or fewer in the heap, :77-79), finds the heap at k when R's first start arrives, opens a gap (x, s) at each
+// of R's first c + 1 - k starts (:83-89; merged by equal begin to (x, y), :119-136) and goes on as on a healthy read:
+// the regions are (0, a), (x, y), (b, len) with a, b the FIRST screen's — it found them and failed on the depth test
+// of a coarse block.  What the hole adds is looked at where it lies, with the first screen's table still in LDS:
+//   1. istar = the first coarse block whose depth bound failed; only it and its successor may have;
+//   2. 64 sub-bins over those two blocks, the depth D0 in front of them (> c) carried through; jstar = the first
+//      sub-bin that holds a start and whose bound (its own ends first) is <= c; loR = its smallest start;
+//   3. hiL = the largest end <= loR, k = the intervals across loR, no start of the left half within W of hiL, no end
+//      within W behind loR;
+//   4. x and y from W one-position bins below hiL / above loR (k carried);
+//   5. behind jstar every sub-bin that may hold a start at or behind R's smallest end must be deep again (the starts
+//      in front of that end are the ramp: nothing popped yet).
+// A wrong guess anywhere costs the closed form, nothing else: the read is left to the sort.
+// want: this group tries (uniform in the group); gF: the first screen's F, to the whole group.  Returns the verdict
+// (uniform in the group); x, y are meaningful in the group's last lane.
+template <int LANES, int WPB>
+__device__ __forceinline__ bool hole_form(const uint4 (&v)[4], const bool (&real0)[4], const bool (&real1)[4], u32 len, i32 c,
+                                          u32 pmin, u32 pmax, i32 gF, bool want, u32 &x_out, u32 &y_out)
+{
+    constexpr int NB = LANES, W = kScreenWindow, NBIN = 2 * W + NB, ZPER = NBIN / LANES, NSUB = 64, PERF = NSUB / LANES,
+                  PER = W / LANES;
+    constexpr u32 kEnd = 1u << 10, kField = kEnd - 1u;
+    static_assert(NSUB * 4 <= NBIN * 4 && 2 * W <= NBIN * 4, "the sub-bins (four copies) and the two windows fit the group's table");
+    const u32 lane = lane_id(), lig = lane & (u32)(LANES - 1), grp = lane / (u32)LANES;
+    const int last_addr = (int)((lane | (u32)(LANES - 1)) << 2);
+    u32 *tab = wave_screen_scratch<WPB>() + grp * (u32)(NBIN * 4);
+    uint4 *bins = reinterpret_cast<uint4 *>(tab);
+    char *tb = reinterpret_cast<char *>(tab);
+    const i32 bits = 32 - (i32)__builtin_clz(len | 1u) - ilog2c(NB) + (len != 0 ? 0 : -1);
+    const u32 sh = (u32)max(bits, ilog2c(W)), fsh = sh + 1u - (u32)ilog2c(NSUB);
+    const u32 gshift = lane & (u32)(64 - LANES);
+    const u64 gmask = LANES == 64 ? ~0ull : ((1ull << (LANES & 63)) - 1ull);
+    auto to_group = [&](u32 x) { return (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)x); }; // the last lane's value (an inclusive scan's total)
+    bool ok = want;
+
+    // ---- 1. the first screen's coarse blocks (bins W .. W + NB - 1, still in the table): which bounds failed
+    u32 istar;
+    {
+        const uint4 c4 = bins[(u32)W + lig];
+        const u32 w = (c4.x + c4.y + c4.z + c4.w) & ((kField << 10) | kField);
+        const u32 wincl = gscan_add<LANES>(w);
+        const i32 x = (i32)((wincl - w) & kField) - (i32)((wincl >> 10) & kField); // starts before - ends through this block
+        const bool failed = ok && (w & kField) != 0u && !(x + gF > c);
+        const u64 fm = (__builtin_amdgcn_ballot_w64(failed) >> gshift) & gmask;
+        istar = fm ? (u32)__builtin_ctzll(fm) : 0u;
+        ok = ok && fm != 0 && istar >= 1u && (fm >> istar) <= 3ull;
+    }
+    if (__builtin_amdgcn_ballot_w64(ok) == 0) return false; // (uniform in the wavefront)
+    const u32 B0 = pmin + (istar << sh);
+
+    // ---- 2. sub-bins over the blocks istar, istar + 1
+    wave_lds_sync();
+#pragma unroll
+    for (int q = 0; q < ZPER; q++) bins[lig + (u32)(LANES * q)] = make_uint4(0u, 0u, 0u, 0u);
+    wave_lds_sync();
+    const u32 cp = (lig & 3u) * 4u;
+    u32 d0 = 0; // starts - ends in front of B0 (two's complement)
+    auto count = [&](u32 s, u32 e, bool real) {
+        const u32 js = (s - B0) >> fsh, je = (e - B0) >> fsh; // (a position below B0 wraps far beyond the 64 sub-bins)
+        d0 += (real && s < B0) ? 1u : 0u;
+        d0 -= (real && e < B0) ? 1u : 0u;
+        if (real && ok && js < (u32)NSUB) atomicAdd(reinterpret_cast<u32 *>(tb + ((js << 4) + cp)), 1u);
+        if (real && ok && je < (u32)NSUB) atomicAdd(reinterpret_cast<u32 *>(tb + ((je << 4) + cp)), kEnd);
+    };
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        count(v[j].x, v[j].y, real0[j]);
+        count(v[j].z, v[j].w, real1[j]);
+    }
+    wave_lds_sync();
+    const i32 D0 = (i32)to_group(gscan_add<LANES>(d0));
+    ok = ok && D0 > c;
+    u32 fs[PERF], fe[PERF];
+    i32 dq[PERF]; // the depth entering each of this lane's sub-bins
+    u32 jcand = (u32)NSUB;
+    {
+        u32 tot = 0;
+#pragma unroll
+        for (int q = 0; q < PERF; q++) {
+            const uint4 b4 = bins[lig * (u32)PERF + q];
+            const u32 w = b4.x + b4.y + b4.z + b4.w;
+            fs[q] = w & kField, fe[q] = (w >> 10) & kField;
+            tot += w & ((kField << 10) | kField);
+        }
+        const u32 incl = gscan_add<LANES>(tot), ex = incl - tot;
+        i32 D = D0 + (i32)(ex & kField) - (i32)((ex >> 10) & kField);
+#pragma unroll
+        for (int q = 0; q < PERF; q++) {
+            dq[q] = D;
+            if (jcand == (u32)NSUB && fs[q] != 0u && D - (i32)fe[q] <= c) jcand = lig * (u32)PERF + q;
+            D += (i32)fs[q] - (i32)fe[q];
+        }
+    }
+    const u32 jstar = to_group(gscan_min<LANES>(ok ? jcand : (u32)NSUB)); // (gscan_min is an inclusive scan: the last lane holds the group's)
+    ok = ok && jstar < (u32)NSUB;
+    if (__builtin_amdgcn_ballot_w64(ok) == 0) return false;
+    u32 lo_c = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (real0[j] && ((v[j].x - B0) >> fsh) == jstar) lo_c = min(lo_c, v[j].x);
+        if (real1[j] && ((v[j].z - B0) >> fsh) == jstar) lo_c = min(lo_c, v[j].z);
+    }
+    const u32 loR = to_group(gscan_min<LANES>(lo_c));
+
+    // ---- 3. the halves: L's largest end, the intervals across loR, R's smallest end
+    u32 hi_c = 0, kc = 0, er_c = 0xFFFFFFFFu;
+    bool anyL = false;
+    auto halves = [&](u32 s, u32 e, bool real) {
+        if (real && e <= loR) hi_c = max(hi_c, e), anyL = true;
+        kc += (real && s < loR && e > loR) ? 1u : 0u;
+        if (real && e > loR) er_c = min(er_c, e);
+    };
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        halves(v[j].x, v[j].y, real0[j]);
+        halves(v[j].z, v[j].w, real1[j]);
+    }
+    const u32 hiL = to_group(gscan_max<LANES>(hi_c));
+    const i32 k = (i32)to_group(gscan_add<LANES>(kc));
+    const u32 emin_r = to_group(gscan_min<LANES>(er_c));
+    const bool hasL = ((__builtin_amdgcn_ballot_w64(anyL) >> gshift) & gmask) != 0;
+    // a start of the left half within W of hiL (or between hiL and loR): not this closed form
+    bool near = false;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        near |= real0[j] && v[j].x < loR && v[j].x + (u32)W > hiL;
+        near |= real1[j] && v[j].z < loR && v[j].z + (u32)W > hiL;
+    }
+    const bool anynear = ((__builtin_amdgcn_ballot_w64(near) >> gshift) & gmask) != 0;
+    ok = ok && hasL && k <= c && !anynear && emin_r != 0xFFFFFFFFu && emin_r - loR >= (u32)W &&
+         B0 + ((jstar + 1u) << fsh) - 1u < emin_r; // (the sub-bin of loR ends in front of R's smallest end: its starts are ramp)
+    if (__builtin_amdgcn_ballot_w64(ok) == 0) return false;
+
+    // ---- 5. behind jstar: deep again wherever a start may lie at or behind R's smallest end
+    {
+        bool shallow = false;
+#pragma unroll
+        for (int q = 0; q < PERF; q++) {
+            const u32 j = lig * (u32)PERF + q;
+            shallow |= j > jstar && fs[q] != 0u && B0 + ((j + 1u) << fsh) - 1u >= emin_r && !(dq[q] - (i32)fe[q] > c);
+        }
+        ok = ok && ((__builtin_amdgcn_ballot_w64(shallow) >> gshift) & gmask) == 0;
+    }
+    if (__builtin_amdgcn_ballot_w64(ok) == 0) return false;
+
+    // ---- 4. x and y: W one-position bins downwards from hiL (ends, high half) and upwards from loR (starts, low half):
+    // bin d of the first W words = position hiL - d, of the next W = loR + d.  One copy: a pile sits on few positions.
+    wave_lds_sync();
+#pragma unroll
+    for (int q = 0; q < ZPER; q++) bins[lig + (u32)(LANES * q)] = make_uint4(0u, 0u, 0u, 0u);
+    wave_lds_sync();
+    auto windows = [&](u32 s, u32 e, bool real) {
+        const u32 dl = hiL - e, dr = s - loR; // (an end above hiL / a start below loR wraps beyond W)
+        if (real && ok && dl < (u32)W) atomicAdd(tab + dl, kEnd);
+        if (real && ok && dr < (u32)W) atomicAdd(tab + (u32)W + dr, 1u);
+    };
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        windows(v[j].x, v[j].y, real0[j]);
+        windows(v[j].z, v[j].w, real1[j]);
+    }
+    wave_lds_sync();
+    u32 f[PER], fw = 0;
+#pragma unroll
+    for (int q = 0; q < PER; q++) {
+        const u32 d = lig * (u32)PER + q;
+        f[q] = (tab[(u32)W + d] & kField) | (tab[d] & (kField << 10));
+        fw += f[q];
+    }
+    const u32 fincl = gscan_add<LANES>(fw);
+    u32 reached = 0;
+    {
+        const u32 k1 = (u32)min(c + 1, 0x1FF) - (u32)k; // (k <= c: at least one)
+        u32 run = fincl - fw + (512u - k1) * (1u | kEnd);
+#pragma unroll
+        for (int q = 0; q < PER; q++) {
+            run += f[q];
+            reached += run & (0x200u | (0x200u << 10));
+        }
+    }
+    const u32 cand = (((u32)PER - ((reached >> 9) & 7u)) << 20) | (((u32)PER - (reached >> 19)) << 26);
+    const u32 wincl = gscan_add<LANES>(cand);
+    // (meaningful in the group's last lane from here on)
+    const i32 FR = (i32)(fincl & kField) + k, GL = (i32)(fincl >> 10) + k;
+    y_out = loR + ((wincl >> 20) & 63u);
+    x_out = hiL - (wincl >> 26);
+    return ok && FR > c && GL > c;
+}
+
+// hole_form behind a CALL that loads the read's intervals AGAIN: kept in registers through the screen for the one
+// wave-item in twenty that needs them here, they pushed the two-items build of the screen over its register budget
+// (spilled loads at the kernel's very start).  The call takes scalars only; what it reads lies in L2 (the screen has
+// just read it).  want: this group tries (uniform in the group; its reads are plain, every interval >= W long, so
+// every slot below n is real).  Returns (verdict, x, y), meaningful in the group's last lane.
+template <int LANES>
+__device__ __attribute__((noinline)) uint4 hole_form_call(const u64 *off, const uint2 *iv, u32 r, u32 len, i32 c, u32 pmin, u32 pmax,
+                                                          i32 gF, u32 want)
+{
+    constexpr int K = 16;
+    const u32 lig = lane_id() & (u32)(LANES - 1);
+    u32 n = 0;
+    const uint2 *src = reinterpret_cast<const uint2 *>(off); // (a group that does not try reads the offsets: always mapped)
+    if (want) {
+        const ulonglong2 oo = *reinterpret_cast<const ulonglong2 *>(off + r);
+        n = (u32)(oo.y - oo.x);
+        src = iv + oo.x;
+    }
+    const u32 last2 = n >= 2u ? n - 2u : 0u;
+    uint4 v[K / 4];
+    bool real0[K / 4], real1[K / 4];
+#pragma unroll
+    for (int j = 0; j < K / 4; j++) {
+        const u32 i0 = 2u * (lig + (u32)LANES * j);
+        v[j] = *reinterpret_cast<const uint4 *>(src + min(i0, last2));
+        real0[j] = i0 + 1u < n; // (.xy is interval i0 only when i0 + 1 exists too: see screen_block)
+        real1[j] = i0 < n;
+    }
+    u32 x = 0, y = 0;
+    const bool ok = hole_form<LANES, 1>(v, real0, real1, len, c, pmin, pmax, gF, want != 0u && n >= 2u, x, y);
+    return make_uint4(ok ? 1u : 0u, x, y, 0u);
+}
+
 // ---- the screen over ITEMS consecutive groups of list entries per wavefront (one-wavefront workgroups)
 // Every level of the dependent chain — list entries, offsets / lengths, intervals — is fetched for all
 // ITEMS at once, so a wavefront has ITEMS x 8 interval loads per lane in flight (8 KB at ITEMS = 2) and
@@ -840,6 +1071,7 @@ __device__ __forceinline__ void screen_block(const SweepArgs &a, u32 block)
         }
         HealthyRead hr;
         bool healthy = healthy_screen<LANES, 1>(v[t], real0, real1, len[t], c, pmin, pmax, hr) && !girr;
+        bool table_intact = true, hole_done = false; // (the first screen's coarse blocks are still in LDS; this group's read got its hole form)
         if constexpr (kScreenSlides > 0 && (ITEMS == 1 || YK_SLIDES_IN_ITEMS2)) {
             // a window that came up short of c + 1 (verdict in the group's last lane): slide it (see kScreenSlides).
             // st = need | F << 1 | G << 11 of the last screen (counts clipped to their ten bits)
@@ -850,6 +1082,7 @@ __device__ __forceinline__ void screen_block(const SweepArgs &a, u32 block)
             // test may have failed for want of the ramp: looked at once more where it stands, the ramp counted
             u32 st = state_of(!healthy && !girr && (i32)n[t] > c && (hr.F <= 3 * c + 6 || hr.G <= c), hr);
             if (__builtin_amdgcn_ballot_w64((st & 1u) != 0 && lig == (u32)(LANES - 1)) != 0) { // (uniform in the wavefront; rare)
+                table_intact = false;
                 u32 emin = v[t][0].y, smax2 = v[t][0].x; // (re-derived here: kept from above they cost the common path registers)
 #pragma unroll
                 for (int j = 0; j < K / 4; j++) {
@@ -885,7 +1118,32 @@ __device__ __forceinline__ void screen_block(const SweepArgs &a, u32 block)
                 }
             }
         }
-        if (lig == (u32)(LANES - 1) && active[t]) { // the group's last lane has the verdict
+        if constexpr (YK_HOLE_FORM) {
+            // the first screen found a and b and failed on a block's depth: one stretch of low coverage inside? (hole_form)
+            const u32 pk = (u32)__builtin_amdgcn_ds_bpermute(
+                last_addr, (int)(((!healthy && !girr && (i32)n[t] > c && hr.F > c && hr.G > c && pmax - pmin >= 2u * (u32)kScreenWindow) ? 1u : 0u) |
+                                 ((u32)min(hr.F, 1023) << 1)));
+            if (table_intact && __builtin_amdgcn_ballot_w64((pk & 1u) != 0) != 0) { // (uniform in the wavefront)
+                const uint4 hv = hole_form_call<LANES>(a.off, a.iv, r[t], len[t], c, pmin, pmax, (i32)(pk >> 1), pk & 1u);
+                const bool hole = hv.x != 0u;
+                const u32 hx = hv.y, hy = hv.z;
+                if (hole && lig == (u32)(LANES - 1) && active[t]) { // (three regions: through the read's slot, not closed[])
+                    u32 rr = r[t];
+                    asm volatile("" : "+v"(rr)); // (the offset is loaded again here, rarely, instead of kept in registers from the top)
+                    uint2 *slot = a.stage + (a.off[rr] + 2 * (u64)rr);
+                    u32 g = 0;
+                    if (hr.a != 0u) slot[g++] = make_uint2(0u, hr.a);
+                    slot[g++] = make_uint2(hx, hy);
+                    if (hr.b != len[t]) slot[g++] = make_uint2(hr.b, len[t]);
+                    a.counts[r[t]] = g;
+                    if (a.prefilter == 2) atomicAdd(&a.ctr->prefiltered, 1u);
+                }
+                if (hole) healthy = false, hole_done = true;
+            }
+        }
+        if (hole_done) {
+            // (its regions are written)
+        } else if (lig == (u32)(LANES - 1) && active[t]) { // the group's last lane has the verdict
             if (healthy || (!girr && (i32)n[t] <= c)) {
                 // never more than c intervals open: the whole read is bad = (0, a) with a = len
                 const u32 ra = (i32)n[t] <= c ? len[t] : hr.a, rb = (i32)n[t] <= c ? len[t] : hr.b;

@@ -723,9 +723,10 @@ def test_fused_defer_build(cov):
 
 @pytest.mark.parametrize("prof,cov", [(0, 4), (1, 3), (1, 0), (0, 9)])
 def test_hole_closed_form_on_chimeras(prof, cov):
-    """Round 4: a read with ONE stretch of low coverage inside — a chimera — gets its three regions in closed form
-    from the screen (sweep_wave.h: hole_form; tests/formulation.py::hole_fast_regions is the emulation).  30 % chimeras,
-    clamped and spread piles, both builds of the screen: bit-exact, and most chimeras no longer reach the sort."""
+    """Round 4: a read with ONE stretch of low coverage inside — a chimera — can get its three regions in closed form
+    from the screen (sweep_wave.h: hole_form, a build option; tests/formulation.py::hole_fast_regions is the emulation).
+    30 % chimeras, clamped and spread piles, both builds of the screen: bit-exact with or without it; with it most
+    chimeras no longer reach the sort."""
     from yacrd_amd import host
     R, O = (6000, 300000) if prof == 0 else (3000, 300000)
     for sflags in (host.synth_f_chimera_pct(30), host.SYNTH_F_JITTER | host.synth_f_chimera_pct(30),
@@ -738,7 +739,9 @@ def test_hole_closed_form_on_chimeras(prof, cov):
                 for rep in range(2):
                     assert_same(e.run(o, iv, ln, cov, 0.4), want, "profile %d cov %d synth flags %d flags %d run %d" % (prof, cov, sflags, flags, rep))
                 t = e.timing()
-                if flags and cov in (3, 4) and not (sflags & (0xFF << 8)):
+                # (the library is built without hole_form by default — sweep_wave.h: YK_HOLE_FORM — where it costs the
+                # screen more than it saves the sort; YACRD_TEST_HOLE_FORM=1 when testing a build that has it)
+                if os.environ.get("YACRD_TEST_HOLE_FORM") == "1" and flags and cov in (3, 4) and not (sflags & (0xFF << 8)):
                     assert chimeric > R // 5 and t["deferred_reads"] < chimeric // 2, (t["deferred_reads"], chimeric)
 
 

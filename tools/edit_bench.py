@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""tools/edit_bench.py [reads overlaps] — the chunk-parallel scrubb alone (no GPU: the oracle makes the table) on a synthetic
+FASTQ in /dev/shm, by threads and by the chunks' way into memory (YACRD_EDIT_IO=pread | mmap): GB/s of FASTQ in."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402  (makes the bad-region table here: no engine in this tool)
+from yacrd_amd import host  # noqa: E402
+R = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+O = int(sys.argv[2]) if len(sys.argv) > 2 else 100_000_000
+d = "/dev/shm"
+fq, out = os.path.join(d, "yacrd_eb_%d.fastq" % os.getpid()), os.path.join(d, "yacrd_eb_%d.out.fastq" % os.getpid())
+try:
+    t0 = time.perf_counter()
+    host.synth_fastq(host.SYNTH_SEQUEL, R, O, 7, R // 200, fq)
+    size = os.path.getsize(fq)
+    print("FASTQ %.1f GB in %.1f s" % (size / 1e9, time.perf_counter() - t0), flush=True)
+    off, iv, ln = host.synth_csr(host.SYNTH_SEQUEL, R, O, 7)
+    bo, br, rt = oracle.run(off, iv, ln.astype(np.uint64), 3, 0.4, n_threads=16)
+    del off, iv
+    names = ["r%09d" % i for i in range(R)]
+    time.sleep(5)
+    ref = None
+    for io in ("pread", "mmap"):
+        os.environ["YACRD_EDIT_IO"] = io
+        for th in (1, 4, 8, 16, 32):
+            if th == 1 and io == "mmap":
+                continue
+            t0 = time.perf_counter()
+            host.edit_file(host.OP_SCRUBB, fq, out, names, ln, bo, br, rt, n_threads=th)
+            dt = time.perf_counter() - t0
+            sig = (os.path.getsize(out),)
+            ref = ref or sig
+            print("%s %2d threads: %.2f s = %.2f GB/s in (out %.1f GB) %s" % (io, th, dt, size / dt / 1e9, sig[0] / 1e9, "" if sig == ref else "SIZE DIFFERS"), flush=True)
+            time.sleep(2)
+finally:
+    for x in (fq, out):
+        if os.path.exists(x):
+            os.remove(x)

@@ -571,15 +571,44 @@ int edit_sequences_parallel(int op, bool fastq, const char *in_path, const char 
     off[0].store(0);
     std::atomic<size_t> next(0);
     std::atomic<int> state(0); // 1 = a chunk did not parse (retry on one thread), 2 = write error
+    // The chunks' bytes come through pread into a buffer the thread keeps (YACRD_EDIT_IO=mmap: straight from the mapping,
+    // which is only used to find the boundaries otherwise): sixteen threads taking minor faults on one mapping get in
+    // each other's way (the parser found the same in round 2), and a buffer that lives as long as its thread is not
+    // mapped, zeroed and unmapped once per chunk by the allocator.
+    const char *io = std::getenv("YACRD_EDIT_IO");
+    const bool use_pread = !(io && std::strcmp(io, "mmap") == 0);
+    const int rfd = use_pread ? ::open(in_path, O_RDONLY) : -1;
+    if (use_pread && rfd < 0) {
+        ::close(ofd);
+        return -1;
+    }
     auto work = [&]() {
+        std::vector<char> ibuf;
+        Writer out;
+        out.open_memory(kEditChunk + kEditChunk / 8 + 4096);
         for (;;) {
             const size_t i = next.fetch_add(1);
             if (i >= n_chunks) break;
+            const size_t len = cut[i + 1] - cut[i];
+            const char *src = base + cut[i];
+            bool skip = state.load() != 0;
+            if (use_pread && !skip) {
+                if (ibuf.size() < len) ibuf.resize(len + len / 8);
+                for (size_t got = 0; got < len;) {
+                    const ssize_t k = ::pread(rfd, ibuf.data() + got, len - got, (off_t)(cut[i] + got));
+                    if (k < 0 && errno == EINTR) continue;
+                    if (k <= 0) {
+                        state.store(1);
+                        skip = true;
+                        break;
+                    }
+                    got += (size_t)k;
+                }
+                src = ibuf.data();
+            }
             Reader in;
-            in.open_memory(base + cut[i], cut[i + 1] - cut[i]);
-            Writer out;
-            out.open_memory(cut[i + 1] - cut[i] + (cut[i + 1] - cut[i]) / 16 + 4096);
-            const bool skip = state.load() != 0;
+            in.open_memory(src, len);
+            out.buf.clear();
             if (!skip && edit_sequences(op, fastq, in, out, bp) != 0) state.store(1);
             long long at;
             while ((at = off[i].load(std::memory_order_acquire)) < 0) std::this_thread::yield();
@@ -602,6 +631,7 @@ int edit_sequences_parallel(int op, bool fastq, const char *in_path, const char 
     work();
     for (auto &x : th) x.join();
     const int rc = ::close(ofd);
+    if (rfd >= 0) ::close(rfd);
     if (state.load() == 1) return -1; // (the one-thread loop truncates the output and words the error)
     if (state.load() == 2 || rc != 0) return yh::fail("Error during writing of the output file");
     return 0;

@@ -451,7 +451,12 @@ struct HealthyRead {
 #endif
 constexpr int kScreenSlides = YK_SCREEN_SLIDES;
 #ifndef YK_HOLE_FORM
-#define YK_HOLE_FORM 1 // the closed form for a read with one stretch of low coverage inside (hole_form below)
+// The closed form for a read with one stretch of low coverage inside (hole_form below): bit-exact (GPU tests, fuzz) and
+// it decides 77 % of what the screen otherwise defers (configs[2]: 47 608 -> 11 032 reads, the deferred sweep 145 -> 68 us)
+// — but its ~1000 instructions are spent by every wave-item that holds such a read, 4.5-9 % of them, inside the kernel
+// that is already short of VALU issue slots: the screen 0.613 -> 0.711 ms on configs[2], 1.43 -> 1.81 ms on configs[4], the
+// step 0.816 -> 0.853 / 1.77 -> 2.06 ms (profiles/r04/e_ab_hole_form.log).  Off; -DYK_HOLE_FORM=1 builds it.
+#define YK_HOLE_FORM 0
 #endif
 #ifndef YK_SLIDES_IN_ITEMS2
 // The two-items build of the screen (long launches from HBM: sweep_small_fused_defer2_kernel) keeps the single look: with

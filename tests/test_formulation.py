@@ -117,7 +117,7 @@ def test_pile_trimming_matches_oracle():
         has_zl = any(s == e for s, e in iv)
         for cov in (0, 1, 4, 9, 50):
             want = oracle.compute_bad_part(iv, L, cov)
-            for nb, F in ((16, 32), (16, 0), (4, 3), (256, 128), (16, 64)):
+            for nb, F in ((16, 32), (16, 0), (4, 3), (256, 128), (16, 64), (64, 32)):  # (64, 32): finish_compact.h trim_item
                 got = trimmed_events(iv, L, cov, nb, F)
                 assert got == want or (got is None and has_zl), (iv, L, cov, nb, F)
                 n_zl_checked += has_zl and got is not None

@@ -12,6 +12,7 @@
 //            (reference src/editor/mod.rs:85-100).
 #pragma once
 #include "plan_compact.h"
+#include "sweep_lds.h"
 #include "sweep_wave.h"
 
 namespace yk {
@@ -248,10 +249,94 @@ __global__ __launch_bounds__(kScanBlock, YK_FINISH_OCC) void finish_compact_kern
 // (First attempt, same log: the marked reads through the sorting build's code — sweep_group_read<32 | 16, 16>, two or
 // four reads per wavefront behind the bin filter — 0.190 ms for configs[2]'s 47 600 reads: per read that code is
 // no cheaper than the 64-lane sort, and pairs / quadruples fill badly from a list of two dozen.)
+// ---- a marked read through the pile-trimming filter (§3.5) and a SHORT register sort (round 4) -------------------
+// The 64-lane sort of a marked read is 847 instructions, most of them spent ordering events that cannot matter: of a
+// chimera's ~400 events the filter keeps the c + 1 outermost of the piles at 0 / len and what lies around the junction —
+// 60-100 keys: one or two per lane instead of eight.  LdsTrim<64, kTrimWords>: 32 one-position bins at either end of the
+// read, up to 64 coarse bins in between, two bins per lane; the plan (lds_trim_plan, sweep_lds.h) is the workgroup classes'
+// with one wavefront as the "workgroup"; the survivors go from LDS into registers — K' = 1, 2, 4 or 8 keys per lane by their
+// number — and through sweep_group_keys, the register classes' sort + sweep.  Plain reads only (start < end <= len):
+// anything else takes the full sort (finish_item).  false = not taken.
+constexpr int kTrimWords = 1280; // per wavefront: 640 survivors at most | 128 zero-length counters | 128 bins x 4 counters
+template <int KP>
+__device__ __forceinline__ void trimmed_keys_sweep(const u32 *keys, u32 m_sort, u32 len, i32 c, u32 rr, const SweepArgs &a, const LaneConst &lc)
+{
+    u32 x[KP];
+    const u32 lane = lane_id();
+#pragma unroll
+    for (int q = 0; q < KP; q++) {
+        const u32 i = lane * (u32)KP + (u32)q;
+        x[q] = i < m_sort ? keys[i] : kPadKey;
+    }
+    sweep_group_keys<64, KP, 0>(x, m_sort, len, c, true, rr, 0ull, 0ull, false, a, lc);
+}
+__device__ __forceinline__ bool trim_item(const SweepArgs &a, u32 rr, u64 o, u32 n, u32 len, u32 *keys, const LaneConst &lc)
+{
+    using F = LdsTrim<64, kTrimWords>;
+    if (len > kMaxKeyPos || n < 2u || !a.prefilter) return false; // (uniform)
+    const u32 lane = lane_id();
+    const typename F::Geo geo = F::geo(len);
+    u32 *tab = F::tab(keys);
+    reinterpret_cast<uint4 *>(tab)[2 * lane] = make_uint4(0u, 0u, 0u, 0u);
+    reinterpret_cast<uint4 *>(tab)[2 * lane + 1] = make_uint4(0u, 0u, 0u, 0u);
+    reinterpret_cast<uint2 *>(F::ztab(keys))[lane] = make_uint2(0u, 0u);
+    const uint2 *iv = a.iv + o;
+    uint2 v[4];
+    bool real[4];
+    u32 irregular = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = iv[min(lane + 64u * (u32)j, n - 1u)];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        real[j] = lane + 64u * (u32)j < n;
+        irregular |= (real[j] && (v[j].x >= v[j].y || v[j].y > len)) ? 1u : 0u;
+    }
+    if (__builtin_amdgcn_ballot_w64(irregular != 0) != 0) return false; // (uniform: the full sort knows every kind of interval)
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (real[j]) {
+            const u32 ks = (v[j].x << kKeyShift) | 3u, ke = v[j].y << kKeyShift;
+            atomicAdd(tab + F::idx(geo, ks) * 4u + (lane & 3u), 1u);
+            atomicAdd(tab + F::idx(geo, ke) * 4u + (lane & 3u), 0x10000u);
+        }
+    }
+    wave_lds_sync();
+    u32 syn_start = 0;
+    const u32 m_sort = lds_trim_plan<64, kTrimWords>(keys, len, a.cov, nullptr, syn_start);
+    if (m_sort == 0 || m_sort > 512u) return false; // (uniform; counts[rr] is still the mark: the caller sorts the read whole)
+    auto take = [&](u32 *cur) -> u32 {
+        return (i32)*reinterpret_cast<volatile u32 *>(cur) >= 0x10000 ? atomicAdd(cur, F::kTakeOne) : 0u;
+    };
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if (real[j]) {
+            const u32 ks = (v[j].x << kKeyShift) | 3u, ke = v[j].y << kKeyShift;
+            const u32 is = F::idx(geo, ks), ie = F::idx(geo, ke);
+            const u32 ps = take(tab + is * 4u + (F::uniform(geo, is) ? 1u : (lane & 3u)));
+            const u32 pe = take(tab + ie * 4u + (F::uniform(geo, ie) ? 0u : (lane & 3u)));
+            if ((i32)ps >= 0x10000) keys[ps & 0xFFFFu] = ks; // quota left: kept, at the slot in the low half
+            if ((i32)pe >= 0x10000) keys[pe & 0xFFFFu] = ke;
+        }
+    }
+    wave_lds_sync();
+    const i32 c = (i32)min(a.cov, 0x3FFFFFFFu);
+    if (m_sort <= 64u) trimmed_keys_sweep<1>(keys, m_sort, len, c, rr, a, lc);
+    else if (m_sort <= 128u) trimmed_keys_sweep<2>(keys, m_sort, len, c, rr, a, lc);
+    else if (m_sort <= 256u) trimmed_keys_sweep<4>(keys, m_sort, len, c, rr, a, lc);
+    else trimmed_keys_sweep<8>(keys, m_sort, len, c, rr, a, lc);
+    return true;
+}
+
 constexpr int kDeferSlab = 1024, kDeferThreads = 256;
 
+#ifndef YK_DEFER_TRIM
+#define YK_DEFER_TRIM 1 // the marked reads through the pile-trimming filter and a short sort first (trim_item)
+#endif
 #ifndef YK_DEFER_SWEEP_OCC
-#define YK_DEFER_SWEEP_OCC 6 // wavefronts per SIMD the register budget allows (8 / 6 / 5: 0.164 / 0.158 / 0.159 ms of follow-on time on configs[2], profiles/r04/c_ab_follow_on.log)
+// wavefronts per SIMD the register budget allows.  Without the trimming path: 8 / 6 / 5 gave 0.164 / 0.158 / 0.159 ms of
+// follow-on time on configs[2] (profiles/r04/c_ab_follow_on.log); with it the kernel wants 128 registers.
+#define YK_DEFER_SWEEP_OCC (YK_DEFER_TRIM ? 4 : 6)
 #endif
 __global__ __launch_bounds__(kDeferThreads, YK_DEFER_SWEEP_OCC) void deferred_sweep_kernel(SweepArgs a, u32 n_reads)
 {
@@ -308,6 +393,10 @@ __global__ __launch_bounds__(kDeferThreads, YK_DEFER_SWEEP_OCC) void deferred_sw
         atomicAdd((unsigned long long *)&a.ctr->deferred_iv, s_iv);
     }
     constexpr u32 kWaves = kDeferThreads / 64;
+#if YK_DEFER_TRIM
+    __shared__ __attribute__((aligned(16))) u32 s_trim[kWaves][kTrimWords];
+    const LaneConst lc = make_lane_const(lane);
+#endif
     // one read per wavefront and turn, the long ones (8 keys per lane) first: list position p < n8 is s_list[p],
     // p >= n8 is the (p - n8)-th entry from the back
     for (u32 p = threadIdx.x >> 6; p < n_marked; p += kWaves) { // (uniform in the wavefront)
@@ -315,6 +404,9 @@ __global__ __launch_bounds__(kDeferThreads, YK_DEFER_SWEEP_OCC) void deferred_sw
         const uint2 e = s_list[at];
         const u32 rr = slab0 + (e.x & 0xFFFFu), n = e.x >> 16, len = e.y;
         const u64 o = s_off[at];
+#if YK_DEFER_TRIM
+        if (trim_item(a, rr, o, n, len, s_trim[threadIdx.x >> 6], lc)) continue;
+#endif
         if (n > 128u) finish_item<8>(a.off, a.iv, a.len, a.stage, a.counts, a.rej_list, a.rej_count, a.ctr, a.cov, rr, o, n, len);
         else finish_item<4>(a.off, a.iv, a.len, a.stage, a.counts, a.rej_list, a.rej_count, a.ctr, a.cov, rr, o, n, len);
     }

@@ -211,7 +211,7 @@ __device__ __forceinline__ u32 lds_trim_plan(u32 *keys, u32 len, u32 cov, u32 *s
 {
     using F = LdsTrim<T, CAP>;
     const typename F::Geo g = F::geo(len);
-    const u32 tid = threadIdx.x;
+    const u32 tid = T == 64 ? lane_id() : threadIdx.x; // (T = 64: one wavefront of a larger workgroup may be the "workgroup": finish_compact.h)
     const i32 c = (i32)min(cov, 0x3FFFFFFFu);
     uint4 *bins = reinterpret_cast<uint4 *>(F::tab(keys));
     const u32 *zt = F::ztab(keys);
@@ -306,7 +306,8 @@ __device__ __forceinline__ u32 lds_trim_plan(u32 *keys, u32 len, u32 cov, u32 *s
         base += nsyn[k];
         if (nsyn[k] && (synkey[k] & 1u)) syn_start = max(syn_start, synkey[k]);
     }
-    __syncthreads();
+    if (T == 64) wave_lds_sync();
+    else __syncthreads();
     return m_new;
 }
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """tools/edit_bench.py [reads overlaps] — the chunk-parallel scrubb alone (no GPU: the oracle makes the table) on a synthetic
-FASTQ in /dev/shm, by threads and by the chunks' way into memory (YACRD_EDIT_IO=pread | mmap): GB/s of FASTQ in."""
+FASTQ in /dev/shm, by threads, by the chunks' way into memory (YACRD_EDIT_IO=pread | mmap) and out of it (YACRD_EDIT_OUT=
+map | pwrite): GB/s of FASTQ in.  (1 thread = the one-thread loop: stream in, stream out.)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,10 +23,12 @@ try:
     names = ["r%09d" % i for i in range(R)]
     time.sleep(5)
     ref = None
-    for io in ("pread", "mmap"):
+    for io, oo in (("pread", "map"), ("pread", "pwrite"), ("mmap", "map")):
         os.environ["YACRD_EDIT_IO"] = io
+        os.environ["YACRD_EDIT_OUT"] = oo
+        io = "in " + io + " / out " + oo
         for th in (1, 4, 8, 16, 32):
-            if th == 1 and io == "mmap":
+            if th == 1 and oo != "pwrite":
                 continue
             t0 = time.perf_counter()
             host.edit_file(host.OP_SCRUBB, fq, out, names, ln, bo, br, rt, n_threads=th)

@@ -518,9 +518,14 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
                                 (fused_iv >= defer_min_intervals() && e->nodefer_left == 0));
             // two groups of list entries per wavefront in the screened classes when the launch streams from
             // HBM (more than the 256 MiB Infinity Cache holds): twice the loads in flight per wavefront
+            // ... unless the last such launch left more than a tenth of its reads to the sort: the one-item build has the
+            // second looks (sliding windows, sweep_wave.h) the two-items build has no registers for, and dovetail ends
+            // spread by hundreds of positions need them (configs[2] at sigma = 300: 79 % decided against 96 %)
             const int items = !defer ? 1
                               : (e->flags & YACRD_F_SCREEN_ITEMS_1) ? 1
-                              : ((e->flags & YACRD_F_SCREEN_ITEMS_2) || fused_iv >= 40000000ull) ? 2 : 1;
+                              : (e->flags & YACRD_F_SCREEN_ITEMS_2) ? 2
+                              : (fused_iv >= 40000000ull && e->items1_left == 0) ? 2 : 1;
+            e->last_items = (uint32_t)items;
             fa.base.over_list = nullptr; // (the deferring build marks its reads in counts[])
             fa.base.over_count = nullptr;
             fa.n_entries = 0;
@@ -924,6 +929,8 @@ int conclude_run(yacrd_engine *e, yk::Counters c0, bool predicted, uint64_t n_re
     if (screened) {
         const uint64_t looked_at = (uint64_t)c0.n[yk::CLS_R16] + c0.n[yk::CLS_H16];
         e->nodefer_left = (!(e->flags & YACRD_F_ALWAYS_DEFER) && 4 * (uint64_t)c1.deferred > looked_at) ? kProbeEvery - 1 : 0;
+        if (e->last_items == 2) e->items1_left = 10 * (uint64_t)c1.deferred > looked_at ? kProbeEvery - 1 : 0;
+        else if (e->items1_left) e->items1_left--;
     } else if (e->nodefer_left) {
         e->nodefer_left--;
     }

@@ -331,7 +331,11 @@ __device__ __forceinline__ bool trim_item(const SweepArgs &a, u32 rr, u64 o, u32
 constexpr int kDeferSlab = 1024, kDeferThreads = 256;
 
 #ifndef YK_DEFER_TRIM
-#define YK_DEFER_TRIM 1 // the marked reads through the pile-trimming filter and a short sort first (trim_item)
+// The marked reads through the pile-trimming filter and a short sort first (trim_item): bit-exact (GPU tests and fuzz with
+// the two-kernel follow-on forced), and no faster — the filter's two counting passes, its plan and the scatter cost what the
+// shorter sort saves: 43.6 M VALU instructions against 40.3 M for configs[2]'s 47 608 reads, the follow-on step 0.173 against
+// 0.155 ms (profiles/r04/g_ab_trimmed_deferred_sweep.log; round 2 found the same inside the register-sort kernel).  Off.
+#define YK_DEFER_TRIM 0
 #endif
 #ifndef YK_DEFER_SWEEP_OCC
 // wavefronts per SIMD the register budget allows.  Without the trimming path: 8 / 6 / 5 gave 0.164 / 0.158 / 0.159 ms of

@@ -98,7 +98,8 @@ def roofline_of(yacrd_amd, t, n_launches, R, G, key, note):
     dom, cname, dom_ms, c_reads, c_iv = dominant(t, K, yacrd_amd)
     deferred = 0
     if cname == "R2..H16" and t.get("screened"):
-        dom = "sweep_small_fused_defer2_kernel" if c_iv >= 40_000_000 else "sweep_small_fused_defer_kernel"
+        items = int(t.get("screen_items", 0)) or (2 if c_iv >= 40_000_000 else 1)  # (what the engine's last run used)
+        dom = "sweep_small_fused_defer2_kernel" if items == 2 else "sweep_small_fused_defer_kernel"
         deferred = int(t.get("deferred_reads", 0))
         c_iv -= int(t.get("deferred_intervals", 0))
         c_reads -= deferred

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define YACRD_ABI_VERSION 3
+#define YACRD_ABI_VERSION 4 /* 4: yacrd_timing grew by screen_items; yacrd_engine_ingest_overlaps_mem */
 
 /* src/editor/mod.rs:42-59 ReadType; numeric encoding is ours, names are the reference's. */
 enum { YACRD_NOT_BAD = 0, YACRD_CHIMERIC = 1, YACRD_NOT_COVERED = 2 };
@@ -131,6 +131,10 @@ typedef struct {
      * in yacrd_engine_timing_total (fused_ms / class_ms are sums over these runs: with
      * YACRD_F_TIMING_SAMPLED not every run is one) */
     uint32_t timed_runs;
+    /* groups of list entries per wavefront the screen ran with (1 or 2; the last run's): 2 for long launches unless the one
+     * before left more than a tenth of its reads to the sort — the one-item build has the sliding windows */
+    uint32_t screen_items;
+    uint32_t reserved0;
 } yacrd_timing;
 
 /* size classes, in the order of yacrd_timing.class_*: R<K> = four reads per wavefront (16-lane

@@ -23,7 +23,7 @@ try:
     names = ["r%09d" % i for i in range(R)]
     time.sleep(5)
     ref = None
-    for io, oo in (("pread", "map"), ("pread", "pwrite"), ("mmap", "map")):
+    for io, oo in (("pread", "pwrite"), ("pread", "map"), ("mmap", "pwrite")):
         os.environ["YACRD_EDIT_IO"] = io
         os.environ["YACRD_EDIT_OUT"] = oo
         io = "in " + io + " / out " + oo

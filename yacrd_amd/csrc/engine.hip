@@ -94,7 +94,8 @@ int launch_compact(yacrd_engine *e, const yk::SweepArgs &sa, u32 n_reads, double
     if ((uint64_t)n_reads >= split_min_reads()) {
         ca.host_ctr = e->h_ctr;
         if (screened)
-            hipLaunchKernelGGL(yk::deferred_sweep_kernel, dim3(nb), dim3(yk::kDeferThreads), 0, e->stream, ca.sweep, n_reads);
+            hipLaunchKernelGGL(yk::deferred_sweep_kernel, dim3((n_reads + yk::kDeferSlab - 1) / yk::kDeferSlab), dim3(yk::kDeferThreads), 0,
+                               e->stream, ca.sweep, n_reads);
         hipLaunchKernelGGL(yk::scan_compact_kernel, dim3((n_reads + yk::kScanReads - 1) / yk::kScanReads), dim3(yk::kScanThreads), 0, e->stream, ca);
         return YACRD_OK;
     }
@@ -935,6 +936,7 @@ int conclude_run(yacrd_engine *e, yk::Counters c0, bool predicted, uint64_t n_re
         e->nodefer_left--;
     }
     t.screened = screened ? 1u : 0u;
+    t.screen_items = screened ? e->last_items : 0u;
     t.fused_reads = t.fused_intervals = 0;
     t.prefiltered_reads = c1.prefiltered;
     if (fused_marked) t.fused_ms = ev_ms(e->ev_cls[22], e->ev_cls[23]);

@@ -328,7 +328,14 @@ __device__ __forceinline__ bool trim_item(const SweepArgs &a, u32 rr, u64 o, u32
     return true;
 }
 
-constexpr int kDeferSlab = 1024, kDeferThreads = 256;
+#ifndef YK_DEFER_SLAB
+#define YK_DEFER_SLAB 1024
+#endif
+#ifndef YK_DEFER_THREADS
+#define YK_DEFER_THREADS 256
+#endif
+constexpr int kDeferSlab = YK_DEFER_SLAB, kDeferThreads = YK_DEFER_THREADS; // (A/B: profiles/r04)
+static_assert(kDeferSlab % kDeferThreads == 0 && kDeferSlab <= 65536, "a thread looks at whole reads; list entries hold a 16-bit index");
 
 #ifndef YK_DEFER_TRIM
 // The marked reads through the pile-trimming filter and a short sort first (trim_item): bit-exact (GPU tests and fuzz with

@@ -567,13 +567,14 @@ int edit_sequences_parallel(int op, bool fastq, const char *in_path, const char 
     if (n_chunks < 2) return -1;
     const int ofd = ::open(out_path, O_RDWR | O_CREAT | O_TRUNC, 0666);
     if (ofd < 0) return yh::fail(std::string("cannot create ") + out_path);
-    // The output goes through a SHARED MAPPING of the file, not through pwrite: buffered writes to one file take its
-    // inode lock one after the other — sixteen threads with pwrite were slower than one (tools/edit_bench.py: 2.6 against
-    // 3.4 GB/s) — while page faults on a mapping only meet at the page.  The file grows ahead of the writers in steps
-    // (touching a mapped page beyond the end of the file is a SIGBUS) and is cut to its size at the end.  YACRD_EDIT_OUT=
-    // pwrite: the old way (A/B).
+    // The output: pwrite at the chunk's offset (default), or — YACRD_EDIT_OUT=map — memcpy into a shared mapping of the
+    // file, grown ahead of the writers in steps and cut to size at the end.  Neither scales on the box this was measured
+    // on (tools/edit_bench.py, 20 GB of FASTQ in /dev/shm, profiles/r04/h_edit_bench_map_vs_pwrite.log): pwrite 3.1 GB/s
+    // on one thread, 5.0 on four, 4.9 on eight, 4.4 on sixteen; the mapping 4.7 on four, 2.9 on sixteen, 1.7 on
+    // thirty-two.  What the threads share is the kernel's allocation of the output's fresh pages (one memory cgroup):
+    // more threads only queue up there — hence the default of at most eight.
     const char *oio = std::getenv("YACRD_EDIT_OUT");
-    const bool out_map = !(oio && std::strcmp(oio, "pwrite") == 0);
+    const bool out_map = oio && std::strcmp(oio, "map") == 0;
     const size_t map_len = 2 * size + ((size_t)64 << 20);
     char *obase = nullptr;
     if (out_map) {
@@ -859,7 +860,7 @@ int yacrd_edit_file_mt(int op, const char *in_path, const char *out_path, const 
     if (!(seq || (ovl && (op == OP_FILTER || op == OP_EXTRACT))))
         return yh::fail(std::string("Can't run ") + op_name(op) + " on " + type_name(ft) +
                         " file " + in_path);
-    unsigned T = n_threads > 0 ? (unsigned)n_threads : yh::usable_cpus();
+    unsigned T = n_threads > 0 ? (unsigned)n_threads : std::min(yh::usable_cpus(), 8u); // (more only queue up at the page allocator: edit_sequences_parallel)
     if (const char *e = std::getenv("YACRD_EDIT_THREADS"))
         if (*e) T = (unsigned)std::max(1, std::atoi(e));
     T = std::min(T, 64u);

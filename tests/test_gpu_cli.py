@@ -121,7 +121,9 @@ def test_several_engines_stream_group_path(work, golden_dir, tmp_path):
     p = subprocess.run([BIN, "-i", str(work / "reads.paf"), "-o", str(work / "g2.yacrd"), "--gpus", "64"],
                        capture_output=True, text=True)
     assert p.returncode != 0 and "device" in p.stderr
-    env = dict(os.environ, YACRD_GPUS_ON_DEVICE="0")
+    # (round 4: an input that fits one GPU is parsed and swept on device 0 whatever N is; YACRD_NO_DEVICE_PARSER=1 sends it
+    # down the path of the inputs that do not — the host parser and the stream group — which is what this test is about)
+    env = dict(os.environ, YACRD_GPUS_ON_DEVICE="0", YACRD_NO_DEVICE_PARSER="1")
     from yacrd_amd import host
     big = str(tmp_path / "big.paf")
     host.synth_paf(host.SYNTH_ONT, 3000, 60000, 20250303, big)
@@ -135,6 +137,11 @@ def test_several_engines_stream_group_path(work, golden_dir, tmp_path):
                                capture_output=True, text=True)
             assert p.returncode == 0, p.stderr
             assert open(out).read() == open(one).read()
+            if n == "2":  # the default route for N > 1: device 0 parses, with a notice
+                env2 = dict(os.environ, YACRD_GPUS_ON_DEVICE="0")
+                p = subprocess.run([BIN, "-i", src, "-o", out, "-c", cov, "--gpus", n], env=env2, capture_output=True, text=True)
+                assert p.returncode == 0 and "fits one GPU" in p.stderr, p.stderr
+                assert open(out).read() == open(one).read()
 
 
 def test_bad_usage_is_loud(work):

@@ -5,7 +5,7 @@
 //   yacrd -i <overlaps.paf|.m4|.mhap|report.yacrd> -o <report.yacrd> [-t N] [-c COV] [-n RATIO]
 //         [--read-buffer-size N] [-d PREFIX] [--ondisk-buffer-size N]
 //         [scrubb|filter|extract|split -i <in> -o <out>]
-// Additive flags only: --gpus N (reads partitioned over N GPUs by id handle, default 1).
+// Additive flags only: --gpus N (default 1): an input beyond one GPU's memory is partitioned over N GPUs by id handle.
 // The bad-region computation and the read classification run on the GPU through
 // include/yacrd_engine.h; there is no CPU fallback — without a gfx950 device this exits non-zero.
 #include <algorithm>
@@ -178,7 +178,11 @@ int main(int argc, char **argv)
         int dev_parse = YACRD_EFALLBACK;
         // YACRD_NO_DEVICE_PARSER=1: the host parser for everything (A/B, tools/e2e_cli_paf.py)
         const char *no_dev = std::getenv("YACRD_NO_DEVICE_PARSER");
-        if (engines.size() == 1 && (paf || m4) && !(no_dev && *no_dev == '1')) {
+        // (--gpus N > 1: an input that one GPU can parse is parsed and swept on device 0 — its text reaches HBM at the
+        // link's rate and the detection takes milliseconds: N GPUs fed by the host parser are five times slower end to end,
+        // DESIGN.md §7 — and only an input beyond one GPU's memory, which the call below refuses before it allocates
+        // anything, is routed to all N by the stream group)
+        if ((paf || m4) && !(no_dev && *no_dev == '1')) {
             // one GPU, PAF or M4 text: the host only moves the file to HBM, the device parses it, numbers the reads,
             // builds the CSR and runs the engine (yacrd_engine_ingest_overlaps).  Whatever is not a plain file of
             // plain records (compressed, quoted fields, lone CRs, 0x integers, malformed lines ...) comes back as
@@ -207,6 +211,9 @@ int main(int argc, char **argv)
             if (dev_parse != YACRD_OK && dev_parse != YACRD_EFALLBACK) die(yacrd_last_error());
         }
         if (dev_parse == YACRD_OK) {
+            if (engines.size() > 1)
+                std::fprintf(stderr, "[INFO] --gpus %zu: the input fits one GPU: parsed and swept on device 0 (the other devices are for "
+                                     "inputs beyond one GPU's memory)\n", engines.size());
             view.n_reads = dev_reads.n_reads;
             view.name_off = dev_reads.name_off;
             view.names = dev_reads.names;

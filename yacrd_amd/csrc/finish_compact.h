@@ -236,7 +236,7 @@ __global__ __launch_bounds__(kScanBlock, YK_FINISH_OCC) void finish_compact_kern
 // turn and 8 for a second while the slab's scan waits (the sorts are ~600 dependent instructions per read: 29 M of
 // them for configs[2]'s 47 600 reads = 47 us of VALU time when every SIMD issues; the kernel needed ~100).
 // For batches of kPlanSmallReads reads and more the engine launches instead:
-//   deferred_sweep_kernel   256 threads per slab of 1024 reads: the slab's marked reads are listed in LDS, the long
+//   deferred_sweep_kernel   512 threads per slab of 2048 reads: the slab's marked reads are listed in LDS, the long
 //                           ones first, and sorted one per wavefront and turn — the same 64-lane sorts, but four
 //                           wavefronts take six turns each instead of sixteen taking one and a half, eight
 //                           workgroups share a CU, and nothing else waits for them;
@@ -328,11 +328,14 @@ __device__ __forceinline__ bool trim_item(const SweepArgs &a, u32 rr, u64 o, u32
     return true;
 }
 
+// reads per slab / threads per workgroup (follow-on step on configs[2] / configs[4], profiles/r04/i_ab_deferred_slab_size.log):
+// 256 / 256: 0.231 / 0.541 ms; 512 / 256: 0.158 / 0.347; 1024 / 256: 0.152 / 0.297; 2048 / 512: 0.134 / 0.283 — longer lists
+// fill the wavefronts' turns evenly and fewer workgroups post the two counter atomics
 #ifndef YK_DEFER_SLAB
-#define YK_DEFER_SLAB 1024
+#define YK_DEFER_SLAB 2048
 #endif
 #ifndef YK_DEFER_THREADS
-#define YK_DEFER_THREADS 256
+#define YK_DEFER_THREADS 512
 #endif
 constexpr int kDeferSlab = YK_DEFER_SLAB, kDeferThreads = YK_DEFER_THREADS; // (A/B: profiles/r04)
 static_assert(kDeferSlab % kDeferThreads == 0 && kDeferSlab <= 65536, "a thread looks at whole reads; list entries hold a 16-bit index");

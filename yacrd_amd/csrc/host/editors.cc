@@ -571,8 +571,9 @@ int edit_sequences_parallel(int op, bool fastq, const char *in_path, const char 
     // file, grown ahead of the writers in steps and cut to size at the end.  Neither scales on the box this was measured
     // on (tools/edit_bench.py, 20 GB of FASTQ in /dev/shm, profiles/r04/h_edit_bench_map_vs_pwrite.log): pwrite 3.1 GB/s
     // on one thread, 5.0 on four, 4.9 on eight, 4.4 on sixteen; the mapping 4.7 on four, 2.9 on sixteen, 1.7 on
-    // thirty-two.  What the threads share is the kernel's allocation of the output's fresh pages (one memory cgroup):
-    // more threads only queue up there — hence the default of at most eight.
+    // thirty-two — and on two other boxes of the same kind one thread (3.4 / 3.8 GB/s) beat every larger number (2.5-2.9:
+    // profiles/r04/f_*, i_*).  What the threads share is the kernel's allocation of the output's fresh pages (one memory
+    // cgroup): more threads only queue up there — hence the default of at most four.
     const char *oio = std::getenv("YACRD_EDIT_OUT");
     const bool out_map = oio && std::strcmp(oio, "map") == 0;
     const size_t map_len = 2 * size + ((size_t)64 << 20);
@@ -860,7 +861,7 @@ int yacrd_edit_file_mt(int op, const char *in_path, const char *out_path, const 
     if (!(seq || (ovl && (op == OP_FILTER || op == OP_EXTRACT))))
         return yh::fail(std::string("Can't run ") + op_name(op) + " on " + type_name(ft) +
                         " file " + in_path);
-    unsigned T = n_threads > 0 ? (unsigned)n_threads : std::min(yh::usable_cpus(), 8u); // (more only queue up at the page allocator: edit_sequences_parallel)
+    unsigned T = n_threads > 0 ? (unsigned)n_threads : std::min(yh::usable_cpus(), 4u); // (more only queue up at the page allocator: edit_sequences_parallel)
     if (const char *e = std::getenv("YACRD_EDIT_THREADS"))
         if (*e) T = (unsigned)std::max(1, std::atoi(e));
     T = std::min(T, 64u);

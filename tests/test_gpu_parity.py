@@ -771,3 +771,23 @@ def test_hole_closed_form_fuzz():
         for flags in (yacrd_amd.F_ALWAYS_DEFER, yacrd_amd.F_ALWAYS_DEFER | yacrd_amd.F_SCREEN_ITEMS_2):
             with yacrd_amd.Engine(flags=flags) as e:
                 assert_same(e.run(offsets, intervals, lengths, cov, 0.4), want, "hole fuzz cov %d flags %d" % (cov, flags))
+
+
+def test_fused_workgroup_screens_of_several_engines_take_turns():
+    """Round 4: screen_wg_fused_kernel is a persistent grid sized to be resident as a whole; the engines that share a device
+    launch theirs one after the other (engine.hip: g_fused_lane) — three engines, batches of workgroup-class reads large enough
+    to fill the device, submitted without waiting: every result bit-exact, nothing hangs."""
+    rng = np.random.default_rng(99)
+    sizes = rng.integers(513, 2500, size=2500)
+    csr = make_csr(6161, sizes, ("regular", "sparse", "abutting", "dups"), len_lo=20000, len_hi=300000, mode_block=5)
+    want = oracle.run(csr[0], csr[1], csr[2].astype(np.uint64), 3, 0.4, n_threads=8)
+    engs = [yacrd_amd.Engine() for _ in range(3)]
+    try:
+        for rep in range(4):
+            for e in engs:  # three batches in flight: H2D, kernels and D2H of one overlap the others'
+                e.submit(*csr, 3, 0.4)
+            for j, e in enumerate(engs):
+                assert_same(e.collect(), want, "engine %d, round %d" % (j, rep))
+    finally:
+        for e in engs:
+            e.close()

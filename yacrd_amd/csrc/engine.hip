@@ -637,7 +637,15 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
                 fa.head = &ctr->fbq_head[k];
                 fa.done = &ctr->fbq_done[k];
                 const u32 gs = (u32)std::min<uint64_t>(set.n[cls], (uint64_t)e->num_cu * (uint64_t)e->screen_fused_wgs_per_cu);
-                hipLaunchKernelGGL(yk::screen_wg_fused_kernel, dim3(gs), dim3(yk::kWsT), 0, e->stream, fa);
+                {
+                    FusedLane &fl = g_fused_lane[e->device & 63];
+                    std::lock_guard<std::mutex> turn(fl.mu);
+                    if (fl.owner != nullptr && fl.owner != e && fl.last) HIP_TRY(hipStreamWaitEvent(e->stream, fl.last, 0));
+                    hipLaunchKernelGGL(yk::screen_wg_fused_kernel, dim3(gs), dim3(yk::kWsT), 0, e->stream, fa);
+                    HIP_TRY(hipEventRecord(e->ev_fused, e->stream));
+                    fl.last = e->ev_fused;
+                    fl.owner = e;
+                }
                 if (k == 1) { // what does not fit the in-kernel fallback's 16 384 events even filtered (usually nothing)
                     sa.list = over_med;
                     sa.list_n = &ctr->over_med;
@@ -1138,6 +1146,7 @@ int yacrd_engine_create(const yacrd_engine_cfg *cfg, yacrd_engine **out)
     for (int i = 0; i < EV_COUNT && err == hipSuccess; i++) err = hipEventCreate(&e->ev[i]);
     for (int i = 0; i < 24 && err == hipSuccess; i++) err = hipEventCreate(&e->ev_cls[i]);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_done, hipEventBlockingSync | hipEventDisableTiming);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_fused, hipEventDisableTiming);
     if (err == hipSuccess) err = hipEventCreate(&e->ev_h2d0);
     if (err == hipSuccess) err = hipEventCreate(&e->ev_h2d1);
     if (err == hipSuccess) err = hipEventCreate(&e->ev_d2h0);
@@ -1172,6 +1181,14 @@ void yacrd_engine_destroy(yacrd_engine *e)
             lane.last = nullptr;
         }
     }
+    {
+        FusedLane &fl = g_fused_lane[e->device & 63];
+        std::lock_guard<std::mutex> g(fl.mu);
+        if (fl.owner == e) {
+            fl.owner = nullptr;
+            fl.last = nullptr;
+        }
+    }
     DevBuf *bufs[] = {&e->in_off, &e->in_iv, &e->in_len, &e->lists, &e->ctrl2[0], &e->ctrl2[1], &e->stage,
                       &e->counts, &e->closed, &e->gen_sizes, &e->gen_scratch_off,
                       &e->gen_scratch, &e->big_tab, &e->big_keys, &e->big_redo, &e->bt_tab, &e->bt_hist, &e->bt_cur, &e->bt_keys, &e->bs_seg, &e->bs_chunk, &e->bs_hist,
@@ -1189,7 +1206,7 @@ void yacrd_engine_destroy(yacrd_engine *e)
         if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
     for (int i = 0; i < 24; i++)
         if (e->ev_cls[i]) (void)hipEventDestroy(e->ev_cls[i]);
-    hipEvent_t extra[] = {e->ev_h2d0, e->ev_h2d1, e->ev_d2h0, e->ev_d2h1, e->ev_done};
+    hipEvent_t extra[] = {e->ev_h2d0, e->ev_h2d1, e->ev_d2h0, e->ev_d2h1, e->ev_done, e->ev_fused};
     for (hipEvent_t x : extra)
         if (x) (void)hipEventDestroy(x);
     if (e->stream) (void)hipStreamDestroy(e->stream);

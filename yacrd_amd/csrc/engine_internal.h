@@ -95,6 +95,15 @@ struct BigLane {
     int n_engines = 0;
 };
 static BigLane g_big_lane[64];
+// One per device: the persistent screen + fallback launches (screen_wg_fused_kernel) of the engines that share it go one
+// after the other.  Each is sized to be resident as a whole, and its workgroups wait for each other's queue entries: two of
+// them side by side, each half resident, would wait for workgroups that the other's spinning ones keep from being scheduled.
+struct FusedLane {
+    std::mutex mu;
+    hipEvent_t last = nullptr; // recorded behind the last such launch
+    struct yacrd_engine *owner = nullptr;
+};
+static FusedLane g_fused_lane[64];
 
 // A batch that was submitted without waiting for it (yacrd_engine_submit_device).
 struct Pending {
@@ -120,6 +129,7 @@ struct yacrd_engine {
     hipEvent_t ev_h2d0 = nullptr, ev_h2d1 = nullptr, ev_d2h0 = nullptr, ev_d2h1 = nullptr;
     hipEvent_t ev_cls[24] = {}; // brackets around class kernels
     hipEvent_t ev_done = nullptr; // hipEventBlockingSync: the final wait of YACRD_F_BLOCKING_WAIT
+    hipEvent_t ev_fused = nullptr; // behind this engine's last screen_wg_fused_kernel (g_fused_lane)
     int num_cu = 256;
     int screen_fused_wgs_per_cu = 0; // workgroups of screen_wg_fused_kernel a CU holds at once (its grid must be resident as a whole)
 

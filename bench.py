@@ -224,7 +224,7 @@ def resident_block(cx, label, profile, R, O, cov, nc, seed, jitter, steps, warmu
     r0, r1 = int(cuts[cx.rank]), int(cuts[cx.rank + 1])
     off, iv, ln = ydist.local_csr(offsets, intervals, lengths, r0, r1)
     if cx.world > 1:  # (slices of the shared maps: private copies, the files go away below)
-        off, iv, ln = np.ascontiguousarray(off), np.ascontiguousarray(iv), np.ascontiguousarray(ln)
+        off, iv, ln = np.array(off), np.array(iv), np.array(ln)  # (copies: the maps are read-only and about to go)
         drop_shared(cx)
     Rl, Il = r1 - r0, int(off[-1])
     t0 = time.perf_counter()

@@ -30,6 +30,10 @@ struct CompactArgs2 {
 };
 
 constexpr int kFinishWaves = kScanBlock / 64;
+#ifndef YK_FINISH_ORDER_REL
+#define YK_FINISH_ORDER_REL __ATOMIC_RELAXED // (A/B: __ATOMIC_RELEASE / __ATOMIC_ACQUIRE, see the look-back below)
+#define YK_FINISH_ORDER_ACQ __ATOMIC_RELAXED
+#endif
 #ifndef YK_FINISH_OCC
 #define YK_FINISH_OCC 8 // register budget of the kernel as wavefronts per SIMD (512 / 8 = 64 VGPRs: two workgroups per CU)
 #endif
@@ -157,12 +161,12 @@ __global__ __launch_bounds__(kScanBlock, YK_FINISH_OCC) void finish_compact_kern
                 // done at the memory side.  Spelled as release here + acquire in the look-back — ADVICE r3 — the
                 // compiler emits an L2 write-back / invalidate per store / poll: the kernel went from 0.150 to 0.344 ms
                 // on configs[2], profiles/r04/b_ab_split_follow_on.log.)
-                __hip_atomic_store(&c.scan_state[bid], kAgg | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&c.scan_state[bid], kAgg | tot, YK_FINISH_ORDER_REL, __HIP_MEMORY_SCOPE_AGENT);
             for (i32 hi = (i32)bid - 1;; hi -= 64) {
                 const i32 idx = hi - (i32)lane; // lane 0 looks at the nearest predecessor
                 u64 v, pre;
                 for (;;) { // until the window holds no empty entry before its nearest prefix
-                    v = idx >= 0 ? __hip_atomic_load(&c.scan_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                    v = idx >= 0 ? __hip_atomic_load(&c.scan_state[idx], YK_FINISH_ORDER_ACQ, __HIP_MEMORY_SCOPE_AGENT)
                                  : kPre; // before the first workgroup: prefix 0
                     pre = __builtin_amdgcn_ballot_w64((v >> 62) == 2);
                     const u64 before = pre ? ((pre & (0 - pre)) - 1ull) : ~0ull; // lanes nearer than it

@@ -160,7 +160,10 @@ __global__ __launch_bounds__(kScanBlock, YK_FINISH_OCC) void finish_compact_kern
                 // performed before this store: they are returning atomics issued by this very lane and waited for, i.e.
                 // done at the memory side.  Spelled as release here + acquire in the look-back — ADVICE r3 — the
                 // compiler emits an L2 write-back / invalidate per store / poll: the kernel went from 0.150 to 0.344 ms
-                // on configs[2], profiles/r04/b_ab_split_follow_on.log.)
+                // on configs[2], profiles/r04/b_ab_split_follow_on.log; on the short batches this kernel still serves:
+                // 20.6 -> 23.0 us for 100 000 reads, 33.7 -> 54.5 us for 390 000, the pipelined batch 26.6 -> 30.0 us,
+                // profiles/r04/m_ab_release_acquire_short_batches.log; -DYK_FINISH_ORDER_REL=__ATOMIC_RELEASE
+                // -DYK_FINISH_ORDER_ACQ=__ATOMIC_ACQUIRE builds it.)
                 __hip_atomic_store(&c.scan_state[bid], kAgg | tot, YK_FINISH_ORDER_REL, __HIP_MEMORY_SCOPE_AGENT);
             for (i32 hi = (i32)bid - 1;; hi -= 64) {
                 const i32 idx = hi - (i32)lane; // lane 0 looks at the nearest predecessor

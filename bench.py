@@ -99,7 +99,8 @@ def roofline_of(yacrd_amd, t, n_launches, R, G, key, note):
     deferred = 0
     if cname == "R2..H16" and t.get("screened"):
         items = int(t.get("screen_items", 0)) or (2 if c_iv >= 40_000_000 else 1)  # (what the engine's last run used)
-        dom = "sweep_small_fused_defer2_kernel" if items == 2 else "sweep_small_fused_defer_kernel"
+        dom = ("sweep_small_fused_defer2_kernel" if items == 2 else
+               "sweep_small_fused_defer_wide_kernel" if int(t.get("screen_wide", 0)) else "sweep_small_fused_defer_kernel")
         deferred = int(t.get("deferred_reads", 0))
         c_iv -= int(t.get("deferred_intervals", 0))
         c_reads -= deferred

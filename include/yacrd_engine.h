@@ -132,9 +132,10 @@ typedef struct {
      * YACRD_F_TIMING_SAMPLED not every run is one) */
     uint32_t timed_runs;
     /* groups of list entries per wavefront the screen ran with (1 or 2; the last run's): 2 for long launches unless the one
-     * before left more than a tenth of its reads to the sort — the one-item build has the sliding windows */
+     * before left more than a tenth of its reads to the sort — then the one-item build with the sliding windows runs */
     uint32_t screen_items;
-    uint32_t reserved0;
+    /* 1: the screen ran in the build with the second looks (sliding windows; always one item) */
+    uint32_t screen_wide;
 } yacrd_timing;
 
 /* size classes, in the order of yacrd_timing.class_*: R<K> = four reads per wavefront (16-lane

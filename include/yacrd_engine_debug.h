@@ -43,5 +43,8 @@
 /* the workgroup classes (513 .. 16 384 intervals) run the screen and its fallback as separate launches (round 3's
  * chain) instead of the persistent screen_wg_fused_kernel; A/B, tests */
 #define YACRD_F_NO_FUSED_SCREEN 1048576u
+/* the screen always runs in its one-item build with the second looks (sliding windows; by default only after a batch that
+ * deferred more than a tenth of what it screened); tests, A/B */
+#define YACRD_F_SCREEN_WIDE 2097152u
 
 #endif

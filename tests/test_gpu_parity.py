@@ -391,19 +391,45 @@ def test_screen_on_jittered_profiles(prof, cov):
         want = oracle.run(o, iv, ln.astype(np.uint64), cov, 0.4, n_threads=4)
         n = np.diff(o.astype(np.int64))
         in_classes = int(((n > 64) & (n <= 256)).sum())
-        for flags in (yacrd_amd.F_ALWAYS_DEFER, yacrd_amd.F_NO_DEFER,
-                      yacrd_amd.F_ALWAYS_DEFER | yacrd_amd.F_SCREEN_ITEMS_2):
+        wide = yacrd_amd.F_ALWAYS_DEFER | yacrd_amd.F_SCREEN_WIDE  # the build with the second looks (sliding windows)
+        for flags in (yacrd_amd.F_ALWAYS_DEFER, yacrd_amd.F_NO_DEFER, yacrd_amd.F_ALWAYS_DEFER | yacrd_amd.F_SCREEN_ITEMS_2, wide):
             with yacrd_amd.Engine(flags=flags | yacrd_amd.F_COUNT_PREFILTERED) as e:
                 assert_same(e.run(o, iv, ln, cov, 0.4), want, "profile %d synth flags %d flags %d" % (prof, sflags, flags))
                 t = e.timing()
-                # (the two-items build of the screen — long launches — keeps the single look: the second looks cost it
-                # registers it does not have, profiles/r04/d_ab_screen_slides_occupancy.log; sigma = 300: 88-89 % decided)
-                wide = sflags == (host.SYNTH_F_JITTER | host.synth_f_sigma(300))
-                one_item = flags == yacrd_amd.F_ALWAYS_DEFER
-                if flags & yacrd_amd.F_ALWAYS_DEFER and sflags != (host.SYNTH_F_JITTER | host.synth_f_sigma(8)) and cov in (3, 4) \
-                        and (one_item or sflags == host.SYNTH_F_JITTER):
-                    assert t["deferred_reads"] <= in_classes * (15 if wide else 10) // 100, (sflags, flags, t["deferred_reads"], in_classes)
-                    assert t["prefiltered_reads"] >= in_classes * (85 if wide else 90) // 100
+                # sigma = 30: every build decides >= 90 %; sigma = 100 / 300: the build with the second looks
+                # does (>= 85 % at 300); the default builds take their first batch without them (the next test)
+                s8 = sflags == (host.SYNTH_F_JITTER | host.synth_f_sigma(8))
+                s300 = sflags == (host.SYNTH_F_JITTER | host.synth_f_sigma(300))
+                if cov in (3, 4) and not s8 and flags & yacrd_amd.F_ALWAYS_DEFER and (flags == wide or sflags == host.SYNTH_F_JITTER):
+                    assert t["deferred_reads"] <= in_classes * (15 if s300 else 10) // 100, (sflags, flags, t["deferred_reads"], in_classes)
+                    assert t["prefiltered_reads"] >= in_classes * (85 if s300 else 90) // 100
+                if flags & yacrd_amd.F_ALWAYS_DEFER:
+                    assert t["screen_wide"] == (1 if flags == wide else 0)
+
+
+@pytest.mark.parametrize("always", [True, False])
+def test_second_looks_are_switched_on_by_the_deferral_rate(always):
+    """Round 4: the default builds of the screen take ONE look (a tenth faster on reads whose dovetail ends lie within the
+    32-position window); a batch that leaves more than a tenth of its screened reads to the sort switches the engine to the
+    build with the second looks (sliding windows + ramp) for the next 15 batches — spread ends (sigma = 100) and back."""
+    from yacrd_amd import host
+    spread = host.synth_csr(host.SYNTH_ONT, 6000, 300000, 81, flags=host.SYNTH_F_JITTER | host.synth_f_sigma(100))
+    tight = host.synth_csr(host.SYNTH_ONT, 6000, 300000, 82, flags=host.SYNTH_F_JITTER)
+    wants = [oracle.run(b[0], b[1], b[2].astype(np.uint64), 4, 0.4, n_threads=4) for b in (spread, tight)]
+    tenth = [int(((np.diff(b[0].astype(np.int64)) > 64) & (np.diff(b[0].astype(np.int64)) <= 256)).sum()) // 10 for b in (spread, tight)]
+    with yacrd_amd.Engine(flags=yacrd_amd.F_ALWAYS_DEFER if always else 0) as e:
+        seen = []
+        for i, which in enumerate([0, 0, 0, 1] + [1] * 16 + [0, 0]):
+            b = (spread, tight)[which]
+            assert_same(e.run(*b, 4, 0.4), wants[which], "batch %d" % i)
+            t = e.timing()
+            assert t["screened"] == 1, (i, t)                  # (the sorting build never takes over here)
+            seen.append((t["screen_wide"], t["deferred_reads"], which))
+        assert seen[0][0] == 0 and seen[0][1] > tenth[0], seen  # the first spread batch: one look, > 10 % left to the sort
+        assert seen[1][0] == 1 and seen[1][1] <= tenth[0], seen # the second: the build with the second looks, <= 10 %
+        assert all(w == 1 for w, _, _ in seen[1:16]), seen      # ... which stays for 15 batches, tight ones included,
+        assert seen[16][0] == 0 and seen[17][0] == 0, seen      # then the default build is tried again (tight batches: it stays)
+        assert seen[-2][0] == 0 and seen[-1][0] == 1, seen      # and a spread batch switches the second looks on once more
 
 
 @pytest.mark.parametrize("cov", [0, 4, 5, 11, 300, 0xFFFFFFFF])

@@ -19,7 +19,8 @@ MODES = ("regular", "abutting", "dups", "beyond", "sparse", "zero_len", "degener
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(time.time()) & 0xFFFF)
 t0, rounds, reads = time.time(), 0, 0
-cflags = yacrd_amd.F_ALWAYS_DEFER | (yacrd_amd.F_SCREEN_ITEMS_2 if os.environ.get("YACRD_FUZZ_ITEMS2") else 0)
+cflags = (yacrd_amd.F_ALWAYS_DEFER | (yacrd_amd.F_SCREEN_ITEMS_2 if os.environ.get("YACRD_FUZZ_ITEMS2") else 0)
+          | (yacrd_amd.F_SCREEN_WIDE if os.environ.get("YACRD_FUZZ_WIDE") else 0))
 with yacrd_amd.Engine(flags=cflags) as e, yacrd_amd.Engine(flags=yacrd_amd.F_NO_PREFILTER) as ref:
     while time.time() - t0 < budget:
         R = int(rng.integers(1, 3000))

@@ -519,14 +519,16 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
                                 (fused_iv >= defer_min_intervals() && e->nodefer_left == 0));
             // two groups of list entries per wavefront in the screened classes when the launch streams from
             // HBM (more than the 256 MiB Infinity Cache holds): twice the loads in flight per wavefront
-            // ... unless the last such launch left more than a tenth of its reads to the sort: the one-item build has the
-            // second looks (sliding windows, sweep_wave.h) the two-items build has no registers for, and dovetail ends
-            // spread by hundreds of positions need them (configs[2] at sigma = 300: 79 % decided against 96 %)
+            // ... unless the last screened batch left more than a tenth of its reads to the sort: then the one-item build WITH
+            // the second looks (sliding windows, sweep_wave.h) takes the next kProbeEvery - 1 — dovetail ends spread by
+            // hundreds of positions need them (configs[1] at sigma = 100: 79 % decided against 95 %; configs[2] at 300: 79 %
+            // against 97 %), reads that do not are a tenth faster without (conclude_run: wide_left)
+            const bool wide = defer && !(e->flags & YACRD_F_SCREEN_ITEMS_2) && ((e->flags & YACRD_F_SCREEN_WIDE) || e->wide_left > 0);
             const int items = !defer ? 1
-                              : (e->flags & YACRD_F_SCREEN_ITEMS_1) ? 1
-                              : (e->flags & YACRD_F_SCREEN_ITEMS_2) ? 2
-                              : (fused_iv >= 40000000ull && e->items1_left == 0) ? 2 : 1;
+                              : (wide || (e->flags & YACRD_F_SCREEN_ITEMS_1)) ? 1
+                              : ((e->flags & YACRD_F_SCREEN_ITEMS_2) || fused_iv >= 40000000ull) ? 2 : 1;
             e->last_items = (uint32_t)items;
+            e->last_wide = wide;
             fa.base.over_list = nullptr; // (the deferring build marks its reads in counts[])
             fa.base.over_count = nullptr;
             fa.n_entries = 0;
@@ -563,6 +565,10 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
                 const bool chain = (e->flags & YACRD_F_SWEEP_TURNS) && (shared || lane.n_engines > 1);
                 if (defer && items == 2)
                     hipExtLaunchKernelGGL(yk::sweep_small_fused_defer2_kernel, dim3(blocks), dim3(64), 0,
+                                          e->stream, mark ? e->ev_cls[22] : (hipEvent_t) nullptr,
+                                          (mark || chain) ? e->ev_cls[23] : (hipEvent_t) nullptr, 0, fa);
+                else if (defer && wide)
+                    hipExtLaunchKernelGGL(yk::sweep_small_fused_defer_wide_kernel, dim3(blocks), dim3(64 * yk::kDeferWaves), 0,
                                           e->stream, mark ? e->ev_cls[22] : (hipEvent_t) nullptr,
                                           (mark || chain) ? e->ev_cls[23] : (hipEvent_t) nullptr, 0, fa);
                 else if (defer)
@@ -937,14 +943,18 @@ int conclude_run(yacrd_engine *e, yk::Counters c0, bool predicted, uint64_t n_re
     // screened had to be sorted after all, the sorting build takes the next kProbeEvery - 1 batches.
     if (screened) {
         const uint64_t looked_at = (uint64_t)c0.n[yk::CLS_R16] + c0.n[yk::CLS_H16];
-        e->nodefer_left = (!(e->flags & YACRD_F_ALWAYS_DEFER) && 4 * (uint64_t)c1.deferred > looked_at) ? kProbeEvery - 1 : 0;
-        if (e->last_items == 2) e->items1_left = 10 * (uint64_t)c1.deferred > looked_at ? kProbeEvery - 1 : 0;
-        else if (e->items1_left) e->items1_left--;
+        // (a one-look batch that left more than a tenth is followed by the build with the second looks first: only when
+        // THAT leaves more than a quarter does the sorting build take over)
+        const bool can_widen = !e->last_wide && !(e->flags & YACRD_F_SCREEN_ITEMS_2);
+        e->nodefer_left = (!(e->flags & YACRD_F_ALWAYS_DEFER) && !can_widen && 4 * (uint64_t)c1.deferred > looked_at) ? kProbeEvery - 1 : 0;
+        if (!e->last_wide) e->wide_left = 10 * (uint64_t)c1.deferred > looked_at ? kProbeEvery - 1 : 0;
+        else if (e->wide_left) e->wide_left--;
     } else if (e->nodefer_left) {
         e->nodefer_left--;
     }
     t.screened = screened ? 1u : 0u;
     t.screen_items = screened ? e->last_items : 0u;
+    t.screen_wide = (screened && e->last_wide) ? 1u : 0u;
     t.fused_reads = t.fused_intervals = 0;
     t.prefiltered_reads = c1.prefiltered;
     if (fused_marked) t.fused_ms = ev_ms(e->ev_cls[22], e->ev_cls[23]);

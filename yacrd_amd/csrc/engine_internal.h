@@ -156,8 +156,9 @@ struct yacrd_engine {
     yacrd_timing timing_sum = {};
     uint64_t timing_runs = 0;
     uint32_t run_seq = 0; // runs since creation (YACRD_F_TIMING_SAMPLED times every 8th)
-    uint32_t items1_left = 0;  // batches a long launch of the screen still takes in its one-item build (sliding windows) before the two-items build is tried again
+    uint32_t wide_left = 0;    // batches the screen still takes in its one-item build WITH the second looks (sliding windows) before the default builds are tried again
     uint32_t last_items = 1;   // groups of list entries per wavefront the last screen ran with
+    bool last_wide = false;    // ... and whether it was the build with the second looks
     uint32_t nodefer_left = 0; // batches the sorting build of the fused launch still takes before the screen is tried again
     // pinned bounce buffers for pageable inputs (yke::h2d), allocated on first use; an event per
     // buffer says when its DMA is done and it may be refilled

@@ -458,13 +458,10 @@ constexpr int kScreenSlides = YK_SCREEN_SLIDES;
 // step 0.816 -> 0.853 / 1.77 -> 2.06 ms (profiles/r04/e_ab_hole_form.log).  Off; -DYK_HOLE_FORM=1 builds it.
 #define YK_HOLE_FORM 0
 #endif
-#ifndef YK_SLIDES_IN_ITEMS2
-// The two-items build of the screen (long launches from HBM: sweep_small_fused_defer2_kernel) keeps the single look: with
-// two items' intervals live the second looks' registers push it over its budget (a spilled load at its very start, or
-// occupancy 5: 0.625 -> 0.66 ms on configs[2]), and the Sequel-depth reads it is quoted on gain nothing from them
-// (97.6 % decided at sigma = 100 and 300 either way: profiles/r04/d_ab_screen_slides_occupancy.log).
-#define YK_SLIDES_IN_ITEMS2 0
-#endif
+// Which builds carry the second looks: only sweep_small_fused_defer_wide_kernel.  The two-items build has no registers for
+// them (a spilled load at its very start, or occupancy 5: 0.625 -> 0.66 ms on configs[2], profiles/r04/d_*; behind a call that
+// reloads the read the call's arguments spill the same load, and the one-item build gets slower still: profiles/r04/n_*), and
+// the plain one-item build is a tenth faster without them.  The engine switches (engine.hip: wide_left).
 
 // The screen works on the raw positions (no event keys are made): v[j] = two intervals (x, y) and
 // (z, w) of this lane, real0[j] / real1[j] = whether those slots belong to the read (the others hold
@@ -994,7 +991,7 @@ __device__ __attribute__((noinline)) uint4 hole_form_call(const u64 *off, const 
 // ITEMS at once, so a wavefront has ITEMS x 8 interval loads per lane in flight (8 KB at ITEMS = 2) and
 // pays each round trip once per ITEMS groups: what an HBM-resident input needs to keep the memory
 // system busy (configs[2]: ... ).  The screens then run one after the other on the same LDS table.
-template <int LANES, int ITEMS>
+template <int LANES, int ITEMS, bool WIDE = false>
 __device__ __forceinline__ void screen_block(const SweepArgs &a, u32 block)
 {
     constexpr int K = 16;
@@ -1077,7 +1074,7 @@ __device__ __forceinline__ void screen_block(const SweepArgs &a, u32 block)
         HealthyRead hr;
         bool healthy = healthy_screen<LANES, 1>(v[t], real0, real1, len[t], c, pmin, pmax, hr) && !girr;
         bool table_intact = true, hole_done = false; // (the first screen's coarse blocks are still in LDS; this group's read got its hole form)
-        if constexpr (kScreenSlides > 0 && (ITEMS == 1 || YK_SLIDES_IN_ITEMS2)) {
+        if constexpr (kScreenSlides > 0 && WIDE) {
             // a window that came up short of c + 1 (verdict in the group's last lane): slide it (see kScreenSlides).
             // st = need | F << 1 | G << 11 of the last screen (counts clipped to their ten bits)
             auto state_of = [&](bool nd, const HealthyRead &h) {
@@ -1235,7 +1232,7 @@ struct FusedArgs {
     const u32 *list_n[5];
 };
 
-template <bool DEFER, int WPB, int ITEMS = 1>
+template <bool DEFER, int WPB, int ITEMS = 1, bool WIDE = false>
 __device__ __forceinline__ void sweep_small_fused_body(const FusedArgs &f)
 {
     // Workgroups are dealt out to the 8 XCDs round robin (XCD = blockIdx.x mod 8); reads that are
@@ -1263,11 +1260,11 @@ __device__ __forceinline__ void sweep_small_fused_body(const FusedArgs &f)
     case CLS_R4: sweep_group_block<16, 4, 0, WPB>(a, b); break;
     case CLS_R8: sweep_group_block<16, 8, 0, WPB>(a, b); break;
     case CLS_R16:
-        if constexpr (DEFER) screen_block<16, ITEMS>(a, b);
+        if constexpr (DEFER) screen_block<16, ITEMS, WIDE>(a, b);
         else sweep_group_block<16, 16, 0, WPB>(a, b);
         break;
     default:
-        if constexpr (DEFER) screen_block<32, ITEMS>(a, b);
+        if constexpr (DEFER) screen_block<32, ITEMS, WIDE>(a, b);
         else sweep_group_block<32, 16, 0, WPB>(a, b);
         break;
     }
@@ -1282,6 +1279,14 @@ __device__ __forceinline__ void sweep_small_fused_body(const FusedArgs &f)
 __global__ __launch_bounds__(64 * kDeferWaves, kDeferOcc) void sweep_small_fused_defer_kernel(FusedArgs f)
 {
     sweep_small_fused_body<true, kDeferWaves>(f);
+}
+// the one-item build WITH the second looks (sliding windows + ramp, §"Windows that slide"): what the engine launches after a
+// batch that left more than a tenth of its screened reads to the sort.  They cost the build four registers and a tenth of its
+// speed on reads that never need them (configs[1]: 24.4 -> 26.7 us per pipelined batch, profiles/r04/n_*), so the default
+// builds do not carry them.
+__global__ __launch_bounds__(64 * kDeferWaves, kDeferOcc) void sweep_small_fused_defer_wide_kernel(FusedArgs f)
+{
+    sweep_small_fused_body<true, kDeferWaves, 1, true>(f);
 }
 // the same with two groups of list entries per wavefront in the screened classes (long launches from HBM)
 #ifndef YK_DEFER2_OCC

@@ -371,6 +371,21 @@ def small_batches_block(cx, jitter=0, chimeras=0):
             unpredicted = {"ms_per_batch": dt * 1e3, "reads_per_sec": R / dt,
                            "what": "one engine, one batch at a time, no prediction of the class counts (a host sync "
                                    "after the plan kernel), no timing events"}
+        # ... and the same as ONE launch (YACRD_F_ONE_LAUNCH: csrc/one_batch.h — no plan, no class counts, one dispatch)
+        with ya.Engine(device_id=cx.dev_index, flags=ya.F_ONE_LAUNCH | ya.F_NO_TIMING) as oe:
+            for _ in range(5):
+                oe.run_device(*ptrs)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(50):
+                oe.run_device(*ptrs)
+            dt1 = (time.perf_counter() - t0) / 50
+            ot = oe.timing()
+            got1 = oe.fetch()
+            one_launch = {"ms_per_batch": dt1 * 1e3, "reads_per_sec": R / dt1, "ran_as_one_launch": bool(ot.get("one_launch")),
+                          "deferred_reads": int(ot.get("deferred_reads", 0)),
+                          "what": "YACRD_F_ONE_LAUNCH: one engine, one batch at a time; one_batch_kernel (slab-owning "
+                                  "workgroups: screen, sorts of what it leaves, scan + compaction + type_of_read)"}
         with ya.Engine(device_id=cx.dev_index, flags=ya.F_TIMING_FULL) as fe:
             for _ in range(5):
                 fe.run_device(*ptrs)
@@ -394,7 +409,7 @@ def small_batches_block(cx, jitter=0, chimeras=0):
                "scaling": "weak", "reads_per_gpu": R, "overlaps_per_gpu": O, "intervals_per_gpu": I, "regions_per_gpu": G,
                "whole_path_algorithmic_bytes": b_alg, "whole_path_GBps": b_alg / (elapsed / K) / 1e9,
                "whole_path_frac_of_peak": b_alg / (elapsed / K) / 1e9 / HBM_PEAK_GBS,
-               "unpredicted_single_batch": unpredicted, "phases_full_timing_ms": phases,
+               "unpredicted_single_batch": unpredicted, "one_launch_single_batch": one_launch, "phases_full_timing_ms": phases,
                "healthy_reads": int(t.get("fused_reads", 0)) - int(t.get("deferred_reads", 0)) if screened else None,
                "deferred_reads": int(t.get("deferred_reads", 0)) if screened else None,
                "batches_through_the_screen": "%d of %d (the others: the sorting build, chosen from the previous batches' deferral rate)" % (int(t.get("screened", 0)), K),
@@ -408,6 +423,10 @@ def small_batches_block(cx, jitter=0, chimeras=0):
         blk["parity"] = ("bit-exact vs oracle on all %d reads" % R
                          if (np.array_equal(got.bad_offsets, want[0]) and np.array_equal(got.bad_regions, want[1])
                              and np.array_equal(got.read_type, want[2])) else "MISMATCH vs oracle")
+        blk["one_launch_single_batch"]["parity"] = (
+            "bit-exact vs oracle on all %d reads" % R
+            if (np.array_equal(got1.bad_offsets, want[0]) and np.array_equal(got1.bad_regions, want[1])
+                and np.array_equal(got1.read_type, want[2])) else "MISMATCH vs oracle")
     keep = (offsets, intervals, lengths, engs, G, cov, nc) if cx.rank == 0 and not jitter and not chimeras else None
     if keep is None:
         for e in engs:

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define YACRD_ABI_VERSION 4 /* 4: yacrd_timing grew by screen_items; yacrd_engine_ingest_overlaps_mem */
+#define YACRD_ABI_VERSION 5 /* 5: YACRD_F_ONE_LAUNCH, yacrd_timing.one_launch; 4: yacrd_timing.screen_items, yacrd_engine_ingest_overlaps_mem */
 
 /* src/editor/mod.rs:42-59 ReadType; numeric encoding is ours, names are the reference's. */
 enum { YACRD_NOT_BAD = 0, YACRD_CHIMERIC = 1, YACRD_NOT_COVERED = 2 };
@@ -72,6 +72,12 @@ typedef struct {
  * events cost ~10 us per batch (host + stream) against a 20 us kernel; yacrd_timing.timed_runs says how
  * many runs were timed */
 #define YACRD_F_TIMING_SAMPLED 32768u
+/* Latency over throughput, for callers that run ONE short batch at a time (the CLI once its input is in HBM): a batch of
+ * fewer than 400 000 reads whose reads all have at most 256 intervals runs as one kernel launch — no size-class plan, no
+ * class counts, no prediction, one dispatch instead of three (csrc/one_batch.h: 100 000 reads in ... us instead of 66-70).
+ * Any other batch takes the default path, as does a batch in which that launch met a read it does not handle (found on
+ * the device; the batch is then run again).  Callers that keep several batches in flight are better off without. */
+#define YACRD_F_ONE_LAUNCH 4194304u
 /* (the A/B and test switches that pin a kernel family or a build live in yacrd_engine_debug.h; the
  * product path is flags = 0) */
 
@@ -136,6 +142,10 @@ typedef struct {
     uint32_t screen_items;
     /* 1: the screen ran in the build with the second looks (sliding windows; always one item) */
     uint32_t screen_wide;
+    /* 1: the batch ran as ONE launch (YACRD_F_ONE_LAUNCH and every read within 256 intervals); the count of such runs in
+     * yacrd_engine_timing_total */
+    uint32_t one_launch;
+    uint32_t reserved0;
 } yacrd_timing;
 
 /* size classes, in the order of yacrd_timing.class_*: R<K> = four reads per wavefront (16-lane

@@ -413,8 +413,9 @@ def test_second_looks_are_switched_on_by_the_deferral_rate(always):
     32-position window); a batch that leaves more than a tenth of its screened reads to the sort switches the engine to the
     build with the second looks (sliding windows + ramp) for the next 15 batches — spread ends (sigma = 100) and back."""
     from yacrd_amd import host
-    spread = host.synth_csr(host.SYNTH_ONT, 6000, 300000, 81, flags=host.SYNTH_F_JITTER | host.synth_f_sigma(100))
-    tight = host.synth_csr(host.SYNTH_ONT, 6000, 300000, 82, flags=host.SYNTH_F_JITTER)
+    R, O = (6000, 300000) if always else (50000, 2500000)  # (default flags: the screen runs from 4 M intervals on)
+    spread = host.synth_csr(host.SYNTH_ONT, R, O, 81, flags=host.SYNTH_F_JITTER | host.synth_f_sigma(100))
+    tight = host.synth_csr(host.SYNTH_ONT, R, O, 82, flags=host.SYNTH_F_JITTER)
     wants = [oracle.run(b[0], b[1], b[2].astype(np.uint64), 4, 0.4, n_threads=4) for b in (spread, tight)]
     tenth = [int(((np.diff(b[0].astype(np.int64)) > 64) & (np.diff(b[0].astype(np.int64)) <= 256)).sum()) // 10 for b in (spread, tight)]
     with yacrd_amd.Engine(flags=yacrd_amd.F_ALWAYS_DEFER if always else 0) as e:

@@ -61,7 +61,7 @@ struct Counters {
     u32 rej_big;             // ... by the 1024-thread LDS sweep (n <= 16384): global-memory path
     u32 region_overflow;     // compaction ran out of bad_regions capacity
     u32 scan_ticket;         // dynamic workgroup id of the single-pass scan
-    u32 scan_done;           // workgroups of the scan kernel that finished
+    u32 ob_unsupported;      // one_batch_kernel met a read it does not handle (> 256 intervals): the batch takes the default path
     u32 prefiltered;         // reads that took the pre-filtered sort (only counted when asked)
     u32 over_med;            // M2 reads whose filtered keys do not fit the 256-thread kernel's LDS
     u32 fb_med[2];           // M1 / M2 reads the workgroup screen (screen_wg.h) left to the trimming filter + sort

@@ -31,6 +31,7 @@
 #include "finish_compact.h"
 #include "screen_wg.h"
 #include "screen_big.h"
+#include "one_batch.h"
 
 using namespace yke;
 
@@ -349,6 +350,7 @@ int wait_for_stream(yacrd_engine *e)
 
 int conclude_run(yacrd_engine *e, yk::Counters c0, bool predicted, uint64_t n_reads64, uint64_t n_iv,
                  const int *cls_b, const int *cls_e, bool fused_marked, bool screened, float extra_ms);
+int finish_pending(yacrd_engine *e);
 
 } // namespace
 
@@ -372,7 +374,12 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         return YACRD_OK;
     }
 
-    const u32 nb = (n_reads + yk::kScanBlock - 1) / yk::kScanBlock;
+    // YACRD_F_ONE_LAUNCH: a short batch as one kernel (one_batch.h) — unless a debug flag pins another path
+    const bool one_launch = (e->flags & YACRD_F_ONE_LAUNCH) && !e->one_launch_off && n_reads64 < split_min_reads() &&
+                            !(e->flags & (YACRD_F_FORCE_GENERAL | YACRD_F_WAVE_ONLY | YACRD_F_FORCE_LDS_SORT | YACRD_F_NO_HALVES |
+                                          YACRD_F_NO_PREFILTER | YACRD_F_NO_DEFER | YACRD_F_XLANE_DS | YACRD_F_NO_FUSED_LAUNCH));
+    // (scan-state words: one per slab of the follow-on kernel, or per slab of one_batch_kernel)
+    const u32 nb = one_launch ? (n_reads + yk::kObSlab - 1) / yk::kObSlab : (n_reads + yk::kScanBlock - 1) / yk::kScanBlock;
     constexpr int kLists = yk::CLS_COUNT + 7; // class lists + three rejection lists + M2 overflow + what the screens leave of M1 / M2 / BIG
     HIP_TRY(e->lists.reserve((size_t)kLists * n_reads * sizeof(u32)));
     const size_t ctrl_bytes = (sizeof(yk::Counters) + (size_t)nb * sizeof(u64) + 255) & ~(size_t)255;
@@ -415,6 +422,35 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     e->ctrl_clean[cur] = 0;
     const size_t other_bytes = std::min<size_t>(e->ctrl2[other].cap, (size_t)1 << 30) & ~(size_t)3;
     if (full) HIP_TRY(hipEventRecord(e->ev[EV_START], e->stream));
+    if (one_launch) {
+        yk::OneBatchArgs oa;
+        yk::SweepArgs &s = oa.c.sweep;
+        s.off = d_off, s.iv = d_iv, s.len = d_len, s.list = nullptr, s.list_n = nullptr, s.first = 0, s.cov = cov;
+        s.prefilter = (e->flags & YACRD_F_COUNT_PREFILTERED) ? 2u : 1u;
+        s.stage = e->stage.as<uint2>(), s.counts = e->counts.as<u32>(), s.closed = e->closed.as<uint2>();
+        s.rej_list = rej_small, s.rej_count = &ctr->rej_small, s.over_list = nullptr, s.over_count = nullptr, s.ctr = ctr;
+        oa.c.scan_state = reinterpret_cast<u64 *>(ctr + 1);
+        oa.c.n_reads = n_reads;
+        oa.c.not_cov = not_cov;
+        oa.c.bad_offsets = e->bad_offsets.as<u64>();
+        oa.c.bad_regions = e->bad_regions.as<uint2>();
+        oa.c.region_cap = (u64)(e->bad_regions.cap / sizeof(uint2));
+        oa.c.read_type = e->read_type.as<uint8_t>();
+        oa.c.host_ctr = e->h_ctr;
+        oa.zero = e->ctrl2[other].as<u32>();
+        oa.zero_words = (u32)(other_bytes / 4);
+        e->h_ctr->ob_unsupported = 0; // (written from the device only when set)
+        e->h_ctr->scan_ticket = 0;    // (the slab that ends the batch sends the counters home: nb tickets then)
+        hipLaunchKernelGGL(yk::one_batch_kernel, dim3(nb), dim3(yk::kObThreads), 0, e->stream, oa);
+        e->ctrl_clean[other] = other_bytes;
+        if (full) HIP_TRY(hipEventRecord(e->ev[EV_COMPACT], e->stream));
+        Pending &p = e->pending;
+        p = Pending{};
+        p.active = true, p.one_launch = true;
+        p.d_off = d_off, p.d_iv = d_iv, p.d_len = d_len, p.n_reads = n_reads64, p.n_iv = n_iv, p.cov = cov, p.not_cov = not_cov;
+        for (int i = 0; i < 12; i++) p.cls_b[i] = p.cls_e[i] = -1;
+        return defer ? YACRD_OK : finish_pending(e); // (yacrd_engine_submit_device: the caller waits later)
+    }
     {
         const u32 plan_mode = (u32)((e->flags & YACRD_F_FORCE_GENERAL) ? 1
                                     : (e->flags & (YACRD_F_WAVE_ONLY | YACRD_F_FORCE_LDS_SORT)) ? 2
@@ -980,6 +1016,7 @@ int conclude_run(yacrd_engine *e, yk::Counters c0, bool predicted, uint64_t n_re
     for (int i = 0; i < 12; i++) ts.class_ms[i] = keep.class_ms[i] + t.class_ms[i];
     ts.fused_ms = keep.fused_ms + t.fused_ms;
     ts.screened = keep.screened + t.screened;
+    ts.one_launch = keep.one_launch;
     ts.timed_runs = keep.timed_runs + t.timed_runs;
     e->timing_runs++;
     return YACRD_OK;
@@ -996,6 +1033,39 @@ int finish_pending(yacrd_engine *e)
     p.active = false;
     int rc = wait_for_stream(e);
     if (rc) return rc;
+    if (p.one_launch) {
+        // a read beyond 256 intervals, one the sort rejected (the exact path's) or more regions than bad_regions holds:
+        // the default path has every redo — the batch takes it from the start
+        const yk::Counters c1 = *e->h_ctr;
+        const u32 slabs = (u32)((p.n_reads + yk::kObSlab - 1) / yk::kObSlab);
+        if (c1.ob_unsupported || c1.rej_small || c1.region_overflow || c1.scan_ticket != slabs) {
+            if (c1.region_overflow) HIP_TRY(e->bad_regions.reserve((size_t)(c1.total_regions + 16) * sizeof(uint2)));
+            e->one_launch_off = true;
+            rc = run_on_device(e, p.d_off, p.d_iv, p.d_len, p.n_reads, p.n_iv, p.cov, p.not_cov);
+            e->one_launch_off = false;
+            return rc;
+        }
+        e->last_reads = p.n_reads;
+        e->last_regions = c1.total_regions;
+        e->has_result = true;
+        yacrd_timing &t = e->timing;
+        t = yacrd_timing{};
+        if (e->flags & YACRD_F_TIMING_FULL) t.total_ms = ev_ms(e->ev[EV_START], e->ev[EV_COMPACT]);
+        t.n_small = p.n_reads, t.iv_small = p.n_iv;
+        t.deferred_reads = c1.deferred, t.deferred_intervals = c1.deferred_iv, t.prefiltered_reads = c1.prefiltered;
+        t.screened = 1u, t.screen_items = (uint32_t)yk::kObItems, t.one_launch = 1u;
+        yacrd_timing &ts = e->timing_sum;
+        const yacrd_timing keep = ts;
+        ts = t;
+        ts.h2d_ms = keep.h2d_ms, ts.d2h_ms = keep.d2h_ms;
+        ts.plan_ms = keep.plan_ms, ts.sweep_small_ms = keep.sweep_small_ms, ts.sweep_medium_ms = keep.sweep_medium_ms;
+        ts.sweep_general_ms = keep.sweep_general_ms, ts.compact_ms = keep.compact_ms, ts.total_ms = keep.total_ms + t.total_ms;
+        for (int i = 0; i < 12; i++) ts.class_ms[i] = keep.class_ms[i];
+        ts.fused_ms = keep.fused_ms, ts.screened = keep.screened + 1u, ts.timed_runs = keep.timed_runs;
+        ts.one_launch = keep.one_launch + 1u;
+        e->timing_runs++;
+        return YACRD_OK;
+    }
     const yk::Counters c = *e->h_ctr;
     bool ok = !c.rej_small && !c.n[yk::CLS_GENERAL] && !c.rej_big && !c.region_overflow;
     for (int cls = 0; cls < yk::CLS_GENERAL; cls++) ok = ok && c.n[cls] <= p.grid_n[cls];

@@ -116,6 +116,7 @@ struct Pending {
     double not_cov = 0;
     u32 grid_n[12] = {};      // reads each class's grid covers
     bool fused_marked = false, screened = false;
+    bool one_launch = false;  // the batch went out as one_batch_kernel (one_batch.h)
     int cls_b[12] = {}, cls_e[12] = {};
 };
 
@@ -159,6 +160,7 @@ struct yacrd_engine {
     uint32_t wide_left = 0;    // batches the screen still takes in its one-item build WITH the second looks (sliding windows) before the default builds are tried again
     uint32_t last_items = 1;   // groups of list entries per wavefront the last screen ran with
     bool last_wide = false;    // ... and whether it was the build with the second looks
+    bool one_launch_off = false; // (while a batch the one-launch form could not take is run again on the default path)
     uint32_t nodefer_left = 0; // batches the sorting build of the fused launch still takes before the screen is tried again
     // pinned bounce buffers for pageable inputs (yke::h2d), allocated on first use; an event per
     // buffer says when its DMA is done and it may be refilled

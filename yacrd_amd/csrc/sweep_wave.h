@@ -991,18 +991,36 @@ __device__ __attribute__((noinline)) uint4 hole_form_call(const u64 *off, const 
 // ITEMS at once, so a wavefront has ITEMS x 8 interval loads per lane in flight (8 KB at ITEMS = 2) and
 // pays each round trip once per ITEMS groups: what an HBM-resident input needs to keep the memory
 // system busy (configs[2]: ... ).  The screens then run one after the other on the same LDS table.
+// Where the screen's verdicts go (the group's last lane calls): the fused launch answers through counts[] / closed[]
+// in global memory (device_common.h: kClosedForm, kDeferredMark) for the follow-on kernel to find; the one-launch form
+// of a short batch (one_batch.h) keeps them in its workgroup's LDS.
+struct VerdictsToGlobal {
+    const SweepArgs &a;
+    __device__ __forceinline__ void closed(u32 r, u32 ra, u32 rb, u32 len) const
+    {
+        if (ra != 0 || rb != len) {
+            a.closed[r] = make_uint2(ra, rb);
+            a.counts[r] = kClosedForm;
+        } else {
+            a.counts[r] = 0;
+        }
+        if (a.prefilter == 2) atomicAdd(&a.ctr->prefiltered, 1u);
+    }
+    __device__ __forceinline__ void deferred(u32 r) const { a.counts[r] = kDeferredMark; }
+};
+
+template <int LANES, int ITEMS, bool WIDE, int WPB = 1, class Sink>
+__device__ __forceinline__ void screen_reads(const SweepArgs &a, const u32 (&r)[ITEMS], const bool (&active)[ITEMS], const Sink &sink);
+
 template <int LANES, int ITEMS, bool WIDE = false>
 __device__ __forceinline__ void screen_block(const SweepArgs &a, u32 block)
 {
-    constexpr int K = 16;
     constexpr u32 GROUPS = 64 / LANES;
-    const u32 lane = lane_id(), lig = lane & (u32)(LANES - 1), grp = lane / (u32)LANES;
+    const u32 grp = lane_id() / (u32)LANES;
     const u32 list_n = *a.list_n;
     const u32 idx0 = a.first + block * (u32)ITEMS * GROUPS;
     if (idx0 >= list_n) return; // grids may be sized for more reads than the class holds
-    const i32 c = (i32)min(a.cov, 0x3FFFFFFFu);
-    u32 r[ITEMS], n[ITEMS], len[ITEMS];
-    u64 o[ITEMS];
+    u32 r[ITEMS];
     bool active[ITEMS];
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) {
@@ -1010,6 +1028,19 @@ __device__ __forceinline__ void screen_block(const SweepArgs &a, u32 block)
         active[t] = idx < list_n;
         r[t] = active[t] ? a.list[idx] : 0u;
     }
+    screen_reads<LANES, ITEMS, WIDE>(a, r, active, VerdictsToGlobal{a});
+}
+
+// ITEMS reads per lane group, given by their ids (active[t]: this group has a t-th read; a t with no active group in the
+// wavefront ends the loop).  WPB: wavefronts per workgroup (each has a table of its own in LDS).
+template <int LANES, int ITEMS, bool WIDE, int WPB, class Sink>
+__device__ __forceinline__ void screen_reads(const SweepArgs &a, const u32 (&r)[ITEMS], const bool (&active)[ITEMS], const Sink &sink)
+{
+    constexpr int K = 16;
+    const u32 lane = lane_id(), lig = lane & (u32)(LANES - 1);
+    const i32 c = (i32)min(a.cov, 0x3FFFFFFFu);
+    u32 n[ITEMS], len[ITEMS];
+    u64 o[ITEMS];
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) {
         o[t] = 0, n[t] = 0, len[t] = 0;
@@ -1038,7 +1069,7 @@ __device__ __forceinline__ void screen_block(const SweepArgs &a, u32 block)
     }
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) {
-        if (t > 0 && idx0 + (u32)t * GROUPS >= list_n) break; // uniform: nothing left for this item
+        if (t > 0 && __builtin_amdgcn_ballot_w64(active[t]) == 0) break; // uniform: nothing left for this item
         const u32 len_c = min(len[t], kMaxKeyPos);
         // The read's smallest start and largest end, from the raw positions of every slot: a slot beyond
         // the read's last interval holds a copy of one of its intervals (the clamped load), so it cannot
@@ -1072,7 +1103,7 @@ __device__ __forceinline__ void screen_block(const SweepArgs &a, u32 block)
             real1[j] = i0 < n_eff;
         }
         HealthyRead hr;
-        bool healthy = healthy_screen<LANES, 1>(v[t], real0, real1, len[t], c, pmin, pmax, hr) && !girr;
+        bool healthy = healthy_screen<LANES, WPB>(v[t], real0, real1, len[t], c, pmin, pmax, hr) && !girr;
         bool table_intact = true, hole_done = false; // (the first screen's coarse blocks are still in LDS; this group's read got its hole form)
         if constexpr (kScreenSlides > 0 && WIDE) {
             // a window that came up short of c + 1 (verdict in the group's last lane): slide it (see kScreenSlides).
@@ -1114,7 +1145,7 @@ __device__ __forceinline__ void screen_block(const SweepArgs &a, u32 block)
                     for (int j = 0; j < K / 4; j++) r0[j] = real0[j] && go, r1[j] = real1[j] && go;
                     wave_lds_sync(); // (the table is zeroed again)
                     HealthyRead h2;
-                    const bool ok2 = healthy_screen<LANES, 1, true>(v[t], r0, r1, len[t], c, pmin + h0, pmax - t0, h2, PQ & 0xFFFFu, PQ >> 16, gemin);
+                    const bool ok2 = healthy_screen<LANES, WPB, true>(v[t], r0, r1, len[t], c, pmin + h0, pmax - t0, h2, PQ & 0xFFFFu, PQ >> 16, gemin);
                     st = go ? state_of(!ok2 && (h2.F <= c || h2.G <= c), h2) : 0u; // (meaningful in the group's last lane)
                     if (go) healthy = ok2, hr.a = h2.a, hr.b = h2.b;
                 }
@@ -1149,15 +1180,9 @@ __device__ __forceinline__ void screen_block(const SweepArgs &a, u32 block)
             if (healthy || (!girr && (i32)n[t] <= c)) {
                 // never more than c intervals open: the whole read is bad = (0, a) with a = len
                 const u32 ra = (i32)n[t] <= c ? len[t] : hr.a, rb = (i32)n[t] <= c ? len[t] : hr.b;
-                if (ra != 0 || rb != len[t]) {
-                    a.closed[r[t]] = make_uint2(ra, rb);
-                    a.counts[r[t]] = kClosedForm;
-                } else {
-                    a.counts[r[t]] = 0;
-                }
-                if (a.prefilter == 2) atomicAdd(&a.ctr->prefiltered, 1u);
+                sink.closed(r[t], ra, rb, len[t]);
             } else {
-                a.counts[r[t]] = kDeferredMark;
+                sink.deferred(r[t]);
             }
         }
         if (t + 1 < ITEMS) wave_lds_sync(); // the next item zeroes the table

@@ -33,6 +33,7 @@ F_SCREEN_ITEMS_1 = 262144
 F_SCREEN_ITEMS_2 = 524288
 F_NO_FUSED_SCREEN = 1048576
 F_SCREEN_WIDE = 2097152
+F_ONE_LAUNCH = 4194304  # include/yacrd_engine.h: a short batch as ONE kernel launch (csrc/one_batch.h)
 
 # every symbol include/yacrd_engine.h declares
 EXPORTED_SYMBOLS = [
@@ -110,7 +111,8 @@ class _Timing(ctypes.Structure):
                 ("fused_reads", ctypes.c_uint64), ("fused_intervals", ctypes.c_uint64),
                 ("prefiltered_reads", ctypes.c_uint64), ("deferred_reads", ctypes.c_uint64),
                 ("deferred_intervals", ctypes.c_uint64), ("screened", ctypes.c_uint32),
-                ("timed_runs", ctypes.c_uint32), ("screen_items", ctypes.c_uint32), ("screen_wide", ctypes.c_uint32)]
+                ("timed_runs", ctypes.c_uint32), ("screen_items", ctypes.c_uint32), ("screen_wide", ctypes.c_uint32),
+                ("one_launch", ctypes.c_uint32), ("reserved0", ctypes.c_uint32)]
 
 CLASS_NAMES = "R2,R4,R8,R16,H16,W2,W4,W8,W16,M1,M2,BIG".split(",")
 CLASS_KERNELS = {  # the HIP kernel behind each class, as rocprofv3 prints it

@@ -24,7 +24,7 @@ def _csr_of(reads):
 
 
 @pytest.mark.parametrize("prof,R,O,cov", [(0, 10000, 500000, 4), (1, 6000, 600000, 3), (0, 100000, 5000000, 4),
-                                          (0, 1, 40, 4), (0, 127, 6000, 0), (0, 129, 6000, 9), (0, 4097, 200000, 4)])
+                                          (0, 16, 800, 4), (0, 127, 6000, 0), (0, 129, 6000, 9), (0, 4097, 200000, 4)])
 def test_generator_batches(prof, R, O, cov):
     """SURVEY 8d's profiles (configs[1] among them), clamped and jittered (sigma 30 / 100): one launch, bit-exact."""
     from yacrd_amd import host

@@ -555,10 +555,11 @@ def test_deferral_rate_swings_between_batches():
 def test_build_choice_follows_the_share_of_bad_reads():
     """Default flags, batches big enough for the screening build (>= 4 M intervals in R16 + H16): with the
     generator's 2 % chimeras every batch goes through the screen; with 40 % (YACRD_SYNTH_F_CHIMERA_PCT) more than a
-    quarter of a screened batch comes back deferred and the engine takes the sorting build for the next 15 batches,
-    then probes the screen again (engine.hip: nodefer_left / kProbeEvery).  Bit-exact either way."""
+    quarter of a screened batch comes back deferred: the second batch tries the build with the second looks (they do not
+    help chimeras), then the engine takes the sorting build for the next 15 batches and probes the screen again with the
+    18th (engine.hip: wide_left / nodefer_left / kProbeEvery).  Bit-exact either way."""
     from yacrd_amd import host
-    for pct, want_screened in ((0, 18), (40, 2)):
+    for pct, want_screened in ((0, 18), (40, 3)):
         off, iv, ln = host.synth_csr(host.SYNTH_ONT, 60000, 3000000, 31 + pct, host.synth_f_chimera_pct(pct))
         want = oracle.run(off, iv, ln.astype(np.uint64), 4, 0.4, n_threads=8)
         with yacrd_amd.Engine() as e:

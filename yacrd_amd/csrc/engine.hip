@@ -378,8 +378,9 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     const bool one_launch = (e->flags & YACRD_F_ONE_LAUNCH) && !e->one_launch_off && n_reads64 < split_min_reads() &&
                             !(e->flags & (YACRD_F_FORCE_GENERAL | YACRD_F_WAVE_ONLY | YACRD_F_FORCE_LDS_SORT | YACRD_F_NO_HALVES |
                                           YACRD_F_NO_PREFILTER | YACRD_F_NO_DEFER | YACRD_F_XLANE_DS | YACRD_F_NO_FUSED_LAUNCH));
-    // (scan-state words: one per slab of the follow-on kernel, or per slab of one_batch_kernel)
-    const u32 nb = one_launch ? (n_reads + yk::kObSlab - 1) / yk::kObSlab : (n_reads + yk::kScanBlock - 1) / yk::kScanBlock;
+    // (scan-state words: one per slab of the follow-on kernel; one_batch_kernel: one per slab + its arrival counters)
+    const u32 ob_slabs = (n_reads + yk::kObSlab - 1) / yk::kObSlab;
+    const u32 nb = one_launch ? 2 * ob_slabs : (n_reads + yk::kScanBlock - 1) / yk::kScanBlock;
     constexpr int kLists = yk::CLS_COUNT + 7; // class lists + three rejection lists + M2 overflow + what the screens leave of M1 / M2 / BIG
     HIP_TRY(e->lists.reserve((size_t)kLists * n_reads * sizeof(u32)));
     const size_t ctrl_bytes = (sizeof(yk::Counters) + (size_t)nb * sizeof(u64) + 255) & ~(size_t)255;
@@ -437,11 +438,13 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         oa.c.region_cap = (u64)(e->bad_regions.cap / sizeof(uint2));
         oa.c.read_type = e->read_type.as<uint8_t>();
         oa.c.host_ctr = e->h_ctr;
+        oa.slab_ctr = oa.c.scan_state + ob_slabs;
+        oa.n_slabs = ob_slabs;
         oa.zero = e->ctrl2[other].as<u32>();
         oa.zero_words = (u32)(other_bytes / 4);
         e->h_ctr->ob_unsupported = 0; // (written from the device only when set)
         e->h_ctr->scan_ticket = 0;    // (the slab that ends the batch sends the counters home: nb tickets then)
-        hipLaunchKernelGGL(yk::one_batch_kernel, dim3(nb), dim3(yk::kObThreads), 0, e->stream, oa);
+        hipLaunchKernelGGL(yk::one_batch_kernel, dim3((n_reads + yk::kObReads - 1) / yk::kObReads), dim3(64), 0, e->stream, oa);
         e->ctrl_clean[other] = other_bytes;
         if (full) HIP_TRY(hipEventRecord(e->ev[EV_COMPACT], e->stream));
         Pending &p = e->pending;

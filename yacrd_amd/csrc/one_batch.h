@@ -21,266 +21,275 @@
 
 namespace yk {
 
-constexpr int kObWaves = 8, kObThreads = 64 * kObWaves;
-constexpr int kObReadsPerWave = 16, kObSlab = kObWaves * kObReadsPerWave; // reads per workgroup
 #ifndef YK_OB_ITEMS
-#define YK_OB_ITEMS 2 // reads per lane group and turn of the screen (loads of both in flight together)
+#define YK_OB_ITEMS 1 // reads per lane group and turn of the screen
 #endif
 #ifndef YK_OB_OCC
-#define YK_OB_OCC 6 // wavefronts per SIMD the register budget allows: three workgroups per CU (LDS: 3 x 44 KB)
+#define YK_OB_OCC 7 // wavefronts per SIMD the register budget allows: 72 VGPRs (LDS: 5 KB per wavefront = 28 of 32 per CU)
 #endif
 constexpr int kObItems = YK_OB_ITEMS;
+constexpr int kObReads = 4 * kObItems;           // consecutive reads per wavefront
+constexpr int kObSlab = 512;                     // reads per slab (one arrival counter, one scan word, one pass of phase B)
+constexpr int kObPer = kObSlab / 64;             // reads per lane in phase B
+static_assert(kObSlab % kObReads == 0 && kObSlab / kObReads < 0xFFFF, "arrivals are counted in 16 bits");
 
 struct OneBatchArgs {
-    CompactArgs2 c;   // sweep (off / iv / len / cov / prefilter / stage / counts / rej_list / rej_count / ctr), scan_state, outputs
+    CompactArgs2 c;   // sweep (off / iv / len / cov / prefilter / stage / counts / closed / rej_list / rej_count / ctr), scan_state, outputs
+    u64 *slab_ctr;    // [slabs] arrivals | deferred reads << 16 | their intervals << 32, zero at launch
+    u32 n_slabs;
     u32 *zero;        // the engine's other control block, zeroed here for the next run (as plan_kernel does)
     u32 zero_words;
 };
 
-struct VerdictsToLds { // (see VerdictsToGlobal)
-    u32 *g;       // [kObSlab] region count | kClosedForm | kDeferredMark, by index inside the slab
-    uint2 *ab;    // [kObSlab]
-    u32 r_base;   // first read of the slab
-    u32 count;    // a.prefilter == 2
-    Counters *ctr;
+// The screen's verdicts, written so that a wavefront on ANOTHER XCD (its own L2) reads them inside this launch: stores at
+// agent scope (write-through), read back with agent-scope loads.  A deferred read is noted in the wavefront's LDS.
+struct VerdictsAcrossXcds {
+    const SweepArgs &a;
+    u32 *s_def; // [kObReads]
+    u32 r0;
     __device__ __forceinline__ void closed(u32 r, u32 ra, u32 rb, u32 len) const
     {
-        const u32 i = r - r_base;
         if (ra != 0 || rb != len) {
-            ab[i] = make_uint2(ra, rb);
-            g[i] = kClosedForm;
+            __hip_atomic_store(reinterpret_cast<u64 *>(a.closed + r), (u64)ra | ((u64)rb << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.counts + r, kClosedForm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            g[i] = 0;
+            __hip_atomic_store(a.counts + r, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (count) atomicAdd(&ctr->prefiltered, 1u);
+        if (a.prefilter == 2) atomicAdd(&a.ctr->prefiltered, 1u);
     }
-    __device__ __forceinline__ void deferred(u32 r) const { g[r - r_base] = kDeferredMark; }
+    __device__ __forceinline__ void deferred(u32 r) const { s_def[r - r0] = 1u; }
 };
 
-__global__ __launch_bounds__(kObThreads, YK_OB_OCC) void one_batch_kernel(OneBatchArgs ob)
+__global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs ob)
 {
-    static_assert(!YK_HOLE_FORM, "hole_form_call uses a one-wavefront table");
+    static_assert(!YK_HOLE_FORM, "the hole form answers through counts[] with plain stores");
     const CompactArgs2 &c = ob.c;
     const SweepArgs &a = c.sweep;
     Counters *ctr = a.ctr;
-    for (u32 i = blockIdx.x * kObThreads + threadIdx.x; i < ob.zero_words; i += gridDim.x * kObThreads) ob.zero[i] = 0;
-
-    __shared__ u32 s_g[kObSlab];
-    __shared__ uint2 s_ab[kObSlab];
-    __shared__ uint8_t s_l16[kObWaves][kObReadsPerWave], s_l32[kObWaves][kObReadsPerWave];
-    __shared__ u32 sc[kObWaves];
-    __shared__ u32 s_bid, s_n_def, s_unsup;
-    __shared__ unsigned long long s_iv_def;
-    __shared__ u64 s_part[kObWaves]; // look-back: per wavefront, the sum of its window up to its nearest prefix
-    __shared__ u32 s_flag[kObWaves]; //            1 = holds a prefix, 2 = an empty entry in front of it
-    if (threadIdx.x == 0) {
-        s_bid = atomicAdd(&ctr->scan_ticket, 1u);
-        s_n_def = 0, s_unsup = 0, s_iv_def = 0;
-    }
-    __syncthreads();
-    const u32 bid = s_bid, lane = lane_id(), wave = threadIdx.x >> 6;
-    const u32 slab0 = bid * (u32)kObSlab;
-
-    // ---- S: this wavefront's 16 reads through the screen
+    for (u32 i = blockIdx.x * 64u + threadIdx.x; i < ob.zero_words; i += gridDim.x * 64u) ob.zero[i] = 0;
+    // (as in the fused launch: every XCD — its own L2 — takes a contiguous eighth of the batch)
+    u32 w = blockIdx.x;
     {
-        const u32 r0 = slab0 + wave * (u32)kObReadsPerWave;
-        const bool in = lane < (u32)kObReadsPerWave && r0 + lane < c.n_reads;
-        u32 n = 0;
-        bool huge = false;
+        const u32 nb = gridDim.x, x = w & 7u, q = nb >> 3, rem = nb & 7u;
+        w = x * q + min(x, rem) + (w >> 3);
+    }
+    __shared__ u32 s_def[kObReads];
+    const u32 lane = lane_id();
+    const u32 r0 = w * (u32)kObReads;
+
+    // ---- S: the wavefront's reads through the screen, by size class
+    u32 n = 0;
+    bool in = false, huge = false;
+    {
+        in = lane < (u32)kObReads && r0 + lane < c.n_reads;
         if (in) {
-            const ulonglong2 oo = *reinterpret_cast<const ulonglong2 *>(a.off + (r0 + lane)); // off[r], off[r + 1] (8-byte aligned 16-byte load)
+            const ulonglong2 oo = *reinterpret_cast<const ulonglong2 *>(a.off + (r0 + lane)); // off[r], off[r + 1]
             const u64 nn = oo.y - oo.x;
             huge = nn > 256;
             n = huge ? 0u : (u32)nn;
         }
-        const bool k16 = in && !huge && n <= 128u, k32 = in && !huge && n > 128u;
-        const u64 m16 = __builtin_amdgcn_ballot_w64(k16), m32 = __builtin_amdgcn_ballot_w64(k32);
-        const u64 lt = (1ull << lane) - 1ull;
-        if (k16) s_l16[wave][__builtin_popcountll(m16 & lt)] = (uint8_t)lane;
-        if (k32) s_l32[wave][__builtin_popcountll(m32 & lt)] = (uint8_t)lane;
-        if (lane < (u32)kObReadsPerWave && !k16 && !k32) s_g[wave * kObReadsPerWave + lane] = 0u; // beyond the batch / not handled here
-        if (__builtin_amdgcn_ballot_w64(huge) != 0 && lane == 0) s_unsup = 1u;
-        wave_lds_sync();
-        const u32 cnt16 = (u32)__builtin_popcountll(m16), cnt32 = (u32)__builtin_popcountll(m32);
-        const VerdictsToLds sink{s_g, s_ab, slab0, a.prefilter == 2 ? 1u : 0u, ctr};
-        for (u32 i0 = 0; i0 < cnt16; i0 += 4u * (u32)kObItems) { // (uniform in the wavefront)
-            u32 r[kObItems];
-            bool act[kObItems];
-#pragma unroll
-            for (int t = 0; t < kObItems; t++) {
-                const u32 idx = i0 + (u32)t * 4u + (lane >> 4);
-                act[t] = idx < cnt16;
-                r[t] = act[t] ? r0 + s_l16[wave][idx] : 0u;
-            }
-            screen_reads<16, kObItems, false, kObWaves>(a, r, act, sink);
-            wave_lds_sync(); // (the next turn zeroes the table)
-        }
-        for (u32 i0 = 0; i0 < cnt32; i0 += 2u * (u32)kObItems) {
-            u32 r[kObItems];
-            bool act[kObItems];
-#pragma unroll
-            for (int t = 0; t < kObItems; t++) {
-                const u32 idx = i0 + (u32)t * 2u + (lane >> 5);
-                act[t] = idx < cnt32;
-                r[t] = act[t] ? r0 + s_l32[wave][idx] : 0u;
-            }
-            screen_reads<32, kObItems, false, kObWaves>(a, r, act, sink);
-            wave_lds_sync();
-        }
-
-        // ---- A: what the screen left, one read per turn on all 64 lanes
-        const bool marked = lane < (u32)kObReadsPerWave && s_g[wave * kObReadsPerWave + lane] == kDeferredMark;
-        u64 todo = __builtin_amdgcn_ballot_w64(marked);
-        if (todo) {
-            u32 n_def = 0;
-            u64 iv_def = 0;
-            while (todo) { // (uniform)
-                const u32 i = (u32)__builtin_ctzll(todo);
-                todo &= todo - 1ull;
-                const u32 rr = r0 + i;
-                const u64 o = a.off[rr];
-                const u32 nr = (u32)(a.off[rr + 1] - o);
-                const u32 length = a.len[rr];
-                if (nr > 128u)
-                    finish_item<8>(a.off, a.iv, a.len, a.stage, a.counts, a.rej_list, a.rej_count, a.ctr, a.cov, rr, o, nr, length);
-                else
-                    finish_item<4>(a.off, a.iv, a.len, a.stage, a.counts, a.rej_list, a.rej_count, a.ctr, a.cov, rr, o, nr, length);
-                n_def++;
-                iv_def += nr;
-            }
-            if (lane == 0) {
-                atomicAdd(&s_n_def, n_def);
-                atomicAdd(&s_iv_def, (unsigned long long)iv_def);
-            }
-        }
+        if (lane < (u32)kObReads) s_def[lane] = 0u;
     }
-    __syncthreads(); // (global stores of this workgroup's wavefronts — counts[], the stage slots — are visible to each other after it)
-    if (threadIdx.x == 0 && (s_n_def || s_unsup)) {
-        // returning atomics, waited for: performed before this slab publishes its aggregate (see finish_compact_kernel)
-        const u32 t0 = s_n_def ? atomicAdd(&ctr->deferred, s_n_def) : 0u;
-        const unsigned long long t1 = s_n_def ? atomicAdd((unsigned long long *)&ctr->deferred_iv, s_iv_def) : 0ull;
-        const u32 t2 = s_unsup ? atomicOr(&ctr->ob_unsupported, 1u) : 0u;
-        asm volatile("" ::"v"(t0), "v"(t1), "v"(t2));
-    }
-
-    // ---- B: scan, compaction, classification (one thread per read)
-    const u32 r = slab0 + threadIdx.x;
-    const bool in = threadIdx.x < (u32)kObSlab && r < c.n_reads;
-    u32 g = in ? s_g[threadIdx.x] : 0u;
-    if (g == kDeferredMark) g = a.counts[r];
-    const u64 off_r = in ? a.off[r] : 0;
-    const u32 L = in ? a.len[r] : 0u;
-    const bool closed = g == kClosedForm;
-    uint2 ab = make_uint2(0u, L);
-    if (closed) {
-        ab = s_ab[threadIdx.x];
-        g = (ab.x != 0u ? 1u : 0u) + (ab.y != L ? 1u : 0u);
-    }
-    u32 tot;
-    const u32 local = block_excl_add<kObThreads>(g, sc, tot);
-
-    // decoupled look-back, kObThreads predecessors per round trip: wavefront w looks at bid - 1 - 64 w - lane
-    constexpr u64 kAgg = 1ull << 62, kPre = 2ull << 62, kVal = (1ull << 62) - 1;
-    if (bid > 0 && threadIdx.x == 0)
-        __hip_atomic_store(&c.scan_state[bid], kAgg | tot, YK_FINISH_ORDER_REL, __HIP_MEMORY_SCOPE_AGENT);
-    u64 base = 0;
-    u32 polls = 0;
-    for (i32 hi = (i32)bid - 1; bid > 0;) { // (uniform in the workgroup)
-        const i32 idx = hi - (i32)threadIdx.x;
-        const u64 v = idx >= 0 ? __hip_atomic_load(&c.scan_state[idx], YK_FINISH_ORDER_ACQ, __HIP_MEMORY_SCOPE_AGENT)
-                               : kPre; // before the first slab: prefix 0
-        const u64 pre = __builtin_amdgcn_ballot_w64((v >> 62) == 2);
-        const u64 before = pre ? ((pre & (0 - pre)) - 1ull) : ~0ull; // lanes nearer than this window's nearest prefix
-        const bool hole = (__builtin_amdgcn_ballot_w64((v >> 62) == 0) & before) != 0;
-        const u32 first_pre = pre ? (u32)__builtin_ctzll(pre) : 64u;
-        u64 part = lane <= first_pre ? (v & kVal) : 0;
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
+    const u32 m16 = (u32)__builtin_amdgcn_ballot_w64(in && !huge && n <= 128u);
+    u32 m32 = (u32)__builtin_amdgcn_ballot_w64(in && !huge && n > 128u);
+    const u32 mh = (u32)__builtin_amdgcn_ballot_w64(huge);
+    if (mh) { // (the engine runs the batch again on the default path)
+        if (huge) __hip_atomic_store(a.counts + (r0 + lane), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (lane == 0) {
-            s_part[wave] = part;
-            s_flag[wave] = (pre ? 1u : 0u) | (hole ? 2u : 0u);
+            const u32 t = atomicOr(&ctr->ob_unsupported, 1u);
+            asm volatile("" ::"v"(t)); // (returning: performed before this wavefront's arrival below)
         }
-        __syncthreads();
-        // nearest window first: sums up to the first window that holds a prefix; an empty entry on the way = look again
-        u64 sum = 0;
-        bool found = false, again = false;
-#pragma unroll
-        for (int w = 0; w < kObWaves; w++) {
-            if (!found && !again) {
-                const u32 f = s_flag[w];
-                if (f & 2u) again = true;
-                else {
-                    sum += s_part[w];
-                    found = (f & 1u) != 0;
-                }
-            }
-        }
-        __syncthreads(); // (s_part / s_flag are written again)
-        if (again) {
-            // (tickets are handed out in slab order, so every predecessor is running or done and this wait ends; the bound
-            // is there so that a broken invariant shows up as a batch sent down the default path, not as a hung device)
-            if (++polls > (1u << 20)) {
-                if (threadIdx.x == 0) {
-                    atomicOr(&ctr->ob_unsupported, 2u);
-                    if (c.host_ctr) __hip_atomic_store(&c.host_ctr->ob_unsupported, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                }
-                break;
-            }
-            __builtin_amdgcn_s_sleep(1);
-            continue;
-        }
-        base += sum;
-        if (found) break;
-        hi -= (i32)kObThreads;
     }
-    const bool last_slab = (u64)(bid + 1) * kObSlab >= c.n_reads;
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(&c.scan_state[bid], kPre | (base + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    wave_lds_sync();
+    const VerdictsAcrossXcds sink{a, s_def, r0};
+    if (m16) { // reads of up to 128 intervals: 16-lane groups, group g takes the wavefront's g-th (and g + 4-th ...) read
+        u32 r[kObItems];
+        bool act[kObItems];
+#pragma unroll
+        for (int t = 0; t < kObItems; t++) {
+            const u32 i = (u32)t * 4u + (lane >> 4);
+            act[t] = ((m16 >> i) & 1u) != 0;
+            r[t] = act[t] ? r0 + i : 0u;
+        }
+        screen_reads<16, kObItems, false, 1>(a, r, act, sink);
+        wave_lds_sync(); // (the next turn zeroes the table)
+    }
+    while (m32) { // up to 256: 32-lane halves, two (2 x ITEMS) of them per turn (uniform)
+        u32 r[kObItems];
+        bool act[kObItems];
+#pragma unroll
+        for (int t = 0; t < kObItems; t++) {
+            const u32 i0 = m32 ? (u32)__builtin_ctz(m32) : 0u;
+            const bool v0 = m32 != 0;
+            m32 &= m32 - 1u;
+            const u32 i1 = m32 ? (u32)__builtin_ctz(m32) : 0u;
+            const bool v1 = m32 != 0;
+            m32 &= m32 - (m32 ? 1u : 0u);
+            act[t] = lane < 32u ? v0 : v1;
+            r[t] = act[t] ? r0 + (lane < 32u ? i0 : i1) : 0u;
+        }
+        screen_reads<32, kObItems, false, 1>(a, r, act, sink);
+        wave_lds_sync();
+    }
+
+    // ---- A: what the screen left, one read per turn on all 64 lanes
+    u32 n_def = 0, iv_def = 0;
+    {
+        u32 todo = (u32)__builtin_amdgcn_ballot_w64(lane < (u32)kObReads && s_def[lane] != 0u);
+        while (todo) { // (uniform)
+            const u32 i = (u32)__builtin_ctz(todo);
+            todo &= todo - 1u;
+            const u32 rr = r0 + i;
+            const u64 o = a.off[rr];
+            const u32 nr = (u32)(a.off[rr + 1] - o);
+            const u32 length = a.len[rr];
+            if (nr > 128u)
+                finish_item<8>(a.off, a.iv, a.len, a.stage, a.counts, a.rej_list, a.rej_count, a.ctr, a.cov, rr, o, nr, length);
+            else
+                finish_item<4>(a.off, a.iv, a.len, a.stage, a.counts, a.rej_list, a.rej_count, a.ctr, a.cov, rr, o, nr, length);
+            n_def++;
+            iv_def += nr;
+        }
+        // (the sorts answer with plain stores — counts[], the stage slots: written back for the other XCDs' sake)
+        if (n_def) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    }
+
+    // ---- the wavefront arrives at its slab; the last one to arrive takes the slab through phase B
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every store above has been acknowledged
+    const u32 slab = r0 / (u32)kObSlab;
+    const u32 slab0 = slab * (u32)kObSlab;
+    const u32 slab_reads = min(c.n_reads - slab0, (u32)kObSlab);
+    u64 seen = 0;
+    if (lane == 0)
+        seen = __hip_atomic_fetch_add(&ob.slab_ctr[slab], 1ull | ((u64)n_def << 16) | ((u64)iv_def << 32), __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);
+    const u32 seen_lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)seen);
+    const u32 seen_hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(seen >> 32));
+    if ((seen_lo & 0xFFFFu) + 1u != (slab_reads + (u32)kObReads - 1u) / (u32)kObReads) return;
+
+    // ---- B: region counts -> scan (decoupled look-back over the slabs) -> CSR, type_of_read
+    {
+        const u32 slab_def = (seen_lo >> 16) + n_def, slab_iv = seen_hi + iv_def;
+        if (slab_def && lane == 0) { // (performed before this slab publishes its aggregate: see finish_compact_kernel)
+            const u32 t0 = atomicAdd(&ctr->deferred, slab_def);
+            const unsigned long long t1 = atomicAdd((unsigned long long *)&ctr->deferred_iv, (unsigned long long)slab_iv);
+            asm volatile("" ::"v"(t0), "v"(t1));
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // (the stage slots other wavefronts' sorts wrote)
+    // pass 1: the slab's region counts (a closed form counts its non-empty ends) and their scan; only the raw counts[] words
+    // and the exclusive sums stay in registers across the look-back
+    u32 g[kObPer], excl[kObPer];
+    u32 tot = 0;
+#pragma unroll
+    for (int k = 0; k < kObPer; k++) {
+        const u32 i = (u32)k * 64u + lane;
+        g[k] = i < slab_reads ? __hip_atomic_load(a.counts + (slab0 + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < kObPer; k++) {
+        const u32 i = (u32)k * 64u + lane;
+        u32 gk = g[k];
+        if (gk == kClosedForm) {
+            const u64 v = __hip_atomic_load(reinterpret_cast<const u64 *>(a.closed + (slab0 + i)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            gk = ((u32)v != 0u ? 1u : 0u) + ((u32)(v >> 32) != a.len[slab0 + i] ? 1u : 0u);
+        }
+        const u32 incl = wave_incl_add(gk);
+        excl[k] = tot + incl - gk;
+        tot += (u32)__shfl((int)incl, 63, 64);
+    }
+    constexpr u64 kAgg = 1ull << 62, kPre = 2ull << 62, kVal = (1ull << 62) - 1;
+    u64 base = 0;
+    if (slab > 0) {
+        if (lane == 0) __hip_atomic_store(&c.scan_state[slab], kAgg | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        u32 polls = 0;
+        for (i32 hi = (i32)slab - 1;; hi -= 64) {
+            const i32 idx = hi - (i32)lane; // lane 0 looks at the nearest predecessor
+            u64 v, pre;
+            for (;;) { // until the window holds no empty entry before its nearest prefix
+                v = idx >= 0 ? __hip_atomic_load(&c.scan_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kPre;
+                pre = __builtin_amdgcn_ballot_w64((v >> 62) == 2);
+                const u64 before = pre ? ((pre & (0 - pre)) - 1ull) : ~0ull; // lanes nearer than it
+                if ((__builtin_amdgcn_ballot_w64((v >> 62) == 0) & before) == 0) break;
+                // (Every earlier slab's wavefronts were dispatched before this one's last: they are running or done, and the
+                // wavefronts that wait here are at most one per slab of far more resident ones, so this wait ends.  The bound
+                // is there so that a broken invariant shows as a batch sent down the default path, not as a hung device.)
+                if (++polls > (1u << 20)) {
+                    if (lane == 0 && c.host_ctr) __hip_atomic_store(&c.host_ctr->ob_unsupported, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    return;
+                }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            const u32 first_pre = pre ? (u32)__builtin_ctzll(pre) : 64u;
+            u64 part = lane <= first_pre ? (v & kVal) : 0;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
+            base += part;
+            if (pre) break;
+        }
+    }
+    const bool last_slab = slab + 1u == ob.n_slabs;
+    if (lane == 0) {
+        __hip_atomic_store(&c.scan_state[slab], kPre | (base + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (last_slab) ctr->total_regions = base + tot;
     }
-    // the counters go home from the slab that ends the batch (finish_compact_kernel: it has seen everyone's aggregate)
-    if (c.host_ctr && last_slab && threadIdx.x < 64) {
+    // The counters go home from the slab that ends the batch: its look-back has seen every slab's aggregate, so every
+    // wavefront of the batch has arrived (the only writers of counters besides the totals set right here).
+    if (c.host_ctr && last_slab) {
         const u64 total = base + tot;
         const u32 *src = reinterpret_cast<const u32 *>(ctr);
         u32 *dst = reinterpret_cast<u32 *>(c.host_ctr);
         constexpr u32 kWords = (u32)(sizeof(Counters) / 4);
         for (u32 i = lane; i < kWords; i += 64u) {
-            u32 w = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (i == (u32)(offsetof(Counters, total_regions) / 4)) w = (u32)total;
-            if (i == (u32)(offsetof(Counters, total_regions) / 4) + 1u) w = (u32)(total >> 32);
-            if (i == (u32)(offsetof(Counters, region_overflow) / 4)) w = total > c.region_cap ? 1u : 0u;
-            if (i == (u32)(offsetof(Counters, ob_unsupported) / 4)) continue; // (see below)
-            dst[i] = w;
-        }
-        // (its own word: a slab whose look-back gave up writes 2 there directly, whenever that happens)
-        if (lane == 0) {
-            const u32 w = __hip_atomic_load(&ctr->ob_unsupported, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (w) __hip_atomic_store(&c.host_ctr->ob_unsupported, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            u32 v = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (i == (u32)(offsetof(Counters, total_regions) / 4)) v = (u32)total;
+            if (i == (u32)(offsetof(Counters, total_regions) / 4) + 1u) v = (u32)(total >> 32);
+            if (i == (u32)(offsetof(Counters, region_overflow) / 4)) v = total > c.region_cap ? 1u : 0u;
+            if (i == (u32)(offsetof(Counters, scan_ticket) / 4)) v = ob.n_slabs; // (the host's sign that this copy happened)
+            if (i == (u32)(offsetof(Counters, ob_unsupported) / 4)) {
+                if (v) __hip_atomic_store(&dst[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // (2 = a look-back gave up: written there directly)
+                continue;
+            }
+            dst[i] = v;
         }
     }
-    if (in) {
-        const u64 dst = base + local;
+    // pass 2: offsets, regions, types (lengths and closed forms are loaded again: the slab is in cache)
+#pragma unroll 1
+    for (int k = 0; k < kObPer; k++) {
+        const u32 i = (u32)k * 64u + lane;
+        if (i >= slab_reads) break;
+        const u32 r = slab0 + i;
+        const u32 Lr = a.len[r];
+        const bool cf = g[k] == kClosedForm;
+        uint2 ab = make_uint2(0u, Lr);
+        u32 gk = g[k];
+        if (cf) {
+            const u64 v = __hip_atomic_load(reinterpret_cast<const u64 *>(a.closed + r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ab = make_uint2((u32)v, (u32)(v >> 32));
+            gk = (ab.x != 0u ? 1u : 0u) + (ab.y != Lr ? 1u : 0u);
+        }
+        const u64 dst = base + excl[k];
         c.bad_offsets[r] = dst;
-        if (r == c.n_reads - 1) c.bad_offsets[c.n_reads] = dst + g;
+        if (r == c.n_reads - 1) c.bad_offsets[c.n_reads] = dst + gk;
         u32 bad = 0;
         bool middle = false;
-        const bool fits = dst + g <= c.region_cap;
-        if (closed) { // (neither region lies in the middle: the first begins at 0, the second ends at len)
-            u32 k = 0;
-            if (ab.x != 0u && fits) c.bad_regions[dst + k++] = make_uint2(0u, ab.x);
-            if (ab.y != L && fits) c.bad_regions[dst + k] = make_uint2(ab.y, L);
-            bad = ab.x + (L - ab.y);
-        } else {
-            const uint2 *slot = a.stage + (off_r + 2 * (u64)r);
-            for (u32 k = 0; k < g; k++) {
-                const uint2 v = slot[k];
-                if (fits) c.bad_regions[dst + k] = v;
+        const bool fits = dst + gk <= c.region_cap;
+        if (cf) { // (neither region lies in the middle: the first begins at 0, the second ends at len)
+            u32 j = 0;
+            if (ab.x != 0u && fits) c.bad_regions[dst + j++] = make_uint2(0u, ab.x);
+            if (ab.y != Lr && fits) c.bad_regions[dst + j] = make_uint2(ab.y, Lr);
+            bad = ab.x + (Lr - ab.y);
+        } else if (gk) {
+            const uint2 *slot = a.stage + (a.off[r] + 2 * (u64)r);
+            for (u32 j = 0; j < gk; j++) {
+                const uint2 v = slot[j];
+                if (fits) c.bad_regions[dst + j] = v;
                 bad += v.y - v.x;
-                middle |= (v.x != 0u) & (v.y != L);
+                middle |= (v.x != 0u) & (v.y != Lr);
             }
         }
         if (!fits) atomicOr(&ctr->region_overflow, 1u);
-        c.read_type[r] = (uint8_t)classify(bad, middle, L, c.not_cov);
+        c.read_type[r] = (uint8_t)classify(bad, middle, Lr, c.not_cov);
     }
 }
 

@@ -29,7 +29,14 @@ namespace yk {
 #endif
 constexpr int kObItems = YK_OB_ITEMS;
 constexpr int kObReads = 4 * kObItems;           // consecutive reads per wavefront
-constexpr int kObSlab = 512;                     // reads per slab (one arrival counter, one scan word, one pass of phase B)
+#ifndef YK_OB_SLAB
+#define YK_OB_SLAB 128
+#endif
+#ifndef YK_OB_LOOK
+#define YK_OB_LOOK 4 // scan words per lane and round trip of the look-back
+#endif
+constexpr int kObLook = YK_OB_LOOK;
+constexpr int kObSlab = YK_OB_SLAB;                 // reads per slab (one arrival counter, one scan word, one pass of phase B)
 constexpr int kObPer = kObSlab / 64;             // reads per lane in phase B
 static_assert(kObSlab % kObReads == 0 && kObSlab / kObReads < 0xFFFF, "arrivals are counted in 16 bits");
 
@@ -177,25 +184,36 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // (the stage slots other wavefronts' sorts wrote)
-    // pass 1: the slab's region counts (a closed form counts its non-empty ends) and their scan; only the raw counts[] words
-    // and the exclusive sums stay in registers across the look-back
-    u32 g[kObPer], excl[kObPer];
-    u32 tot = 0;
+    // pass 1: counts[], closed forms and lengths of the whole slab, every load in flight at once; region counts (a closed
+    // form counts its non-empty ends) and their scan
+    u32 g[kObPer], L[kObPer], excl[kObPer];
+    uint2 ab[kObPer];
+    u32 cfm = 0; // bit k: this lane's k-th read has a closed form
 #pragma unroll
     for (int k = 0; k < kObPer; k++) {
         const u32 i = (u32)k * 64u + lane;
-        g[k] = i < slab_reads ? __hip_atomic_load(a.counts + (slab0 + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        const bool inb = i < slab_reads;
+        g[k] = inb ? __hip_atomic_load(a.counts + (slab0 + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        L[k] = inb ? a.len[slab0 + i] : 0u;
     }
 #pragma unroll
     for (int k = 0; k < kObPer; k++) {
         const u32 i = (u32)k * 64u + lane;
-        u32 gk = g[k];
-        if (gk == kClosedForm) {
+        ab[k] = make_uint2(0u, 0u);
+        if (g[k] == kClosedForm) {
             const u64 v = __hip_atomic_load(reinterpret_cast<const u64 *>(a.closed + (slab0 + i)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            gk = ((u32)v != 0u ? 1u : 0u) + ((u32)(v >> 32) != a.len[slab0 + i] ? 1u : 0u);
+            ab[k] = make_uint2((u32)v, (u32)(v >> 32));
         }
-        const u32 incl = wave_incl_add(gk);
-        excl[k] = tot + incl - gk;
+    }
+    u32 tot = 0;
+#pragma unroll
+    for (int k = 0; k < kObPer; k++) {
+        if (g[k] == kClosedForm) {
+            cfm |= 1u << k;
+            g[k] = (ab[k].x != 0u ? 1u : 0u) + (ab[k].y != L[k] ? 1u : 0u);
+        }
+        const u32 incl = wave_incl_add(g[k]);
+        excl[k] = tot + incl - g[k];
         tot += (u32)__shfl((int)incl, 63, 64);
     }
     constexpr u64 kAgg = 1ull << 62, kPre = 2ull << 62, kVal = (1ull << 62) - 1;
@@ -203,14 +221,32 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
     if (slab > 0) {
         if (lane == 0) __hip_atomic_store(&c.scan_state[slab], kAgg | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         u32 polls = 0;
-        for (i32 hi = (i32)slab - 1;; hi -= 64) {
-            const i32 idx = hi - (i32)lane; // lane 0 looks at the nearest predecessor
-            u64 v, pre;
+        for (i32 hi = (i32)slab - 1;; hi -= 64 * kObLook) {
+            // 64 x kObLook predecessors per round trip: lane l looks at hi - l, hi - 64 - l, ... (the nearest first)
+            u64 part;
+            bool found;
             for (;;) { // until the window holds no empty entry before its nearest prefix
-                v = idx >= 0 ? __hip_atomic_load(&c.scan_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kPre;
-                pre = __builtin_amdgcn_ballot_w64((v >> 62) == 2);
-                const u64 before = pre ? ((pre & (0 - pre)) - 1ull) : ~0ull; // lanes nearer than it
-                if ((__builtin_amdgcn_ballot_w64((v >> 62) == 0) & before) == 0) break;
+                u64 v[kObLook];
+#pragma unroll
+                for (int j = 0; j < kObLook; j++) {
+                    const i32 idx = hi - 64 * j - (i32)lane;
+                    v[j] = idx >= 0 ? __hip_atomic_load(&c.scan_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kPre; // before the first slab: prefix 0
+                }
+                part = 0;
+                found = false;
+                bool hole = false;
+#pragma unroll
+                for (int j = 0; j < kObLook; j++) {
+                    if (!found && !hole) { // (uniform)
+                        const u64 pre = __builtin_amdgcn_ballot_w64((v[j] >> 62) == 2);
+                        const u64 before = pre ? ((pre & (0 - pre)) - 1ull) : ~0ull; // lanes nearer than this group's nearest prefix
+                        hole = (__builtin_amdgcn_ballot_w64((v[j] >> 62) == 0) & before) != 0;
+                        const u32 first_pre = pre ? (u32)__builtin_ctzll(pre) : 64u;
+                        part += lane <= first_pre ? (v[j] & kVal) : 0;
+                        found = pre != 0;
+                    }
+                }
+                if (!hole) break;
                 // (Every earlier slab's wavefronts were dispatched before this one's last: they are running or done, and the
                 // wavefronts that wait here are at most one per slab of far more resident ones, so this wait ends.  The bound
                 // is there so that a broken invariant shows as a batch sent down the default path, not as a hung device.)
@@ -220,12 +256,10 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
                 }
                 __builtin_amdgcn_s_sleep(1);
             }
-            const u32 first_pre = pre ? (u32)__builtin_ctzll(pre) : 64u;
-            u64 part = lane <= first_pre ? (v & kVal) : 0;
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
             base += part;
-            if (pre) break;
+            if (found) break;
         }
     }
     const bool last_slab = slab + 1u == ob.n_slabs;
@@ -253,43 +287,66 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
             dst[i] = v;
         }
     }
-    // pass 2: offsets, regions, types (lengths and closed forms are loaded again: the slab is in cache)
-#pragma unroll 1
+    // pass 2: offsets, regions, types.  A sorted read's regions come from its stage slot: the slot addresses of the whole
+    // slab first, then the first three regions of each (nearly all have fewer), so that the slab pays two round trips, not two
+    // per read
+    u64 so[kObPer];
+#pragma unroll
     for (int k = 0; k < kObPer; k++) {
         const u32 i = (u32)k * 64u + lane;
-        if (i >= slab_reads) break;
-        const u32 r = slab0 + i;
-        const u32 Lr = a.len[r];
-        const bool cf = g[k] == kClosedForm;
-        uint2 ab = make_uint2(0u, Lr);
-        u32 gk = g[k];
-        if (cf) {
-            const u64 v = __hip_atomic_load(reinterpret_cast<const u64 *>(a.closed + r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ab = make_uint2((u32)v, (u32)(v >> 32));
-            gk = (ab.x != 0u ? 1u : 0u) + (ab.y != Lr ? 1u : 0u);
-        }
-        const u64 dst = base + excl[k];
-        c.bad_offsets[r] = dst;
-        if (r == c.n_reads - 1) c.bad_offsets[c.n_reads] = dst + gk;
-        u32 bad = 0;
-        bool middle = false;
-        const bool fits = dst + gk <= c.region_cap;
-        if (cf) { // (neither region lies in the middle: the first begins at 0, the second ends at len)
-            u32 j = 0;
-            if (ab.x != 0u && fits) c.bad_regions[dst + j++] = make_uint2(0u, ab.x);
-            if (ab.y != Lr && fits) c.bad_regions[dst + j] = make_uint2(ab.y, Lr);
-            bad = ab.x + (Lr - ab.y);
-        } else if (gk) {
-            const uint2 *slot = a.stage + (a.off[r] + 2 * (u64)r);
-            for (u32 j = 0; j < gk; j++) {
-                const uint2 v = slot[j];
-                if (fits) c.bad_regions[dst + j] = v;
-                bad += v.y - v.x;
-                middle |= (v.x != 0u) & (v.y != Lr);
+        const bool sorted = i < slab_reads && !((cfm >> k) & 1u) && g[k] != 0u;
+        so[k] = sorted ? a.off[slab0 + i] + 2 * (u64)(slab0 + i) : 0ull;
+    }
+    uint2 s0[kObPer], s1[kObPer], s2[kObPer];
+#pragma unroll
+    for (int k = 0; k < kObPer; k++) {
+        const u32 i = (u32)k * 64u + lane;
+        const bool sorted = i < slab_reads && !((cfm >> k) & 1u) && g[k] != 0u;
+        s0[k] = s1[k] = s2[k] = make_uint2(0u, 0u);
+        if (sorted) s0[k] = a.stage[so[k]];
+        if (sorted && g[k] > 1u) s1[k] = a.stage[so[k] + 1];
+        if (sorted && g[k] > 2u) s2[k] = a.stage[so[k] + 2];
+    }
+#pragma unroll
+    for (int k = 0; k < kObPer; k++) {
+        const u32 i = (u32)k * 64u + lane;
+        if (i < slab_reads) {
+            const u32 r = slab0 + i, Lr = L[k], gk = g[k];
+            const u64 dst = base + excl[k];
+            c.bad_offsets[r] = dst;
+            if (r == c.n_reads - 1) c.bad_offsets[c.n_reads] = dst + gk;
+            u32 bad = 0;
+            bool middle = false;
+            const bool fits = dst + gk <= c.region_cap;
+            if ((cfm >> k) & 1u) { // (neither region lies in the middle: the first begins at 0, the second ends at len)
+                u32 j = 0;
+                if (ab[k].x != 0u && fits) c.bad_regions[dst + j++] = make_uint2(0u, ab[k].x);
+                if (ab[k].y != Lr && fits) c.bad_regions[dst + j] = make_uint2(ab[k].y, Lr);
+                bad = ab[k].x + (Lr - ab[k].y);
+            } else if (gk) {
+                if (fits) c.bad_regions[dst] = s0[k];
+                bad = s0[k].y - s0[k].x;
+                middle = (s0[k].x != 0u) & (s0[k].y != Lr);
+                if (gk > 1u) {
+                    if (fits) c.bad_regions[dst + 1] = s1[k];
+                    bad += s1[k].y - s1[k].x;
+                    middle |= (s1[k].x != 0u) & (s1[k].y != Lr);
+                }
+                if (gk > 2u) {
+                    if (fits) c.bad_regions[dst + 2] = s2[k];
+                    bad += s2[k].y - s2[k].x;
+                    middle |= (s2[k].x != 0u) & (s2[k].y != Lr);
+                }
+                for (u32 j = 3; j < gk; j++) {
+                    const uint2 v = a.stage[so[k] + j];
+                    if (fits) c.bad_regions[dst + j] = v;
+                    bad += v.y - v.x;
+                    middle |= (v.x != 0u) & (v.y != Lr);
+                }
             }
+            if (!fits) atomicOr(&ctr->region_overflow, 1u);
+            c.read_type[r] = (uint8_t)classify(bad, middle, Lr, c.not_cov);
         }
-        if (!fits) atomicOr(&ctr->region_overflow, 1u);
-        c.read_type[r] = (uint8_t)classify(bad, middle, Lr, c.not_cov);
     }
 }
 

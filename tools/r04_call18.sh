@@ -1,9 +1,9 @@
 #!/bin/bash
 # eighteenth GPU call of round 4: one_batch_kernel, phase B with every load in flight; slab sizes / occupancy / items
-out=gpurun_out/r04r; mkdir -p $out
+out=gpurun_out/r04s; mkdir -p $out
 timeout 900 python -m pytest tests/test_gpu_one_launch.py -x -q > $out/pytest_one_launch.log 2>&1; tail -6 $out/pytest_one_launch.log
 Q='import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); h=d["headline"]; o=h["one_launch_single_batch"]; print("pipelined %.5f three-launch single %.5f one-launch single %.5f %s deferred %s %s" % (d["ms_per_step"], h["unpredicted_single_batch"]["ms_per_batch"], o["ms_per_batch"], o["ran_as_one_launch"], o["deferred_reads"], o["parity"][:9]))'
-for v in slab128 slab64 slab256 slab128occ8 slab128items2; do cp variants/libob_$v.so yacrd_amd/lib/libyacrd_hip.so
+for v in slab128 slab256 slab128items2; do cp variants/libob_$v.so yacrd_amd/lib/libyacrd_hip.so
   for j in 0 100; do echo -n "== $v configs[1] jitter $j: "; timeout 600 python bench.py --weak --no-extras --no-cpu-baseline --jitter $j 2>$out/bench_err.log | python -c "$Q"; done
 done > $out/one_launch_single_batch.log 2>&1
 cat $out/one_launch_single_batch.log

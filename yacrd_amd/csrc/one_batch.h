@@ -156,9 +156,21 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
                 finish_item<4>(a.off, a.iv, a.len, a.stage, a.counts, a.rej_list, a.rej_count, a.ctr, a.cov, rr, o, nr, length);
             n_def++;
             iv_def += nr;
+            // The sort answers with plain stores (counts[rr], the stage slot): said again at agent scope by the lane that
+            // wrote the count, so that the wavefront that takes the slab through phase B — maybe on another XCD, behind
+            // another L2 — reads them inside this launch.  (A release fence here and an acquire fence there do the same
+            // by writing back / invalidating a whole L2 each time: 111 us for the batch instead of ..., profiles/r04/p_*.)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the sort's stores — other lanes' among them — have reached the L2)
+            if (lane == 63u) {
+                const u32 gr = a.counts[rr];
+                uint2 *slot = a.stage + (o + 2 * (u64)rr);
+                for (u32 j = 0; j < gr; j++) {
+                    const uint2 v = slot[j];
+                    __hip_atomic_store(reinterpret_cast<u64 *>(slot + j), (u64)v.x | ((u64)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __hip_atomic_store(a.counts + rr, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
-        // (the sorts answer with plain stores — counts[], the stage slots: written back for the other XCDs' sake)
-        if (n_def) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     }
 
     // ---- the wavefront arrives at its slab; the last one to arrive takes the slab through phase B
@@ -183,7 +195,6 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
             asm volatile("" ::"v"(t0), "v"(t1));
         }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); // (the stage slots other wavefronts' sorts wrote)
     // pass 1: counts[], closed forms and lengths of the whole slab, every load in flight at once; region counts (a closed
     // form counts its non-empty ends) and their scan
     u32 g[kObPer], L[kObPer], excl[kObPer];
@@ -290,6 +301,10 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
     // pass 2: offsets, regions, types.  A sorted read's regions come from its stage slot: the slot addresses of the whole
     // slab first, then the first three regions of each (nearly all have fewer), so that the slab pays two round trips, not two
     // per read
+    auto slot_at = [&](u64 at) { // (written at agent scope by the wavefront that sorted the read)
+        const u64 v = __hip_atomic_load(reinterpret_cast<const u64 *>(a.stage + at), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_uint2((u32)v, (u32)(v >> 32));
+    };
     u64 so[kObPer];
 #pragma unroll
     for (int k = 0; k < kObPer; k++) {
@@ -303,9 +318,9 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
         const u32 i = (u32)k * 64u + lane;
         const bool sorted = i < slab_reads && !((cfm >> k) & 1u) && g[k] != 0u;
         s0[k] = s1[k] = s2[k] = make_uint2(0u, 0u);
-        if (sorted) s0[k] = a.stage[so[k]];
-        if (sorted && g[k] > 1u) s1[k] = a.stage[so[k] + 1];
-        if (sorted && g[k] > 2u) s2[k] = a.stage[so[k] + 2];
+        if (sorted) s0[k] = slot_at(so[k]);
+        if (sorted && g[k] > 1u) s1[k] = slot_at(so[k] + 1);
+        if (sorted && g[k] > 2u) s2[k] = slot_at(so[k] + 2);
     }
 #pragma unroll
     for (int k = 0; k < kObPer; k++) {
@@ -338,7 +353,7 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
                     middle |= (s2[k].x != 0u) & (s2[k].y != Lr);
                 }
                 for (u32 j = 3; j < gk; j++) {
-                    const uint2 v = a.stage[so[k] + j];
+                    const uint2 v = slot_at(so[k] + j);
                     if (fits) c.bad_regions[dst + j] = v;
                     bad += v.y - v.x;
                     middle |= (v.x != 0u) & (v.y != Lr);

@@ -22,10 +22,10 @@
 namespace yk {
 
 #ifndef YK_OB_ITEMS
-#define YK_OB_ITEMS 1 // reads per lane group and turn of the screen
+#define YK_OB_ITEMS 2 // reads per lane group and turn of the screen: eight reads per wavefront (half the arrivals of ITEMS = 1: 46 against 56 us)
 #endif
 #ifndef YK_OB_OCC
-#define YK_OB_OCC 7 // wavefronts per SIMD the register budget allows: 72 VGPRs (LDS: 5 KB per wavefront = 28 of 32 per CU)
+#define YK_OB_OCC 6 // wavefronts per SIMD the register budget allows: 80 VGPRs, no scratch (LDS: 5 KB per wavefront)
 #endif
 constexpr int kObItems = YK_OB_ITEMS;
 constexpr int kObReads = 4 * kObItems;           // consecutive reads per wavefront
@@ -173,6 +173,9 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
         }
     }
 
+#if defined(YK_OB_EXPERIMENT) && YK_OB_EXPERIMENT == 1 // (timing only: phases S and A)
+    return;
+#endif
     // ---- the wavefront arrives at its slab; the last one to arrive takes the slab through phase B
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every store above has been acknowledged
     const u32 slab = r0 / (u32)kObSlab;
@@ -183,38 +186,34 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
         seen = __hip_atomic_fetch_add(&ob.slab_ctr[slab], 1ull | ((u64)n_def << 16) | ((u64)iv_def << 32), __ATOMIC_RELAXED,
                                       __HIP_MEMORY_SCOPE_AGENT);
     const u32 seen_lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)seen);
-    const u32 seen_hi = (u32)__builtin_amdgcn_readfirstlane((int)(u32)(seen >> 32));
     if ((seen_lo & 0xFFFFu) + 1u != (slab_reads + (u32)kObReads - 1u) / (u32)kObReads) return;
 
+#if defined(YK_OB_EXPERIMENT) && YK_OB_EXPERIMENT == 2 // (timing only: S, A and the arrivals)
+    return;
+#endif
     // ---- B: region counts -> scan (decoupled look-back over the slabs) -> CSR, type_of_read
-    {
-        const u32 slab_def = (seen_lo >> 16) + n_def, slab_iv = seen_hi + iv_def;
-        if (slab_def && lane == 0) { // (performed before this slab publishes its aggregate: see finish_compact_kernel)
-            const u32 t0 = atomicAdd(&ctr->deferred, slab_def);
-            const unsigned long long t1 = atomicAdd((unsigned long long *)&ctr->deferred_iv, (unsigned long long)slab_iv);
-            asm volatile("" ::"v"(t0), "v"(t1));
-        }
-    }
-    // pass 1: counts[], closed forms and lengths of the whole slab, every load in flight at once; region counts (a closed
-    // form counts its non-empty ends) and their scan
+    // Round trips, not bytes, are what this phase costs (it ends the launch): counts[], closed forms, lengths and offsets of
+    // the whole slab go out together; the sorted reads' regions (their first three: nearly all have fewer) are asked for
+    // before the look-back and arrive during it.
+    auto slot_at = [&](u64 at) { // (written at agent scope by the wavefront that sorted the read)
+        const u64 v = __hip_atomic_load(reinterpret_cast<const u64 *>(a.stage + at), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_uint2((u32)v, (u32)(v >> 32));
+    };
     u32 g[kObPer], L[kObPer], excl[kObPer];
     uint2 ab[kObPer];
+    u64 so[kObPer];
     u32 cfm = 0; // bit k: this lane's k-th read has a closed form
 #pragma unroll
     for (int k = 0; k < kObPer; k++) {
         const u32 i = (u32)k * 64u + lane;
         const bool inb = i < slab_reads;
-        g[k] = inb ? __hip_atomic_load(a.counts + (slab0 + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        L[k] = inb ? a.len[slab0 + i] : 0u;
-    }
-#pragma unroll
-    for (int k = 0; k < kObPer; k++) {
-        const u32 i = (u32)k * 64u + lane;
-        ab[k] = make_uint2(0u, 0u);
-        if (g[k] == kClosedForm) {
-            const u64 v = __hip_atomic_load(reinterpret_cast<const u64 *>(a.closed + (slab0 + i)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ab[k] = make_uint2((u32)v, (u32)(v >> 32));
-        }
+        const u32 r = inb ? slab0 + i : slab0;
+        g[k] = __hip_atomic_load(a.counts + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u64 v = __hip_atomic_load(reinterpret_cast<const u64 *>(a.closed + r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ab[k] = make_uint2((u32)v, (u32)(v >> 32)); // (meaningful when counts[] says so)
+        L[k] = a.len[r];
+        so[k] = a.off[r] + 2 * (u64)r;
+        if (!inb) g[k] = 0u;
     }
     u32 tot = 0;
 #pragma unroll
@@ -227,10 +226,19 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
         excl[k] = tot + incl - g[k];
         tot += (u32)__shfl((int)incl, 63, 64);
     }
-    constexpr u64 kAgg = 1ull << 62, kPre = 2ull << 62, kVal = (1ull << 62) - 1;
+    if (slab > 0 && lane == 0) __hip_atomic_store(&c.scan_state[slab], (1ull << 62) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint2 s0[kObPer], s1[kObPer], s2[kObPer];
+#pragma unroll
+    for (int k = 0; k < kObPer; k++) {
+        const bool sorted = !((cfm >> k) & 1u) && g[k] != 0u;
+        s0[k] = s1[k] = s2[k] = make_uint2(0u, 0u);
+        if (sorted) s0[k] = slot_at(so[k]);
+        if (sorted && g[k] > 1u) s1[k] = slot_at(so[k] + 1);
+        if (sorted && g[k] > 2u) s2[k] = slot_at(so[k] + 2);
+    }
+    constexpr u64 kPre = 2ull << 62, kVal = (1ull << 62) - 1;
     u64 base = 0;
     if (slab > 0) {
-        if (lane == 0) __hip_atomic_store(&c.scan_state[slab], kAgg | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         u32 polls = 0;
         for (i32 hi = (i32)slab - 1;; hi -= 64 * kObLook) {
             // 64 x kObLook predecessors per round trip: lane l looks at hi - l, hi - 64 - l, ... (the nearest first)
@@ -279,8 +287,20 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
         if (last_slab) ctr->total_regions = base + tot;
     }
     // The counters go home from the slab that ends the batch: its look-back has seen every slab's aggregate, so every
-    // wavefront of the batch has arrived (the only writers of counters besides the totals set right here).
+    // wavefront of the batch has arrived — the arrival words hold the final numbers of sorted reads and their intervals
+    // (summed here: no wavefront adds to the shared counters for them), and nobody writes a counter any more.
     if (c.host_ctr && last_slab) {
+        u64 def = 0; // reads | intervals << 32
+        for (u32 i = lane; i < ob.n_slabs; i += 64u) {
+            const u64 v = __hip_atomic_load(&ob.slab_ctr[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            def += ((v >> 16) & 0xFFFFull) | ((v >> 32) << 32);
+        }
+        u32 def_n = (u32)def, def_iv = (u32)(def >> 32);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) {
+            def_n += (u32)__shfl_xor((int)def_n, d, 64);
+            def_iv += (u32)__shfl_xor((int)def_iv, d, 64);
+        }
         const u64 total = base + tot;
         const u32 *src = reinterpret_cast<const u32 *>(ctr);
         u32 *dst = reinterpret_cast<u32 *>(c.host_ctr);
@@ -291,6 +311,9 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
             if (i == (u32)(offsetof(Counters, total_regions) / 4) + 1u) v = (u32)(total >> 32);
             if (i == (u32)(offsetof(Counters, region_overflow) / 4)) v = total > c.region_cap ? 1u : 0u;
             if (i == (u32)(offsetof(Counters, scan_ticket) / 4)) v = ob.n_slabs; // (the host's sign that this copy happened)
+            if (i == (u32)(offsetof(Counters, deferred) / 4)) v = def_n;
+            if (i == (u32)(offsetof(Counters, deferred_iv) / 4)) v = def_iv;
+            if (i == (u32)(offsetof(Counters, deferred_iv) / 4) + 1u) v = 0u; // (< 2^32: fewer than 400 000 reads of at most 256 intervals)
             if (i == (u32)(offsetof(Counters, ob_unsupported) / 4)) {
                 if (v) __hip_atomic_store(&dst[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); // (2 = a look-back gave up: written there directly)
                 continue;
@@ -298,30 +321,7 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
             dst[i] = v;
         }
     }
-    // pass 2: offsets, regions, types.  A sorted read's regions come from its stage slot: the slot addresses of the whole
-    // slab first, then the first three regions of each (nearly all have fewer), so that the slab pays two round trips, not two
-    // per read
-    auto slot_at = [&](u64 at) { // (written at agent scope by the wavefront that sorted the read)
-        const u64 v = __hip_atomic_load(reinterpret_cast<const u64 *>(a.stage + at), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return make_uint2((u32)v, (u32)(v >> 32));
-    };
-    u64 so[kObPer];
-#pragma unroll
-    for (int k = 0; k < kObPer; k++) {
-        const u32 i = (u32)k * 64u + lane;
-        const bool sorted = i < slab_reads && !((cfm >> k) & 1u) && g[k] != 0u;
-        so[k] = sorted ? a.off[slab0 + i] + 2 * (u64)(slab0 + i) : 0ull;
-    }
-    uint2 s0[kObPer], s1[kObPer], s2[kObPer];
-#pragma unroll
-    for (int k = 0; k < kObPer; k++) {
-        const u32 i = (u32)k * 64u + lane;
-        const bool sorted = i < slab_reads && !((cfm >> k) & 1u) && g[k] != 0u;
-        s0[k] = s1[k] = s2[k] = make_uint2(0u, 0u);
-        if (sorted) s0[k] = slot_at(so[k]);
-        if (sorted && g[k] > 1u) s1[k] = slot_at(so[k] + 1);
-        if (sorted && g[k] > 2u) s2[k] = slot_at(so[k] + 2);
-    }
+    // offsets, regions, types
 #pragma unroll
     for (int k = 0; k < kObPer; k++) {
         const u32 i = (u32)k * 64u + lane;

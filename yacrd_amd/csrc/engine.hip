@@ -444,7 +444,8 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         oa.zero_words = (u32)(other_bytes / 4);
         e->h_ctr->ob_unsupported = 0; // (written from the device only when set)
         e->h_ctr->scan_ticket = 0;    // (the slab that ends the batch sends the counters home: nb tickets then)
-        hipLaunchKernelGGL(yk::one_batch_kernel, dim3((n_reads + yk::kObReads - 1) / yk::kObReads), dim3(64), 0, e->stream, oa);
+        // (one wavefront per kObReads reads; slabs go round the XCDs, so the grid is whole rounds of eight slabs)
+        hipLaunchKernelGGL(yk::one_batch_kernel, dim3(((ob_slabs + 7) / 8) * 8 * (u32)(yk::kObSlab / yk::kObReads)), dim3(64), 0, e->stream, oa);
         e->ctrl_clean[other] = other_bytes;
         if (full) HIP_TRY(hipEventRecord(e->ev[EV_COMPACT], e->stream));
         Pending &p = e->pending;

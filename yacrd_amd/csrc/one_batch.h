@@ -74,15 +74,28 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
     const SweepArgs &a = c.sweep;
     Counters *ctr = a.ctr;
     for (u32 i = blockIdx.x * 64u + threadIdx.x; i < ob.zero_words; i += gridDim.x * 64u) ob.zero[i] = 0;
-    // (as in the fused launch: every XCD — its own L2 — takes a contiguous eighth of the batch)
+    // Workgroups are dealt out to the 8 XCDs round robin (XCD = blockIdx.x mod 8).  A slab's wavefronts stay on one XCD
+    // (neighbouring reads share cache lines; its arrivals and phase B meet in one L2) and the slabs go round the XCDs:
+    // XCD x takes slabs x, x + 8, x + 16 ... in dispatch order, so the batch is finished front to back and a slab's
+    // look-back finds its predecessors done.  (A contiguous eighth per XCD, the fused launch's mapping, makes seven
+    // eighths of the slabs wait for the end of the launch: YK_OB_CONTIGUOUS, 41 us against ... for the batch.)
+    constexpr u32 kWavesPerSlab = (u32)(kObSlab / kObReads);
     u32 w = blockIdx.x;
+#ifdef YK_OB_CONTIGUOUS
     {
         const u32 nb = gridDim.x, x = w & 7u, q = nb >> 3, rem = nb & 7u;
         w = x * q + min(x, rem) + (w >> 3);
     }
+#else
+    {
+        const u32 x = w & 7u, i = w >> 3;
+        w = ((i / kWavesPerSlab) * 8u + x) * kWavesPerSlab + i % kWavesPerSlab;
+    }
+#endif
     __shared__ u32 s_def[kObReads];
     const u32 lane = lane_id();
     const u32 r0 = w * (u32)kObReads;
+    if (r0 >= c.n_reads) return; // (the grid is padded to whole rounds of eight slabs)
 
     // ---- S: the wavefront's reads through the screen, by size class
     u32 n = 0;

@@ -18,9 +18,11 @@ from cases import assert_same, make_csr  # noqa: E402
 MODES = ("regular", "abutting", "dups", "beyond", "sparse", "zero_len", "degenerate")
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(time.time()) & 0xFFFF)
-t0, rounds, reads = time.time(), 0, 0
+t0, rounds, reads, ones = time.time(), 0, 0, 0
 cflags = (yacrd_amd.F_ALWAYS_DEFER | (yacrd_amd.F_SCREEN_ITEMS_2 if os.environ.get("YACRD_FUZZ_ITEMS2") else 0)
           | (yacrd_amd.F_SCREEN_WIDE if os.environ.get("YACRD_FUZZ_WIDE") else 0))
+if os.environ.get("YACRD_FUZZ_ONE_LAUNCH"):  # the one-launch form of short batches (csrc/one_batch.h) where it applies
+    cflags = yacrd_amd.F_ONE_LAUNCH
 with yacrd_amd.Engine(flags=cflags) as e, yacrd_amd.Engine(flags=yacrd_amd.F_NO_PREFILTER) as ref:
     while time.time() - t0 < budget:
         R = int(rng.integers(1, 3000))
@@ -46,4 +48,5 @@ with yacrd_amd.Engine(flags=cflags) as e, yacrd_amd.Engine(flags=yacrd_amd.F_NO_
         assert_same(ref.run(*csr, cov, nc), want, ctx + " (no prefilter)")
         rounds += 1
         reads += R
-print("gpu_fuzz: %d rounds, %d reads, all bit-exact" % (rounds, reads))
+        ones += int(e.timing().get("one_launch", 0))
+print("gpu_fuzz: %d rounds, %d reads, all bit-exact%s" % (rounds, reads, " (%d batches as one launch)" % ones if ones else ""))

@@ -1,21 +1,28 @@
 // one_batch.h — a short batch in ONE launch (round 4 prototype).
 //
-// What a batch of 10 000 - 400 000 reads pays for on the default path is not bytes but dispatches: plan_kernel
-// (bins the reads by size), a host sync on its class counts (or a prediction of them), the fused screen launch over
-// the class lists, finish_compact_kernel — three dependent kernels, each with its ramp-up, drain and launch gap, 66-70 us
-// for 100 000 reads of which the memory system is busy for ~15.  Here a workgroup OWNS a slab of 128 consecutive reads
-// from the first byte to the last:
-//   S  every wavefront takes 16 consecutive reads: their offsets (one load), their classes (a ballot: <= 128 intervals
+// What a batch of 10 000 - 400 000 reads pays for on the default path is not bytes but dispatches: plan_kernel (bins the
+// reads by size), a host sync on its class counts (or a prediction of them), the fused screen launch over the class
+// lists, finish_compact_kernel — three dependent kernels, each with its ramp-up, drain and launch gap: 64-66 us for
+// 100 000 reads of which the memory system is busy for ~15.  Here the batch is one grid of one-wavefront workgroups:
+//   S  a wavefront takes 4 x ITEMS consecutive reads: their offsets (one load), their classes (a ballot: <= 128 intervals
 //      -> 16-lane groups, <= 256 -> 32-lane halves; nothing is binned across the batch, so there is nothing to plan),
-//      then the healthy-read screen of sweep_wave.h (screen_reads: the fused launch's code) over them, two reads per
-//      group and turn; verdicts (closed form / deferred) land in the workgroup's LDS, not in counts[] / closed[];
-//   A  the reads the screen left are sorted right there, one per wavefront on 64 lanes (finish_item, finish_compact.h);
-//   B  region counts -> exclusive scan (decoupled look-back over the slabs' aggregates, every wavefront of the
-//      workgroup looking at 64 predecessors at once), regions into the CSR, type_of_read; the slab that ends the batch
-//      sends the counter block home.
-// No class lists, no class counts, no prediction; what the host waits for is one kernel.
+//      then the healthy-read screen of sweep_wave.h (screen_reads: the fused launch's code); the verdicts go to counts[] /
+//      closed[] with agent-scope stores;
+//   A  the reads the screen left are sorted right there, one per turn on 64 lanes (finish_item, finish_compact.h), and
+//      their regions and counts said again at agent scope;
+//   -  the wavefront ARRIVES at its slab of 128 reads (one returning atomic on the slab's word, which also carries the
+//      slab's sorted reads and their intervals); every wavefront but the last to arrive is done;
+//   B  the last one takes the slab through the follow-on step: region counts -> exclusive scan (decoupled look-back over
+//      the slabs' words, 256 of them per round trip), regions into the CSR, type_of_read; the slab that ends the batch
+//      sums the arrival words and sends the counter block home.
+// No class lists, no class counts, no prediction, no fences (an agent-scope release / acquire pair writes back / invalidates
+// a whole L2 per use: the first version with them took 111 us); what the host waits for is one kernel.
+// Measured (configs[1]: 100 000 reads / 10 M intervals; profiles/r04/q_*): S + A 26.6 us (the fused screen alone: 18), with the
+// arrivals 27.8, whole kernel 41-45; one batch at a time 53.5-55 us against 64-66 on the default path.  The tail is phase B
+// of the last slabs — a chain of four dependent round trips to memory behind the last arrival — not its bytes.
 // A read of more than 256 intervals (the workgroup / device-wide classes) is not handled here: the kernel raises
-// Counters::ob_unsupported and the engine runs the batch through the default path (engine.hip: run_one_launch).
+// Counters::ob_unsupported and the engine runs the batch through the default path (engine.hip), as it does for a batch in
+// which the sort rejected a read (exact path) or the regions outgrew their buffer.
 #pragma once
 #include "finish_compact.h"
 
@@ -25,7 +32,7 @@ namespace yk {
 #define YK_OB_ITEMS 2 // reads per lane group and turn of the screen: eight reads per wavefront (half the arrivals of ITEMS = 1: 46 against 56 us)
 #endif
 #ifndef YK_OB_OCC
-#define YK_OB_OCC 6 // wavefronts per SIMD the register budget allows: 80 VGPRs, no scratch (LDS: 5 KB per wavefront)
+#define YK_OB_OCC 6 // wavefronts per SIMD the register budget allows: 80 VGPRs, 8 bytes of scratch (LDS: 5 KB per wavefront)
 #endif
 constexpr int kObItems = YK_OB_ITEMS;
 constexpr int kObReads = 4 * kObItems;           // consecutive reads per wavefront
@@ -74,22 +81,22 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
     const SweepArgs &a = c.sweep;
     Counters *ctr = a.ctr;
     for (u32 i = blockIdx.x * 64u + threadIdx.x; i < ob.zero_words; i += gridDim.x * 64u) ob.zero[i] = 0;
-    // Workgroups are dealt out to the 8 XCDs round robin (XCD = blockIdx.x mod 8).  A slab's wavefronts stay on one XCD
-    // (neighbouring reads share cache lines; its arrivals and phase B meet in one L2) and the slabs go round the XCDs:
-    // XCD x takes slabs x, x + 8, x + 16 ... in dispatch order, so the batch is finished front to back and a slab's
-    // look-back finds its predecessors done.  (A contiguous eighth per XCD, the fused launch's mapping, makes seven
-    // eighths of the slabs wait for the end of the launch: YK_OB_CONTIGUOUS, 41 us against ... for the batch.)
-    constexpr u32 kWavesPerSlab = (u32)(kObSlab / kObReads);
+    // Workgroups are dealt out to the 8 XCDs round robin (XCD = blockIdx.x mod 8); as in the fused launch every XCD — its
+    // own L2 — takes a contiguous eighth of the batch (neighbouring reads share cache lines).  (The other arrangement —
+    // a slab's wavefronts on one XCD and the slabs round the XCDs, so that the batch is finished front to back and a
+    // slab's look-back finds its predecessors done — measured slower: 59 against 53.5 us for the batch,
+    // profiles/r04/q_one_launch_phases.log; -DYK_OB_ROUND_ROBIN builds it.)
     u32 w = blockIdx.x;
-#ifdef YK_OB_CONTIGUOUS
+#ifdef YK_OB_ROUND_ROBIN
     {
-        const u32 nb = gridDim.x, x = w & 7u, q = nb >> 3, rem = nb & 7u;
-        w = x * q + min(x, rem) + (w >> 3);
+        constexpr u32 kWavesPerSlab = (u32)(kObSlab / kObReads);
+        const u32 x = w & 7u, i = w >> 3;
+        w = ((i / kWavesPerSlab) * 8u + x) * kWavesPerSlab + i % kWavesPerSlab;
     }
 #else
     {
-        const u32 x = w & 7u, i = w >> 3;
-        w = ((i / kWavesPerSlab) * 8u + x) * kWavesPerSlab + i % kWavesPerSlab;
+        const u32 nb = gridDim.x, x = w & 7u, q = nb >> 3, rem = nb & 7u;
+        w = x * q + min(x, rem) + (w >> 3);
     }
 #endif
     __shared__ u32 s_def[kObReads];

@@ -384,8 +384,8 @@ def small_batches_block(cx, jitter=0, chimeras=0):
             got1 = oe.fetch()
             one_launch = {"ms_per_batch": dt1 * 1e3, "reads_per_sec": R / dt1, "ran_as_one_launch": bool(ot.get("one_launch")),
                           "deferred_reads": int(ot.get("deferred_reads", 0)),
-                          "what": "YACRD_F_ONE_LAUNCH: one engine, one batch at a time; one_batch_kernel (slab-owning "
-                                  "workgroups: screen, sorts of what it leaves, scan + compaction + type_of_read)"}
+                          "what": "YACRD_F_ONE_LAUNCH: one engine, one batch at a time; one_batch_kernel (one wavefront per eight "
+                                  "reads: screen + sorts; the last to arrive at a 128-read slab scans, compacts, classifies it)"}
         with ya.Engine(device_id=cx.dev_index, flags=ya.F_TIMING_FULL) as fe:
             for _ in range(5):
                 fe.run_device(*ptrs)

@@ -438,8 +438,6 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         oa.c.region_cap = (u64)(e->bad_regions.cap / sizeof(uint2));
         oa.c.read_type = e->read_type.as<uint8_t>();
         oa.c.host_ctr = e->h_ctr;
-        HIP_TRY(e->ob_rec.reserve((size_t)n_reads * 32));
-        oa.rec = e->ob_rec.as<u64>();
         oa.slab_ctr = oa.c.scan_state + ob_slabs;
         oa.n_slabs = ob_slabs;
         oa.zero = e->ctrl2[other].as<u32>();
@@ -1278,7 +1276,7 @@ void yacrd_engine_destroy(yacrd_engine *e)
     DevBuf *bufs[] = {&e->in_off, &e->in_iv, &e->in_len, &e->lists, &e->ctrl2[0], &e->ctrl2[1], &e->stage,
                       &e->counts, &e->closed, &e->gen_sizes, &e->gen_scratch_off,
                       &e->gen_scratch, &e->big_tab, &e->big_keys, &e->big_redo, &e->bt_tab, &e->bt_hist, &e->bt_cur, &e->bt_keys, &e->bs_seg, &e->bs_chunk, &e->bs_hist,
-                      &e->bad_offsets, &e->bad_regions, &e->read_type, &e->ob_rec};
+                      &e->bad_offsets, &e->bad_regions, &e->read_type};
     for (DevBuf *b : bufs) b->release();
     if (e->h_ctr) (void)hipHostFree(e->h_ctr);
     if (e->h_out) (void)hipHostFree(e->h_out);

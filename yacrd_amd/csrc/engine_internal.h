@@ -144,7 +144,6 @@ struct yacrd_engine {
     int ctrl_cur = 0;
     // results
     yke::DevBuf bad_offsets, bad_regions, read_type;
-    yke::DevBuf ob_rec; // one_batch_kernel's per-read records (one_batch.h: ReadRecord), 32 bytes each
     yk::Counters *h_ctr = nullptr; // pinned
 
     uint64_t last_reads = 0, last_regions = 0;

@@ -50,42 +50,25 @@ static_assert(kObSlab % kObReads == 0 && kObSlab / kObReads < 0xFFFF, "arrivals 
 struct OneBatchArgs {
     CompactArgs2 c;   // sweep (off / iv / len / cov / prefilter / stage / counts / closed / rej_list / rej_count / ctr), scan_state, outputs
     u64 *slab_ctr;    // [slabs] arrivals | deferred reads << 16 | their intervals << 32, zero at launch
-    u64 *rec;         // [n_reads][4] one 32-byte record per read: region count, its first three regions (see ReadRecord)
     u32 n_slabs;
     u32 *zero;        // the engine's other control block, zeroed here for the next run (as plan_kernel does)
     u32 zero_words;
 };
 
-// What phase B needs of a read, in ONE place it can ask for without knowing anything else about the read: 8 words
-//   [count, r0.x, r0.y, r1.x, r1.y, r2.x, r2.y, -]
-// = the read's region count and its first three regions (a closed form has at most two; a sorted read with more keeps the
-// rest in its stage slot).  Written with agent-scope stores (through the XCD's L2) and read back with agent-scope loads:
-// the wavefront that takes the slab through phase B may sit on ANOTHER XCD, behind another L2.  The read's type is final
-// where its regions are known, so it is stored right there (a plain store: nobody reads it inside the launch).
-struct ReadRecord {
-    static __device__ __forceinline__ void put(u64 *rec, u32 r, u32 g, uint2 r0, uint2 r1, uint2 r2)
-    {
-        u64 *p = rec + 4 * (u64)r;
-        __hip_atomic_store(p, (u64)g | ((u64)r0.x << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (g > 0u) __hip_atomic_store(p + 1, (u64)r0.y | ((u64)r1.x << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (g > 1u) __hip_atomic_store(p + 2, (u64)r1.y | ((u64)r2.x << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (g > 2u) __hip_atomic_store(p + 3, (u64)r2.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-};
+// The screen's verdicts, written so that a wavefront on ANOTHER XCD (its own L2) reads them inside this launch: stores at
+// agent scope (write-through), read back with agent-scope loads.  A deferred read is noted in the wavefront's LDS.
 struct VerdictsAcrossXcds {
     const SweepArgs &a;
-    u64 *rec;
-    uint8_t *read_type;
-    double not_cov;
-    u32 *s_def; // [kObReads] in the wavefront's LDS: this read is left to the sort
+    u32 *s_def; // [kObReads]
     u32 r0;
     __device__ __forceinline__ void closed(u32 r, u32 ra, u32 rb, u32 len) const
     {
-        // regions (0, a) and (b, len), whichever is not empty; neither lies in the middle of the read
-        const uint2 head = make_uint2(0u, ra), tail = make_uint2(rb, len);
-        const bool h = ra != 0u, t = rb != len;
-        ReadRecord::put(rec, r, (h ? 1u : 0u) + (t ? 1u : 0u), h ? head : tail, tail, make_uint2(0u, 0u));
-        read_type[r] = (uint8_t)classify(ra + (len - rb), false, len, not_cov);
+        if (ra != 0 || rb != len) {
+            __hip_atomic_store(reinterpret_cast<u64 *>(a.closed + r), (u64)ra | ((u64)rb << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(a.counts + r, kClosedForm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __hip_atomic_store(a.counts + r, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (a.prefilter == 2) atomicAdd(&a.ctr->prefiltered, 1u);
     }
     __device__ __forceinline__ void deferred(u32 r) const { s_def[r - r0] = 1u; }
@@ -138,14 +121,14 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
     u32 m32 = (u32)__builtin_amdgcn_ballot_w64(in && !huge && n > 128u);
     const u32 mh = (u32)__builtin_amdgcn_ballot_w64(huge);
     if (mh) { // (the engine runs the batch again on the default path)
-        if (huge) ReadRecord::put(ob.rec, r0 + lane, 0u, make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u));
+        if (huge) __hip_atomic_store(a.counts + (r0 + lane), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (lane == 0) {
             const u32 t = atomicOr(&ctr->ob_unsupported, 1u);
             asm volatile("" ::"v"(t)); // (returning: performed before this wavefront's arrival below)
         }
     }
     wave_lds_sync();
-    const VerdictsAcrossXcds sink{a, ob.rec, c.read_type, c.not_cov, s_def, r0};
+    const VerdictsAcrossXcds sink{a, s_def, r0};
     if (m16) { // reads of up to 128 intervals: 16-lane groups, group g takes the wavefront's g-th (and g + 4-th ...) read
         u32 r[kObItems];
         bool act[kObItems];
@@ -193,28 +176,19 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
                 finish_item<4>(a.off, a.iv, a.len, a.stage, a.counts, a.rej_list, a.rej_count, a.ctr, a.cov, rr, o, nr, length);
             n_def++;
             iv_def += nr;
-            // The sort answers with plain stores (counts[rr], the stage slot).  The lane that wrote the count puts the
-            // read's record together from them (count, first three regions; its type), and says any further region again at
-            // agent scope where it lies.  (A release fence here and an acquire fence in phase B would do the same by writing
-            // back / invalidating a whole L2 each time: 111 us for the batch instead of 54, profiles/r04/q_*.)
+            // The sort answers with plain stores (counts[rr], the stage slot): said again at agent scope by the lane that
+            // wrote the count, so that the wavefront that takes the slab through phase B — maybe on another XCD, behind
+            // another L2 — reads them inside this launch.  (A release fence here and an acquire fence there do the same
+            // by writing back / invalidating a whole L2 each time: 111 us for the batch instead of ..., profiles/r04/p_*.)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the sort's stores — other lanes' among them — have reached the L2)
             if (lane == 63u) {
                 const u32 gr = a.counts[rr];
                 uint2 *slot = a.stage + (o + 2 * (u64)rr);
-                uint2 first[3] = {make_uint2(0u, 0u), make_uint2(0u, 0u), make_uint2(0u, 0u)};
-                u32 bad = 0;
-                bool middle = false;
                 for (u32 j = 0; j < gr; j++) {
                     const uint2 v = slot[j];
-                    if (j == 0) first[0] = v;
-                    else if (j == 1) first[1] = v;
-                    else if (j == 2) first[2] = v;
-                    else __hip_atomic_store(reinterpret_cast<u64 *>(slot + j), (u64)v.x | ((u64)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    bad += v.y - v.x;
-                    middle |= (v.x != 0u) & (v.y != length);
+                    __hip_atomic_store(reinterpret_cast<u64 *>(slot + j), (u64)v.x | ((u64)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                ReadRecord::put(ob.rec, rr, gr, first[0], first[1], first[2]);
-                c.read_type[rr] = (uint8_t)classify(bad, middle, length, c.not_cov);
+                __hip_atomic_store(a.counts + rr, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         }
     }
@@ -237,56 +211,81 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
 #if defined(YK_OB_EXPERIMENT) && YK_OB_EXPERIMENT == 2 // (timing only: S, A and the arrivals)
     return;
 #endif
-    // ---- B: region counts -> scan (decoupled look-back over the slabs) -> CSR
-    // Round trips, not bytes, are what this phase costs (it ends the launch).  The slab's records and the first window of
-    // the look-back are asked for together: one trip; a second one only for a sorted read of more than three regions.
-    constexpr u64 kPre = 2ull << 62, kVal = (1ull << 62) - 1;
-    u64 rw[kObPer][4];
+    // ---- B: region counts -> scan (decoupled look-back over the slabs) -> CSR, type_of_read
+    // Round trips, not bytes, are what this phase costs (it ends the launch): counts[], closed forms, lengths and offsets of
+    // the whole slab go out together; the sorted reads' regions (their first three: nearly all have fewer) are asked for
+    // before the look-back and arrive during it.
+    auto slot_at = [&](u64 at) { // (written at agent scope by the wavefront that sorted the read)
+        const u64 v = __hip_atomic_load(reinterpret_cast<const u64 *>(a.stage + at), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return make_uint2((u32)v, (u32)(v >> 32));
+    };
+    u32 g[kObPer], L[kObPer], excl[kObPer];
+    uint2 ab[kObPer];
+    u64 so[kObPer];
+    u32 cfm = 0; // bit k: this lane's k-th read has a closed form
 #pragma unroll
     for (int k = 0; k < kObPer; k++) {
         const u32 i = (u32)k * 64u + lane;
-        const u64 *p = ob.rec + 4 * (u64)(slab0 + (i < slab_reads ? i : 0u));
-#pragma unroll
-        for (int q = 0; q < 4; q++) rw[k][q] = __hip_atomic_load(p + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool inb = i < slab_reads;
+        const u32 r = inb ? slab0 + i : slab0;
+        g[k] = __hip_atomic_load(a.counts + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u64 v = __hip_atomic_load(reinterpret_cast<const u64 *>(a.closed + r), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ab[k] = make_uint2((u32)v, (u32)(v >> 32)); // (meaningful when counts[] says so)
+        L[k] = a.len[r];
+        so[k] = a.off[r] + 2 * (u64)r;
+        if (!inb) g[k] = 0u;
     }
-    u64 v[kObLook]; // 64 x kObLook predecessors per round trip: lane l looks at hi - l, hi - 64 - l, ... (the nearest first)
-    i32 hi = (i32)slab - 1;
-    auto look = [&]() {
-#pragma unroll
-        for (int j = 0; j < kObLook; j++) {
-            const i32 idx = hi - 64 * j - (i32)lane;
-            v[j] = idx >= 0 ? __hip_atomic_load(&c.scan_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kPre; // before the first slab: prefix 0
-        }
-    };
-    if (slab > 0) look();
-    u32 g[kObPer], excl[kObPer];
     u32 tot = 0;
 #pragma unroll
     for (int k = 0; k < kObPer; k++) {
-        g[k] = (u32)k * 64u + lane < slab_reads ? (u32)rw[k][0] : 0u;
+        if (g[k] == kClosedForm) {
+            cfm |= 1u << k;
+            g[k] = (ab[k].x != 0u ? 1u : 0u) + (ab[k].y != L[k] ? 1u : 0u);
+        }
         const u32 incl = wave_incl_add(g[k]);
         excl[k] = tot + incl - g[k];
         tot += (u32)__shfl((int)incl, 63, 64);
     }
+    if (slab > 0 && lane == 0) __hip_atomic_store(&c.scan_state[slab], (1ull << 62) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint2 s0[kObPer], s1[kObPer], s2[kObPer];
+#pragma unroll
+    for (int k = 0; k < kObPer; k++) {
+        const bool sorted = !((cfm >> k) & 1u) && g[k] != 0u;
+        s0[k] = s1[k] = s2[k] = make_uint2(0u, 0u);
+        if (sorted) s0[k] = slot_at(so[k]);
+        if (sorted && g[k] > 1u) s1[k] = slot_at(so[k] + 1);
+        if (sorted && g[k] > 2u) s2[k] = slot_at(so[k] + 2);
+    }
+    constexpr u64 kPre = 2ull << 62, kVal = (1ull << 62) - 1;
     u64 base = 0;
     if (slab > 0) {
-        if (lane == 0) __hip_atomic_store(&c.scan_state[slab], (1ull << 62) | tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         u32 polls = 0;
-        for (;;) {
-            u64 part = 0;
-            bool found = false, hole = false;
+        for (i32 hi = (i32)slab - 1;; hi -= 64 * kObLook) {
+            // 64 x kObLook predecessors per round trip: lane l looks at hi - l, hi - 64 - l, ... (the nearest first)
+            u64 part;
+            bool found;
+            for (;;) { // until the window holds no empty entry before its nearest prefix
+                u64 v[kObLook];
 #pragma unroll
-            for (int j = 0; j < kObLook; j++) {
-                if (!found && !hole) { // (uniform)
-                    const u64 pre = __builtin_amdgcn_ballot_w64((v[j] >> 62) == 2);
-                    const u64 before = pre ? ((pre & (0 - pre)) - 1ull) : ~0ull; // lanes nearer than this group's nearest prefix
-                    hole = (__builtin_amdgcn_ballot_w64((v[j] >> 62) == 0) & before) != 0;
-                    const u32 first_pre = pre ? (u32)__builtin_ctzll(pre) : 64u;
-                    part += lane <= first_pre ? (v[j] & kVal) : 0;
-                    found = pre != 0;
+                for (int j = 0; j < kObLook; j++) {
+                    const i32 idx = hi - 64 * j - (i32)lane;
+                    v[j] = idx >= 0 ? __hip_atomic_load(&c.scan_state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kPre; // before the first slab: prefix 0
                 }
-            }
-            if (hole) { // an empty word before the window's nearest prefix: look again
+                part = 0;
+                found = false;
+                bool hole = false;
+#pragma unroll
+                for (int j = 0; j < kObLook; j++) {
+                    if (!found && !hole) { // (uniform)
+                        const u64 pre = __builtin_amdgcn_ballot_w64((v[j] >> 62) == 2);
+                        const u64 before = pre ? ((pre & (0 - pre)) - 1ull) : ~0ull; // lanes nearer than this group's nearest prefix
+                        hole = (__builtin_amdgcn_ballot_w64((v[j] >> 62) == 0) & before) != 0;
+                        const u32 first_pre = pre ? (u32)__builtin_ctzll(pre) : 64u;
+                        part += lane <= first_pre ? (v[j] & kVal) : 0;
+                        found = pre != 0;
+                    }
+                }
+                if (!hole) break;
                 // (Every earlier slab's wavefronts were dispatched before this one's last: they are running or done, and the
                 // wavefronts that wait here are at most one per slab of far more resident ones, so this wait ends.  The bound
                 // is there so that a broken invariant shows as a batch sent down the default path, not as a hung device.)
@@ -295,15 +294,11 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
                     return;
                 }
                 __builtin_amdgcn_s_sleep(1);
-                look();
-                continue;
             }
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
             base += part;
             if (found) break;
-            hi -= 64 * kObLook;
-            look();
         }
     }
     const bool last_slab = slab + 1u == ob.n_slabs;
@@ -346,30 +341,46 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
             dst[i] = v;
         }
     }
-    // offsets and regions (the types are written where the regions were found)
+    // offsets, regions, types
 #pragma unroll
     for (int k = 0; k < kObPer; k++) {
         const u32 i = (u32)k * 64u + lane;
         if (i < slab_reads) {
-            const u32 r = slab0 + i, gk = g[k];
+            const u32 r = slab0 + i, Lr = L[k], gk = g[k];
             const u64 dst = base + excl[k];
             c.bad_offsets[r] = dst;
             if (r == c.n_reads - 1) c.bad_offsets[c.n_reads] = dst + gk;
+            u32 bad = 0;
+            bool middle = false;
             const bool fits = dst + gk <= c.region_cap;
-            if (fits) {
-                if (gk > 0u) c.bad_regions[dst] = make_uint2((u32)(rw[k][0] >> 32), (u32)rw[k][1]);
-                if (gk > 1u) c.bad_regions[dst + 1] = make_uint2((u32)(rw[k][1] >> 32), (u32)rw[k][2]);
-                if (gk > 2u) c.bad_regions[dst + 2] = make_uint2((u32)(rw[k][2] >> 32), (u32)rw[k][3]);
-                if (gk > 3u) { // (rare: the rest of a sorted read's regions, from its stage slot)
-                    const u64 so = a.off[r] + 2 * (u64)r;
-                    for (u32 j = 3; j < gk; j++) {
-                        const u64 w = __hip_atomic_load(reinterpret_cast<const u64 *>(a.stage + (so + j)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        c.bad_regions[dst + j] = make_uint2((u32)w, (u32)(w >> 32));
-                    }
+            if ((cfm >> k) & 1u) { // (neither region lies in the middle: the first begins at 0, the second ends at len)
+                u32 j = 0;
+                if (ab[k].x != 0u && fits) c.bad_regions[dst + j++] = make_uint2(0u, ab[k].x);
+                if (ab[k].y != Lr && fits) c.bad_regions[dst + j] = make_uint2(ab[k].y, Lr);
+                bad = ab[k].x + (Lr - ab[k].y);
+            } else if (gk) {
+                if (fits) c.bad_regions[dst] = s0[k];
+                bad = s0[k].y - s0[k].x;
+                middle = (s0[k].x != 0u) & (s0[k].y != Lr);
+                if (gk > 1u) {
+                    if (fits) c.bad_regions[dst + 1] = s1[k];
+                    bad += s1[k].y - s1[k].x;
+                    middle |= (s1[k].x != 0u) & (s1[k].y != Lr);
                 }
-            } else {
-                atomicOr(&ctr->region_overflow, 1u);
+                if (gk > 2u) {
+                    if (fits) c.bad_regions[dst + 2] = s2[k];
+                    bad += s2[k].y - s2[k].x;
+                    middle |= (s2[k].x != 0u) & (s2[k].y != Lr);
+                }
+                for (u32 j = 3; j < gk; j++) {
+                    const uint2 v = slot_at(so[k] + j);
+                    if (fits) c.bad_regions[dst + j] = v;
+                    bad += v.y - v.x;
+                    middle |= (v.x != 0u) & (v.y != Lr);
+                }
             }
+            if (!fits) atomicOr(&ctr->region_overflow, 1u);
+            c.read_type[r] = (uint8_t)classify(bad, middle, Lr, c.not_cov);
         }
     }
 }

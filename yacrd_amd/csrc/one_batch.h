@@ -39,6 +39,9 @@ constexpr int kObReads = 4 * kObItems;           // consecutive reads per wavefr
 #ifndef YK_OB_SLAB
 #define YK_OB_SLAB 128
 #endif
+#ifndef YK_OB_NAP
+#define YK_OB_NAP 32 // x 64 cycles between two looks at the word a slab's look-back waits for
+#endif
 #ifndef YK_OB_LOOK
 #define YK_OB_LOOK 4 // scan words per lane and round trip of the look-back
 #endif
@@ -100,6 +103,9 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
     }
 #endif
     __shared__ u32 s_def[kObReads];
+#ifdef YK_OB_STAMPS
+    const u64 ob_stamp0 = wall_clock64();
+#endif
     const u32 lane = lane_id();
     const u32 r0 = w * (u32)kObReads;
     if (r0 >= c.n_reads) return; // (the grid is padded to whole rounds of eight slabs)
@@ -197,7 +203,13 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
     return;
 #endif
     // ---- the wavefront arrives at its slab; the last one to arrive takes the slab through phase B
+#ifdef YK_OB_STAMPS // (diagnosis: where the last slabs' time goes; wall clock, 100 MHz)
+    const u64 st_start = ob_stamp0, st_sa = wall_clock64();
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // every store above has been acknowledged
+#ifdef YK_OB_STAMPS
+    const u64 st_acked = wall_clock64();
+#endif
     const u32 slab = r0 / (u32)kObSlab;
     const u32 slab0 = slab * (u32)kObSlab;
     const u32 slab_reads = min(c.n_reads - slab0, (u32)kObSlab);
@@ -207,6 +219,10 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
                                       __HIP_MEMORY_SCOPE_AGENT);
     const u32 seen_lo = (u32)__builtin_amdgcn_readfirstlane((int)(u32)seen);
     if ((seen_lo & 0xFFFFu) + 1u != (slab_reads + (u32)kObReads - 1u) / (u32)kObReads) return;
+#ifdef YK_OB_STAMPS
+    const u64 st_arrived = wall_clock64();
+    u32 st_hops = 0;
+#endif
 
 #if defined(YK_OB_EXPERIMENT) && YK_OB_EXPERIMENT == 2 // (timing only: S, A and the arrivals)
     return;
@@ -257,9 +273,15 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
         if (sorted && g[k] > 2u) s2[k] = slot_at(so[k] + 2);
     }
     constexpr u64 kPre = 2ull << 62, kVal = (1ull << 62) - 1;
+#ifdef YK_OB_STAMPS
+    u64 st_loaded = wall_clock64();
+#endif
     u64 base = 0;
     if (slab > 0) {
         u32 polls = 0;
+#ifdef YK_OB_STAMPS
+        st_loaded = wall_clock64();
+#endif
         for (i32 hi = (i32)slab - 1;; hi -= 64 * kObLook) {
             // 64 x kObLook predecessors per round trip: lane l looks at hi - l, hi - 64 - l, ... (the nearest first)
             u64 part;
@@ -273,35 +295,52 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
                 }
                 part = 0;
                 found = false;
-                bool hole = false;
+                i32 hole = -1; // the nearest empty word in front of the window's nearest prefix
 #pragma unroll
                 for (int j = 0; j < kObLook; j++) {
-                    if (!found && !hole) { // (uniform)
+                    if (!found && hole < 0) { // (uniform)
                         const u64 pre = __builtin_amdgcn_ballot_w64((v[j] >> 62) == 2);
                         const u64 before = pre ? ((pre & (0 - pre)) - 1ull) : ~0ull; // lanes nearer than this group's nearest prefix
-                        hole = (__builtin_amdgcn_ballot_w64((v[j] >> 62) == 0) & before) != 0;
+                        const u64 empty = __builtin_amdgcn_ballot_w64((v[j] >> 62) == 0) & before;
+                        if (empty) hole = hi - 64 * j - (i32)__builtin_ctzll(empty);
                         const u32 first_pre = pre ? (u32)__builtin_ctzll(pre) : 64u;
                         part += lane <= first_pre ? (v[j] & kVal) : 0;
                         found = pre != 0;
                     }
                 }
-                if (!hole) break;
+                if (hole < 0) break;
+                // Wait for THAT word, one load per look, asleep in between: a slab at the front of an XCD's share waits for
+                // the slabs of the XCD before it, i.e. for most of the launch, and so do all the slabs behind it — seven
+                // eighths of them.  (Looking at the whole window every 64 cycles instead, each of those ~700 wavefronts kept
+                // 256 loads of the same 6 KB in flight: the screening wavefronts took 13-20 us each instead of 6-8,
+                // profiles/r04/q_one_launch_stamps.log.)
                 // (Every earlier slab's wavefronts were dispatched before this one's last: they are running or done, and the
                 // wavefronts that wait here are at most one per slab of far more resident ones, so this wait ends.  The bound
                 // is there so that a broken invariant shows as a batch sent down the default path, not as a hung device.)
-                if (++polls > (1u << 20)) {
-                    if (lane == 0 && c.host_ctr) __hip_atomic_store(&c.host_ctr->ob_unsupported, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    return;
+                for (;;) {
+                    u64 w = 0;
+                    if (lane == 0) w = __hip_atomic_load(&c.scan_state[hole], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__builtin_amdgcn_readfirstlane((int)(u32)(w >> 62)) != 0) break;
+                    if (++polls > (1u << 18)) {
+                        if (lane == 0 && c.host_ctr) __hip_atomic_store(&c.host_ctr->ob_unsupported, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                        return;
+                    }
+                    __builtin_amdgcn_s_sleep(YK_OB_NAP);
                 }
-                __builtin_amdgcn_s_sleep(1);
             }
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) part += __shfl_xor(part, d, 64);
             base += part;
+#ifdef YK_OB_STAMPS
+            st_hops++;
+#endif
             if (found) break;
         }
     }
     const bool last_slab = slab + 1u == ob.n_slabs;
+#ifdef YK_OB_STAMPS
+    const u64 st_looked = wall_clock64();
+#endif
     if (lane == 0) {
         __hip_atomic_store(&c.scan_state[slab], kPre | (base + tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (last_slab) ctr->total_regions = base + tot;
@@ -383,6 +422,15 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
             c.read_type[r] = (uint8_t)classify(bad, middle, Lr, c.not_cov);
         }
     }
+#ifdef YK_OB_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const u64 st_end = wall_clock64();
+    if (lane == 0 && (slab % 49u == 48u || last_slab || slab < 2u))
+        printf("slab %u of %u: wave start %llu | S+A %llu | stores acked %llu | arrived %llu | loads+scan %llu | look-back %llu (%u hops) | outputs acked %llu (x10 ns, from the wave's start)\n",
+               slab, ob.n_slabs, (unsigned long long)st_start, (unsigned long long)(st_sa - st_start), (unsigned long long)(st_acked - st_start),
+               (unsigned long long)(st_arrived - st_start), (unsigned long long)(st_loaded - st_start), (unsigned long long)(st_looked - st_start),
+               st_hops, (unsigned long long)(st_end - st_start));
+#endif
 }
 
 } // namespace yk

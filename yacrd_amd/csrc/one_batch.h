@@ -17,9 +17,11 @@
 //      sums the arrival words and sends the counter block home.
 // No class lists, no class counts, no prediction, no fences (an agent-scope release / acquire pair writes back / invalidates
 // a whole L2 per use: the first version with them took 111 us); what the host waits for is one kernel.
-// Measured (configs[1]: 100 000 reads / 10 M intervals; profiles/r04/q_*): S + A 26.6 us (the fused screen alone: 18), with the
-// arrivals 27.8, whole kernel 41-45; one batch at a time 53.5-55 us against 64-66 on the default path.  The tail is phase B
-// of the last slabs — a chain of four dependent round trips to memory behind the last arrival — not its bytes.
+// Measured (configs[1]: 100 000 reads / 10 M intervals; profiles/r04/q_*): S + A 26.6 us under rocprofv3 (the fused screen
+// alone: 18), with the arrivals 27.8, whole kernel 41-45; one batch at a time 52-57 us against 64-66 on the default path.
+// Timestamps inside the kernel (-DYK_OB_STAMPS) put the time in the screening wavefronts, not in phase B: they live 6-20 us
+// (three dependent trips, two screens, a sort in every fifth), 1 563 of them per XCD on 768 slots; a slab's own phase B is
+// 3-4 us, and a later slab's look-back simply ends when the screening in front of it does.
 // A read of more than 256 intervals (the workgroup / device-wide classes) is not handled here: the kernel raises
 // Counters::ob_unsupported and the engine runs the batch through the default path (engine.hip), as it does for a batch in
 // which the sort rejected a read (exact path) or the regions outgrew their buffer.

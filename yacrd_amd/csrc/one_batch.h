@@ -113,15 +113,18 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
     if (r0 >= c.n_reads) return; // (the grid is padded to whole rounds of eight slabs)
 
     // ---- S: the wavefront's reads through the screen, by size class
-    u32 n = 0;
+    u32 n = 0, len_l = 0;
+    u64 o_l = 0;
     bool in = false, huge = false;
     {
         in = lane < (u32)kObReads && r0 + lane < c.n_reads;
         if (in) {
             const ulonglong2 oo = *reinterpret_cast<const ulonglong2 *>(a.off + (r0 + lane)); // off[r], off[r + 1]
+            len_l = a.len[r0 + lane];
             const u64 nn = oo.y - oo.x;
             huge = nn > 256;
             n = huge ? 0u : (u32)nn;
+            o_l = oo.x;
         }
         if (lane < (u32)kObReads) s_def[lane] = 0u;
     }
@@ -137,21 +140,30 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
     }
     wave_lds_sync();
     const VerdictsAcrossXcds sink{a, s_def, r0};
+    // (the screen gets extent and length of its reads from the lanes that classified them: one dependent trip less)
+    auto known_from = [&](u32 i, u64 &o, u32 &nn, u32 &ll) {
+        o = (u64)(u32)__shfl((int)(u32)o_l, (int)i, 64) | ((u64)(u32)__shfl((int)(u32)(o_l >> 32), (int)i, 64) << 32);
+        nn = (u32)__shfl((int)n, (int)i, 64);
+        ll = (u32)__shfl((int)len_l, (int)i, 64);
+    };
     if (m16) { // reads of up to 128 intervals: 16-lane groups, group g takes the wavefront's g-th (and g + 4-th ...) read
         u32 r[kObItems];
         bool act[kObItems];
+        ReadsKnown<kObItems> kn;
 #pragma unroll
         for (int t = 0; t < kObItems; t++) {
             const u32 i = (u32)t * 4u + (lane >> 4);
             act[t] = ((m16 >> i) & 1u) != 0;
             r[t] = act[t] ? r0 + i : 0u;
+            known_from(i, kn.o[t], kn.n[t], kn.len[t]);
         }
-        screen_reads<16, kObItems, false, 1>(a, r, act, sink);
+        screen_reads<16, kObItems, false, 1>(a, r, act, sink, &kn);
         wave_lds_sync(); // (the next turn zeroes the table)
     }
     while (m32) { // up to 256: 32-lane halves, two (2 x ITEMS) of them per turn (uniform)
         u32 r[kObItems];
         bool act[kObItems];
+        ReadsKnown<kObItems> kn;
 #pragma unroll
         for (int t = 0; t < kObItems; t++) {
             const u32 i0 = m32 ? (u32)__builtin_ctz(m32) : 0u;
@@ -162,8 +174,9 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
             m32 &= m32 - (m32 ? 1u : 0u);
             act[t] = lane < 32u ? v0 : v1;
             r[t] = act[t] ? r0 + (lane < 32u ? i0 : i1) : 0u;
+            known_from(lane < 32u ? i0 : i1, kn.o[t], kn.n[t], kn.len[t]);
         }
-        screen_reads<32, kObItems, false, 1>(a, r, act, sink);
+        screen_reads<32, kObItems, false, 1>(a, r, act, sink, &kn);
         wave_lds_sync();
     }
 
@@ -189,15 +202,15 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
             // another L2 — reads them inside this launch.  (A release fence here and an acquire fence there do the same
             // by writing back / invalidating a whole L2 each time: 111 us for the batch instead of ..., profiles/r04/p_*.)
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // (the sort's stores — other lanes' among them — have reached the L2)
-            if (lane == 63u) {
-                const u32 gr = a.counts[rr];
-                uint2 *slot = a.stage + (o + 2 * (u64)rr);
-                for (u32 j = 0; j < gr; j++) {
-                    const uint2 v = slot[j];
-                    __hip_atomic_store(reinterpret_cast<u64 *>(slot + j), (u64)v.x | ((u64)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                __hip_atomic_store(a.counts + rr, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            u32 gr = 0;
+            if (lane == 63u) gr = a.counts[rr];
+            gr = (u32)__builtin_amdgcn_readlane((int)gr, 63);
+            uint2 *slot = a.stage + (o + 2 * (u64)rr);
+            for (u32 j = lane; j < gr; j += 64u) { // (one trip for the whole slot, not one per region)
+                const uint2 v = slot[j];
+                __hip_atomic_store(reinterpret_cast<u64 *>(slot + j), (u64)v.x | ((u64)v.y << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            if (lane == 63u) __hip_atomic_store(a.counts + rr, gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
 

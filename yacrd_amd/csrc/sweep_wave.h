@@ -1009,8 +1009,15 @@ struct VerdictsToGlobal {
     __device__ __forceinline__ void deferred(u32 r) const { a.counts[r] = kDeferredMark; }
 };
 
+// (extent and length of the reads, when the caller has them already: one_batch.h)
+template <int ITEMS>
+struct ReadsKnown {
+    u64 o[ITEMS];
+    u32 n[ITEMS], len[ITEMS];
+};
 template <int LANES, int ITEMS, bool WIDE, int WPB = 1, class Sink>
-__device__ __forceinline__ void screen_reads(const SweepArgs &a, const u32 (&r)[ITEMS], const bool (&active)[ITEMS], const Sink &sink);
+__device__ __forceinline__ void screen_reads(const SweepArgs &a, const u32 (&r)[ITEMS], const bool (&active)[ITEMS], const Sink &sink,
+                                             const ReadsKnown<ITEMS> *known = nullptr);
 
 template <int LANES, int ITEMS, bool WIDE = false>
 __device__ __forceinline__ void screen_block(const SweepArgs &a, u32 block)
@@ -1034,7 +1041,8 @@ __device__ __forceinline__ void screen_block(const SweepArgs &a, u32 block)
 // ITEMS reads per lane group, given by their ids (active[t]: this group has a t-th read; a t with no active group in the
 // wavefront ends the loop).  WPB: wavefronts per workgroup (each has a table of its own in LDS).
 template <int LANES, int ITEMS, bool WIDE, int WPB, class Sink>
-__device__ __forceinline__ void screen_reads(const SweepArgs &a, const u32 (&r)[ITEMS], const bool (&active)[ITEMS], const Sink &sink)
+__device__ __forceinline__ void screen_reads(const SweepArgs &a, const u32 (&r)[ITEMS], const bool (&active)[ITEMS], const Sink &sink,
+                                             const ReadsKnown<ITEMS> *known)
 {
     constexpr int K = 16;
     const u32 lane = lane_id(), lig = lane & (u32)(LANES - 1);
@@ -1044,7 +1052,9 @@ __device__ __forceinline__ void screen_reads(const SweepArgs &a, const u32 (&r)[
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) {
         o[t] = 0, n[t] = 0, len[t] = 0;
-        if (active[t]) {
+        if (known) { // (a constant once inlined)
+            if (active[t]) o[t] = known->o[t], n[t] = known->n[t], len[t] = known->len[t];
+        } else if (active[t]) {
             const ulonglong2 oo = *reinterpret_cast<const ulonglong2 *>(a.off + r[t]); // off[r], off[r + 1]: one load
             o[t] = oo.x;
             n[t] = (u32)(oo.y - oo.x);

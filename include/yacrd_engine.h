@@ -74,7 +74,7 @@ typedef struct {
 #define YACRD_F_TIMING_SAMPLED 32768u
 /* Latency over throughput, for callers that run ONE short batch at a time (the CLI once its input is in HBM): a batch of
  * fewer than 400 000 reads whose reads all have at most 256 intervals runs as one kernel launch — no size-class plan, no
- * class counts, no prediction, one dispatch instead of three (csrc/one_batch.h: 100 000 reads in 52-57 us instead of 64-66).
+ * class counts, no prediction, one dispatch instead of three (csrc/one_batch.h: 100 000 reads in 51-55 us instead of 64-66).
  * Any other batch takes the default path, as does a batch in which that launch met a read it does not handle (found on
  * the device; the batch is then run again).  Callers that keep several batches in flight are better off without. */
 #define YACRD_F_ONE_LAUNCH 4194304u

@@ -18,7 +18,7 @@
 // No class lists, no class counts, no prediction, no fences (an agent-scope release / acquire pair writes back / invalidates
 // a whole L2 per use: the first version with them took 111 us); what the host waits for is one kernel.
 // Measured (configs[1]: 100 000 reads / 10 M intervals; profiles/r04/q_*): S + A 26.6 us under rocprofv3 (the fused screen
-// alone: 18), with the arrivals 27.8, whole kernel 41-45; one batch at a time 52-57 us against 64-66 on the default path.
+// alone: 18), with the arrivals 27.8, whole kernel 41-45; one batch at a time 51-55 us against 64-66 on the default path.
 // Timestamps inside the kernel (-DYK_OB_STAMPS) put the time in the screening wavefronts, not in phase B: they live 6-20 us
 // (three dependent trips, two screens, a sort in every fifth), 1 563 of them per XCD on 768 slots; a slab's own phase B is
 // 3-4 us, and a later slab's look-back simply ends when the screening in front of it does.

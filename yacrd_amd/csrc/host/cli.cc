@@ -142,7 +142,11 @@ int main(int argc, char **argv)
     // YACRD_GPUS_ON_DEVICE=<d>: every engine on device d (how the N > 1 path is tested on a one-GPU box)
     const char *same_dev = std::getenv("YACRD_GPUS_ON_DEVICE");
     for (unsigned long long g = 0; g < gpus; g++) {
-        yacrd_engine_cfg cfg = {same_dev && *same_dev ? (int32_t)std::atoi(same_dev) : (int32_t)g, YACRD_F_DEFAULT};
+        // a process runs ONE batch per engine: a short one goes out as one kernel launch (csrc/one_batch.h; anything that
+        // launch does not take falls back to the default path inside the engine); YACRD_CLI_NO_ONE_LAUNCH=1 for A/B
+        const char *no_one = std::getenv("YACRD_CLI_NO_ONE_LAUNCH");
+        const uint32_t eflags = (no_one && *no_one && *no_one != '0') ? YACRD_F_DEFAULT : YACRD_F_ONE_LAUNCH;
+        yacrd_engine_cfg cfg = {same_dev && *same_dev ? (int32_t)std::atoi(same_dev) : (int32_t)g, eflags};
         yacrd_engine *e = nullptr;
         if (yacrd_engine_create(&cfg, &e) != YACRD_OK) die(yacrd_last_error());
         engines.push_back(e);

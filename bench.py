@@ -115,6 +115,8 @@ def roofline_of(yacrd_amd, t, n_launches, R, G, key, note):
             "traffic_source": ("profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE (separate passes) of "
                                "%s, measured %s (%s); not re-measured by this run" % (tr.get("kernel"), tr.get("measured"), tr.get("source"))
                                if tr else None),
+            "traffic_source_short": ("profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of this kernel on this "
+                                     "workload, %s; not re-measured by this run" % tr.get("measured") if tr else None),
             "algorithmic_bytes": b_dom, "kernel_ms": dom_ms, "timed_launches": K, "launches": n_launches,
             "kernel_reads": c_reads, "kernel_intervals": c_iv, "deferred_reads": deferred,
             "deferred_intervals": int(t.get("deferred_intervals", 0)) if deferred else 0, "note": note}
@@ -458,6 +460,7 @@ def cpu_baseline(offsets, intervals, lengths, cov, nc, label):
             "sample": "the first %d reads (%d intervals) of %s once on %d threads (= usable CPUs: hardware threads "
                       "capped by the cgroup cpu.max quota): %.2f s; single-thread (reference default -t 1) on the "
                       "first %d reads: %.0f reads/s" % (rs, int(off[-1]), label, ncores, cpu_all, r1, r1 / cpu_1),
+            "sample_short": "first %d reads of %s once on %d threads: %.2f s; 1 thread on %d reads" % (rs, label, ncores, cpu_all, r1),
             "value_1thread": r1 / cpu_1}
 
 
@@ -674,6 +677,94 @@ def guarded(fn, *a, **k):
         return {"error": repr(ex)}
 
 
+def no_nan(x):
+    """NaN / Infinity -> None, numpy scalars -> Python's: the line must survive a strict json.loads."""
+    if isinstance(x, dict):
+        return {str(k): no_nan(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [no_nan(v) for v in x]
+    if isinstance(x, (np.floating, float)):
+        x = float(x)
+        return x if x == x and x not in (float("inf"), float("-inf")) else None
+    if isinstance(x, np.integer):
+        return int(x)
+    if isinstance(x, np.bool_):
+        return bool(x)
+    return x
+
+
+def _dig(d, *path):
+    for k in path:
+        if not isinstance(d, dict) or k not in d:
+            return None
+        d = d[k]
+    return d
+
+
+def _r(x, nd=4):
+    return round(x, nd) if isinstance(x, float) else x
+
+
+COMPACT_LIMIT = 4096  # bytes: the driver parses the LAST stdout line; round 4's 30 KB line came back `parsed: null`
+
+
+def compact_line(full, extras_path):
+    """The line the driver parses: the contract's keys, `roofline`, `cpu_baseline` and a handful of scalars taken
+    from the extra blocks — everything else is in bench_extras.json (`--print-extras` prints it on an earlier line)."""
+    keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data")
+    out = {k: full.get(k) for k in keys}
+    cfg = dict(full.get("config") or {})
+    cfg["workload"] = full.get("workload_short") or cfg.get("workload", "")[:300]
+    out["config"] = cfg
+    out["parity"] = full.get("parity")
+    rf = full.get("roofline") or {}
+    out["roofline"] = {k: _r(rf.get(k)) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic",
+                                                  "algorithmic_bytes", "kernel_ms", "timed_launches", "kernel_reads",
+                                                  "deferred_reads")}
+    out["roofline"]["traffic_source"] = rf.get("traffic_source_short")
+    cb = full.get("cpu_baseline")
+    if isinstance(cb, dict):
+        out["cpu_baseline"] = ({k: _r(cb.get(k), 1) for k in ("value", "unit", "cores", "kind", "value_1thread")}
+                               if "error" not in cb else cb)
+        if "error" not in cb:
+            out["cpu_baseline"]["sample"] = cb.get("sample_short") or str(cb.get("sample"))[:160]
+    sc = {"whole_path_frac_of_peak": _dig(full, "headline", "whole_path_frac_of_peak"),
+          "kernel_overlaps_per_sec": full.get("kernel_overlaps_per_sec"),
+          "follow_on_ms": _dig(full, "roofline", "finish_compact_kernel_ms"),
+          "configs2_ms": _dig(full, "configs2", "ms_per_step"),
+          "configs2_frac": _dig(full, "configs2", "roofline", "frac"),
+          "skewed_ms": _dig(full, "skewed", "ms_per_step"),
+          "skewed_frac": _dig(full, "skewed", "roofline", "frac"),
+          "configs1_pipelined_us": None, "configs1_one_at_a_time_us": None, "one_launch_us": None,
+          "e2e_overlaps_per_sec": _dig(full, "end_to_end", "overlaps_per_sec"),
+          "e2e_at_scale_overlaps_per_sec": _dig(full, "end_to_end", "at_scale", "device_parser", "overlaps_per_sec"),
+          "pcie_inclusive_reads_per_sec": _dig(full, "pcie_inclusive", "reads_per_sec")}
+    sb = full.get("small_batches") or (full.get("headline") if full.get("scaling") == "weak" else None)
+    if isinstance(sb, dict):
+        for k, path in (("configs1_pipelined_us", ("ms_per_step",)),
+                        ("configs1_one_at_a_time_us", ("unpredicted_single_batch", "ms_per_batch")),
+                        ("one_launch_us", ("one_launch_single_batch", "ms_per_batch"))):
+            v = _dig(sb, *path)
+            sc[k] = v * 1e3 if isinstance(v, (int, float)) else None
+    out.update({k: _r(v) for k, v in sc.items()})
+    if isinstance(full.get("value_sigma100"), dict):
+        out["value_sigma100"] = {k: _r(v) for k, v in full["value_sigma100"].items()}
+    jit = full.get("jitter")
+    if isinstance(jit, dict):  # [ms per step, frac, share of the screened reads decided] per (config, sigma)
+        share = jit.get("healthy_share_of_screened_reads") or {}
+        out["jitter"] = {k: [_r(_dig(b, "ms_per_step")), _r(_dig(b, "roofline", "frac")), _r(share.get(k))]
+                         for k, b in jit.items() if isinstance(b, dict) and k != "healthy_share_of_screened_reads"}
+    out["extras"] = extras_path if extras_path.startswith("not written") else os.path.basename(extras_path)
+    s = json.dumps(out, allow_nan=False, separators=(",", ":"))
+    for drop in ("jitter", "value_sigma100"):  # (never expected: every string above is bounded)
+        if len(s) <= COMPACT_LIMIT:
+            break
+        out.pop(drop, None)
+        s = json.dumps(out, allow_nan=False, separators=(",", ":"))
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -701,7 +792,11 @@ def main():
                     help="small batches: events on the dominant kernel of EVERY step (default: every 8th step of an engine "
                          "when there are more than 64 steps: the events cost ~10 us per step against a 20 us kernel)")
     ap.add_argument("--no-extras", action="store_true", help="headline only")
+    ap.add_argument("--extras-file", type=str, default="", help="where the full object goes (default: bench_extras.json beside bench.py)")
+    ap.add_argument("--print-extras", action="store_true", help="also print the full object, on a line BEFORE the compact one")
     ap.add_argument("--sub-steps", type=int, default=10, help="timed steps of the configs[2] / configs[3] sub-blocks")
+    ap.add_argument("--sigma100-steps", type=int, default=5,
+                    help="timed steps of the `value_sigma100` block (the headline workload from the jittered generator; 0 = skip)")
     ap.add_argument("--jitter-sigmas", type=str, default="30,100,300",
                     help="sigmas of the `jitter` block (comma separated; empty = no jitter block)")
     ap.add_argument("--scale", type=float, default=1.0,
@@ -757,6 +852,8 @@ def main():
             "config": {"workload": ("SCALED x%g (not a measurement): " % args.scale if args.scale != 1.0 else "") + head["workload"] + "; see pcie_inclusive / end_to_end for the rates that include PCIe and the parse",
                        "parallelism": "read-partition x%d, no collective" % world,
                        "torch_distributed_backend": backend if backend else "none (one process)"},
+            "workload_short": ("SCALED x%g (not a measurement): " % args.scale if args.scale != 1.0 else "") + head["workload"].split(", read-partitioned")[0].split("; KERNELS ONLY")[0]
+                              + "; kernels only, inputs resident in HBM",
             "kernel_overlaps_per_sec": head["kernel_overlaps_per_sec"],
             "parity": head["parity"],
             "roofline": head["roofline"],
@@ -781,6 +878,22 @@ def main():
                                                   args.sub_steps, 2, 20000, traffic_key="configs[%d]" % k)
                 except Exception as ex:
                     line[key] = {"error": repr(ex)}
+            if args.config == 4 and not args.jitter and args.sigma100_steps > 0:
+                # the headline's input is SURVEY 8d's generator, which CLAMPS the dovetail ends onto 0 / len — the screen's best
+                # case.  The same workload with the ends spread (sigma = 100 positions), beside it:
+                pk = CONFIGS[4]
+                try:
+                    b, _ = resident_block(cx, "configs[4]", pk[0], args.reads or pk[1], args.overlaps or pk[2], pk[3], pk[4], pk[5],
+                                          100, args.sigma100_steps, 2, 20000)
+                    h, df = b.get("healthy_reads_rank0"), b.get("deferred_reads_rank0")
+                    line["value_sigma100"] = {"value": b["reads_per_sec"], "ms_per_step": b["ms_per_step"], "steps": b["steps"],
+                                              "frac": b["roofline"]["frac"], "kernel": b["roofline"]["kernel"],
+                                              "whole_path_frac_of_peak": b["whole_path_frac_of_peak"],
+                                              "decided_share": None if h is None or df is None else h / max(1, h + df),
+                                              "parity": b["parity"]}
+                    line["configs4_sigma100"] = b
+                except Exception as ex:
+                    line["value_sigma100"] = {"error": repr(ex)}
             line["small_batches"], keep_small = small_batches_block(cx)
         sigmas = [int(x) for x in args.jitter_sigmas.split(",") if x.strip()]
         if sigmas:
@@ -827,7 +940,16 @@ def main():
         for e in keep_small[3]:
             e.close()
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        full = no_nan(line)
+        extras_path = args.extras_file or os.path.join(ROOT, "bench_extras.json")
+        try:
+            with open(extras_path, "w") as fh:
+                json.dump(full, fh, allow_nan=False)
+        except OSError as ex:  # (a read-only checkout: the compact line still goes out)
+            extras_path = "not written: %r" % ex
+        if args.print_extras:  # the whole object on an EARLIER line; the LAST line stays the compact one
+            print(json.dumps(full, allow_nan=False), flush=True)
+        print(json.dumps(compact_line(full, extras_path), allow_nan=False, separators=(",", ":")), flush=True)
     if cx.dist is not None:
         cx.dist.destroy_process_group()
 

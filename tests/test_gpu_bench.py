@@ -15,16 +15,43 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _reject_constant(name):
+    raise ValueError("non-strict JSON constant %s in the driver's line" % name)
+
+
 def _last_json(text):
-    return json.loads([l for l in text.splitlines() if l.startswith("{")][-1])
+    """The driver's view: the LAST stdout line, compact (a 30 KB line came back `parsed: null`),
+    strict JSON (no NaN / Infinity)."""
+    last = text.rstrip("\n").splitlines()[-1]
+    assert last.startswith("{") and len(last.encode()) < 4096, len(last)
+    return json.loads(last, parse_constant=_reject_constant)
 
 
-def test_single_gpu_line_scaled():
+def test_single_gpu_line_scaled(tmp_path):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2",
-                        "--scale", "0.02", "--small-steps", "20", "--sub-steps", "3"],
+                        "--scale", "0.02", "--small-steps", "20", "--sub-steps", "3", "--sigma100-steps", "2",
+                        "--extras-file", str(tmp_path / "extras.json")],
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
-    d = _last_json(p.stdout)
+    line = _last_json(p.stdout)
+    assert len([l for l in p.stdout.splitlines() if l.strip()]) == 1  # nothing but the compact line on stdout
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "parity", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["roofline"]["bound"] == "hbm" and "traffic" in line["roofline"] and "traffic_source" in line["roofline"]
+    assert line["cpu_baseline"]["cores"] >= 1 and line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["sample"]
+    assert "configs[4]" in line["config"]["workload"] and line["config"]["workload"].startswith("SCALED")
+    for k in ("whole_path_frac_of_peak", "configs2_ms", "skewed_ms", "one_launch_us", "e2e_overlaps_per_sec",
+              "configs1_pipelined_us", "configs1_one_at_a_time_us"):
+        assert isinstance(line[k], float) and line[k] > 0, (k, line[k])
+    v100 = line["value_sigma100"]
+    assert v100["parity"].startswith("bit-exact") and v100["ms_per_step"] > 0 and v100["steps"] == 2
+    assert set(line["jitter"]) == {"configs[1]", "configs[2]", "configs[1]_sigma100", "configs[2]_sigma100",
+                                   "configs[1]_sigma300", "configs[2]_sigma300"}
+    assert line["extras"] == "extras.json"
+    d = json.loads((tmp_path / "extras.json").read_text(), parse_constant=_reject_constant)
+    for k in ("metric", "value", "ms_per_step", "steps", "parity"):
+        assert d[k] == line[k], k
     assert d["metric"] == "reads_per_sec_classified" and d["n_gpus"] == 1 and d["scaling"] == "strong"
     assert "configs[4]" in d["config"]["workload"] and d["config"]["workload"].startswith("SCALED")
     assert d["headline"]["reads"] == 100000 and d["config"]["torch_distributed_backend"].startswith("none")
@@ -58,7 +85,7 @@ def test_single_gpu_line_scaled():
 
 
 @pytest.mark.parametrize("weak", [False, True])
-def test_two_ranks_on_one_device(weak):
+def test_two_ranks_on_one_device(weak, tmp_path):
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
@@ -68,9 +95,12 @@ def test_two_ranks_on_one_device(weak):
            "--gpus", "2", "--steps", "6", "--warmup", "2", "--scale", "0.03"]
     if weak:
         cmd.append("--weak")
+    cmd += ["--extras-file", str(tmp_path / "extras.json")]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
-    d = _last_json(p.stdout)
+    line = _last_json(p.stdout)
+    d = json.loads((tmp_path / "extras.json").read_text())
+    assert line["n_gpus"] == 2 and line["value"] == d["value"] and line["config"]["torch_distributed_backend"] == "gloo"
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["parity"].startswith("bit-exact")
     if weak:
         assert d["scaling"] == "weak" and "configs[1]" in d["config"]["workload"]

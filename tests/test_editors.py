@@ -231,3 +231,22 @@ def test_parallel_editors_malformed_record_is_the_one_thread_error(tmp_path, mon
             host.edit_file(host.OP_FILTER, src, out, *table, n_threads=th)
         outs.append(str(ei.value))
     assert outs[0] == outs[1] and "fastq format failed" in outs[0]
+
+
+def test_parallel_editors_stream_to_a_pipe(tmp_path, monkeypatch):
+    """A FIFO as output: the chunk-parallel path needs a seekable file, so such an output takes the
+    one-thread loop, which streams like the reference's BufWriter — same bytes as to a regular file."""
+    import threading
+    fq, table = _synthetic_case(tmp_path, n_reads=120, n_ovl=3000)
+    want_p = str(tmp_path / "want.fastq")
+    host.edit_file(host.OP_SCRUBB, fq, want_p, *table, n_threads=1)
+    want = open(want_p, "rb").read()
+    monkeypatch.setenv("YACRD_EDIT_CHUNK", "2000")  # (many chunks: the parallel path would be taken for a regular file)
+    fifo = str(tmp_path / "out.fifo")
+    os.mkfifo(fifo)
+    got = []
+    t = threading.Thread(target=lambda: got.append(open(fifo, "rb").read()))
+    t.start()
+    host.edit_file(host.OP_SCRUBB, fq, fifo, *table, n_threads=4)
+    t.join(timeout=60)
+    assert not t.is_alive() and got and got[0] == want

@@ -375,7 +375,13 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     }
 
     // YACRD_F_ONE_LAUNCH: a short batch as one kernel (one_batch.h) — unless a debug flag pins another path
-    const bool one_launch = (e->flags & YACRD_F_ONE_LAUNCH) && !e->one_launch_off && n_reads64 < split_min_reads() &&
+    // — and only where its look-back's progress argument holds (one_batch.h): the slabs at the front of an XCD's
+    // contiguous eighth wait for the XCD before it, so up to 7/8 of the slab-finishing wavefronts sit in wave slots for
+    // most of the launch; that needs the 8-XCD part and far more resident slots than waiters.  The cap on the reads is
+    // the kernel's own (32-bit deferred-interval sum), not the follow-on step's A/B knob.
+    const uint64_t ob_waiters = (n_reads64 + yk::kObSlab - 1) / yk::kObSlab * 7 / 8;
+    const bool one_launch = (e->flags & YACRD_F_ONE_LAUNCH) && !e->one_launch_off && n_reads64 < (uint64_t)yk::kObMaxReads &&
+                            e->num_xcc == 8 && 2 * ob_waiters <= (uint64_t)e->num_cu * 4 * YK_OB_OCC &&
                             !(e->flags & (YACRD_F_FORCE_GENERAL | YACRD_F_WAVE_ONLY | YACRD_F_FORCE_LDS_SORT | YACRD_F_NO_HALVES |
                                           YACRD_F_NO_PREFILTER | YACRD_F_NO_DEFER | YACRD_F_XLANE_DS | YACRD_F_NO_FUSED_LAUNCH));
     // (scan-state words: one per slab of the follow-on kernel; one_batch_kernel: one per slab + its arrival counters)
@@ -1220,6 +1226,12 @@ int yacrd_engine_create(const yacrd_engine_cfg *cfg, yacrd_engine **out)
     e->device = dev;
     e->flags = cfg ? cfg->flags : 0;
     e->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    {
+        int xcc = 0;
+        if (hipDeviceGetAttribute(&xcc, hipDeviceAttributeNumberOfXccs, dev) != hipSuccess) xcc = 0;
+        (void)hipGetLastError();
+        e->num_xcc = xcc;
+    }
     {
         int per_cu = 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, yk::screen_wg_fused_kernel, yk::kWsT, 0) == hipSuccess && per_cu > 0)

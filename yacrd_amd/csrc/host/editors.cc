@@ -565,8 +565,17 @@ int edit_sequences_parallel(int op, bool fastq, const char *in_path, const char 
     cut.push_back(size);
     const size_t n_chunks = cut.size() - 1;
     if (n_chunks < 2) return -1;
+    // The chunks land at their offsets (pwrite / a shared mapping): a regular file only.  A FIFO, /dev/stdout into a pipe
+    // or a process substitution takes the one-thread loop, which streams like the reference's BufWriter — asked
+    // BEFORE the open, so that a pipe's reader never sees a writer come and go.
+    struct stat ost;
+    if (::stat(out_path, &ost) == 0 && !S_ISREG(ost.st_mode)) return -1;
     const int ofd = ::open(out_path, O_RDWR | O_CREAT | O_TRUNC, 0666);
     if (ofd < 0) return yh::fail(std::string("cannot create ") + out_path);
+    if (fstat(ofd, &ost) != 0 || !S_ISREG(ost.st_mode)) {
+        ::close(ofd);
+        return -1;
+    }
     // The output: pwrite at the chunk's offset (default), or — YACRD_EDIT_OUT=map — memcpy into a shared mapping of the
     // file, grown ahead of the writers in steps and cut to size at the end.  Neither scales on the box this was measured
     // on (tools/edit_bench.py, 20 GB of FASTQ in /dev/shm, profiles/r04/h_edit_bench_map_vs_pwrite.log): pwrite 3.1 GB/s
@@ -655,7 +664,7 @@ int edit_sequences_parallel(int op, bool fastq, const char *in_path, const char 
                 const ssize_t k = ::pwrite(ofd, out.buf.data() + done, n - done, (off_t)(at + (long long)done));
                 if (k < 0 && errno == EINTR) continue;
                 if (k <= 0) {
-                    state.store(2);
+                    state.store(k < 0 && (errno == ESPIPE || errno == EINVAL) ? 1 : 2); // (not seekable after all: the one-thread loop)
                     break;
                 }
                 done += (size_t)k;

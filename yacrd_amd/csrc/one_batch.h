@@ -48,6 +48,7 @@ constexpr int kObReads = 4 * kObItems;           // consecutive reads per wavefr
 #define YK_OB_LOOK 4 // scan words per lane and round trip of the look-back
 #endif
 constexpr int kObLook = YK_OB_LOOK;
+constexpr u32 kObMaxReads = 400000u;               // batches below this many reads (the 32-bit sum of the deferred reads' intervals; engine.hip bounds the waiters)
 constexpr int kObSlab = YK_OB_SLAB;                 // reads per slab (one arrival counter, one scan word, one pass of phase B)
 constexpr int kObPer = kObSlab / 64;             // reads per lane in phase B
 static_assert(kObSlab % kObReads == 0 && kObSlab / kObReads < 0xFFFF, "arrivals are counted in 16 bits");
@@ -119,7 +120,8 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
     {
         in = lane < (u32)kObReads && r0 + lane < c.n_reads;
         if (in) {
-            const ulonglong2 oo = *reinterpret_cast<const ulonglong2 *>(a.off + (r0 + lane)); // off[r], off[r + 1]
+            struct alignas(8) U64x2 { u64 x, y; }; // (8-byte aligned only: r0 + lane may be odd)
+            const U64x2 oo = *reinterpret_cast<const U64x2 *>(a.off + (r0 + lane)); // off[r], off[r + 1]
             len_l = a.len[r0 + lane];
             const u64 nn = oo.y - oo.x;
             huge = nn > 256;
@@ -329,14 +331,17 @@ __global__ __launch_bounds__(64, YK_OB_OCC) void one_batch_kernel(OneBatchArgs o
                 // eighths of them.  (Looking at the whole window every 64 cycles instead, each of those ~700 wavefronts kept
                 // 256 loads of the same 6 KB in flight: the screening wavefronts took 13-20 us each instead of 6-8,
                 // profiles/r04/q_one_launch_stamps.log.)
-                // (Every earlier slab's wavefronts were dispatched before this one's last: they are running or done, and the
-                // wavefronts that wait here are at most one per slab of far more resident ones, so this wait ends.  The bound
-                // is there so that a broken invariant shows as a batch sent down the default path, not as a hung device.)
+                // Progress: under the contiguous-eighth map the first slabs of XCD x's share have LOW blockIdx and wait for
+                // XCD x - 1's last slabs, whose blockIdx is near the grid's end — up to 7/8 of the slab-finishing wavefronts
+                // sit here while those are dispatched.  The engine only takes this kernel where that fits (engine.hip:
+                // 8 XCDs, twice as many resident wave slots as such waiters); the bound (~20 ms) is there so that anything
+                // else — a CU mask, a device shared with another process — shows as a batch sent down the default path,
+                // not as a hung device.
                 for (;;) {
                     u64 w = 0;
                     if (lane == 0) w = __hip_atomic_load(&c.scan_state[hole], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     if (__builtin_amdgcn_readfirstlane((int)(u32)(w >> 62)) != 0) break;
-                    if (++polls > (1u << 18)) {
+                    if (++polls > (1u << 14)) {
                         if (lane == 0 && c.host_ctr) __hip_atomic_store(&c.host_ctr->ob_unsupported, 2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                         return;
                     }

@@ -875,3 +875,112 @@ def unified_screen_regions(intervals, length, cov, nb, W):
         if S[i] and cs_ex >= k1 and not (cs_ex - ce > cov):
             return None
     return ([(0, a)] if a != 0 else []) + ([(b, length)] if b != length else [])
+
+
+def filtered_sweep_regions(intervals, length, cov, nb, W, cap, stats=None):
+    """finish_compact.h's follow-on for the reads the screen defers (round 5): the screen's closed form for the two ENDS
+    of the read, an exact sweep over what lies in its UNSAFE coarse blocks for the inside — any number of holes, no
+    sort of the whole read.  The table is healthy_screen's: W one-position bins from the smallest start pmin upwards
+    (F starts) and from the largest end pmax downwards (G ends), nb coarse blocks of 2^sh positions for the rest
+    (start -> block (s - pmin) >> sh when s - pmin >= W; end -> block (e - pmin) >> sh when it lies in front of the
+    tail window).  Every interval at least W long: no end inside the head window, no start inside the tail window;
+    F > cov and G > cov: a = the (cov+1)-th smallest start and b = the (cov+1)-th largest end lie in their windows and
+    the reference (src/stack.rs:83-113) gives (0, a) in front and (b, len) behind.
+    D_i = F + (coarse starts - coarse ends of the blocks before i) is the EXACT depth on entry to block i, D_i - E_i
+    the least depth any of its events sees: a block with D_i - E_i > cov is safe — its starts are never low
+    (:83), its ends are all flagged (:77-79).  A low start s (depth <= cov) therefore lies in an unsafe block, and
+    the flagged end the reference pairs it with — the last one in front of it — lies in an unsafe block too or is
+    the largest end of the nearest block in front that holds an end (every end of a safe block is flagged).  Kept:
+    the unsafe blocks and, for each, the nearest block in front that holds an end.  The kept events are sorted and
+    swept with their true depths (D of the block + the kept events in front inside it); a run of low starts still
+    open when the keys end is closed by the tail (G > cov: the (cov+1)-th largest end is flagged behind it).
+    None: not this kind of read, or more than `cap` kept events — the caller sorts the read whole."""
+    n = len(intervals)
+    if n < 2 or length >= 2**30 - 1 or n <= cov:
+        return None
+    if any(not (0 <= s < e <= length) or e - s < W for s, e in intervals):
+        return None
+    pmin = min(s for s, e in intervals)
+    pmax = max(e for s, e in intervals)
+    span = pmax - pmin
+    T = span - W
+    sh = bin_shift(length, nb)
+    while (1 << sh) < W:
+        sh += 1
+    FH, FT = [0] * W, [0] * W
+    S, E = [0] * (nb + 1), [0] * (nb + 1)
+    for s, e in intervals:
+        ds, dx = s - pmin, e - pmin
+        if ds < W:
+            FH[ds] += 1
+        else:
+            S[ds >> sh] += 1
+        if dx > T:
+            FT[span - dx] += 1
+        else:
+            E[dx >> sh] += 1
+    F, G = sum(FH), sum(FT)
+    if F <= cov or G <= cov:
+        return None
+    acc, a = 0, None
+    for i in range(W):
+        acc += FH[i]
+        if acc >= cov + 1:
+            a = pmin + i
+            break
+    acc, b = 0, None
+    for i in range(W):
+        acc += FT[i]
+        if acc >= cov + 1:
+            b = pmax - i
+            break
+    iT = T >> sh
+    D, d = [0] * (iT + 1), F
+    for i in range(iT + 1):
+        D[i] = d
+        d += S[i] - E[i]
+    unsafe = [S[i] + E[i] > 0 and D[i] - E[i] <= cov for i in range(iT + 1)]
+    kept = list(unsafe)
+    for i in range(iT + 1):
+        if not unsafe[i] and E[i] > 0:
+            nxt = next((j for j in range(i + 1, iT + 1) if unsafe[j] or E[j] > 0), None)
+            kept[i] = nxt is not None and unsafe[nxt]
+    m = sum(S[i] + E[i] for i in range(iT + 1) if kept[i])
+    if stats is not None:
+        stats.append(m)
+    if m > cap:
+        return None
+    corr, before = {}, 0
+    for i in range(iT + 1):
+        if kept[i]:
+            corr[i] = D[i] - before
+            before += S[i] - E[i]
+    keys = []
+    for s, e in intervals:
+        ds, dx = s - pmin, e - pmin
+        if ds >= W and kept[ds >> sh]:
+            keys.append((s << SH) | 3)
+        if dx <= T and kept[dx >> sh]:
+            keys.append(e << SH)
+    keys.sort()
+    assert len(keys) == m
+    out, run, tc, cml = [], 0, None, None
+    for key in keys:
+        pos = key >> SH
+        depth = run + corr[(pos - pmin) >> sh]
+        if key & 1:
+            if depth <= cov:
+                if tc is None:
+                    return None  # (cannot happen with F > cov: kept for the kernel's guard)
+                cml = pos
+            run += 1
+        else:
+            if depth > cov:
+                if cml is not None and cml >= tc:
+                    out.append((tc, cml))
+                    cml = None
+                tc = pos
+            run -= 1
+    if cml is not None and cml >= tc:
+        out.append((tc, cml))
+    return ([(0, a)] if a != 0 else []) + out + ([(b, length)] if b != length else [])

@@ -415,3 +415,50 @@ def test_hole_screen_tiny_exhaustive():
                     for nb, W, nbf in ((4, 1, 8), (2, 1, 4), (2, 2, 8)):
                         got = hole_fast_regions(list(iv), L, cov, nb, W, nbf)
                         assert got is None or got == want, (iv, L, cov, nb, W, nbf, got, want)
+
+
+def test_filtered_sweep_matches_oracle():
+    """Round 5: the follow-on step's filtered exact sweep (formulation.filtered_sweep_regions): wherever it decides it
+    equals the oracle — healthy reads, chimeras with any gap, several holes, spread piles, coarse grids — and it
+    decides nearly all of the generator's chimeras within its key budget."""
+    from formulation import filtered_sweep_regions
+    rng = np.random.default_rng(5150)
+    fired = total = decided = 0
+    for it in range(2500):
+        L = int(rng.integers(50, 600)) if it % 5 == 0 else int(rng.integers(600, 60000))
+        n = int(rng.integers(2, 40)) if it % 4 == 0 else int(rng.integers(40, 256))
+        jitter = (0.0, 5.0, 30.0, 100.0)[it % 4]
+        base = _survey_read if it % 2 else _pile_read
+        iv = _chimera_read(rng, n, L, jitter, base) if it % 3 else base(rng, n, L, jitter)
+        if it % 7 == 0:  # a second junction
+            iv = _chimera_read(rng, n, L, jitter, lambda *_: iv)
+        if it % 13 == 0:
+            g = max(1, L // 16)
+            iv = [(min((s // g) * g, L - 1), min(max((e // g) * g, (s // g) * g + 1), L)) for s, e in iv]
+            iv = [(s, max(e, s + 1)) for s, e in iv]
+        for cov in (0, 1, 3, 4, 9):
+            want = oracle.compute_bad_part(iv, L, cov)
+            for nb, W, cap in ((16, 32, 64), (32, 32, 128), (16, 8, 64), (4, 4, 16), (32, 32, 1 << 20)):
+                got = filtered_sweep_regions(iv, L, cov, nb, W, cap)
+                assert got is None or got == want, (iv, L, cov, nb, W, cap, got, want)
+                decided += got is not None
+                if it % 3 and it % 2 and nb == 32 and cap == 128 and cov in (3, 4) and L >= 4000 and n >= 80 and it % 13:
+                    total += 1
+                    fired += got is not None
+    assert fired > total * 8 // 10 and decided > 10000, (fired, total, decided)
+
+
+def test_filtered_sweep_tiny_exhaustive():
+    import itertools
+    from formulation import filtered_sweep_regions
+    for L in range(2, 9):
+        pairs = [(s, e) for s in range(L + 1) for e in range(s + 1, L + 1)]
+        for k in range(2, 5):
+            for iv in itertools.combinations_with_replacement(pairs, k):
+                if k == 4 and (sum(a for a, b in iv) + L) % 3:
+                    continue  # (a third of the quadruples)
+                for cov in range(0, 3):
+                    want = oracle.compute_bad_part(list(iv), L, cov)
+                    for nb, W in ((4, 1), (2, 1), (4, 2), (8, 1)):
+                        got = filtered_sweep_regions(list(iv), L, cov, nb, W, 1 << 20)
+                        assert got is None or got == want, (iv, L, cov, nb, W, got, want)

@@ -145,7 +145,10 @@ typedef struct {
     /* 1: the batch ran as ONE launch (YACRD_F_ONE_LAUNCH and every read within 256 intervals); the count of such runs in
      * yacrd_engine_timing_total */
     uint32_t one_launch;
-    uint32_t reserved0;
+    /* 1: the batch was run a second time with the workgroup classes down the three-launch chain, because a workgroup of the
+     * persistent screen + fallback kernel ran out of looks at its queue slot (its grid was not resident as a whole: a device
+     * shared with another process, a CU mask); the count of such runs in yacrd_engine_timing_total.  (Was reserved0: ABI 5.) */
+    uint32_t fused_reruns;
 } yacrd_timing;
 
 /* size classes, in the order of yacrd_timing.class_*: R<K> = four reads per wavefront (16-lane

@@ -10,6 +10,8 @@ from cases import assert_same, make_csr
 
 pytestmark = pytest.mark.gpu
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 @pytest.fixture(scope="module")
 def engine():
@@ -474,6 +476,43 @@ def test_workgroup_fallback_queue(cov):
     with yacrd_amd.Engine() as e:
         for rep in range(2):
             assert_same(e.run(o, iv, ln, cov, 0.4), w2, "skewed, run %d" % rep)
+
+
+def test_fused_workgroup_screen_gives_up_when_not_resident(tmp_path):
+    """screen_wg_fused_kernel's workgroups wait for each other's queue entries, which needs the whole grid
+    resident.  With a grid eight times what the device holds (YACRD_TEST_FUSED_GRID_MULT, read once per process: a
+    subprocess) the resident workgroups run out of looks, raise Counters::fused_gave_up and leave; the engine runs
+    the batch again down the three-launch chain — bit-exact, no hung device, and yacrd_timing says so."""
+    import subprocess
+    import sys
+    code = r"""
+import sys, time, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import oracle, yacrd_amd
+from cases import assert_same, make_csr
+rng = np.random.default_rng(77)
+sizes = np.concatenate([rng.integers(513, 3000, size=3000), rng.integers(4097, 9000, size=700)])
+csr = make_csr(4711, sizes, ("sparse", "regular", "abutting", "dups"), len_lo=20000, len_hi=600000, mode_block=7)
+want = oracle.run(csr[0], csr[1], csr[2].astype(np.uint64), 3, 0.4, n_threads=8)
+with yacrd_amd.Engine() as e:
+    for rep in range(2):
+        t0 = time.time()
+        assert_same(e.run(*csr, 3, 0.4), want, "oversized fused grid, run %%d" %% rep)
+        t = e.timing()
+        assert t["fused_reruns"] == 1, t["fused_reruns"]
+        assert time.time() - t0 < 20
+print("gave up and ran again: ok")
+""" % (ROOT, os.path.join(ROOT, "tests"))
+    env = dict(os.environ, YACRD_TEST_FUSED_GRID_MULT="8")
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0 and "gave up and ran again: ok" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
+    # ... and on a grid of the right size nothing is run twice
+    rng = np.random.default_rng(78)
+    sizes = rng.integers(513, 3000, size=1200)
+    csr = make_csr(4712, sizes, ("sparse", "regular"), len_lo=20000, len_hi=600000, mode_block=7)
+    with yacrd_amd.Engine() as e:
+        e.run(*csr, 3, 0.4)
+        assert e.timing()["fused_reruns"] == 0
 
 
 @pytest.mark.parametrize("cov", [0, 4, 600])

@@ -69,6 +69,7 @@ struct Counters {
     u32 fbq_head[2];         // screen_wg_fused_kernel's queue of M1 / M2 reads (fb_med[] is its tail): slots claimed,
     u32 fbq_done[2];         // workgroups that have finished screening
     u32 bs_chunks;           // chunks of the device-wide screen (written by its setup kernel)
+    u32 fused_gave_up;       // a workgroup of screen_wg_fused_kernel ran out of looks at its queue slot: the engine runs the batch again without that kernel
     u64 total_regions;       // G, written by the last scan workgroup
     // reads the screen deferred and finish_compact_kernel sorted, and their intervals: one atomic each per
     // workgroup of 1024 reads.  (Counting where they are found does not work on this 8-XCD part:

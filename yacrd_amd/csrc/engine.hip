@@ -72,6 +72,15 @@ static uint64_t split_min_reads()
     return v;
 }
 
+static uint64_t fused_grid_mult()
+{
+    static const uint64_t v = [] {
+        const char *e = std::getenv("YACRD_TEST_FUSED_GRID_MULT");
+        return e ? std::max<uint64_t>(1, std::strtoull(e, nullptr, 10)) : (uint64_t)1;
+    }();
+    return v;
+}
+
 int launch_compact(yacrd_engine *e, const yk::SweepArgs &sa, u32 n_reads, double not_cov, bool screened)
 {
     const u32 nb = (n_reads + yk::kScanBlock - 1) / yk::kScanBlock;
@@ -355,6 +364,18 @@ int finish_pending(yacrd_engine *e);
 } // namespace
 
 namespace yke {
+// A workgroup of the fused workgroup screen ran out of looks at its queue slot (screen_wg.h: the grid was not resident as a
+// whole): whatever the batch's kernels wrote is void — the batch from the start, the workgroup classes down the three-launch chain.
+static int rerun_without_fused(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u32 *d_len, uint64_t n_reads64,
+                               uint64_t n_iv, uint32_t cov, double not_cov)
+{
+    e->fused_off = true;
+    e->pred_valid = false;
+    const int rc = run_on_device(e, d_off, d_iv, d_len, n_reads64, n_iv, cov, not_cov, false);
+    e->fused_off = false;
+    return rc;
+}
+
 int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u32 *d_len,
                   uint64_t n_reads64, uint64_t n_iv, uint32_t cov, double not_cov, bool defer)
 {
@@ -669,7 +690,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
             HIP_TRY(before_class(cls));
             sa.list = list_of(cls);
             sa.list_n = &ctr->n[cls];
-            if (sa.prefilter && !(e->flags & YACRD_F_NO_FUSED_SCREEN) && e->screen_fused_wgs_per_cu > 0) {
+            if (sa.prefilter && !(e->flags & YACRD_F_NO_FUSED_SCREEN) && !e->fused_off && e->screen_fused_wgs_per_cu > 0) {
                 // the screen and the fallback of what it leaves in ONE persistent launch (screen_wg.h): the grid must be
                 // resident as a whole (workgroups wait for each other's queue entries)
                 if (again) { // (a second pass over the class: the queue starts over)
@@ -688,7 +709,8 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
                 fa.tail = &ctr->fb_med[k];
                 fa.head = &ctr->fbq_head[k];
                 fa.done = &ctr->fbq_done[k];
-                const u32 gs = (u32)std::min<uint64_t>(set.n[cls], (uint64_t)e->num_cu * (uint64_t)e->screen_fused_wgs_per_cu);
+                // (YACRD_TEST_FUSED_GRID_MULT, tests only: a grid that is NOT resident as a whole, so that its workgroups run out of looks)
+                const u32 gs = (u32)std::min<uint64_t>(set.n[cls], (uint64_t)e->num_cu * (uint64_t)e->screen_fused_wgs_per_cu * fused_grid_mult());
                 {
                     FusedLane &fl = g_fused_lane[e->device & 63];
                     std::lock_guard<std::mutex> turn(fl.mu);
@@ -835,6 +857,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     rc = wait_for_stream(e);
     if (rc) return rc;
     timing_on = false;
+    if (e->h_ctr->fused_gave_up && !e->fused_off) return rerun_without_fused(e, d_off, d_iv, d_len, n_reads64, n_iv, cov, not_cov);
 
     // ---- rare slow paths: a class the prediction missed; degenerate reads too large for the
     // LDS exact path; region overflow.  Each ends with a redo of the compaction.
@@ -1001,6 +1024,7 @@ int conclude_run(yacrd_engine *e, yk::Counters c0, bool predicted, uint64_t n_re
     t.screened = screened ? 1u : 0u;
     t.screen_items = screened ? e->last_items : 0u;
     t.screen_wide = (screened && e->last_wide) ? 1u : 0u;
+    t.fused_reruns = e->fused_off ? 1u : 0u;
     t.fused_reads = t.fused_intervals = 0;
     t.prefiltered_reads = c1.prefiltered;
     if (fused_marked) t.fused_ms = ev_ms(e->ev_cls[22], e->ev_cls[23]);
@@ -1027,6 +1051,7 @@ int conclude_run(yacrd_engine *e, yk::Counters c0, bool predicted, uint64_t n_re
     ts.fused_ms = keep.fused_ms + t.fused_ms;
     ts.screened = keep.screened + t.screened;
     ts.one_launch = keep.one_launch;
+    ts.fused_reruns = keep.fused_reruns + t.fused_reruns;
     ts.timed_runs = keep.timed_runs + t.timed_runs;
     e->timing_runs++;
     return YACRD_OK;
@@ -1077,6 +1102,7 @@ int finish_pending(yacrd_engine *e)
         return YACRD_OK;
     }
     const yk::Counters c = *e->h_ctr;
+    if (c.fused_gave_up && !e->fused_off) return yke::rerun_without_fused(e, p.d_off, p.d_iv, p.d_len, p.n_reads, p.n_iv, p.cov, p.not_cov);
     bool ok = !c.rej_small && !c.n[yk::CLS_GENERAL] && !c.rej_big && !c.region_overflow;
     for (int cls = 0; cls < yk::CLS_GENERAL; cls++) ok = ok && c.n[cls] <= p.grid_n[cls];
     if (!ok) {

@@ -96,9 +96,9 @@ struct BigLane {
 };
 static BigLane g_big_lane[64];
 // One per device: the persistent screen + fallback launches (screen_wg_fused_kernel) of the engines that share it go one
-// after the other.  Each is sized to be resident as a whole; its workgroups help with each other's queue entries for a bounded
-// number of looks (screen_wg.h: no residency REQUIREMENT since round 5), so two of them side by side, each half resident, would
-// finish — but with half of each grid waiting out its bound behind the other's.
+// after the other.  Each is sized to be resident as a whole, and its workgroups wait for each other's queue entries: two of them
+// side by side, each half resident, would wait for workgroups that the other's spinning ones keep from being scheduled — until
+// their looks run out (screen_wg.h: kFusedPolls) and the batch is run again down the three-launch chain.
 struct FusedLane {
     std::mutex mu;
     hipEvent_t last = nullptr; // recorded behind the last such launch
@@ -133,6 +133,7 @@ struct yacrd_engine {
     hipEvent_t ev_done = nullptr; // hipEventBlockingSync: the final wait of YACRD_F_BLOCKING_WAIT
     hipEvent_t ev_fused = nullptr; // behind this engine's last screen_wg_fused_kernel (g_fused_lane)
     int num_cu = 256;
+    bool fused_off = false; // this run: the workgroup classes down the three-launch chain (a fused launch gave up: Counters::fused_gave_up)
     int num_xcc = 0; // XCDs of this device / partition (one_batch_kernel's read-to-XCD map assumes 8)
     int screen_fused_wgs_per_cu = 0; // workgroups of screen_wg_fused_kernel a CU holds at once (its grid must be resident as a whole)
 

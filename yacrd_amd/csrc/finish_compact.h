@@ -14,6 +14,7 @@
 #include "plan_compact.h"
 #include "sweep_lds.h"
 #include "sweep_wave.h"
+#include "sweep_filtered.h"
 
 namespace yk {
 
@@ -354,11 +355,58 @@ static_assert(kDeferSlab % kDeferThreads == 0 && kDeferSlab <= 65536, "a thread 
 // 0.155 ms (profiles/r04/g_ab_trimmed_deferred_sweep.log; round 2 found the same inside the register-sort kernel).  Off.
 #define YK_DEFER_TRIM 0
 #endif
+#ifndef YK_DEFER_FILTER
+// The marked reads through the FILTERED exact sweep first (sweep_filtered.h, round 5): two (129..256 intervals) or four
+// (<= 128) reads per wavefront and turn; what it does not take — not plain, an interval shorter than the screen's window,
+// a window short of c + 1, more than 128 kept events: ~15 % of the generator's deferred reads — is listed again and
+// sorted whole, one read per wavefront, as before.  0 builds round 4's kernel.
+#define YK_DEFER_FILTER 1
+#endif
 #ifndef YK_DEFER_SWEEP_OCC
 // wavefronts per SIMD the register budget allows.  Without the trimming path: 8 / 6 / 5 gave 0.164 / 0.158 / 0.159 ms of
-// follow-on time on configs[2] (profiles/r04/c_ab_follow_on.log); with it the kernel wants 128 registers.
-#define YK_DEFER_SWEEP_OCC (YK_DEFER_TRIM ? 4 : 6)
+// follow-on time on configs[2] (profiles/r04/c_ab_follow_on.log); with it the kernel wants 128 registers.  The filtered
+// sweep's tables (5 KB per wavefront) leave two workgroups per CU: four per SIMD.
+#define YK_DEFER_SWEEP_OCC ((YK_DEFER_TRIM || YK_DEFER_FILTER) ? 4 : 6)
 #endif
+
+// One turn of the filtered sweep: this lane group's read (active: it has one) — loads and tests as screen_reads', then
+// filtered_group_sweep.  True: done (uniform in the group).
+template <int LANES, int WPB>
+__device__ __forceinline__ bool filtered_turn(const SweepArgs &a, bool active, u32 r, u64 o, u32 n, u32 len, const LaneConst &lc)
+{
+    constexpr int K = 16;
+    const u32 lane = lane_id(), lig = lane & (u32)(LANES - 1);
+    const i32 c = (i32)min(a.cov, 0x3FFFFFFFu);
+    const bool two = active && n >= 2u;
+    const uint2 *src = two ? a.iv + o : reinterpret_cast<const uint2 *>(a.off);
+    const u32 last2 = two ? n - 2u : 0u;
+    uint4 v[K / 4];
+#pragma unroll
+    for (int j = 0; j < K / 4; j++) v[j] = *reinterpret_cast<const uint4 *>(src + min(2u * (lig + (u32)LANES * j), last2));
+    u32 smin = v[0].x, emax = v[0].y, smax = v[0].x;
+    i32 tmin = 0x7FFFFFFF;
+#pragma unroll
+    for (int j = 0; j < K / 4; j++) {
+        smin = min(smin, min(v[j].x, v[j].z));
+        smax = max(smax, max(v[j].x, v[j].z));
+        emax = max(emax, max(v[j].y, v[j].w));
+        tmin = min(tmin, min((i32)(v[j].y - v[j].x), (i32)(v[j].w - v[j].z)));
+    }
+    const int last_addr = (int)((lane | (u32)(LANES - 1)) << 2);
+    const u32 pmin = (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)gscan_min<LANES>(smin));
+    const u32 pmax = (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)gscan_max<LANES>(emax));
+    const bool irregular = !two || pmax > min(len, kMaxKeyPos) || smax > kMaxKeyPos || tmin < (i32)kScreenWindow;
+    const bool girr = group_any<LANES>(__builtin_amdgcn_ballot_w64(irregular));
+    const u32 n_eff = girr ? 0u : n;
+    bool real0[K / 4], real1[K / 4];
+#pragma unroll
+    for (int j = 0; j < K / 4; j++) {
+        const u32 i0 = 2u * (lig + (u32)LANES * j);
+        real0[j] = i0 + 1u < n_eff; // (.xy is interval i0 only when i0 + 1 exists too: see screen_reads)
+        real1[j] = i0 < n_eff;
+    }
+    return filtered_group_sweep<LANES, WPB>(a, v, real0, real1, r, o, n, len, c, pmin, pmax, !girr, lc);
+}
 __global__ __launch_bounds__(kDeferThreads, YK_DEFER_SWEEP_OCC) void deferred_sweep_kernel(SweepArgs a, u32 n_reads)
 {
     // what the thread that found the mark already knows about the read — offset, index inside the slab | intervals << 16,
@@ -417,6 +465,44 @@ __global__ __launch_bounds__(kDeferThreads, YK_DEFER_SWEEP_OCC) void deferred_sw
 #if YK_DEFER_TRIM
     __shared__ __attribute__((aligned(16))) u32 s_trim[kWaves][kTrimWords];
     const LaneConst lc = make_lane_const(lane);
+#endif
+#if YK_DEFER_FILTER
+    // ---- first the filtered sweep, several reads per wavefront and turn; what it leaves is listed in s_fb
+    __shared__ unsigned short s_fb[kDeferSlab];
+    __shared__ u32 s_nfb;
+    {
+        if (threadIdx.x == 0) s_nfb = 0;
+        __syncthreads();
+        const LaneConst lcf = make_lane_const(lane);
+        const u32 wv = threadIdx.x >> 6;
+        auto turn = [&](auto lanes_tag, u32 p, bool have, u32 at) {
+            constexpr int LANES = decltype(lanes_tag)::value;
+            const uint2 e = s_list[have ? at : 0u];
+            const u64 o = s_off[have ? at : 0u];
+            const bool done = filtered_turn<LANES, (int)kWaves>(a, have, slab0 + (e.x & 0xFFFFu), o, e.x >> 16, e.y, lcf);
+            if (have && !done && (lane & (u32)(LANES - 1)) == (u32)(LANES - 1)) s_fb[atomicAdd(&s_nfb, 1u)] = (unsigned short)at;
+            (void)p;
+        };
+        for (u32 p0 = wv * 2u; p0 < n8; p0 += kWaves * 2u) { // (uniform in the wavefront)
+            const u32 p = p0 + (lane >> 5);
+            turn(std::integral_constant<int, 32>{}, p, p < n8, p);
+        }
+        for (u32 p0 = wv * 4u; p0 < n4; p0 += kWaves * 4u) {
+            const u32 p = p0 + (lane >> 4);
+            turn(std::integral_constant<int, 16>{}, p, p < n4, (u32)kDeferSlab - 1u - p);
+        }
+        __syncthreads();
+        const u32 nfb = s_nfb;
+        for (u32 i = wv; i < nfb; i += kWaves) { // (uniform in the wavefront): sorted whole, one read per wavefront
+            const u32 at = s_fb[i];
+            const uint2 e = s_list[at];
+            const u32 rr = slab0 + (e.x & 0xFFFFu), n = e.x >> 16, len = e.y;
+            const u64 o = s_off[at];
+            if (n > 128u) finish_item<8>(a.off, a.iv, a.len, a.stage, a.counts, a.rej_list, a.rej_count, a.ctr, a.cov, rr, o, n, len);
+            else finish_item<4>(a.off, a.iv, a.len, a.stage, a.counts, a.rej_list, a.rej_count, a.ctr, a.cov, rr, o, n, len);
+        }
+        return;
+    }
 #endif
     // one read per wavefront and turn, the long ones (8 keys per lane) first: list position p < n8 is s_list[p],
     // p >= n8 is the (p - n8)-th entry from the back

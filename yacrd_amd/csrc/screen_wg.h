@@ -201,8 +201,9 @@ __global__ __launch_bounds__(kWsT) void screen_wg_kernel(SweepArgs a)
 // every workgroup that has nothing else to do.  What does not fit 16 384 events even after the filter goes to
 // over_list for the 1024-thread kernel (launched behind this one; usually nothing).
 // Queue: q[] starts out as kQueueEmpty in every slot a read of the class could take (the plan kernel writes the
-// marker where it writes the class list), tail = slots handed out, head = slots claimed (never beyond tail), done =
-// workgroups that finished screening.
+// marker where it writes the class list), tail = slots handed out, head = slots claimed, done = workgroups that
+// finished screening.  A claimed slot beyond tail is waited for until it is filled or `done` says it never will be —
+// for a bounded number of looks (below).
 constexpr u32 kQueueEmpty = 0xFFFFFFFFu;
 constexpr int kWsFbCap = 16384; // events the in-kernel fallback sorts (64 KB of LDS; two workgroups per CU by registers anyway)
 struct ScreenFusedArgs {
@@ -226,44 +227,44 @@ __global__ __launch_bounds__(kWsT, 4) void screen_wg_fused_kernel(ScreenFusedArg
         if (!screen_wg_read(a, r, tab, red, sc) && tid == 0)
             __hip_atomic_store(&f.q[atomicAdd(f.tail, 1u)], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    __shared__ u32 s_last;
     if (tid == 0) {
         __threadfence(); // this workgroup's appends before its "done"
-        s_last = atomicAdd(f.done, 1u) + 1u == gridDim.x ? 1u : 0u;
+        atomicAdd(f.done, 1u);
     }
     LaneConst lc;
 #pragma unroll
     for (int i = 0; i < 6; i++) lc.k[i] = (tid & (1u << i)) ? 0xFFFFFFFFu : 0u;
     lc.k[6] = 0;
     lc.addr32 = ((tid & 63u) ^ 32u) << 2;
-    // The queue is drained WITHOUT a residency requirement: a slot is claimed only when it has been handed
-    // out (compare-and-swap on head while head < tail), so a workgroup that leaves takes no claim with it; the workgroup
-    // whose `done` was the grid's last sees the final tail (every append precedes its workgroup's `done`) and drains
-    // all of it; the others help for as long as entries may still come, but give up after kFusedPolls empty looks — a
-    // grid that is not resident as a whole (another process on the device, a CU mask) then runs on instead of
-    // spinning for workgroups that its own spinning ones keep from being dispatched.
-    constexpr u32 kFusedPolls = 1u << 13; // x (s_sleep 8 + two L2 round trips) ~ 10 ms
+    // A claimed slot beyond `tail` is waited for until it is filled or `done` says it never will be.  That wait needs
+    // the workgroups it waits for to RUN: the grid is sized to be resident as a whole, but a second process on the
+    // device, a CU mask or anything else that holds LDS / wave slots can leave some of them undispatched behind the
+    // spinning ones.  So the wait is bounded (kFusedPolls looks, ~10 ms — a healthy launch is over in a
+    // fraction of one): a workgroup that runs out raises Counters::fused_gave_up and leaves, every other one then
+    // leaves at its next look, the kernel ends, and the engine runs the batch again down the three-launch chain
+    // (engine.hip: fused_off), which waits for nothing.  (Claims by compare-and-swap — none is lost when a workgroup
+    // leaves — were tried first: 512 workgroups retrying on one address took the pass from 0.32 to 1.59 ms.)
+    constexpr u32 kFusedPolls = 1u << 14;
     for (;;) {
         if (tid == 0) {
-            const bool last = s_last != 0u;
+            const u32 idx = atomicAdd(f.head, 1u);
             u32 r = kQueueEmpty, polls = 0;
             for (;;) {
-                const u32 h = __hip_atomic_load(f.head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (h < __hip_atomic_load(f.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                    if (atomicCAS(f.head, h, h + 1u) != h) continue;
-                    // handed out, so its writer (a running wavefront, one store behind its tail increment) fills it
-                    while ((r = __hip_atomic_load(&f.q[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == kQueueEmpty)
+                if (idx < __hip_atomic_load(f.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    // handed out: its writer (a running wavefront, one store behind its tail increment) fills it
+                    while ((r = __hip_atomic_load(&f.q[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == kQueueEmpty)
                         __builtin_amdgcn_s_sleep(2);
                     break;
                 }
-                if (last) break; // (the tail is final and every slot below it is claimed)
                 if (__hip_atomic_load(f.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x) {
                     // every workgroup has screened its share: the tail is final
-                    if (__hip_atomic_load(f.head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <
-                        __hip_atomic_load(f.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
+                    if (idx < __hip_atomic_load(f.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
                     break;
                 }
-                if (++polls > kFusedPolls) break; // (the last finisher takes what is still to come)
+                if (++polls > kFusedPolls || __hip_atomic_load(&a.ctr->fused_gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                    __hip_atomic_store(&a.ctr->fused_gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break; // (r = kQueueEmpty: this workgroup leaves; the batch is run again)
+                }
                 __builtin_amdgcn_s_sleep(8);
             }
             s_next = r;

@@ -112,7 +112,7 @@ class _Timing(ctypes.Structure):
                 ("prefiltered_reads", ctypes.c_uint64), ("deferred_reads", ctypes.c_uint64),
                 ("deferred_intervals", ctypes.c_uint64), ("screened", ctypes.c_uint32),
                 ("timed_runs", ctypes.c_uint32), ("screen_items", ctypes.c_uint32), ("screen_wide", ctypes.c_uint32),
-                ("one_launch", ctypes.c_uint32), ("reserved0", ctypes.c_uint32)]
+                ("one_launch", ctypes.c_uint32), ("fused_reruns", ctypes.c_uint32)]
 
 CLASS_NAMES = "R2,R4,R8,R16,H16,W2,W4,W8,W16,M1,M2,BIG".split(",")
 CLASS_KERNELS = {  # the HIP kernel behind each class, as rocprofv3 prints it

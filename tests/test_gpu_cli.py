@@ -177,3 +177,75 @@ def test_synthetic_pipeline_config5_shape(tmp_path):
             assert f.read() == want
     types = [l.split("\t")[0] for l in lines(rep)]
     assert types.count("Chimeric") > 0 and types.count("NotCovered") > 0
+
+
+def test_scrubb_whole_output_at_a_hundredth_of_configs4(tmp_path):
+    """configs[4] ("bit-exact vs CPU scrubb output") at 1/100 of its size — 50 000 reads / 5 M overlaps, ~1 GB of FASTQ —
+    through the CLI with default flags, checked the way tools/e2e_scrubb_full.py checks the full size (round 5): every
+    line of the report, the scrubbed file's record and byte totals against what the oracle's regions imply, byte-exact
+    windows spread over the whole file (reference: src/editor/scrubbing.rs:156-236, tests/run.rs:254-300)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import e2e_scrubb_full as chk
+    from yacrd_amd import host
+    d = "/dev/shm" if os.access("/dev/shm", os.W_OK) else str(tmp_path)
+    R, O, seed = 50_000, 5_000_000, 20241108 + 5
+    tag = os.path.join(d, "yacrd_test_%d_" % os.getpid())
+    paf, fq, rep, out = tag + "s.paf", tag + "s.fastq", tag + "r.yacrd", tag + "o.fastq"
+    try:
+        host.synth_paf(host.SYNTH_SEQUEL, R, O, seed, paf)
+        host.synth_fastq(host.SYNTH_SEQUEL, R, O, seed, R // 200, fq)
+        run("-i", paf, "-o", rep, "-c", "3", "-n", "0.4", "scrubb", "-i", fq, "-o", out)
+        off, iv, ln = host.synth_csr(host.SYNTH_SEQUEL, R, O, seed)
+        res = chk.verify_scrubb(fq, out, rep, off, iv, ln, 3, 0.4, R // 200, n_windows=200, window_bytes=300_000, log=lambda s: None)
+        assert res["ok"], res
+        assert res["windows"]["records"] > 2000 and res["totals"]["types"][1] > 500 and res["totals"]["types"][2] > 500
+    finally:
+        for x in (paf, fq, rep, out):
+            if os.path.exists(x):
+                os.remove(x)
+
+
+# filter / extract on OVERLAP files through the CLI: the reference's unit vectors (src/editor/filter.rs:289-359,
+# extract.rs:293-362: read 1 bad — regions (10, 490), (510, 1000) of 1000 — here from a .yacrd report), N4
+_PAF_UNIT = ("1\t12000\t20\t4500\t-\t2\t10000\t5500\t10000\t4500\t4500\t255\n"
+             "1\t12000\t5500\t10000\t-\t3\t10000\t0\t4500\t4500\t4500\t255\n")
+_M4_UNIT = "1 2 0.1 2 0 100 450 1000 0 550 900 1000\n1 3 0.1 2 0 550 900 1000 0 100 450 1000\n"
+_REPORT_UNIT = "NotCovered\t1\t1000\t480,10,490;490,510,1000\nNotBad\t2\t1000\t\nNotBad\t3\t1000\t\n"
+
+
+@pytest.mark.parametrize("op", ["filter", "extract"])
+@pytest.mark.parametrize("ext,text", [(".paf", _PAF_UNIT), (".m4", _M4_UNIT), (".mhap", _M4_UNIT)])
+def test_overlap_file_editors_through_the_cli(tmp_path, op, ext, text):
+    rep = tmp_path / "in.yacrd"
+    rep.write_text(_REPORT_UNIT)
+    src, out = tmp_path / ("ovl" + ext), tmp_path / ("out" + ext)
+    src.write_text(text)
+    run("-i", str(rep), "-o", str(tmp_path / "again.yacrd"), op, "-i", str(src), "-o", str(out))
+    # every line names read 1: filter drops them all, extract keeps them all
+    assert out.read_text() == ("" if op == "filter" else text)
+    # ... and a line between two good reads survives filter / is dropped by extract
+    more = text + (("2\t1000\t0\t500\t+\t3\t1000\t500\t1000\t500\t500\t255\n") if ext == ".paf" else "2 3 0.1 2 0 0 500 1000 0 500 1000 1000\n")
+    src.write_text(more)
+    run("-i", str(rep), "-o", str(tmp_path / "again.yacrd"), op, "-i", str(src), "-o", str(out))
+    assert out.read_text() == (more[len(text):] if op == "filter" else text)
+
+
+def test_overlap_file_editors_from_a_detection_run(work, tmp_path):
+    """The same with the bad parts coming from the GPU (detection on reads.paf, -c 0 -n 0.8: 4 chimeric reads), the
+    overlap file being the PAF itself: filter keeps exactly the lines whose two reads are NotBad, extract the others
+    (filter.rs:140-183, extract.rs:144-187), against the oracle's classification."""
+    import oracle
+    paf = work / "reads.paf"
+    with open(paf) as f:
+        reads = oracle.parse_paf(f)
+    bad = {k for k, (iv, ln) in reads.items() if oracle.type_of_read(ln, oracle.compute_bad_part(iv, ln, 0), 0.8) != oracle.NOT_BAD}
+    assert len(bad) == 4
+    src = lines(paf)
+    for op in ("filter", "extract"):
+        out = tmp_path / (op + ".paf")
+        run("-i", str(paf), "-o", str(tmp_path / (op + ".yacrd")), op, "-i", str(paf), "-o", str(out))
+        hit = [l for l in src if (l.split("\t")[0] in bad or l.split("\t")[5] in bad)]
+        want = [l for l in src if l not in hit] if op == "filter" else hit
+        assert lines(out) == want, op
+    assert 0 < len(hit) < len(src)

@@ -365,13 +365,13 @@ static_assert(kDeferSlab % kDeferThreads == 0 && kDeferSlab <= 65536, "a thread 
 #ifndef YK_DEFER_SWEEP_OCC
 // wavefronts per SIMD the register budget allows.  Without the trimming path: 8 / 6 / 5 gave 0.164 / 0.158 / 0.159 ms of
 // follow-on time on configs[2] (profiles/r04/c_ab_follow_on.log); with it the kernel wants 128 registers.  The filtered
-// sweep's tables (5 KB per wavefront) leave two workgroups per CU: four per SIMD.
-#define YK_DEFER_SWEEP_OCC ((YK_DEFER_TRIM || YK_DEFER_FILTER) ? 4 : 6)
+// sweep (32-lane groups only, 3 KB of tables per wavefront, 8-byte list entries: 44 KB per workgroup) keeps three workgroups per CU.
+#define YK_DEFER_SWEEP_OCC (YK_DEFER_TRIM ? 4 : 6)
 #endif
 
 // One turn of the filtered sweep: this lane group's read (active: it has one) — loads and tests as screen_reads', then
 // filtered_group_sweep.  True: done (uniform in the group).
-template <int LANES, int WPB>
+template <int LANES, int WPB, int TABW = kScreenTabWords>
 __device__ __forceinline__ bool filtered_turn(const SweepArgs &a, bool active, u32 r, u64 o, u32 n, u32 len, const LaneConst &lc)
 {
     constexpr int K = 16;
@@ -405,8 +405,78 @@ __device__ __forceinline__ bool filtered_turn(const SweepArgs &a, bool active, u
         real0[j] = i0 + 1u < n_eff; // (.xy is interval i0 only when i0 + 1 exists too: see screen_reads)
         real1[j] = i0 < n_eff;
     }
-    return filtered_group_sweep<LANES, WPB>(a, v, real0, real1, r, o, n, len, c, pmin, pmax, !girr, lc);
+    return filtered_group_sweep<LANES, WPB, TABW>(a, v, real0, real1, r, o, n, len, c, pmin, pmax, !girr, lc);
 }
+#if YK_DEFER_FILTER
+// (round 5) The marked reads of a slab — listed in LDS with their intervals and length, eight bytes each — go through the
+// filtered exact sweep two per wavefront and turn, on 32-lane groups whatever their size (a read of <= 128 intervals on 16
+// lanes would share its turn with three others, but its table — 5 KB per wavefront instead of 3 — costs the kernel a
+// workgroup per CU: deferred_sweep_kernel serves long batches, and with lists of 16-byte entries and 5 KB tables it was
+// no faster than round 4's on configs[4], 0.291 against 0.282 ms of follow-on step, for all its 33 % fewer VALU
+// instructions: profiles/r05/c_ab_deferred_filtered_2048_1024_none.log); what the filter does not take is listed again and
+// sorted whole, one read per wavefront.
+__global__ __launch_bounds__(kDeferThreads, YK_DEFER_SWEEP_OCC) void deferred_sweep_kernel(SweepArgs a, u32 n_reads)
+{
+    constexpr u32 kWaves = kDeferThreads / 64;
+    constexpr int kTabWords = 2 * (2 * kScreenWindow + 32) * 4; // two 32-lane groups
+    __shared__ uint2 s_list[kDeferSlab]; // index inside the slab | intervals << 16, length
+    __shared__ unsigned short s_fb[kDeferSlab];
+    __shared__ u32 s_n, s_nfb;
+    __shared__ unsigned long long s_iv;
+    if (threadIdx.x == 0) s_n = 0, s_nfb = 0, s_iv = 0;
+    __syncthreads();
+    const u32 lane = lane_id();
+    const u32 slab0 = blockIdx.x * (u32)kDeferSlab;
+    constexpr int PER = kDeferSlab / kDeferThreads;
+#pragma unroll
+    for (int k = 0; k < PER; k++) {
+        const u32 i = (u32)k * kDeferThreads + threadIdx.x, r = slab0 + i;
+        const bool marked = r < n_reads && a.counts[r] == kDeferredMark;
+        const u64 mm = __builtin_amdgcn_ballot_w64(marked);
+        if (mm == 0) continue; // (uniform in the wavefront)
+        u32 n = 0, len0 = 0;
+        if (marked) {
+            n = (u32)(a.off[r + 1] - a.off[r]);
+            len0 = a.len[r];
+        }
+        u32 base = 0;
+        if (lane == (u32)__builtin_ctzll(mm)) base = atomicAdd(&s_n, (u32)__builtin_popcountll(mm));
+        base = (u32)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(mm));
+        if (marked) s_list[base + (u32)__builtin_popcountll(mm & ((1ull << lane) - 1ull))] = make_uint2(i | (n << 16), len0);
+        u64 iv = n; // intervals of the marked reads, for the roofline's exact byte count
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) iv += __shfl_xor(iv, d, 64);
+        if (lane == 0) atomicAdd(&s_iv, (unsigned long long)iv);
+    }
+    __syncthreads();
+    const u32 n_marked = s_n;
+    if (n_marked == 0) return; // uniform in the workgroup
+    if (threadIdx.x == 0) {
+        atomicAdd(&a.ctr->deferred, n_marked);
+        atomicAdd((unsigned long long *)&a.ctr->deferred_iv, s_iv);
+    }
+    const LaneConst lcf = make_lane_const(lane);
+    const u32 wv = threadIdx.x >> 6;
+    for (u32 p0 = wv * 2u; p0 < n_marked; p0 += kWaves * 2u) { // (uniform in the wavefront)
+        const u32 p = p0 + (lane >> 5);
+        const bool have = p < n_marked;
+        const uint2 e = s_list[have ? p : p0];
+        const u32 rr = slab0 + (e.x & 0xFFFFu);
+        const u64 o = a.off[rr]; // (in the L2: the listing has just read it)
+        const bool done = filtered_turn<32, (int)kWaves, kTabWords>(a, have, rr, o, e.x >> 16, e.y, lcf);
+        if (have && !done && (lane & 31u) == 31u) s_fb[atomicAdd(&s_nfb, 1u)] = (unsigned short)p;
+    }
+    __syncthreads();
+    const u32 nfb = s_nfb;
+    for (u32 i = wv; i < nfb; i += kWaves) { // (uniform in the wavefront): sorted whole, one read per wavefront
+        const uint2 e = s_list[s_fb[i]];
+        const u32 rr = slab0 + (e.x & 0xFFFFu), n = e.x >> 16, len = e.y;
+        const u64 o = a.off[rr];
+        if (n > 128u) finish_item<8>(a.off, a.iv, a.len, a.stage, a.counts, a.rej_list, a.rej_count, a.ctr, a.cov, rr, o, n, len);
+        else finish_item<4>(a.off, a.iv, a.len, a.stage, a.counts, a.rej_list, a.rej_count, a.ctr, a.cov, rr, o, n, len);
+    }
+}
+#else
 __global__ __launch_bounds__(kDeferThreads, YK_DEFER_SWEEP_OCC) void deferred_sweep_kernel(SweepArgs a, u32 n_reads)
 {
     // what the thread that found the mark already knows about the read — offset, index inside the slab | intervals << 16,
@@ -466,7 +536,7 @@ __global__ __launch_bounds__(kDeferThreads, YK_DEFER_SWEEP_OCC) void deferred_sw
     __shared__ __attribute__((aligned(16))) u32 s_trim[kWaves][kTrimWords];
     const LaneConst lc = make_lane_const(lane);
 #endif
-#if YK_DEFER_FILTER
+#if 0
     // ---- first the filtered sweep, several reads per wavefront and turn; what it leaves is listed in s_fb
     __shared__ unsigned short s_fb[kDeferSlab];
     __shared__ u32 s_nfb;
@@ -518,6 +588,8 @@ __global__ __launch_bounds__(kDeferThreads, YK_DEFER_SWEEP_OCC) void deferred_sw
         else finish_item<4>(a.off, a.iv, a.len, a.stage, a.counts, a.rej_list, a.rej_count, a.ctr, a.cov, rr, o, n, len);
     }
 }
+
+#endif // YK_DEFER_FILTER
 
 constexpr int kScanThreads = 1024, kScanPer = 4, kScanReads = kScanThreads * kScanPer;
 static_assert(kScanReads % kScanBlock == 0, "the control block holds one scan word per 1024 reads: more than this kernel's workgroups use");

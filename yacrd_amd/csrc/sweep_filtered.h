@@ -34,7 +34,7 @@ static_assert(kScreenWindow * 4 >= kFilteredCap, "the keys live in the tail wind
 // real, the others copies), `want`: this group holds a plain read of >= 2 intervals, each at least W long (uniform in
 // the group).  r / o / len: the read, its first interval's index, its length.  True (uniform in the group): the
 // read's regions and their count are written.
-template <int LANES, int WPB>
+template <int LANES, int WPB, int TABW = kScreenTabWords>
 __device__ __forceinline__ bool filtered_group_sweep(const SweepArgs &a, const uint4 (&v)[4], const bool (&real0)[4], const bool (&real1)[4],
                                                      u32 r, u64 o, u32 n, u32 len, i32 c, u32 pmin, u32 pmax, bool want, const LaneConst &lc)
 {
@@ -47,7 +47,8 @@ __device__ __forceinline__ bool filtered_group_sweep(const SweepArgs &a, const u
     constexpr u32 gmask = LANES == 32 ? 0xFFFFFFFFu : 0xFFFFu;
     auto to_group = [&](u32 x) { return (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)x); }; // the last lane's value
     auto group_bits = [&](bool b) { return (u32)(__builtin_amdgcn_ballot_w64(b) >> gshift) & gmask; };
-    u32 *tab = wave_screen_scratch<WPB>() + grp * (u32)(NBIN * 4);
+    static_assert((64 / LANES) * NBIN * 4 <= TABW, "scratch");
+    u32 *tab = wave_screen_scratch<WPB, TABW>() + grp * (u32)(NBIN * 4);
     uint4 *bins = reinterpret_cast<uint4 *>(tab);
     u32 *info = tab;                              // [2 * NB] in the head window's bins: slot cursor, depth correction per block
     u32 *keys = tab + (u32)((W + NB) * 4);        // [kFilteredCap] in the tail window's bins
@@ -58,7 +59,7 @@ __device__ __forceinline__ bool filtered_group_sweep(const SweepArgs &a, const u
     bool r0[4], r1[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) r0[j] = real0[j] && want, r1[j] = real1[j] && want;
-    const bool healthy = healthy_screen<LANES, WPB>(v, r0, r1, len, c, pmin, pmax, hr);
+    const bool healthy = healthy_screen<LANES, WPB, false, TABW>(v, r0, r1, len, c, pmin, pmax, hr);
     const u32 hF = to_group((u32)min(max(hr.F, 0), 1023) | ((hr.G > c && want && (i32)n > c) ? 0x400u : 0u) | (healthy ? 0x800u : 0u));
     const i32 F = (i32)(hF & 1023u);
     bool ok = (hF & 0x400u) != 0u && F > c;

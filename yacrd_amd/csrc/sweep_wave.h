@@ -416,10 +416,10 @@ __device__ __forceinline__ u32 *wave_filter_scratch()
 constexpr int kScreenWindow = YK_SCREEN_WINDOW; // W: positions per window (a multiple of 32)
 // per group: W head-window bins + LANES coarse blocks + W tail-window bins, 16 bytes (four copies) each
 constexpr int kScreenTabWords = (64 / 16) * (16 + 2 * kScreenWindow) * 4;
-template <int WPB> // wavefronts per workgroup
+template <int WPB, int WORDS = kScreenTabWords> // wavefronts per workgroup; words per wavefront (a kernel of 32-lane groups only needs 768)
 __device__ __forceinline__ u32 *wave_screen_scratch()
 {
-    __shared__ __attribute__((aligned(16))) u32 s_tab[WPB][kScreenTabWords];
+    __shared__ __attribute__((aligned(16))) u32 s_tab[WPB][WORDS];
     return s_tab[threadIdx.x >> 6];
 }
 
@@ -486,7 +486,7 @@ constexpr int kScreenSlides = YK_SCREEN_SLIDES;
 // emin (SLID): the read's smallest end.  Starts behind the head window but in front of it — the RAMP — find nothing
 // popped yet and every earlier start still open: more than c once a has passed, so they are never low; they are
 // counted like the window's starts (open in front of every coarse-counted start), not into a coarse block.
-template <int LANES, int WPB, bool SLID = false>
+template <int LANES, int WPB, bool SLID = false, int TABW = kScreenTabWords>
 __device__ __forceinline__ bool healthy_screen(const uint4 (&v)[4], const bool (&real0)[4], const bool (&real1)[4],
                                                u32 len, i32 c, u32 pmin, u32 pmax, HealthyRead &hr, u32 P = 0, u32 Q = 0,
                                                u32 emin = 0)
@@ -495,9 +495,9 @@ __device__ __forceinline__ bool healthy_screen(const uint4 (&v)[4], const bool (
                   ZPER = NBIN / LANES;
     constexpr u32 kEnd = 1u << 10, kField = kEnd - 1u;
     static_assert(W % LANES == 0 && PER >= 1 && W <= 64, "window bins per lane; a window index has six bits");
-    static_assert(NBIN % LANES == 0 && GROUPS * NBIN * 4 <= kScreenTabWords, "scratch");
+    static_assert(NBIN % LANES == 0 && GROUPS * NBIN * 4 <= TABW, "scratch");
     const u32 lane = lane_id(), lig = lane & (u32)(LANES - 1), grp = lane / (u32)LANES;
-    u32 *tab = wave_screen_scratch<WPB>() + grp * (u32)(NBIN * 4);
+    u32 *tab = wave_screen_scratch<WPB, TABW>() + grp * (u32)(NBIN * 4);
     uint4 *bins = reinterpret_cast<uint4 *>(tab);
     char *tb = reinterpret_cast<char *>(tab);
 

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define YACRD_ABI_VERSION 5 /* 5: YACRD_F_ONE_LAUNCH, yacrd_timing.one_launch; 4: yacrd_timing.screen_items, yacrd_engine_ingest_overlaps_mem */
+#define YACRD_ABI_VERSION 6 /* 6: yacrd_engines_ingest_overlaps[_mem]; 5: YACRD_F_ONE_LAUNCH, yacrd_timing.one_launch; 4: yacrd_timing.screen_items, yacrd_engine_ingest_overlaps_mem */
 
 /* src/editor/mod.rs:42-59 ReadType; numeric encoding is ours, names are the reference's. */
 enum { YACRD_NOT_BAD = 0, YACRD_CHIMERIC = 1, YACRD_NOT_COVERED = 2 };
@@ -351,6 +351,22 @@ int yacrd_engine_ingest_overlaps(yacrd_engine *e, const char *path, int format, 
 int yacrd_engine_ingest_overlaps_mem(yacrd_engine *e, const char *text, uint64_t n_bytes, int format, int n_threads,
                                      uint32_t coverage, double not_coverage, yacrd_result *out, yacrd_reads *reads,
                                      yacrd_ingest_stats *stats /* may be NULL */);
+/* The same with SEVERAL engines (one per GPU; engines that share a device take shares of it) — the N-GPU form of
+ * Reads2Ovl::init_paf / init_m4 (src/reads2ovl/mod.rs:83-145) + compute_all_bad_part (src/stack.rs:143-162: reads are
+ * independent).  Engine d moves and parses a byte range of the text — over its own PCIe link —, cut on 4 MiB boundaries; a
+ * line belongs to the range it STARTS in (the range's mirror reaches one chunk beyond it).  The ranges' read lists (name,
+ * first position in the file, first length, intervals: a few dozen bytes per read and range) go to engines[0], which numbers
+ * the reads of the whole file by first appearance; every engine rewrites its records to those numbers, the reads are dealt
+ * out as contiguous ranges of numbers with about the same number of intervals each, every engine builds the CSR of its
+ * reads from the records of all ranges (copied device to device where they live elsewhere: the one exchange step the
+ * path has) and sweeps it.  Results, names and lengths as from one engine, bit for bit.  YACRD_EFALLBACK as there (any
+ * range's text may ask for the host parser).  A text of fewer than two chunks is engines[0]'s alone. */
+int yacrd_engines_ingest_overlaps(yacrd_engine *const *engines, uint32_t n_engines, const char *path, int format, int n_threads,
+                                  uint32_t coverage, double not_coverage, yacrd_result *out, yacrd_reads *reads,
+                                  yacrd_ingest_stats *stats /* may be NULL */);
+int yacrd_engines_ingest_overlaps_mem(yacrd_engine *const *engines, uint32_t n_engines, const char *text, uint64_t n_bytes,
+                                      int format, int n_threads, uint32_t coverage, double not_coverage, yacrd_result *out,
+                                      yacrd_reads *reads, yacrd_ingest_stats *stats /* may be NULL */);
 void yacrd_reads_free(yacrd_reads *r);
 /* The device parser keeps its buffers between calls (the text's mirror, the id table, the records: about twice the
  * file's size; a call into warm buffers is 2-3 times faster than one that has to allocate them): this gives them back. */

@@ -47,4 +47,14 @@
  * deferred more than a tenth of what it screened); tests, A/B */
 #define YACRD_F_SCREEN_WIDE 2097152u
 
+/* the device parser's sort on its own (yacrd_amd/csrc/radix_sort.h): (key, value) pairs in host memory, sorted in place by key,
+ * stable; keys must be below key_bound (it decides the number of passes); tests only */
+#ifdef __cplusplus
+extern "C" {
+#endif
+int yacrd_debug_sort_pairs(yacrd_engine *e, uint64_t *keys, uint32_t *vals, uint64_t n, uint64_t key_bound);
+#ifdef __cplusplus
+}
+#endif
+
 #endif

@@ -121,13 +121,16 @@ def test_several_engines_stream_group_path(work, golden_dir, tmp_path):
     p = subprocess.run([BIN, "-i", str(work / "reads.paf"), "-o", str(work / "g2.yacrd"), "--gpus", "64"],
                        capture_output=True, text=True)
     assert p.returncode != 0 and "device" in p.stderr
-    # (round 4: an input that fits one GPU is parsed and swept on device 0 whatever N is; YACRD_NO_DEVICE_PARSER=1 sends it
-    # down the path of the inputs that do not — the host parser and the stream group — which is what this test is about)
+    # (round 5: --gpus N parses on all N engines, yacrd_engines_ingest_overlaps; YACRD_NO_DEVICE_PARSER=1 sends the input down
+    # the path of the inputs the device parser does not take — the host parser and the stream group)
     env = dict(os.environ, YACRD_GPUS_ON_DEVICE="0", YACRD_NO_DEVICE_PARSER="1")
     from yacrd_amd import host
     big = str(tmp_path / "big.paf")
     host.synth_paf(host.SYNTH_ONT, 3000, 60000, 20250303, big)
-    for src, cov in ((str(work / "reads.paf"), "0"), (big, "4")):
+    bigger = str(tmp_path / "bigger.paf")  # more than three 4 MiB chunks: every engine of --gpus 2 / 3 gets a range of its own
+    host.synth_paf(host.SYNTH_ONT, 9000, 200000, 20250304, bigger)
+    assert os.path.getsize(bigger) > (13 << 20)
+    for src, cov in ((str(work / "reads.paf"), "0"), (big, "4"), (bigger, "4")):
         one = str(tmp_path / "one.yacrd")
         p = subprocess.run([BIN, "-i", src, "-o", one, "-c", cov, "-t", "4"], capture_output=True, text=True)
         assert p.returncode == 0, p.stderr
@@ -137,11 +140,18 @@ def test_several_engines_stream_group_path(work, golden_dir, tmp_path):
                                capture_output=True, text=True)
             assert p.returncode == 0, p.stderr
             assert open(out).read() == open(one).read()
-            if n == "2":  # the default route for N > 1: device 0 parses, with a notice
-                env2 = dict(os.environ, YACRD_GPUS_ON_DEVICE="0")
-                p = subprocess.run([BIN, "-i", src, "-o", out, "-c", cov, "--gpus", n], env=env2, capture_output=True, text=True)
-                assert p.returncode == 0 and "fits one GPU" in p.stderr, p.stderr
-                assert open(out).read() == open(one).read()
+            # the default route for N > 1: the device parser on every engine
+            env2 = dict(os.environ, YACRD_GPUS_ON_DEVICE="0", YACRD_CLI_TIMING="1")
+            p = subprocess.run([BIN, "-i", src, "-o", out, "-c", cov, "--gpus", n], env=env2, capture_output=True, text=True)
+            assert p.returncode == 0 and "device parser: %s engine(s)" % n in p.stderr, p.stderr
+            assert open(out).read() == open(one).read()
+    # ... and a compressed input through it (inflated on the host, the text handed to all engines)
+    import gzip
+    with open(bigger, "rb") as f, gzip.open(bigger + ".gz", "wb", compresslevel=1) as g:
+        g.write(f.read())
+    p = subprocess.run([BIN, "-i", bigger + ".gz", "-o", out, "-c", "4", "--gpus", "3"], env=env2, capture_output=True, text=True)
+    assert p.returncode == 0 and "device parser: 3 engine(s)" in p.stderr, p.stderr
+    assert open(out).read() == open(one).read()
 
 
 def test_bad_usage_is_loud(work):

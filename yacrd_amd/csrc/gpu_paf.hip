@@ -16,13 +16,14 @@
 //            fields checked as the host's fast path checks them, both ids hashed and looked up in an open-addressing table whose slots name the text
 //            position of the id's FIRST CLAIMANT (an id is compared against the text itself: no copies), the
 //            smallest position of every id kept with atomicMin; one 24-byte overlap record per line
-//   number   occupied slots sorted by first position (hipcub radix sort) = first-appearance numbering; the
+//   number   occupied slots sorted by first position (radix_sort.h) = first-appearance numbering; the
 //            length that follows the id at that position = the read's length; names gathered for the host
 //   build    csr_build.h's count / scan / scatter on the records, then the engine's launch sequence
 // Whatever the fast path does not take — a quote, a lone CR, a 0x integer, a malformed line, a length beyond
 // u32 — makes the call return YACRD_EFALLBACK: the caller runs the host parser, which knows the csv crate's
 // whole syntax and the error messages.  Plain files only (the codecs live in the host library).
 #include "engine_internal.h"
+#include "radix_sort.h"
 
 #include <fcntl.h>
 #include <sys/stat.h>
@@ -40,7 +41,6 @@
 #include <thread>
 #include <vector>
 
-#include <hipcub/hipcub.hpp>
 
 using namespace yke;
 
@@ -62,6 +62,9 @@ struct GpArgs {
     u64 begin, end;     // scan: bytes [begin, end); parse: the tiles from begin / kGpTile on (its grid = their number)
     u64 avail;          // bytes [0, avail) of the mirror have landed (== n for the last segment)
     u32 delim;          // the field delimiter: '\t' (PAF) or ' ' (M4: src/reads2ovl/mod.rs:116-117)
+    u32 partial;        // the mirror ends in front of the file's end (a range + its overhang): a record that reaches the mirror's end is not whole
+    u32 skip_head;      // the mirror is a byte RANGE of the file and the byte in front of it is no newline: position 0 lies
+                        // inside a line that belongs to the range before (yacrd_engines_ingest_overlaps)
 };
 
 constexpr int kGpT = 256; // threads per workgroup
@@ -220,6 +223,10 @@ __global__ __launch_bounds__(kGpT) void gp_parse_kernel(GpArgs a)
         u64 q = lo - 1;
         while (q < hi && (q < tile0 ? (u32)a.text[q] : t[q]) != '\n') q++;
         p = q + 1; // (>= hi when no line starts here)
+    } else if (a.skip_head) { // (a range that begins inside a line: that line is the previous range's)
+        u64 q = 0;
+        while (q < hi && t[q] != '\n') q++;
+        p = q + 1;
     }
     while (p < hi) {
         // the line's first byte decides: empty lines are skipped (csv), "\r\n" alone is one as well
@@ -318,7 +325,7 @@ __global__ __launch_bounds__(kGpT) void gp_parse_kernel(GpArgs a)
             }
             ok = ok && la <= 0xFFFFFFFFull && lb <= 0xFFFFFFFFull; // (the engine's limit; the host parser says so)
             if (!ok) status |= kNeedHost;
-            if (q >= n && n < a.n) status |= kNeedHost; // (a record that reaches into text still on its way: megabytes long)
+            if (q >= n && (n < a.n || a.partial)) status |= kNeedHost; // (a record that reaches into text still on its way, or beyond a range's overhang: megabytes long)
             next = q; // the rest of the line holds nothing for the record: its newline is looked for below
         }
         u32 s1 = 0, s2 = 0;
@@ -453,6 +460,115 @@ __global__ __launch_bounds__(256) void gp_names_kernel(const unsigned char *t, c
     for (u64 i = 0; i < n; i++) names[to + i] = t[from + i];
 }
 
+
+// ==== several engines, one file: the reads of the engines' byte ranges merged (yacrd_engines_ingest_overlaps) ============
+// Every engine has parsed a byte range of the text (parse_range) and numbered the reads IT saw.  The same read shows up in
+// many ranges; the merge engine gets every range's read list — name, first position in the file, first length, number of
+// intervals: a few dozen bytes per read and range, against the gigabytes of text that never leave their device — and
+// interns the names once more, in a table whose slots name list ENTRIES.  Then, as for one engine: occupied slots
+// sorted by first position = first-appearance numbering over the whole file; a read's length is the one seen at that
+// position (src/reads2ovl/fullmemory.rs:82-90).  Every entry learns its read's number, every engine rewrites its records
+// from table slots to those numbers, and the reads are dealt out to the engines as contiguous ranges of numbers.
+struct GmArgs {
+    const unsigned char *names; // every range's names, end to end
+    const u64 *noff;            // [M + 1] entry -> its name's extent in `names`
+    const u64 *fp;              // [M] first position in the FILE * 2 + side
+    const u32 *len, *cnt;       // [M] the length seen there; intervals of the read inside the range
+    u64 M;
+    u64 *claim, *first_pos;     // [cap]: entry + 1 of the slot's first claimant; smallest first position
+    u32 *slot_cnt;              // [cap]
+    u32 mask;
+    u32 *entry_slot;            // [M]
+    u32 *status;
+};
+__global__ __launch_bounds__(256) void gm_shift_kernel(u64 *fp, u64 *noff, u64 n, u64 fp_add, u64 noff_add)
+{
+    const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (i < n) fp[i] += fp_add, noff[i] += noff_add;
+}
+__global__ __launch_bounds__(256) void gm_intern_kernel(GmArgs a)
+{
+    const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (i >= a.M) return;
+    const u64 p = a.noff[i];
+    const u32 n = (u32)(a.noff[i + 1] - p);
+    u64 h = 0xcbf29ce484222325ull ^ ((u64)n * 0x9E3779B97F4A7C15ull);
+    for (u32 k = 0; k < n; k++) h = (h ^ a.names[p + k]) * 0x100000001b3ull;
+    h ^= h >> 29;
+    h *= 0xbf58476d1ce4e5b9ull;
+    h ^= h >> 32;
+    u32 s = (u32)h & a.mask, found = ~0u;
+    for (u32 probes = 0; probes <= a.mask; probes++, s = (s + 1u) & a.mask) {
+        u64 w = __hip_atomic_load(&a.claim[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (w == 0) {
+            const u64 old = atomicCAS((unsigned long long *)&a.claim[s], 0ull, (unsigned long long)(i + 1));
+            if (old == 0) {
+                found = s;
+                break;
+            }
+            w = old;
+        }
+        const u64 c = w - 1, q = a.noff[c];
+        bool same = (u32)(a.noff[c + 1] - q) == n;
+        for (u32 k = 0; same && k < n; k++) same = a.names[q + k] == a.names[p + k];
+        if (same) {
+            found = s;
+            break;
+        }
+    }
+    if (found == ~0u) { // (cannot happen: the table has twice as many slots as there are entries)
+        atomicOr(a.status, kTableFull);
+        return;
+    }
+    a.entry_slot[i] = found;
+    atomicMin((unsigned long long *)&a.first_pos[found], (unsigned long long)a.fp[i]);
+    atomicAdd(&a.slot_cnt[found], a.cnt[i]);
+}
+// read g of the whole file = the name first seen at keys[g]: its slot -> g, its intervals, where its name lies
+__global__ __launch_bounds__(256) void gm_number_kernel(GmArgs a, const u32 *slots, u32 n_reads, u32 *slot_read, u32 *cnt,
+                                                        u32 *name_len, u64 *name_at)
+{
+    const u32 g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= n_reads) return;
+    const u32 s = slots[g];
+    slot_read[s] = g;
+    cnt[g] = a.slot_cnt[s];
+    const u64 c = a.claim[s] - 1;
+    name_at[g] = a.noff[c];
+    name_len[g] = (u32)(a.noff[c + 1] - a.noff[c]);
+}
+// every entry: its read's number; the entry that saw the read first gives it its length
+__global__ __launch_bounds__(256) void gm_entry_kernel(GmArgs a, const u32 *slot_read, u32 *entry_read, u32 *lengths)
+{
+    const u64 i = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (i >= a.M) return;
+    const u32 s = a.entry_slot[i], g = slot_read[s];
+    entry_read[i] = g;
+    if (a.fp[i] == a.first_pos[s]) lengths[g] = a.len[i];
+}
+// on every engine: table slot -> the range's read -> the file's read; then the records' handles
+__global__ __launch_bounds__(256) void gm_slot_read_kernel(u32 *slot_map, u64 cap, const u32 *range_read_to_file)
+{
+    const u64 s = (u64)blockIdx.x * 256u + threadIdx.x;
+    if (s >= cap) return;
+    const u32 l = slot_map[s];
+    if (l != 0xFFFFFFFFu) slot_map[s] = range_read_to_file[l];
+}
+__global__ __launch_bounds__(256) void gm_rewrite_kernel(OvlRec *recs, u64 n, const u32 *slot_map)
+{
+    for (u64 i = (u64)blockIdx.x * 256u + threadIdx.x; i < n; i += (u64)gridDim.x * 256u) {
+        uint2 *ab = reinterpret_cast<uint2 *>(recs + i);
+        const uint2 v = *ab;
+        *ab = make_uint2(slot_map[v.x], slot_map[v.y]);
+    }
+}
+// the reads [lo, hi) are this engine's (numbered from 0 here), every other one lives elsewhere
+__global__ __launch_bounds__(256) void gm_own_kernel(u32 *own, u32 n_reads, u32 lo, u32 hi)
+{
+    const u32 g = blockIdx.x * 256u + threadIdx.x;
+    if (g < n_reads) own[g] = (g >= lo && g < hi) ? g - lo : (u32)YACRD_HANDLE_ELSEWHERE;
+}
+
 } // namespace yk
 
 namespace {
@@ -462,9 +578,51 @@ double now_ms()
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// (first position, slot) pairs by first position, on the engine's stream: radix_sort.h, as many eight-bit passes as keys
+// below `key_bound` need.  The passes go back and forth between the two pairs of arrays (the inputs are scratch: clobbered);
+// an odd number of them, so that the last one lands in the outputs.
+int sort_by_first_position(yacrd_engine *e, u64 *keys, u64 *keys_out, u32 *slots, u32 *slots_out, u32 n, u64 key_bound, DevBuf &tmp,
+                           DevBuf &part)
+{
+    int bits = 1;
+    while (bits < 64 && (key_bound >> bits) != 0) bits++;
+    int passes = (bits + 7) / 8;
+    passes |= 1;
+    const u32 tiles = (u32)(((u64)n + yk::kRsTile - 1) / yk::kRsTile);
+    const size_t cells = (size_t)256 * tiles;
+    const size_t first_at = (cells * sizeof(u32) + 255) & ~(size_t)255;
+    HIP_TRY(tmp.reserve(first_at + (cells + 1) * sizeof(u64) + 64));
+    u32 *hist = tmp.as<u32>();
+    u64 *first = reinterpret_cast<u64 *>(tmp.as<char>() + first_at);
+    u64 *ka = keys, *kb = keys_out;
+    u32 *va = slots, *vb = slots_out;
+    for (int p = 0; p < passes; p++) {
+        const u32 shift = (u32)std::min(8 * p, 56); // (a pass beyond the key's bits sees digit 0 everywhere: a stable copy)
+        const bool beyond = 8 * p >= 64;
+        hipLaunchKernelGGL(yk::rs_hist_kernel, dim3(tiles), dim3(yk::kRsThreads), 0, e->stream, ka, (u64)n, beyond ? 63u : shift, tiles, hist);
+        if (const int rcs = scan_u32_to_u64(e, hist, (u64)cells, first, part)) return rcs;
+        hipLaunchKernelGGL(yk::rs_scatter_kernel, dim3(tiles), dim3(yk::kRsThreads), 0, e->stream, ka, va, (u64)n, beyond ? 63u : shift, tiles,
+                           first, kb, vb);
+        std::swap(ka, kb);
+        std::swap(va, vb);
+    }
+    return YACRD_OK;
+}
+// gzip / bzip2 / xz (the magic bytes niffler looks at, src/util.rs:57-70)
+bool is_compressed_magic(int fd)
+{
+    unsigned char mg[6] = {0};
+    const ssize_t k = ::pread(fd, mg, sizeof mg, 0);
+    return k >= 2 && ((mg[0] == 0x1f && mg[1] == 0x8b) || (k >= 3 && mg[0] == 'B' && mg[1] == 'Z' && mg[2] == 'h') ||
+                      (k >= 6 && mg[0] == 0xFD && std::memcmp(mg + 1, "7zXZ", 4) == 0 && mg[5] == 0));
+}
+
 struct Scratch { // the call's device buffers; they stay with the engine (grow-only) and go when it is destroyed
     DevBuf text, claim, first_pos, slot_cnt, recs, ctl, keys, keys2, slots, slots2, tmp, map, name_len, name_at, name_off,
-        names, cnt, part, err;
+        names, cnt, part, err, gather, gmap;
+    // the merge engine's (yacrd_engines_ingest_overlaps)
+    DevBuf m_fp, m_len, m_cnt, m_noff, m_names, m_slot, m_read, g_claim, g_fp, g_cnt, g_keys, g_slots, g_keys2, g_slots2, g_slot_read,
+        g_rcnt, g_nlen, g_nat, g_noff, g_names, g_len;
     size_t bytes()
     {
         size_t n = 0;
@@ -481,7 +639,9 @@ private:
     std::vector<DevBuf *> all()
     {
         return {&text, &claim, &first_pos, &slot_cnt, &recs, &ctl, &keys, &keys2, &slots, &slots2, &tmp, &map, &name_len,
-                &name_at, &name_off, &names, &cnt, &part, &err};
+                &name_at, &name_off, &names, &cnt, &part, &err, &gather, &gmap, &m_fp, &m_len, &m_cnt, &m_noff, &m_names, &m_slot,
+                &m_read, &g_claim, &g_fp, &g_cnt, &g_keys, &g_slots, &g_keys2, &g_slots2, &g_slot_read, &g_rcnt, &g_nlen, &g_nat, &g_noff,
+                &g_names, &g_len};
     }
 };
 
@@ -575,15 +735,10 @@ int yacrd_engine_ingest_overlaps(yacrd_engine *e, const char *path, int format, 
     } fdg{fd};
     struct stat st;
     if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) return fail(YACRD_EFALLBACK, "not a regular file: the host parser reads it");
-    {
-        // gzip / bzip2 / xz (the magic bytes niffler looks at, src/util.rs:57-70): not text — the caller inflates the file
-        // (yacrd_text_from_file, libyacrd_host) and hands the text to yacrd_engine_ingest_overlaps_mem, or takes the host parser
-        unsigned char mg[6] = {0};
-        const ssize_t k = ::pread(fd, mg, sizeof mg, 0);
-        if (k >= 2 && ((mg[0] == 0x1f && mg[1] == 0x8b) || (k >= 3 && mg[0] == 'B' && mg[1] == 'Z' && mg[2] == 'h') ||
-                       (k >= 6 && mg[0] == 0xFD && std::memcmp(mg + 1, "7zXZ", 4) == 0 && mg[5] == 0)))
-            return fail(YACRD_EFALLBACK, "a compressed file: inflate it (yacrd_text_from_file + yacrd_engine_ingest_overlaps_mem) or take the host parser");
-    }
+    // gzip / bzip2 / xz: not text — the caller inflates the file (yacrd_text_from_file, libyacrd_host) and hands the text to
+    // yacrd_engine_ingest_overlaps_mem, or takes the host parser
+    if (is_compressed_magic(fd))
+        return fail(YACRD_EFALLBACK, "a compressed file: inflate it (yacrd_text_from_file + yacrd_engine_ingest_overlaps_mem) or take the host parser");
     TextSource src;
     src.fd = fd;
     return ingest_text(e, src, (u64)st.st_size, m4, n_threads, coverage, not_coverage, out, reads, stats);
@@ -608,17 +763,36 @@ int yacrd_engine_ingest_overlaps_mem(yacrd_engine *e, const char *text, uint64_t
 
 namespace {
 
-int ingest_text(yacrd_engine *e, const TextSource &src, u64 n, bool m4, int n_threads, uint32_t coverage, double not_coverage,
-                yacrd_result *out, yacrd_reads *reads, yacrd_ingest_stats *stats)
+// (allocating and freeing ~0.8 GB of HBM per call cost 1.5 ms of a 15 ms run: the buffers stay with the engine)
+Scratch *scratch_of(yacrd_engine *e)
 {
-    DeviceGuard guard(e->device);
-    // (allocating and freeing ~0.8 GB of HBM per call cost 1.5 ms of a 15 ms run)
     if (!e->paf_scratch) {
         e->paf_scratch = new (std::nothrow) Scratch();
         e->paf_scratch_free = [](void *p) { delete static_cast<Scratch *>(p); };
-        if (!e->paf_scratch) return fail(YACRD_ENOMEM, "host allocation failed");
     }
-    Scratch &S = *static_cast<Scratch *>(e->paf_scratch);
+    return static_cast<Scratch *>(e->paf_scratch);
+}
+
+// Bytes [begin, begin + len) of the text -> on the engine: the overlap records of the lines that START there (handles = id-table
+// slots), the table, and the range's reads numbered by first appearance INSIDE the range: S.map (slot -> read), S.keys2 (first
+// positions * 2 + side, relative to `begin`), e->in_len (lengths), S.cnt (intervals), S.name_off / S.names.  The whole file for
+// one engine; a range per engine for several (yacrd_engines_ingest_overlaps), cut on chunk boundaries.
+struct RangeOut {
+    u64 n_recs = 0, cap = 0, name_bytes = 0;
+    u32 R = 0;
+    double t_start = 0, t_text = 0, t_parse = 0;
+};
+int parse_range(yacrd_engine *e, const TextSource &src, u64 file_n, u64 begin, u64 len, bool skip_head, bool m4, int n_threads, RangeOut &ro)
+{
+    DeviceGuard guard(e->device);
+    Scratch *Sp = scratch_of(e);
+    if (!Sp) return fail(YACRD_ENOMEM, "host allocation failed");
+    Scratch &S = *Sp;
+    // the mirror holds the range and, behind it, up to one chunk more of the file: a line that starts in the range ends there
+    // (or the parse says so: kNeedHost)
+    constexpr u64 kOverhang = (u64)4 << 20;
+    const u64 n = std::min<u64>(file_n, begin + len + (begin + len < file_n ? kOverhang : 0)) - begin; // bytes in the mirror
+    const u64 parse_end = len; // lines that start at or behind it are the next range's
     const double t_start = now_ms();
     {
         // The parse on the device wants the text, a 24-byte record per line, the id table, the CSR and the region
@@ -627,7 +801,7 @@ int ingest_text(yacrd_engine *e, const TextSource &src, u64 n, bool m4, int n_th
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
             const double have = (double)free_b + (double)S.text.cap + (double)S.recs.cap + (double)e->stage.cap +
-                                (double)e->in_iv.cap;
+                                (double)e->in_iv.cap + (double)S.gather.cap;
             if (2.6 * (double)n + (double)((size_t)256 << 20) > have)
                 return fail(YACRD_EFALLBACK, "the file is too large to be parsed in this device's free memory: the host parser streams it");
         }
@@ -660,7 +834,7 @@ int ingest_text(yacrd_engine *e, const TextSource &src, u64 n, bool m4, int n_th
     {
         const size_t sample = (size_t)std::min<u64>(n, (u64)1 << 20);
         std::vector<char> head(sample + 1);
-        if (!src.fetch(head.data(), sample, 0)) return fail(YACRD_EINVAL, "read error in the overlap file");
+        if (!src.fetch(head.data(), sample, begin)) return fail(YACRD_EINVAL, "read error in the overlap file");
         u64 nl = 0;
         for (const char *q = head.data(), *end = q + sample; (q = (const char *)std::memchr(q, '\n', (size_t)(end - q))) != nullptr; q++) nl++;
         if (nl) rec_cap = std::min<u64>(rec_cap, (u64)((double)n / (double)sample * (double)nl * 1.25) + 4096);
@@ -680,6 +854,8 @@ int ingest_text(yacrd_engine *e, const TextSource &src, u64 n, bool m4, int n_th
     ga.recs = S.recs.as<yk::OvlRec>();
     ga.rec_cap = rec_cap;
     ga.delim = m4 ? (u32)' ' : (u32)'\t';
+    ga.skip_head = skip_head ? 1u : 0u;
+    ga.partial = begin + n < file_n ? 1u : 0u;
     if ((n + yk::kGpTile - 1) / yk::kGpTile >= 0x7FFFFFFFull) return fail(YACRD_EFALLBACK, "file too large for the device parser");
     // scan + parse of the bytes [begin, end) on the engine's stream (begin on a tile boundary)
     auto launch_segment = [&](u64 begin, u64 end, u64 avail) {
@@ -731,15 +907,15 @@ int ingest_text(yacrd_engine *e, const TextSource &src, u64 n, bool m4, int n_th
                 const size_t b = (size_t)2 * t + (size_t)turn;
                 if (prev[turn] >= 0 && hipEventSynchronize(ev[(size_t)prev[turn]]) != hipSuccess) bad = 1;
                 char *dst = arena + b * kChunk;
-                const size_t off = c * kChunk, len = (size_t)std::min<u64>(kChunk, n - off);
-                if (!src.fetch(dst, len, (u64)off)) bad = 2;
+                const size_t off = c * kChunk, clen = (size_t)std::min<u64>(kChunk, n - off);
+                if (!src.fetch(dst, clen, begin + (u64)off)) bad = 2;
                 if (bad.load()) break;
-                if (blit && (len & 15)) std::memset(dst + len, 0, 16 - (len & 15)); // (the file's last piece: zeros, not leftovers, behind it)
+                if (blit && (clen & 15)) std::memset(dst + clen, 0, 16 - (clen & 15)); // (the file's last piece: zeros, not leftovers, behind it)
                 if (blit) { // (the arena's buffers are 4 MiB: whole 16-byte pieces; the mirror is padded by 64 bytes)
                     hipLaunchKernelGGL(yk::gp_blit_kernel, dim3(256), dim3(256), 0, copy[t], reinterpret_cast<uint4 *>(S.text.as<char>() + off),
-                                       reinterpret_cast<const uint4 *>(dst), (u64)((len + 15) / 16));
+                                       reinterpret_cast<const uint4 *>(dst), (u64)((clen + 15) / 16));
                     if (hipEventRecord(ev[c], copy[t]) != hipSuccess) bad = 1;
-                } else if (hipMemcpyAsync(S.text.as<char>() + off, dst, len, hipMemcpyHostToDevice, copy[t]) != hipSuccess ||
+                } else if (hipMemcpyAsync(S.text.as<char>() + off, dst, clen, hipMemcpyHostToDevice, copy[t]) != hipSuccess ||
                            hipEventRecord(ev[c], copy[t]) != hipSuccess)
                     bad = 1;
                 prev[turn] = (long)c;
@@ -764,7 +940,8 @@ int ingest_text(yacrd_engine *e, const TextSource &src, u64 n, bool m4, int n_th
                 waited++;
             }
             if (bad.load()) break;
-            launch_segment((u64)c0 * kChunk, std::min<u64>(n, (u64)c1 * kChunk), std::min<u64>(n, (u64)need * kChunk));
+            if ((u64)c0 * kChunk < parse_end)
+                launch_segment((u64)c0 * kChunk, std::min<u64>(parse_end, (u64)c1 * kChunk), std::min<u64>(n, (u64)need * kChunk));
         }
         for (auto &x : th) x.join();
         for (hipStream_t s2 : copy)
@@ -791,7 +968,7 @@ int ingest_text(yacrd_engine *e, const TextSource &src, u64 n, bool m4, int n_th
     const u64 n_lines = h_ctl[0];
     if (n_lines >= 0x7FFFFFFFull * 2) return fail(YACRD_EFALLBACK, "too many lines for the device parser");
     u64 n_recs = h_ctl[1];
-    if (n_recs > n_lines + 1) return fail(YACRD_EINTERNAL, "device parser: more records than lines");
+    if (n_recs > n_lines + 2) return fail(YACRD_EINTERNAL, "device parser: more records than lines");
     if (n_recs > rec_cap) { // the estimate fell short (line lengths far from uniform): once more, with room for every record
         rec_cap = n_recs + 1;
         HIP_TRY(S.recs.reserve((size_t)rec_cap * sizeof(yk::OvlRec)));
@@ -801,7 +978,7 @@ int ingest_text(yacrd_engine *e, const TextSource &src, u64 n, bool m4, int n_th
         HIP_TRY(hipMemsetAsync(S.claim.p, 0, (size_t)cap * sizeof(u64), e->stream));
         HIP_TRY(hipMemsetAsync(S.first_pos.p, 0xFF, (size_t)cap * sizeof(u64), e->stream));
         HIP_TRY(hipMemsetAsync(S.slot_cnt.p, 0, (size_t)cap * sizeof(u32), e->stream));
-        launch_segment(0, n, n);
+        launch_segment(0, parse_end, n);
         HIP_TRY(hipMemcpyAsync(h_ctl, S.ctl.p, sizeof(h_ctl), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
         HIP_TRY(hipGetLastError());
@@ -822,15 +999,9 @@ int ingest_text(yacrd_engine *e, const TextSource &src, u64 n, bool m4, int n_th
     // sort (first position, slot)
     HIP_TRY(S.keys2.reserve((size_t)R * sizeof(u64) + 64));
     HIP_TRY(S.slots2.reserve((size_t)R * sizeof(u32) + 64));
-    size_t tmp_bytes = 0;
     if (R) {
-        if (hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, S.keys.as<u64>(), S.keys2.as<u64>(), S.slots.as<u32>(),
-                                               S.slots2.as<u32>(), (int)R, 0, 64, e->stream) != hipSuccess)
-            return fail(YACRD_ENODEV, "hipcub sort (size query) failed");
-        HIP_TRY(S.tmp.reserve(tmp_bytes + 64));
-        if (hipcub::DeviceRadixSort::SortPairs(S.tmp.p, tmp_bytes, S.keys.as<u64>(), S.keys2.as<u64>(), S.slots.as<u32>(),
-                                               S.slots2.as<u32>(), (int)R, 0, 64, e->stream) != hipSuccess)
-            return fail(YACRD_ENODEV, "hipcub sort failed");
+        const int rcs = sort_by_first_position(e, S.keys.as<u64>(), S.keys2.as<u64>(), S.slots.as<u32>(), S.slots2.as<u32>(), R, 2 * n + 2, S.tmp, S.part);
+        if (rcs) return rcs;
     }
     HIP_TRY(S.map.reserve((size_t)cap * sizeof(u32)));
     HIP_TRY(S.name_len.reserve((size_t)(R + 4) * sizeof(u32)));
@@ -855,6 +1026,21 @@ int ingest_text(yacrd_engine *e, const TextSource &src, u64 n, bool m4, int n_th
     if (R)
         hipLaunchKernelGGL(yk::gp_names_kernel, dim3(rg), dim3(256), 0, e->stream, ga.text, S.name_at.as<u64>(), S.name_off.as<u64>(), R,
                            S.names.as<unsigned char>());
+    ro.n_recs = n_recs, ro.R = R, ro.cap = cap, ro.name_bytes = name_bytes;
+    ro.t_start = t_start, ro.t_text = t_text, ro.t_parse = t_parse;
+    return YACRD_OK;
+}
+
+int ingest_text(yacrd_engine *e, const TextSource &src, u64 n, bool m4, int n_threads, uint32_t coverage, double not_coverage,
+                yacrd_result *out, yacrd_reads *reads, yacrd_ingest_stats *stats)
+{
+    DeviceGuard guard(e->device);
+    RangeOut ro;
+    if (const int rcp = parse_range(e, src, n, 0, n, false, m4, n_threads, ro)) return rcp;
+    Scratch &S = *static_cast<Scratch *>(e->paf_scratch);
+    const u32 R = ro.R;
+    const u64 n_recs = ro.n_recs, cap = ro.cap, name_bytes = ro.name_bytes;
+    const double t_start = ro.t_start, t_text = ro.t_text, t_parse = ro.t_parse;
     // the reads, to the host (while the CSR is built)
     reads->n_reads = R;
     reads->n_records = n_recs;
@@ -898,3 +1084,382 @@ int ingest_text(yacrd_engine *e, const TextSource &src, u64 n, bool m4, int n_th
 }
 
 } // namespace
+
+// ---- several engines, one file --------------------------------------------------------------------------------------
+namespace {
+// device memory of engine `from` -> device memory of engine `to`, on `to`'s stream (the source is complete: its stream was waited for)
+hipError_t copy_between(yacrd_engine *to, void *dst, yacrd_engine *from, const void *src, size_t bytes)
+{
+    if (!bytes) return hipSuccess;
+    if (to->device == from->device) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, to->stream);
+    return hipMemcpyPeerAsync(dst, to->device, src, from->device, bytes, to->stream);
+}
+
+int ingest_text_group(yacrd_engine *const *E, uint32_t N, const TextSource &src, u64 n, bool m4, int n_threads, uint32_t coverage,
+                      double not_coverage, yacrd_result *out, yacrd_reads *reads, yacrd_ingest_stats *stats)
+{
+    // ---- byte ranges: whole 4 MiB chunks (the parse's segments begin on tile boundaries), the same number for every engine
+    constexpr u64 kChunk = (u64)4 << 20;
+    const u64 chunks = (n + kChunk - 1) / kChunk, per = (chunks + N - 1) / N;
+    std::vector<u64> B(N + 1);
+    for (uint32_t d = 0; d <= N; d++) B[d] = std::min<u64>(n, (u64)d * per * kChunk);
+    uint32_t active = 0;
+    while (active < N && B[active] < B[active + 1]) active++;
+    if (active < 2) return ingest_text(E[0], src, n, m4, n_threads, coverage, not_coverage, out, reads, stats);
+    const uint32_t A = active; // engines that parse (every engine sweeps, below)
+    std::vector<char> head_skip(A, 0);
+    for (uint32_t d = 1; d < A; d++) {
+        char c = 0;
+        if (!src.fetch(&c, 1, B[d] - 1)) return fail(YACRD_EINVAL, "read error in the overlap file");
+        head_skip[d] = c != '\n';
+    }
+    const double t0 = now_ms();
+    std::vector<RangeOut> ro(A);
+    std::vector<int> codes(N, YACRD_OK);
+    std::vector<std::string> errs(N);
+    auto run_all = [&](uint32_t count, auto &&fn) { // fn(d) on `count` host threads, one per engine; the first failure wins
+        std::vector<std::thread> th;
+        for (uint32_t d = 1; d < count; d++)
+            th.emplace_back([&, d] {
+                codes[d] = fn(d);
+                if (codes[d]) errs[d] = err_slot();
+            });
+        codes[0] = fn(0);
+        if (codes[0]) errs[0] = err_slot();
+        for (auto &t : th) t.join();
+        // (a real error before "not for the device parser")
+        for (uint32_t d = 0; d < count; d++)
+            if (codes[d] && codes[d] != YACRD_EFALLBACK) return fail(codes[d], "engine " + std::to_string(d) + ": " + errs[d]);
+        for (uint32_t d = 0; d < count; d++)
+            if (codes[d]) return fail(codes[d], errs[d]);
+        return (int)YACRD_OK;
+    };
+    // the threads that move text are shared out (engines on one device share its link as well)
+    const int copy_threads = std::max(1, (n_threads > 0 ? n_threads : 8) / (int)A);
+    int rc = run_all(A, [&](uint32_t d) -> int {
+        const int r = parse_range(E[d], src, n, B[d], B[d + 1] - B[d], head_skip[d] != 0, m4, copy_threads, ro[d]);
+        if (r) return r;
+        DeviceGuard guard(E[d]->device);
+        HIP_TRY(hipStreamSynchronize(E[d]->stream)); // (the names kernel: other engines read what this one made)
+        return YACRD_OK;
+    });
+    if (rc) return rc;
+    const double t_parsed = now_ms();
+
+    // ---- the merge, on engine 0
+    yacrd_engine *e0 = E[0];
+    Scratch &S0 = *scratch_of(e0);
+    std::vector<u64> eb(A + 1, 0), nb(A + 1, 0);
+    for (uint32_t d = 0; d < A; d++) eb[d + 1] = eb[d] + ro[d].R, nb[d + 1] = nb[d] + ro[d].name_bytes;
+    const u64 M = eb[A], NB = nb[A];
+    if (M >= 0x7FFFFFFFull) return fail(YACRD_EFALLBACK, "too many read ids for the device parser");
+    u64 capG = 1024;
+    while (capG < 2 * M) capG <<= 1;
+    u32 Rg = 0;
+    u64 g_name_bytes = 0;
+    std::vector<u32> h_rcnt;
+    {
+        DeviceGuard guard(e0->device);
+        HIP_TRY(S0.m_fp.reserve((size_t)(M + 1) * sizeof(u64)));
+        HIP_TRY(S0.m_len.reserve((size_t)(M + 1) * sizeof(u32)));
+        HIP_TRY(S0.m_cnt.reserve((size_t)(M + 1) * sizeof(u32)));
+        HIP_TRY(S0.m_noff.reserve((size_t)(M + 2) * sizeof(u64)));
+        HIP_TRY(S0.m_names.reserve((size_t)NB + 64));
+        HIP_TRY(S0.m_slot.reserve((size_t)(M + 1) * sizeof(u32)));
+        HIP_TRY(S0.m_read.reserve((size_t)(M + 1) * sizeof(u32)));
+        HIP_TRY(S0.g_claim.reserve((size_t)capG * sizeof(u64)));
+        HIP_TRY(S0.g_fp.reserve((size_t)capG * sizeof(u64)));
+        HIP_TRY(S0.g_cnt.reserve((size_t)capG * sizeof(u32)));
+        HIP_TRY(S0.g_slot_read.reserve((size_t)capG * sizeof(u32)));
+        HIP_TRY(S0.ctl.reserve(64));
+        for (uint32_t d = 0; d < A; d++) {
+            Scratch &Sd = *scratch_of(E[d]);
+            const size_t R = ro[d].R;
+            HIP_TRY(copy_between(e0, S0.m_fp.as<u64>() + eb[d], E[d], Sd.keys2.p, R * sizeof(u64)));
+            HIP_TRY(copy_between(e0, S0.m_len.as<u32>() + eb[d], E[d], E[d]->in_len.p, R * sizeof(u32)));
+            HIP_TRY(copy_between(e0, S0.m_cnt.as<u32>() + eb[d], E[d], Sd.cnt.p, R * sizeof(u32)));
+            HIP_TRY(copy_between(e0, S0.m_noff.as<u64>() + eb[d], E[d], Sd.name_off.p, R * sizeof(u64)));
+            HIP_TRY(copy_between(e0, S0.m_names.as<char>() + nb[d], E[d], Sd.names.p, (size_t)ro[d].name_bytes));
+            if (R)
+                hipLaunchKernelGGL(yk::gm_shift_kernel, dim3((u32)((R + 255) / 256)), dim3(256), 0, e0->stream, S0.m_fp.as<u64>() + eb[d],
+                                   S0.m_noff.as<u64>() + eb[d], (u64)R, 2 * B[d], nb[d]);
+        }
+        HIP_TRY(hipMemcpyAsync(S0.m_noff.as<u64>() + M, &NB, sizeof(u64), hipMemcpyHostToDevice, e0->stream));
+        HIP_TRY(hipMemsetAsync(S0.ctl.p, 0, 64, e0->stream));
+        HIP_TRY(hipMemsetAsync(S0.g_claim.p, 0, (size_t)capG * sizeof(u64), e0->stream));
+        HIP_TRY(hipMemsetAsync(S0.g_fp.p, 0xFF, (size_t)capG * sizeof(u64), e0->stream));
+        HIP_TRY(hipMemsetAsync(S0.g_cnt.p, 0, (size_t)capG * sizeof(u32), e0->stream));
+        yk::GmArgs gm{};
+        gm.names = S0.m_names.as<unsigned char>(), gm.noff = S0.m_noff.as<u64>(), gm.fp = S0.m_fp.as<u64>();
+        gm.len = S0.m_len.as<u32>(), gm.cnt = S0.m_cnt.as<u32>(), gm.M = M;
+        gm.claim = S0.g_claim.as<u64>(), gm.first_pos = S0.g_fp.as<u64>(), gm.slot_cnt = S0.g_cnt.as<u32>(), gm.mask = (u32)(capG - 1);
+        gm.entry_slot = S0.m_slot.as<u32>();
+        gm.status = reinterpret_cast<u32 *>(S0.ctl.as<unsigned long long>() + 2);
+        u32 *d_nreads = reinterpret_cast<u32 *>(S0.ctl.as<unsigned long long>() + 3);
+        const u32 mg = (u32)((M + 255) / 256);
+        if (M) hipLaunchKernelGGL(yk::gm_intern_kernel, dim3(mg), dim3(256), 0, e0->stream, gm);
+        HIP_TRY(S0.g_keys.reserve((size_t)capG * sizeof(u64) + 64));
+        HIP_TRY(S0.g_slots.reserve((size_t)capG * sizeof(u32) + 64));
+        hipLaunchKernelGGL(yk::gp_collect_kernel, dim3((u32)std::min<u64>((capG + 255) / 256, (u64)e0->num_cu * 8)), dim3(256), 0, e0->stream,
+                           gm.claim, gm.first_pos, (u32)capG, S0.g_keys.as<u64>(), S0.g_slots.as<u32>(), d_nreads);
+        unsigned long long h_ctl[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(h_ctl, S0.ctl.p, sizeof(h_ctl), hipMemcpyDeviceToHost, e0->stream));
+        HIP_TRY(hipStreamSynchronize(e0->stream));
+        HIP_TRY(hipGetLastError());
+        if ((u32)h_ctl[2]) return fail(YACRD_EINTERNAL, "device parser: the merge table overflowed");
+        Rg = (u32)h_ctl[3];
+        HIP_TRY(S0.g_keys2.reserve((size_t)Rg * sizeof(u64) + 64));
+        HIP_TRY(S0.g_slots2.reserve((size_t)Rg * sizeof(u32) + 64));
+        if (Rg) {
+            const int rcs = sort_by_first_position(e0, S0.g_keys.as<u64>(), S0.g_keys2.as<u64>(), S0.g_slots.as<u32>(), S0.g_slots2.as<u32>(), Rg, 2 * n + 2, S0.tmp, S0.part);
+            if (rcs) return rcs;
+        }
+        HIP_TRY(S0.g_rcnt.reserve((size_t)(Rg + 4) * sizeof(u32)));
+        HIP_TRY(S0.g_nlen.reserve((size_t)(Rg + 4) * sizeof(u32)));
+        HIP_TRY(S0.g_nat.reserve((size_t)(Rg + 1) * sizeof(u64)));
+        HIP_TRY(S0.g_noff.reserve((size_t)(Rg + 2) * sizeof(u64)));
+        HIP_TRY(S0.g_len.reserve((size_t)(Rg + 1) * sizeof(u32)));
+        const u32 rg = (Rg + 255) / 256;
+        if (Rg) {
+            hipLaunchKernelGGL(yk::gm_number_kernel, dim3(rg), dim3(256), 0, e0->stream, gm, S0.g_slots2.as<u32>(), Rg, S0.g_slot_read.as<u32>(),
+                               S0.g_rcnt.as<u32>(), S0.g_nlen.as<u32>(), S0.g_nat.as<u64>());
+            hipLaunchKernelGGL(yk::gm_entry_kernel, dim3(mg), dim3(256), 0, e0->stream, gm, S0.g_slot_read.as<u32>(), S0.m_read.as<u32>(),
+                               S0.g_len.as<u32>());
+        }
+        if (const int rcs = scan_u32_to_u64(e0, S0.g_nlen.as<u32>(), (u64)Rg, S0.g_noff.as<u64>(), S0.part)) return rcs;
+        HIP_TRY(hipMemcpyAsync(&g_name_bytes, S0.g_noff.as<u64>() + Rg, sizeof(u64), hipMemcpyDeviceToHost, e0->stream));
+        HIP_TRY(hipStreamSynchronize(e0->stream));
+        HIP_TRY(S0.g_names.reserve((size_t)g_name_bytes + 64));
+        if (Rg)
+            hipLaunchKernelGGL(yk::gp_names_kernel, dim3(rg), dim3(256), 0, e0->stream, gm.names, S0.g_nat.as<u64>(), S0.g_noff.as<u64>(), Rg,
+                               S0.g_names.as<unsigned char>());
+        // the reads, to the host
+        reads->n_reads = Rg;
+        reads->n_records = 0;
+        for (uint32_t d = 0; d < A; d++) reads->n_records += ro[d].n_recs;
+        reads->lengths = (uint32_t *)std::malloc(((size_t)Rg + 1) * sizeof(uint32_t));
+        reads->name_off = (uint64_t *)std::malloc(((size_t)Rg + 1) * sizeof(uint64_t));
+        reads->names = (char *)std::malloc((size_t)g_name_bytes + 1);
+        h_rcnt.resize((size_t)Rg + 1);
+        if (!reads->lengths || !reads->name_off || !reads->names) return fail(YACRD_ENOMEM, "host allocation failed");
+        if (Rg) HIP_TRY(hipMemcpyAsync(reads->lengths, S0.g_len.p, (size_t)Rg * sizeof(u32), hipMemcpyDeviceToHost, e0->stream));
+        HIP_TRY(hipMemcpyAsync(reads->name_off, S0.g_noff.p, ((size_t)Rg + 1) * sizeof(u64), hipMemcpyDeviceToHost, e0->stream));
+        if (g_name_bytes) HIP_TRY(hipMemcpyAsync(reads->names, S0.g_names.p, (size_t)g_name_bytes, hipMemcpyDeviceToHost, e0->stream));
+        if (Rg) HIP_TRY(hipMemcpyAsync(h_rcnt.data(), S0.g_rcnt.p, (size_t)Rg * sizeof(u32), hipMemcpyDeviceToHost, e0->stream));
+        HIP_TRY(hipStreamSynchronize(e0->stream));
+    }
+    // ---- who sweeps what: contiguous ranges of read numbers with about the same number of intervals each (every engine,
+    // also one that had no text to parse)
+    std::vector<u32> cut(N + 1, Rg);
+    {
+        u64 total = 0;
+        for (u32 g = 0; g < Rg; g++) total += h_rcnt[g];
+        u64 run = 0;
+        uint32_t o = 1;
+        cut[0] = 0;
+        for (u32 g = 0; g < Rg && o < N; g++) {
+            while (o < N && run >= (total * o + N - 1) / N) cut[o++] = g;
+            run += h_rcnt[g];
+        }
+        // (cut[o..N] stay Rg: engines behind the last cut own nothing)
+    }
+    // ---- every parsing engine: its records from table slots to the file's read numbers
+    rc = run_all(A, [&](uint32_t d) -> int {
+        yacrd_engine *e = E[d];
+        DeviceGuard guard(e->device);
+        Scratch &S = *scratch_of(e);
+        const size_t R = ro[d].R;
+        HIP_TRY(S.gmap.reserve((size_t)(std::max<u64>(R, Rg) + 4) * sizeof(u32)));
+        HIP_TRY(copy_between(e, S.gmap.p, e0, S0.m_read.as<u32>() + eb[d], R * sizeof(u32)));
+        hipLaunchKernelGGL(yk::gm_slot_read_kernel, dim3((u32)((ro[d].cap + 255) / 256)), dim3(256), 0, e->stream, S.map.as<u32>(), ro[d].cap,
+                           S.gmap.as<u32>());
+        if (ro[d].n_recs)
+            hipLaunchKernelGGL(yk::gm_rewrite_kernel, dim3((u32)std::min<u64>((ro[d].n_recs + 255) / 256, (u64)e->num_cu * 16)), dim3(256), 0,
+                               e->stream, S.recs.as<yk::OvlRec>(), ro[d].n_recs, S.map.as<u32>());
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipGetLastError());
+        return YACRD_OK;
+    });
+    if (rc) return rc;
+    const double t_merged = now_ms();
+
+    // ---- every engine: the records of ALL ranges (its own in place, the others' copied over when they live on another
+    // device), the halves that name its reads kept (csr_build.h: YACRD_HANDLE_ELSEWHERE), CSR, sweep
+    std::vector<yacrd_result> parts(N);
+    std::vector<double> t_built(N, 0), t_ran(N, 0);
+    rc = run_all(N, [&](uint32_t o) -> int {
+        yacrd_engine *e = E[o];
+        DeviceGuard guard(e->device);
+        Scratch &S = *scratch_of(e);
+        const u32 lo = cut[o], hi = cut[o + 1], Ro = hi - lo;
+        std::vector<RecSlab> slabs(A);
+        u64 foreign = 0;
+        for (uint32_t d = 0; d < A; d++)
+            if (E[d]->device != e->device) foreign += ro[d].n_recs;
+        HIP_TRY(S.gather.reserve((size_t)foreign * sizeof(yk::OvlRec) + 64));
+        u64 at = 0;
+        for (uint32_t d = 0; d < A; d++) {
+            Scratch &Sd = *scratch_of(E[d]);
+            if (E[d]->device == e->device) {
+                slabs[d] = RecSlab{Sd.recs.as<yk::OvlRec>(), ro[d].n_recs};
+            } else {
+                yk::OvlRec *dst = S.gather.as<yk::OvlRec>() + at;
+                HIP_TRY(copy_between(e, dst, E[d], Sd.recs.p, (size_t)ro[d].n_recs * sizeof(yk::OvlRec)));
+                slabs[d] = RecSlab{dst, ro[d].n_recs};
+                at += ro[d].n_recs;
+            }
+        }
+        HIP_TRY(S.gmap.reserve((size_t)(Rg + 4) * sizeof(u32)));
+        if (Rg) hipLaunchKernelGGL(yk::gm_own_kernel, dim3((Rg + 255) / 256), dim3(256), 0, e->stream, S.gmap.as<u32>(), Rg, lo, hi);
+        HIP_TRY(e->in_len.reserve((size_t)(Ro + 1) * sizeof(u32)));
+        HIP_TRY(copy_between(e, e->in_len.p, e0, S0.g_len.as<u32>() + lo, (size_t)Ro * sizeof(u32)));
+        u64 n_iv = 0;
+        int r = csr_from_records(e, slabs.data(), slabs.size(), S.gmap.as<u32>(), Rg, Ro, S.cnt, S.part, S.err, nullptr, &n_iv, false);
+        if (r) return r;
+        t_built[o] = now_ms();
+        r = run_on_device(e, e->in_off.as<u64>(), e->in_iv.as<uint2>(), e->in_len.as<u32>(), Ro, n_iv, coverage, not_coverage);
+        if (r) return r;
+        t_ran[o] = now_ms();
+        return fetch_result(e, &parts[o]);
+    });
+    auto drop = [&]() {
+        for (auto &r : parts) yacrd_result_free(&r);
+    };
+    if (rc) {
+        drop();
+        return rc;
+    }
+    // ---- the results, end to end: the ranges are in first-appearance order already
+    u64 G = 0;
+    for (auto &r : parts) G += r.n_regions;
+    out->bad_offsets = (uint64_t *)std::malloc(((size_t)Rg + 1) * sizeof(uint64_t));
+    out->bad_regions = (uint32_t *)std::malloc((size_t)(2 * G + 2) * sizeof(uint32_t));
+    out->read_type = (uint8_t *)std::malloc((size_t)Rg + 1);
+    if (!out->bad_offsets || !out->bad_regions || !out->read_type) {
+        drop();
+        yacrd_result_free(out);
+        return fail(YACRD_ENOMEM, "host allocation failed");
+    }
+    u64 g0 = 0;
+    for (uint32_t o = 0; o < N; o++) {
+        const u32 lo = cut[o], Ro = cut[o + 1] - lo;
+        if (parts[o].n_reads != Ro) {
+            drop();
+            yacrd_result_free(out);
+            return fail(YACRD_EINTERNAL, "device parser: an engine returned another number of reads than it was given");
+        }
+        for (u32 l = 0; l < Ro; l++) out->bad_offsets[lo + l] = g0 + parts[o].bad_offsets[l];
+        if (parts[o].n_regions) std::memcpy(out->bad_regions + 2 * g0, parts[o].bad_regions, (size_t)parts[o].n_regions * 2 * sizeof(uint32_t));
+        if (Ro) std::memcpy(out->read_type + lo, parts[o].read_type, Ro);
+        g0 += parts[o].n_regions;
+    }
+    out->bad_offsets[Rg] = g0;
+    out->n_reads = Rg;
+    out->n_regions = g0;
+    drop();
+    if (stats) {
+        stats->text_bytes = n;
+        stats->n_records = reads->n_records;
+        stats->n_reads = Rg;
+        double tt = 0, tp = 0;
+        for (uint32_t d = 0; d < A; d++) tt = std::max(tt, ro[d].t_text - ro[d].t_start), tp = std::max(tp, ro[d].t_parse - ro[d].t_text);
+        stats->text_ms = (float)tt;
+        stats->parse_ms = (float)std::max(0.0, (t_parsed - t0) - tt);
+        (void)tp;
+        double tb = 0, tr = 0;
+        for (uint32_t o = 0; o < N; o++) tb = std::max(tb, t_built[o] - t_merged), tr = std::max(tr, t_ran[o] - t_built[o]);
+        stats->build_ms = (float)((t_merged - t_parsed) + tb);
+        stats->run_ms = (float)tr;
+        stats->d2h_ms = (float)std::max(0.0, now_ms() - t_merged - tb - tr);
+    }
+    return YACRD_OK;
+}
+} // namespace
+
+extern "C" {
+
+static int group_args(yacrd_engine *const *engines, uint32_t n_engines, yacrd_result *out, yacrd_reads *reads, yacrd_ingest_stats *stats)
+{
+    if (!engines || !n_engines || !out || !reads) return fail(YACRD_EINVAL, "null argument");
+    for (uint32_t d = 0; d < n_engines; d++) {
+        if (!engines[d]) return fail(YACRD_EINVAL, "engine is null");
+        if (engines[d]->pending.active || engines[d]->host_pending) return fail(YACRD_EINVAL, "an engine has a submitted batch pending");
+        for (uint32_t k = 0; k < d; k++)
+            if (engines[k] == engines[d]) return fail(YACRD_EINVAL, "the same engine twice");
+    }
+    std::memset(out, 0, sizeof(*out));
+    std::memset(reads, 0, sizeof(*reads));
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    return YACRD_OK;
+}
+
+int yacrd_engines_ingest_overlaps(yacrd_engine *const *engines, uint32_t n_engines, const char *path, int format, int n_threads,
+                                  uint32_t coverage, double not_coverage, yacrd_result *out, yacrd_reads *reads, yacrd_ingest_stats *stats)
+{
+    if (const int rca = group_args(engines, n_engines, out, reads, stats)) return rca;
+    if (n_engines == 1) return yacrd_engine_ingest_overlaps(engines[0], path, format, n_threads, coverage, not_coverage, out, reads, stats);
+    if (!path) return fail(YACRD_EINVAL, "null argument");
+    bool m4 = false;
+    if (const int rcf = ingest_format(path, format, m4)) return rcf;
+    const int fd = ::open(path, O_RDONLY);
+    if (fd < 0) return fail(YACRD_EINVAL, std::string("cannot open ") + path);
+    struct FdGuard {
+        int fd;
+        ~FdGuard() { ::close(fd); }
+    } fdg{fd};
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode)) return fail(YACRD_EFALLBACK, "not a regular file: the host parser reads it");
+    if (is_compressed_magic(fd))
+        return fail(YACRD_EFALLBACK, "a compressed file: inflate it (yacrd_text_from_file + yacrd_engines_ingest_overlaps_mem) or take the host parser");
+    TextSource src;
+    src.fd = fd;
+    const int rc = ingest_text_group(engines, n_engines, src, (u64)st.st_size, m4, n_threads, coverage, not_coverage, out, reads, stats);
+    if (rc) yacrd_reads_free(reads);
+    return rc;
+}
+
+int yacrd_engines_ingest_overlaps_mem(yacrd_engine *const *engines, uint32_t n_engines, const char *text, uint64_t n, int format,
+                                      int n_threads, uint32_t coverage, double not_coverage, yacrd_result *out, yacrd_reads *reads,
+                                      yacrd_ingest_stats *stats)
+{
+    if (const int rca = group_args(engines, n_engines, out, reads, stats)) return rca;
+    if (n_engines == 1)
+        return yacrd_engine_ingest_overlaps_mem(engines[0], text, n, format, n_threads, coverage, not_coverage, out, reads, stats);
+    if (!text && n) return fail(YACRD_EINVAL, "null argument");
+    bool m4 = false;
+    if (const int rcf = ingest_format(nullptr, format, m4)) return rcf;
+    TextSource src;
+    src.mem = text ? text : "";
+    const int rc = ingest_text_group(engines, n_engines, src, n, m4, n_threads, coverage, not_coverage, out, reads, stats);
+    if (rc) yacrd_reads_free(reads);
+    return rc;
+}
+
+/* include/yacrd_engine_debug.h: the device parser's sort on its own (tests) */
+int yacrd_debug_sort_pairs(yacrd_engine *e, uint64_t *keys, uint32_t *vals, uint64_t n, uint64_t key_bound)
+{
+    if (!e || (n && (!keys || !vals))) return fail(YACRD_EINVAL, "null argument");
+    if (n >= 0x7FFFFFFFull) return fail(YACRD_EINVAL, "too many pairs");
+    DeviceGuard guard(e->device);
+    DevBuf k0, k1, v0, v1, tmp, part;
+    auto body = [&]() -> int {
+        HIP_TRY(k0.reserve((size_t)n * sizeof(u64) + 64));
+        HIP_TRY(k1.reserve((size_t)n * sizeof(u64) + 64));
+        HIP_TRY(v0.reserve((size_t)n * sizeof(u32) + 64));
+        HIP_TRY(v1.reserve((size_t)n * sizeof(u32) + 64));
+        if (!n) return YACRD_OK;
+        HIP_TRY(hipMemcpyAsync(k0.p, keys, (size_t)n * sizeof(u64), hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(v0.p, vals, (size_t)n * sizeof(u32), hipMemcpyHostToDevice, e->stream));
+        if (const int rcs = sort_by_first_position(e, k0.as<u64>(), k1.as<u64>(), v0.as<u32>(), v1.as<u32>(), (u32)n, key_bound, tmp, part)) return rcs;
+        HIP_TRY(hipMemcpyAsync(keys, k1.p, (size_t)n * sizeof(u64), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(vals, v1.p, (size_t)n * sizeof(u32), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipGetLastError());
+        return YACRD_OK;
+    };
+    const int rc = body();
+    for (DevBuf *b : {&k0, &k1, &v0, &v1, &tmp, &part}) b->release();
+    return rc;
+}
+
+} // extern "C"

@@ -182,10 +182,9 @@ int main(int argc, char **argv)
         int dev_parse = YACRD_EFALLBACK;
         // YACRD_NO_DEVICE_PARSER=1: the host parser for everything (A/B, tools/e2e_cli_paf.py)
         const char *no_dev = std::getenv("YACRD_NO_DEVICE_PARSER");
-        // (--gpus N > 1: an input that one GPU can parse is parsed and swept on device 0 — its text reaches HBM at the
-        // link's rate and the detection takes milliseconds: N GPUs fed by the host parser are five times slower end to end,
-        // DESIGN.md §7 — and only an input beyond one GPU's memory, which the call below refuses before it allocates
-        // anything, is routed to all N by the stream group)
+        // (--gpus N > 1: every GPU moves and parses a byte range of the text over its own link and sweeps a range of the reads,
+        // yacrd_engines_ingest_overlaps; an input beyond the GPUs' memory, which the call refuses before it allocates
+        // anything, is routed to all N by the host parser's stream group)
         if ((paf || m4) && !(no_dev && *no_dev == '1')) {
             // one GPU, PAF or M4 text: the host only moves the file to HBM, the device parses it, numbers the reads,
             // builds the CSR and runs the engine (yacrd_engine_ingest_overlaps).  Whatever is not a plain file of
@@ -202,22 +201,20 @@ int main(int argc, char **argv)
             if (rct == 1) die(yacrd_host_last_error());
             stage("inflate");
             if (rct == 0)
-                dev_parse = yacrd_engine_ingest_overlaps_mem(engines[0], text.data, text.n, m4 ? 2 : 1, copy_threads, cov32,
-                                                             not_coverage, &res, &dev_reads, nullptr);
+                dev_parse = yacrd_engines_ingest_overlaps_mem(engines.data(), (uint32_t)engines.size(), text.data, text.n, m4 ? 2 : 1,
+                                                              copy_threads, cov32, not_coverage, &res, &dev_reads, nullptr);
             else
-                dev_parse = yacrd_engine_ingest_overlaps(engines[0], input.c_str(), m4 ? 2 : 1, copy_threads, cov32, not_coverage,
-                                                         &res, &dev_reads, nullptr);
+                dev_parse = yacrd_engines_ingest_overlaps(engines.data(), (uint32_t)engines.size(), input.c_str(), m4 ? 2 : 1, copy_threads,
+                                                          cov32, not_coverage, &res, &dev_reads, nullptr);
             if (dev_parse == YACRD_ENOMEM) { // HBM ran out on the way (the parse wants ~2.6 x the file): the streamed host parse needs a fifth
                 std::fprintf(stderr, "[INFO] device parser: %s; falling back to the host parser\n", yacrd_last_error());
-                (void)yacrd_engine_trim(engines[0]);
+                for (yacrd_engine *en : engines) (void)yacrd_engine_trim(en);
                 dev_parse = YACRD_EFALLBACK;
             }
             if (dev_parse != YACRD_OK && dev_parse != YACRD_EFALLBACK) die(yacrd_last_error());
         }
         if (dev_parse == YACRD_OK) {
-            if (engines.size() > 1)
-                std::fprintf(stderr, "[INFO] --gpus %zu: the input fits one GPU: parsed and swept on device 0 (the other devices are for "
-                                     "inputs beyond one GPU's memory)\n", engines.size());
+            if (std::getenv("YACRD_CLI_TIMING")) std::fprintf(stderr, "[timing] device parser: %zu engine(s)\n", engines.size());
             view.n_reads = dev_reads.n_reads;
             view.name_off = dev_reads.name_off;
             view.names = dev_reads.names;

@@ -43,6 +43,8 @@ constexpr int kWsBins = kWsT;
 // The screen of ONE read by the whole workgroup (kWsT threads): true = decided, its regions and count written.
 // tab: kWsBins * 4 words, red: NW x 4, sc: NW + 1 words of LDS; ends with a barrier.
 // (o, n, len: the read's first interval, its intervals, its length — the persistent kernel has them before the turn starts)
+// A thread takes its intervals two at a time (16-byte loads: pair P = tid + kWsT * j holds intervals 2P and 2P + 1, the load
+// clamped to the read's last pair — as the register classes' screen does, sweep_wave.h).
 __device__ __forceinline__ bool screen_wg_read(const SweepArgs &a, u32 r, u64 o, u32 n, u32 len, u32 *tab, u32 (*red)[4], u32 *sc)
 {
     constexpr int T = kWsT, R = kWsR, W = kWsW, NW = T / 64;
@@ -56,20 +58,21 @@ __device__ __forceinline__ bool screen_wg_read(const SweepArgs &a, u32 r, u64 o,
     bool fallback = n < 2u || len > kMaxKeyPos;
 
     // ---- the read's smallest start, largest end, largest start and shortest interval (signed)
-    uint2 v[R];
+    uint4 v[R / 2];
     u32 smin = 0xFFFFFFFFu, emax = 0, smax = 0;
     i32 tmin = 0x7FFFFFFF;
     if (!fallback) {
         for (u32 ch = 0; ch < chunks; ch++) {
-            const u32 base = ch * (u32)(T * R) + tid;
+            const u32 base = ch * (u32)(T * R / 2) + tid; // (pairs)
 #pragma unroll
-            for (int j = 0; j < R; j++) v[j] = iv[min(base + (u32)(j * T), n - 1u)]; // (copies of the last interval beyond it)
+            for (int j = 0; j < R / 2; j++) // (slots beyond the read: copies of its last two intervals)
+                v[j] = *reinterpret_cast<const uint4 *>(iv + min(2u * (base + (u32)(j * T)), n - 2u));
 #pragma unroll
-            for (int j = 0; j < R; j++) {
-                smin = min(smin, v[j].y != 0u ? v[j].x : 0xFFFFFFFFu); // ((0, 0) intervals are inert: left out)
-                smax = max(smax, v[j].x);
-                emax = max(emax, v[j].y);
-                tmin = min(tmin, (i32)(v[j].y - v[j].x));
+            for (int j = 0; j < R / 2; j++) {
+                smin = min(smin, min(v[j].y != 0u ? v[j].x : 0xFFFFFFFFu, v[j].w != 0u ? v[j].z : 0xFFFFFFFFu)); // ((0, 0) intervals are inert: left out)
+                smax = max(smax, max(v[j].x, v[j].z));
+                emax = max(emax, max(v[j].y, v[j].w));
+                tmin = min(tmin, min((i32)(v[j].y - v[j].x), (i32)(v[j].w - v[j].z)));
             }
         }
     }
@@ -103,21 +106,27 @@ __device__ __forceinline__ bool screen_wg_read(const SweepArgs &a, u32 r, u64 o,
         const u32 span = pmax - pmin, Tt = span - (u32)W;
         const u32 cp = (tid & 3u) * 4u;
         // ---- count: one map for starts and ends
+        auto count = [&](u32 s0, u32 e0, bool real) {
+            const u32 ds = s0 - pmin, dx = e0 - pmin;
+            const u32 is = min(ds, (u32)W) + (ds >> sh) + __builtin_elementwise_sub_sat(ds, Tt);
+            const u32 ie = min(dx, (u32)W) + (dx >> sh) + __builtin_elementwise_sub_sat(dx, Tt);
+            if (real && e0 != 0u) {
+                atomicAdd(reinterpret_cast<u32 *>(tb + ((is << 4) + cp)), 1u);
+                atomicAdd(reinterpret_cast<u32 *>(tb + ((ie << 4) + cp)), kEnd);
+            }
+        };
         for (u32 ch = 0; ch < chunks; ch++) {
-            const u32 base = ch * (u32)(T * R) + tid;
+            const u32 base = ch * (u32)(T * R / 2) + tid;
             if (chunks > 1u) {
 #pragma unroll
-                for (int j = 0; j < R; j++) v[j] = iv[min(base + (u32)(j * T), n - 1u)];
+                for (int j = 0; j < R / 2; j++)
+                    v[j] = *reinterpret_cast<const uint4 *>(iv + min(2u * (base + (u32)(j * T)), n - 2u));
             }
 #pragma unroll
-            for (int j = 0; j < R; j++) {
-                const u32 ds = v[j].x - pmin, dx = v[j].y - pmin;
-                const u32 is = min(ds, (u32)W) + (ds >> sh) + __builtin_elementwise_sub_sat(ds, Tt);
-                const u32 ie = min(dx, (u32)W) + (dx >> sh) + __builtin_elementwise_sub_sat(dx, Tt);
-                if (base + (u32)(j * T) < n && v[j].y != 0u) {
-                    atomicAdd(reinterpret_cast<u32 *>(tb + ((is << 4) + cp)), 1u);
-                    atomicAdd(reinterpret_cast<u32 *>(tb + ((ie << 4) + cp)), kEnd);
-                }
+            for (int j = 0; j < R / 2; j++) {
+                const u32 i0 = 2u * (base + (u32)(j * T));
+                count(v[j].x, v[j].y, i0 + 1u < n); // (.xy is interval i0 only when i0 + 1 exists too: the clamped last pair)
+                count(v[j].z, v[j].w, i0 < n);
             }
         }
         __syncthreads();
@@ -178,7 +187,6 @@ __device__ __forceinline__ bool screen_wg_read(const SweepArgs &a, u32 r, u32 *t
     const u64 o = a.off[r];
     return screen_wg_read(a, r, o, (u32)(a.off[r + 1] - o), a.len[r], tab, red, sc);
 }
-
 // SweepArgs.list / list_n: the class list; over_list / over_count: the reads the screen leaves to the sort.
 __global__ __launch_bounds__(kWsT) void screen_wg_kernel(SweepArgs a)
 {
@@ -210,130 +218,88 @@ __global__ __launch_bounds__(kWsT) void screen_wg_kernel(SweepArgs a)
 // for a bounded number of looks (below).
 constexpr u32 kQueueEmpty = 0xFFFFFFFFu;
 constexpr int kWsFbCap = 16384; // events the in-kernel fallback sorts (64 KB of LDS; two workgroups per CU by registers anyway)
+#ifndef YK_WG_OCC
+#define YK_WG_OCC 4 // wavefronts per SIMD the register budget allows (two workgroups per CU)
+#endif
 struct ScreenFusedArgs {
     SweepArgs sweep;  // list / list_n: the class; over_list / over_count: beyond kWsFbCap; rej_*: degenerate reads
     u32 *q;           // the queue's slots
     u32 *tail, *head, *done;
 };
-__global__ __launch_bounds__(kWsT, 4) void screen_wg_fused_kernel(ScreenFusedArgs f)
+__global__ __launch_bounds__(kWsT, YK_WG_OCC) void screen_wg_fused_kernel(ScreenFusedArgs f)
 {
     constexpr int NW = kWsT / 64;
     __shared__ __attribute__((aligned(16))) u32 tab[kWsBins * 4];
     __shared__ u32 red[NW][4];
     __shared__ u32 sc[NW + 1];
     __shared__ u32 keys[kWsFbCap];
-    __shared__ u32 s_next, s_mine;
+    __shared__ u32 s_next;
     const SweepArgs &a = f.sweep;
     const u32 tid = threadIdx.x;
     const u32 list_n = *a.list_n;
+    // ---- the share, then the queue: two loops.  Round 5 measured three other shapes of this kernel on configs[3]
+    // (profiles/r05/e_*, f_*; this form: 0.221-0.229 ms):
+    //  * the next read's list entry, extent and length asked for a turn ahead: 0.232-0.234 (the two round trips it saves are
+    //    hidden by the CU's other workgroup already);
+    //  * one loop, the queue looked at between the turns so that a fallback read (a ~50 us chain) starts while others still
+    //    screen: 0.313-0.316 — the sort's registers and the screen's live side by side (44 bytes of scratch per thread), and
+    //    a workgroup that takes a fallback read early delays its own share by as much as it saves the tail;
+    //  * the next read's first 64 KB staged in LDS a turn ahead (global_load_lds_dwordx4 into the sort's idle key array,
+    //    LDS-only barriers so that the loads stay in flight across the turn): 0.241-0.243 — a second set of registers
+    //    for them does not fit 128 VGPRs, and through LDS the copy costs what the overlap gains: two workgroups per CU
+    //    already alternate their load and count phases.
+    for (u32 b = blockIdx.x; b < list_n; b += gridDim.x) { // (uniform)
+        const u32 r = a.list[b];
+        if (!screen_wg_read(a, r, tab, red, sc) && tid == 0)
+            __hip_atomic_store(&f.q[atomicAdd(f.tail, 1u)], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (tid == 0) {
+        __threadfence(); // this workgroup's appends before its "done"
+        atomicAdd(f.done, 1u);
+    }
     LaneConst lc;
 #pragma unroll
     for (int i = 0; i < 6; i++) lc.k[i] = (tid & (1u << i)) ? 0xFFFFFFFFu : 0u;
     lc.k[6] = 0;
     lc.addr32 = ((tid & 63u) ^ 32u) << 2;
-    // Round 5, two things about the latency chain a turn is (list entry -> extent -> intervals -> table -> verdict):
-    //  * the NEXT read's list entry, extent and length are asked for before this read's intervals, so a turn starts with its
-    //    interval loads (two dependent round trips less per read);
-    //  * the queue is looked at BETWEEN the turns, not only after the last one: a read the screen left (a ~50 us chain of
-    //    its own: two passes, the trimming plan, the sort, four sweep passes) used to wait for a workgroup that had finished
-    //    its whole share — all of them at about the same time, so the fallbacks of a batch ran as one tail behind the
-    //    screening (profiles/r04: 226 us = ~170 of screening + the tail).  Now a workgroup that finds an entry handed out
-    //    takes it on the spot; a claim that comes back beyond `tail` (two workgroups after one entry) is kept — `mine` —
-    //    and looked at again after every turn: nobody waits before its share is done.
-    // A claimed slot beyond `tail` is waited for — once the workgroup's share is done — until it is filled or `done` says
-    // it never will be.  That wait needs the workgroups it waits for to RUN: the grid is sized to be resident as a whole,
-    // but a second process on the device, a CU mask or anything else that holds LDS / wave slots can leave some of them
-    // undispatched behind the spinning ones.  So the wait is bounded (kFusedPolls looks, ~10 ms — a healthy
-    // launch is over in a fraction of one): a workgroup that runs out raises Counters::fused_gave_up and leaves, every
-    // other one then leaves at its next look, the kernel ends, and the engine runs the batch again down the three-launch
-    // chain (engine.hip: fused_off), which waits for nothing.  (Claims by compare-and-swap — none is lost when a
-    // workgroup leaves — were tried first: 512 workgroups retrying on one address took the pass from 0.32 to 1.59 ms.)
+    // A claimed slot beyond `tail` is waited for until it is filled or `done` says it never will be.  That wait needs
+    // the workgroups it waits for to RUN: the grid is sized to be resident as a whole, but a second process on the
+    // device, a CU mask or anything else that holds LDS / wave slots can leave some of them undispatched behind the
+    // spinning ones.  So the wait is bounded (kFusedPolls looks, ~10 ms — a healthy launch is over in a
+    // fraction of one): a workgroup that runs out raises Counters::fused_gave_up and leaves, every other one then
+    // leaves at its next look, the kernel ends, and the engine runs the batch again down the three-launch chain
+    // (engine.hip: fused_off), which waits for nothing.  (Claims by compare-and-swap — none is lost when a workgroup
+    // leaves — were tried first: 512 workgroups retrying on one address took the pass from 0.32 to 1.59 ms.)
     constexpr u32 kFusedPolls = 1u << 14;
-    u32 mine = kQueueEmpty; // a claimed slot that was not handed out yet
-    // (two turns ahead: the list entry; one turn ahead: that read's extent and length — nothing a turn issues waits for
-    // anything but its own intervals)
-    const u32 g = gridDim.x;
-    u32 b = blockIdx.x;
-    u32 r_n = 0, n_n = 0, len_n = 0, r_nn = 0;
-    u64 o_n = 0;
-    if (b < list_n) {
-        r_n = a.list[b];
-        o_n = a.off[r_n];
-        n_n = (u32)(a.off[r_n + 1] - o_n);
-        len_n = a.len[r_n];
-    }
-    if (b + g < list_n) r_nn = a.list[b + g];
-    bool screening = true;
-    for (;;) { // one turn: a read of the share through the screen and / or one queue entry through the sort (uniform)
-        u32 r_fb = kQueueEmpty;
-        if (screening && b < list_n) {
-            const u32 r = r_n, n = n_n, len = len_n;
-            const u64 o = o_n;
-            b += g;
-            if (b < list_n) { // the next turn's read: asked for now, used after this read's verdict
-                r_n = r_nn;
-                o_n = a.off[r_n];
-                n_n = (u32)(a.off[r_n + 1] - o_n);
-                len_n = a.len[r_n];
-                if (b + g < list_n) r_nn = a.list[b + g];
-            }
-            u32 qh = 0, qt = 0; // the queue's head and tail as they stand when the turn starts (used after it)
-            if (tid == 0 && mine == kQueueEmpty) {
-                qh = __hip_atomic_load(f.head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                qt = __hip_atomic_load(f.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (!screen_wg_read(a, r, o, n, len, tab, red, sc) && tid == 0)
-                __hip_atomic_store(&f.q[atomicAdd(f.tail, 1u)], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // between the turns: one queue entry, if one is to be had — a slot claimed now or before, if it is filled
-            if (tid == 0) {
-                u32 slot = mine != kQueueEmpty ? mine : (qh < qt ? atomicAdd(f.head, 1u) : kQueueEmpty);
-                u32 rq = kQueueEmpty;
-                if (slot != kQueueEmpty && slot < __hip_atomic_load(f.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                    while ((rq = __hip_atomic_load(&f.q[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == kQueueEmpty)
-                        __builtin_amdgcn_s_sleep(2); // (handed out: its writer is one store behind the tail increment)
-                    slot = kQueueEmpty;
+    for (;;) {
+        if (tid == 0) {
+            const u32 idx = atomicAdd(f.head, 1u);
+            u32 r = kQueueEmpty, polls = 0;
+            for (;;) {
+                if (idx < __hip_atomic_load(f.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    // handed out: its writer (a running wavefront, one store behind its tail increment) fills it
+                    while ((r = __hip_atomic_load(&f.q[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == kQueueEmpty)
+                        __builtin_amdgcn_s_sleep(2);
+                    break;
                 }
-                s_next = rq, s_mine = slot;
-            }
-            __syncthreads();
-            r_fb = s_next, mine = s_mine;
-        } else {
-            if (screening) { // the share is done
-                screening = false;
-                if (tid == 0) {
-                    __threadfence(); // this workgroup's appends before its "done"
-                    atomicAdd(f.done, 1u);
+                if (__hip_atomic_load(f.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x) {
+                    // every workgroup has screened its share: the tail is final
+                    if (idx < __hip_atomic_load(f.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
+                    break;
                 }
-            }
-            if (tid == 0) {
-                const u32 idx = mine != kQueueEmpty ? mine : atomicAdd(f.head, 1u); // (first the claim kept from the turns)
-                u32 rq = kQueueEmpty, polls = 0;
-                for (;;) {
-                    if (idx < __hip_atomic_load(f.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                        while ((rq = __hip_atomic_load(&f.q[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == kQueueEmpty)
-                            __builtin_amdgcn_s_sleep(2);
-                        break;
-                    }
-                    if (__hip_atomic_load(f.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x) {
-                        // every workgroup has screened its share: the tail is final
-                        if (idx < __hip_atomic_load(f.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
-                        break;
-                    }
-                    if (++polls > kFusedPolls || __hip_atomic_load(&a.ctr->fused_gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                        __hip_atomic_store(&a.ctr->fused_gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        break; // (rq = kQueueEmpty: this workgroup leaves; the batch is run again)
-                    }
-                    __builtin_amdgcn_s_sleep(8);
+                if (++polls > kFusedPolls || __hip_atomic_load(&a.ctr->fused_gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
+                    __hip_atomic_store(&a.ctr->fused_gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break; // (r = kQueueEmpty: this workgroup leaves; the batch is run again)
                 }
-                s_next = rq;
+                __builtin_amdgcn_s_sleep(8);
             }
-            __syncthreads();
-            r_fb = s_next;
-            mine = kQueueEmpty;
-            if (r_fb == kQueueEmpty) break; // (uniform)
+            s_next = r;
         }
-        if (r_fb != kQueueEmpty) sweep_lds_read<kWsT, kWsFbCap>(a, r_fb, keys, sc, lc);
-        __syncthreads(); // keys / sc / s_next / s_mine reused
+        __syncthreads();
+        const u32 r = s_next;
+        if (r == kQueueEmpty) break; // (uniform)
+        sweep_lds_read<kWsT, kWsFbCap>(a, r, keys, sc, lc);
+        __syncthreads(); // keys / sc / s_next reused
     }
 }
 

@@ -44,7 +44,8 @@ EXPORTED_SYMBOLS = [
     "yacrd_engine_submit", "yacrd_engine_collect", "yacrd_pinned_alloc", "yacrd_pinned_free",
     "yacrd_stream_open", "yacrd_stream_sink", "yacrd_stream_acquire", "yacrd_stream_commit",
     "yacrd_stream_finish", "yacrd_stream_last_stats", "yacrd_stream_reset", "yacrd_stream_close",
-    "yacrd_engine_ingest_paf", "yacrd_engine_ingest_overlaps", "yacrd_engine_ingest_overlaps_mem", "yacrd_reads_free", "yacrd_engine_trim",
+    "yacrd_engine_ingest_paf", "yacrd_engine_ingest_overlaps", "yacrd_engine_ingest_overlaps_mem", "yacrd_engines_ingest_overlaps",
+    "yacrd_engines_ingest_overlaps_mem", "yacrd_reads_free", "yacrd_engine_trim",
     "yacrd_stream_device_of", "yacrd_stream_group_open", "yacrd_stream_group_sink", "yacrd_stream_group_finish",
     "yacrd_stream_group_last_stats", "yacrd_stream_group_reset", "yacrd_stream_group_close",
 ]
@@ -239,6 +240,13 @@ def load_library():
     lib.yacrd_engine_ingest_overlaps_mem.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
                                                      ctypes.c_uint32, ctypes.c_double, ctypes.POINTER(_Result), ctypes.POINTER(_Reads),
                                                      ctypes.POINTER(_IngestStats)]
+    lib.yacrd_engines_ingest_overlaps.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.c_char_p, ctypes.c_int,
+                                                  ctypes.c_int, ctypes.c_uint32, ctypes.c_double, ctypes.POINTER(_Result),
+                                                  ctypes.POINTER(_Reads), ctypes.POINTER(_IngestStats)]
+    lib.yacrd_engines_ingest_overlaps_mem.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint64,
+                                                      ctypes.c_int, ctypes.c_int, ctypes.c_uint32, ctypes.c_double,
+                                                      ctypes.POINTER(_Result), ctypes.POINTER(_Reads), ctypes.POINTER(_IngestStats)]
+    lib.yacrd_debug_sort_pairs.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64]
     lib.yacrd_engine_trim.argtypes = [ctypes.c_void_p]
     lib.yacrd_reads_free.argtypes = [ctypes.POINTER(_Reads)]
     lib.yacrd_reads_free.restype = None
@@ -332,6 +340,29 @@ def run_partitioned(engines, offsets, intervals, lengths, coverage, not_coverage
         _ptr(lengths, ctypes.c_uint32), offsets.shape[0] - 1, min(int(coverage), 0xFFFFFFFF),
         float(not_coverage), ctypes.byref(res)))
     return _take(lib, res)
+
+
+def ingest_overlaps(engines, source, coverage, not_coverage, n_threads=0, fmt=1):
+    """yacrd_engines_ingest_overlaps[_mem]: overlap text -> (Result, names, lengths, stats), every engine parsing a byte
+    range of the text and sweeping a range of the reads.  `source`: a path, bytes, or (address, n_bytes) of text in host
+    memory.  Raises NeedsHostParser when the input is not for the device parser."""
+    lib = load_library()
+    handles = (ctypes.c_void_p * len(engines))(*[e._h for e in engines])
+    res, rd, st = _Result(), _Reads(), _IngestStats()
+    cov = min(int(coverage), 0xFFFFFFFF)
+    if isinstance(source, (str, os.PathLike)):
+        rc = lib.yacrd_engines_ingest_overlaps(handles, len(engines), os.fsencode(source), int(fmt), int(n_threads), cov,
+                                               float(not_coverage), ctypes.byref(res), ctypes.byref(rd), ctypes.byref(st))
+    else:
+        if isinstance(source, tuple):
+            addr, n, keep = int(source[0]), int(source[1]), None
+        else:
+            keep = ctypes.create_string_buffer(bytes(source), len(source))
+            addr, n = ctypes.addressof(keep), len(source)
+        rc = lib.yacrd_engines_ingest_overlaps_mem(handles, len(engines), addr, n, int(fmt), int(n_threads), cov, float(not_coverage),
+                                                   ctypes.byref(res), ctypes.byref(rd), ctypes.byref(st))
+        del keep
+    return engines[0]._ingested(rc, res, rd, st)
 
 
 def run_device_batches(engines, batches, done=None):
@@ -453,6 +484,13 @@ class Engine:
         stats = {n: getattr(st, n) for n, _ in _IngestStats._fields_}
         self._lib.yacrd_reads_free(ctypes.byref(rd))
         return _take(self._lib, res), names, lengths, stats
+
+    def debug_sort_pairs(self, keys, vals, key_bound):
+        """yacrd_debug_sort_pairs (tests): (u64 key, u32 value) pairs sorted by key on the device, stable; returns copies."""
+        keys = np.array(keys, dtype=np.uint64)
+        vals = np.array(vals, dtype=np.uint32)
+        _check(self._lib, self._lib.yacrd_debug_sort_pairs(self._h, keys.ctypes.data, vals.ctypes.data, keys.shape[0], int(key_bound)))
+        return keys, vals
 
     def trim(self):
         """yacrd_engine_trim: give the device parser's buffers back."""

@@ -651,6 +651,21 @@ def end_to_end_at_scale(ya, host, eng, d, R=600_000, O=60_000_000):
             el.yacrd_reads_free(ctypes.byref(rd))
             if best is None or dt < best["seconds"]:
                 best = {"seconds": dt, **{k: getattr(stt, k) for k in ("text_ms", "parse_ms", "build_ms", "run_ms", "d2h_ms")}}
+        # the N-GPU form of the device parser with its N engines on THIS device (no second GPU on the box): two engines
+        # share the one link and the one GPU, so "no slower than one" is what there is to see; on N GPUs each has a link
+        two = None
+        with ya.Engine(device_id=eng.device_id) as e2:
+            for rep in range(3):
+                time.sleep(1.0)
+                t0 = time.perf_counter()
+                g_res, g_names, g_len, g_st = ya.ingest_overlaps([eng, e2], paf, 3, 0.4, n_threads=6)
+                dt = time.perf_counter() - t0
+                g_sig = (len(g_names), int(g_res.bad_offsets[-1]), int(g_res.read_type.sum()))
+                if two is None or dt < two["seconds"]:
+                    two = {"seconds": dt, "overlaps_per_sec": O / dt, "same_as_one_engine": g_sig == sig,
+                           **{k: g_st[k] for k in ("text_ms", "parse_ms", "build_ms", "run_ms", "d2h_ms")}}
+                del g_res, g_names, g_len
+            e2.trim()
         with ya.StreamGroup([eng]) as grp:
             t0 = time.perf_counter()
             c = host.ingest_stream(paf, grp.sink(), n_threads=0)
@@ -660,6 +675,7 @@ def end_to_end_at_scale(ya, host, eng, d, R=600_000, O=60_000_000):
         return {"workload": "SEQUEL profile, %d reads / %d overlaps as PAF text" % (R, O), "paf_bytes": size,
                 "device_parser": {"overlaps_per_sec": O / best["seconds"], "reads_per_sec": R / best["seconds"],
                                   "text_GBps": size / best["seconds"] / 1e9, **best},
+                "device_parser_two_engines_on_this_device": two,
                 "host_parser_streamed": {"overlaps_per_sec": O / dt_host, "seconds": dt_host},
                 "same_reads_regions_types": same}
     finally:
@@ -739,6 +755,7 @@ def compact_line(full, extras_path):
           "configs1_pipelined_us": None, "configs1_one_at_a_time_us": None, "one_launch_us": None,
           "e2e_overlaps_per_sec": _dig(full, "end_to_end", "overlaps_per_sec"),
           "e2e_at_scale_overlaps_per_sec": _dig(full, "end_to_end", "at_scale", "device_parser", "overlaps_per_sec"),
+          "e2e_at_scale_two_engines_overlaps_per_sec": _dig(full, "end_to_end", "at_scale", "device_parser_two_engines_on_this_device", "overlaps_per_sec"),
           "pcie_inclusive_reads_per_sec": _dig(full, "pcie_inclusive", "reads_per_sec")}
     sb = full.get("small_batches") or (full.get("headline") if full.get("scaling") == "weak" else None)
     if isinstance(sb, dict):

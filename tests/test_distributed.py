@@ -188,3 +188,103 @@ def test_bench_input_is_generated_once_per_node(tmp_path):
     outs = [p.communicate(timeout=300) for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "RESULT OK" in outs[0][0], outs
+
+
+RANGE_WORKER = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import oracle, yacrd_amd
+from yacrd_amd import dist as ydist, host
+# what yacrd_engines_ingest_overlaps does (gpu_paf.hip), with Python standing in for the device: every rank parses a byte
+# RANGE of the text, cut on chunk boundaries — a line belongs to the range it starts in —, numbers the reads it saw; the
+# ranges' read lists (name, first position, first length, intervals) meet, the reads of the whole file are numbered by
+# first appearance, a read's length is the one seen first; the reads are dealt out as contiguous ranges of numbers balanced
+# by intervals, every rank gets the halves of ALL ranges' records that name its reads, sweeps them; end to end the results
+# must be the whole file's.  (The chunk is 64 KiB here instead of 4 MiB so that a small file has several.)
+CHUNK = 64 << 10
+paf = os.path.join(sys.argv[2], "r.paf")
+rank, local_rank, world = ydist.env_rank()
+d = ydist.init(backend="gloo")
+if rank == 0:
+    host.synth_paf(host.SYNTH_ONT, 2500, 50000, 20250930, paf)
+d.barrier()
+text = open(paf, "rb").read()
+n = len(text)
+per = ((n + CHUNK - 1) // CHUNK + world - 1) // world
+B = [min(n, r * per * CHUNK) for r in range(world + 1)]
+lo, hi = B[rank], B[rank + 1]
+p = lo
+if lo and text[lo - 1:lo] != b"\n":          # the range begins inside a line: that line is the range's before
+    p = text.index(b"\n", lo) + 1
+mine = {}                                    # name -> [first position * 2 + side, first length, [(s, e) ...]]
+while p < hi:
+    q = text.find(b"\n", p)
+    q = n if q < 0 else q
+    f = text[p:q].rstrip(b"\r").split(b"\t")
+    if len(f) >= 9:
+        for side, (k, l, s, e) in enumerate(((f[0], f[1], f[2], f[3]), (f[5], f[6], f[7], f[8]))):
+            rec = mine.setdefault(k, [2 * p + side, int(l), []])
+            rec[2].append((int(s), int(e)))
+    p = q + 1
+lists = [None] * world
+d.all_gather_object(lists, [(k, v[0], v[1], len(v[2])) for k, v in mine.items()])
+merged = {}                                  # name -> [first position, length seen there, intervals in the whole file]
+for lst in lists:
+    for k, fp, ln, cnt in lst:
+        m = merged.setdefault(k, [fp, ln, 0])
+        if fp < m[0]:
+            m[0], m[1] = fp, ln
+        m[2] += cnt
+order = sorted(merged, key=lambda k: merged[k][0])        # first-appearance numbering of the whole file
+number = {k: g for g, k in enumerate(order)}
+counts = np.array([merged[k][2] for k in order], np.int64)
+total, cuts, run, o = int(counts.sum()), [0], 0, 1
+for g in range(len(order)):
+    while o < world and run >= (total * o + world - 1) // world:
+        cuts.append(g); o += 1
+    run += int(counts[g])
+cuts += [len(order)] * (world + 1 - len(cuts))
+out = [dict() for _ in range(world)]         # the exchange: the halves that name a rank's reads, to that rank
+for k, v in mine.items():
+    g = number[k]
+    owner = max(r for r in range(world) if cuts[r] <= g)
+    out[owner][g] = v[2]
+boxes = [None] * world
+d.all_gather_object(boxes, out)
+r0, r1 = cuts[rank], cuts[rank + 1]
+per_read = [[] for _ in range(r1 - r0)]
+for src in range(world):                     # (rank order = file order, as in the reference)
+    for g, ivs in boxes[src][rank].items():
+        per_read[g - r0].extend(ivs)
+off = np.zeros(r1 - r0 + 1, np.uint64); off[1:] = np.cumsum([len(x) for x in per_read])
+iv = np.array([x for r in per_read for x in r], dtype=np.uint32).reshape(-1, 2)
+ln = np.array([merged[order[g]][1] for g in range(r0, r1)], np.uint64)
+part = oracle.run(off, iv, ln, 4, 0.4)
+full = ydist.gather_results(d, part)
+if rank == 0:
+    reads = oracle.parse_paf(text.decode())
+    names, woff, wiv, wln = oracle.to_csr(reads)
+    want = oracle.run(woff, wiv, wln, 4, 0.4)
+    ok = [k.decode() for k in order] == list(names) and [merged[k][1] for k in order] == [int(x) for x in wln]
+    ok = ok and all(np.array_equal(a, b) for a, b in zip(full, want)) and len(set(B)) == world + 1
+    print("RESULT", "OK" if ok else "MISMATCH", B, cuts)
+d.destroy_process_group()
+"""
+
+
+def test_two_rank_text_range_partition_gloo(tmp_path):
+    script = tmp_path / "rworker.py"
+    script.write_text(RANGE_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(tmp_path)], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "RESULT OK" in outs[0][0], outs

@@ -149,7 +149,7 @@ def test_m4_and_fallbacks_and_small_texts(engines, tmp_path):
     got = yacrd_amd.ingest_overlaps(engines[:4], small.encode(), 0, 0.8)
     _same_ingest(got, engines[0].ingest_text(small.encode(), 0, 0.8), "small text")
     got = yacrd_amd.ingest_overlaps(engines[:2], b"", 0, 0.8)
-    assert got[1] == [] and got[0].n_reads == 0
+    assert got[1] == [] and len(got[0].read_type) == 0 and int(got[0].bad_offsets[-1]) == 0
     # the engines are usable afterwards, each on its own
     _same_ingest(engines[2].ingest_text(small.encode(), 0, 0.8), engines[0].ingest_text(small.encode(), 0, 0.8), "afterwards")
 

@@ -142,8 +142,21 @@ __device__ __forceinline__ bool screen_wg_read(const SweepArgs &a, u32 r, u64 o,
             const uint4 t4 = bins[it];
             f = (w & kField) | ((t4.x + t4.y + t4.z + t4.w) & (kField << 16));
         }
-        u32 ftot;
-        const u32 fex = block_excl_add<T>(f, sc, ftot);
+        // ---- the window scan and the depth scan share their barrier (red[][0..1]; red[] is free again: every wavefront
+        // took pmin .. from it in front of the count), the two reductions behind them theirs (red[][2..3]): five barriers a
+        // read instead of eleven
+        const u32 f_incl = wave_incl_add(f), w_incl = wave_incl_add(w);
+        if (lane == 63u) red[wv][0] = f_incl, red[wv][1] = w_incl;
+        __syncthreads();
+        u32 fbase = 0, ftot = 0, wbase = 0;
+#pragma unroll
+        for (u32 k = 0; k < (u32)NW; k++) {
+            const u32 x = red[k][0], y = red[k][1];
+            fbase += k < wv ? x : 0u;
+            wbase += k < wv ? y : 0u;
+            ftot += x;
+        }
+        const u32 fex = fbase + f_incl - f, wex = wbase + w_incl - w;
         const i32 F = (i32)(ftot & kField), G = (i32)(ftot >> 16);
         // positions whose running count has not reached c + 1 yet: their number is a - pmin / pmax - b;
         // an end at a head position at or before a spoils the closed form
@@ -155,15 +168,16 @@ __device__ __forceinline__ bool screen_wg_read(const SweepArgs &a, u32 r, u64 o,
             notyet = ((run & kField) < k1 ? 1u : 0u) | ((run >> 16) < k1 ? kEnd : 0u);
             spoiled = (w >> 16) != 0u && (fex & kField) < k1;
         }
-        u32 ntot;
-        block_excl_add<T>(notyet, sc, ntot);
         // ---- depth: a bin that holds a start beyond the first c + 1 needs more than c intervals open after
         // all of its own ends
-        u32 wtot;
-        const u32 wex = block_excl_add<T>(w, sc, wtot);
         const i32 cs_ex = (i32)(wex & kField), ce_in = (i32)((wex >> 16) + (w >> 16));
         const bool shallow = (w & kField) != 0u && cs_ex >= (i32)k1 && !(cs_ex - ce_in > c);
-        const u32 any_bad = block_or<T>((shallow || spoiled) ? 1u : 0u, sc);
+        const u32 n_incl = wave_incl_add(notyet), bad_w = wave_or((shallow || spoiled) ? 1u : 0u);
+        if (lane == 63u) red[wv][2] = n_incl, red[wv][3] = bad_w;
+        __syncthreads();
+        u32 ntot = 0, any_bad = 0;
+#pragma unroll
+        for (u32 k = 0; k < (u32)NW; k++) ntot += red[k][2], any_bad |= red[k][3];
         healthy = any_bad == 0u && F > c && G > c;
         ra = pmin + (ntot & kField);
         rb = pmax - (ntot >> 16);

@@ -389,6 +389,7 @@ class Engine:
     def __init__(self, device_id=-1, flags=0):
         self._lib = load_library()
         self._h = ctypes.c_void_p()
+        self.device_id = device_id
         cfg = _Cfg(device_id, flags)
         _check(self._lib, self._lib.yacrd_engine_create(ctypes.byref(cfg), ctypes.byref(self._h)))
 

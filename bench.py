@@ -655,16 +655,21 @@ def end_to_end_at_scale(ya, host, eng, d, R=600_000, O=60_000_000):
         # share the one link and the one GPU, so "no slower than one" is what there is to see; on N GPUs each has a link
         two = None
         with ya.Engine(device_id=eng.device_id) as e2:
+            handles = (ctypes.c_void_p * 2)(eng._h, e2._h)
             for rep in range(3):
                 time.sleep(1.0)
+                res, rd, stt = ya.engine._Result(), ya.engine._Reads(), ya.engine._IngestStats()
                 t0 = time.perf_counter()
-                g_res, g_names, g_len, g_st = ya.ingest_overlaps([eng, e2], paf, 3, 0.4, n_threads=6)
+                rc = el.yacrd_engines_ingest_overlaps(handles, 2, paf.encode(), 1, 6, 3, 0.4, ctypes.byref(res), ctypes.byref(rd), ctypes.byref(stt))
                 dt = time.perf_counter() - t0
-                g_sig = (len(g_names), int(g_res.bad_offsets[-1]), int(g_res.read_type.sum()))
+                if rc != 0:
+                    raise RuntimeError("device parser, two engines: %d %s" % (rc, el.yacrd_last_error().decode()))
+                g_sig = (int(rd.n_reads), int(res.n_regions), int(np.ctypeslib.as_array(res.read_type, shape=(int(res.n_reads),)).sum()))
+                el.yacrd_result_free(ctypes.byref(res))
+                el.yacrd_reads_free(ctypes.byref(rd))
                 if two is None or dt < two["seconds"]:
                     two = {"seconds": dt, "overlaps_per_sec": O / dt, "same_as_one_engine": g_sig == sig,
-                           **{k: g_st[k] for k in ("text_ms", "parse_ms", "build_ms", "run_ms", "d2h_ms")}}
-                del g_res, g_names, g_len
+                           **{k: getattr(stt, k) for k in ("text_ms", "parse_ms", "build_ms", "run_ms", "d2h_ms")}}
             e2.trim()
         with ya.StreamGroup([eng]) as grp:
             t0 = time.perf_counter()

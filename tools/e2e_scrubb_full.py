@@ -239,6 +239,19 @@ def main():
                 rep_no, dt, stages, os.path.getsize(fq) / max(stages.get("edit", dt), 1e-9) / 1e9, os.path.getsize(rep) >> 20,
                 os.path.getsize(out) / 1e9), flush=True)
             time.sleep(3)
+        # the same report from TWO engines on this device (yacrd_engines_ingest_overlaps: a byte range of the text each, a
+        # range of the reads each): byte for byte the one-engine report
+        rep2 = rep + ".gpus2"
+        t0 = time.perf_counter()
+        p = subprocess.run([exe, "-i", paf, "-o", rep2, "-c", "3", "-n", "0.4", "--gpus", "2"],
+                           env=dict(os.environ, YACRD_CLI_TIMING="1", YACRD_GPUS_ON_DEVICE="0"), capture_output=True, text=True)
+        dt = time.perf_counter() - t0
+        assert p.returncode == 0 and "device parser: 2 engine(s)" in p.stderr, p.stderr
+        stages = {l.split()[1]: float(l.split()[2]) for l in p.stderr.splitlines() if l.startswith("[timing]")}
+        same2 = subprocess.run(["cmp", "-s", rep, rep2]).returncode == 0
+        print("--gpus 2 on one device: %.2f s wall; stages %s; report %s" % (dt, stages, "byte-identical to one engine's" if same2 else "DIFFERS"), flush=True)
+        os.remove(rep2)
+        assert same2
         os.remove(paf)  # (room for the checker's arrays)
         off, iv, ln = host.synth_csr(host.SYNTH_SEQUEL, R, O, seed)
         res = verify_scrubb(fq, out, rep, off, iv, ln, 3, 0.4, n_extras, log=lambda s: print(s, flush=True))

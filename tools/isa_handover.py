@@ -95,10 +95,17 @@ def dominated_by_wait(ins, i, what):
     return i - j
 
 
+def kernels(funcs, name):
+    """every instantiation of the kernel `name` (scan_compact_kernel is a template over the reads per thread)"""
+    hits = sorted(k for k in funcs if name in k and not k.endswith(".kd"))
+    assert hits, name
+    return [(k, funcs[k]) for k in hits]
+
+
 def kernel(funcs, name):
-    hits = [k for k in funcs if name in k and not k.endswith(".kd")]
-    assert len(hits) == 1, (name, hits)
-    return funcs[hits[0]]
+    hits = kernels(funcs, name)
+    assert len(hits) == 1, (name, [k for k, _ in hits])
+    return hits[0][1]
 
 
 def is_store(t):
@@ -108,8 +115,9 @@ def is_store(t):
 def check(path):
     funcs = disassemble(path)
     report = {}
-    for name in ("one_batch_kernel", "finish_compact_kernel", "scan_compact_kernel"):
-        ins = kernel(funcs, name)
+    for name, sym, ins in [(n, k, i) for n in ("one_batch_kernel", "finish_compact_kernel", "scan_compact_kernel") for k, i in kernels(funcs, n)]:
+        tmpl = re.search(r"ILi(\d+)E", sym)
+        name = name + ("<%s>" % tmpl.group(1) if tmpl else "")
         fences = [t for t in ins if t.startswith(("buffer_wbl2", "buffer_inv"))]
         assert not fences, "%s holds cache maintenance (%s): the hand-overs were measured WITHOUT fences" % (name, fences[:3])
         st = [t for t in ins if t.startswith("global_store")]
@@ -144,7 +152,10 @@ def check(path):
         assert j < len(fc)
     report["finish_compact_kernel"]["counter_atomics_checked"] = len(ctr)
     assert report["finish_compact_kernel"]["stores_sc1"] >= 2 and report["finish_compact_kernel"]["loads_sc1"] >= 2
-    assert report["scan_compact_kernel"]["stores_sc1"] >= 2 and report["scan_compact_kernel"]["loads_sc1"] >= 1
+    scans = [k for k in report if k.startswith("scan_compact_kernel")]
+    assert scans
+    for k in scans:
+        assert report[k]["stores_sc1"] >= 2 and report[k]["loads_sc1"] >= 1, (k, report[k])
     return report
 
 

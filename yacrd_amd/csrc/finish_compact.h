@@ -591,11 +591,14 @@ __global__ __launch_bounds__(kDeferThreads, YK_DEFER_SWEEP_OCC) void deferred_sw
 
 #endif // YK_DEFER_FILTER
 
-constexpr int kScanThreads = 1024, kScanPer = 4, kScanReads = kScanThreads * kScanPer;
-static_assert(kScanReads % kScanBlock == 0, "the control block holds one scan word per 1024 reads: more than this kernel's workgroups use");
-
+constexpr int kScanThreads = 1024;
+// PER consecutive reads per thread: 4, or 8 for batches of kPlanLongReads reads and more (half the tickets and half the
+// look-back chain again: configs[4] 1 221 -> 611 workgroups)
+template <int PER>
 __global__ __launch_bounds__(kScanThreads) void scan_compact_kernel(CompactArgs2 c)
 {
+    constexpr int kScanPer = PER, kScanReads = kScanThreads * PER;
+    static_assert(PER % 4 == 0 && kScanReads % kScanBlock == 0, "16-byte loads; the control block holds one scan word per 1024 reads: more than this kernel's workgroups use");
     __shared__ u32 sc[kScanThreads / 64];
     __shared__ u32 s_bid;
     __shared__ u64 s_base;
@@ -612,10 +615,13 @@ __global__ __launch_bounds__(kScanThreads) void scan_compact_kernel(CompactArgs2
     // caller's: their alignment is looked at)
     const bool vec = r0 + kScanPer <= c.n_reads && (reinterpret_cast<uintptr_t>(a.len) & 15u) == 0;
     if (vec) {
-        const uint4 g4 = *reinterpret_cast<const uint4 *>(a.counts + r0);
-        const uint4 l4 = *reinterpret_cast<const uint4 *>(a.len + r0);
-        g[0] = g4.x, g[1] = g4.y, g[2] = g4.z, g[3] = g4.w;
-        L[0] = l4.x, L[1] = l4.y, L[2] = l4.z, L[3] = l4.w;
+#pragma unroll
+        for (int q = 0; q < kScanPer / 4; q++) {
+            const uint4 g4 = *reinterpret_cast<const uint4 *>(a.counts + r0 + 4 * q);
+            const uint4 l4 = *reinterpret_cast<const uint4 *>(a.len + r0 + 4 * q);
+            g[4 * q] = g4.x, g[4 * q + 1] = g4.y, g[4 * q + 2] = g4.z, g[4 * q + 3] = g4.w;
+            L[4 * q] = l4.x, L[4 * q + 1] = l4.y, L[4 * q + 2] = l4.z, L[4 * q + 3] = l4.w;
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < kScanPer; k++) {
@@ -634,11 +640,12 @@ __global__ __launch_bounds__(kScanThreads) void scan_compact_kernel(CompactArgs2
     }
     if (any_closed) { // the screen's closed form (device_common.h: kClosedForm)
         if (vec) {
-            const uint4 c0 = *reinterpret_cast<const uint4 *>(a.closed + r0), c1 = *reinterpret_cast<const uint4 *>(a.closed + r0 + 2);
-            const uint2 t[4] = {make_uint2(c0.x, c0.y), make_uint2(c0.z, c0.w), make_uint2(c1.x, c1.y), make_uint2(c1.z, c1.w)};
 #pragma unroll
-            for (int k = 0; k < kScanPer; k++)
-                if (closed[k]) ab[k] = t[k];
+            for (int q = 0; q < kScanPer / 2; q++) {
+                const uint4 c0 = *reinterpret_cast<const uint4 *>(a.closed + r0 + 2 * q);
+                if (closed[2 * q]) ab[2 * q] = make_uint2(c0.x, c0.y);
+                if (closed[2 * q + 1]) ab[2 * q + 1] = make_uint2(c0.z, c0.w);
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < kScanPer; k++)
@@ -701,7 +708,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_compact_kernel(CompactArgs2
     if (r0 >= c.n_reads) return;
     u64 dst = s_base + local;
     u64 offs[kScanPer];
-    u32 types = 0;
+    u64 types = 0;
     bool overflow = false;
 #pragma unroll
     for (int k = 0; k < kScanPer; k++) {
@@ -726,7 +733,7 @@ __global__ __launch_bounds__(kScanThreads) void scan_compact_kernel(CompactArgs2
                 }
             }
             overflow |= !fits;
-            types |= classify(bad, middle, L[k], c.not_cov) << (8 * k);
+            types |= (u64)classify(bad, middle, L[k], c.not_cov) << (8 * k);
             if (r == c.n_reads - 1) c.bad_offsets[c.n_reads] = dst + g[k];
         }
         dst += g[k];
@@ -734,9 +741,10 @@ __global__ __launch_bounds__(kScanThreads) void scan_compact_kernel(CompactArgs2
     if (overflow) atomicOr(&ctr->region_overflow, 1u);
     if (r0 + kScanPer <= c.n_reads) {
         ulonglong2 *bo = reinterpret_cast<ulonglong2 *>(c.bad_offsets + r0); // (engine-owned: 256-byte aligned, r0 % 4 == 0)
-        bo[0] = make_ulonglong2(offs[0], offs[1]);
-        bo[1] = make_ulonglong2(offs[2], offs[3]);
-        *reinterpret_cast<u32 *>(c.read_type + r0) = types;
+#pragma unroll
+        for (int q = 0; q < kScanPer / 2; q++) bo[q] = make_ulonglong2(offs[2 * q], offs[2 * q + 1]);
+        if constexpr (kScanPer == 4) *reinterpret_cast<u32 *>(c.read_type + r0) = (u32)types;
+        else *reinterpret_cast<u64 *>(c.read_type + r0) = types;
     } else {
 #pragma unroll
         for (int k = 0; k < kScanPer; k++)

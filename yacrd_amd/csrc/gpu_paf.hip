@@ -1313,8 +1313,12 @@ int ingest_text_group(yacrd_engine *const *E, uint32_t N, const TextSource &src,
         if (Rg) hipLaunchKernelGGL(yk::gm_own_kernel, dim3((Rg + 255) / 256), dim3(256), 0, e->stream, S.gmap.as<u32>(), Rg, lo, hi);
         HIP_TRY(e->in_len.reserve((size_t)(Ro + 1) * sizeof(u32)));
         HIP_TRY(copy_between(e, e->in_len.p, e0, S0.g_len.as<u32>() + lo, (size_t)Ro * sizeof(u32)));
+        // (the merge has summed every read's intervals over the ranges: the CSR build's count pass — one more pass over
+        // every range's records on every engine — is not needed)
+        HIP_TRY(S.cnt.reserve((size_t)(Ro + 4) * sizeof(u32)));
+        HIP_TRY(copy_between(e, S.cnt.p, e0, S0.g_rcnt.as<u32>() + lo, (size_t)Ro * sizeof(u32)));
         u64 n_iv = 0;
-        int r = csr_from_records(e, slabs.data(), slabs.size(), S.gmap.as<u32>(), Rg, Ro, S.cnt, S.part, S.err, nullptr, &n_iv, false);
+        int r = csr_from_records(e, slabs.data(), slabs.size(), S.gmap.as<u32>(), Rg, Ro, S.cnt, S.part, S.err, nullptr, &n_iv, true);
         if (r) return r;
         t_built[o] = now_ms();
         r = run_on_device(e, e->in_off.as<u64>(), e->in_iv.as<uint2>(), e->in_len.as<u32>(), Ro, n_iv, coverage, not_coverage);

@@ -214,7 +214,7 @@ int main(int argc, char **argv)
             if (dev_parse != YACRD_OK && dev_parse != YACRD_EFALLBACK) die(yacrd_last_error());
         }
         if (dev_parse == YACRD_OK) {
-            if (std::getenv("YACRD_CLI_TIMING")) std::fprintf(stderr, "[timing] device parser: %zu engine(s)\n", engines.size());
+            if (std::getenv("YACRD_CLI_TIMING")) std::fprintf(stderr, "[info] device parser: %zu engine(s)\n", engines.size());
             view.n_reads = dev_reads.n_reads;
             view.name_off = dev_reads.name_off;
             view.names = dev_reads.names;

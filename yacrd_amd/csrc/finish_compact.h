@@ -592,8 +592,8 @@ __global__ __launch_bounds__(kDeferThreads, YK_DEFER_SWEEP_OCC) void deferred_sw
 #endif // YK_DEFER_FILTER
 
 constexpr int kScanThreads = 1024;
-// PER consecutive reads per thread: 4, or 8 for batches of kPlanLongReads reads and more (half the tickets and half the
-// look-back chain again: configs[4] 1 221 -> 611 workgroups)
+// PER consecutive reads per thread.  4; 8 (half the tickets and half the look-back chain again: configs[4] 1 221 -> 611
+// workgroups) measured 65.1 us against 55.6 on configs[4], profiles/r05/m_*: the engine instantiates <4> only.
 template <int PER>
 __global__ __launch_bounds__(kScanThreads) void scan_compact_kernel(CompactArgs2 c)
 {

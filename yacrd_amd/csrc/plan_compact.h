@@ -10,7 +10,6 @@ namespace yk {
 // per workgroup.  (One LDS atomic per read serialised 1024 lanes on one address: 8 us -> 3 us.)
 constexpr int kPlanBlock = 1024; // threads; a workgroup takes PER slabs of 1024 consecutive reads (PER reads per thread)
 constexpr u32 kPlanSmallReads = 400000; // batches below this: PER = 1
-constexpr u32 kPlanLongReads = 3000000; // batches from this on: PER = 8 (round 5; configs[4]: 1 221 -> 611 workgroups)
 #ifndef YK_PLAN_SMALL_BLOCK
 #define YK_PLAN_SMALL_BLOCK 1024
 #endif

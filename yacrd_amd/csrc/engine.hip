@@ -72,15 +72,6 @@ static uint64_t split_min_reads()
     return v;
 }
 
-static int screen_items_override()
-{
-    static const int v = [] {
-        const char *e = std::getenv("YACRD_SCREEN_ITEMS");
-        return e ? std::atoi(e) : 0;
-    }();
-    return v;
-}
-
 static uint64_t fused_grid_mult()
 {
     static const uint64_t v = [] {
@@ -601,10 +592,9 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
             // hundreds of positions need them (configs[1] at sigma = 100: 79 % decided against 95 %; configs[2] at 300: 79 %
             // against 97 %), reads that do not are a tenth faster without (conclude_run: wide_left)
             const bool wide = defer && !(e->flags & YACRD_F_SCREEN_ITEMS_2) && ((e->flags & YACRD_F_SCREEN_WIDE) || e->wide_left > 0);
-            int items = !defer ? 1
+            const int items = !defer ? 1
                               : (wide || (e->flags & YACRD_F_SCREEN_ITEMS_1)) ? 1
                               : ((e->flags & YACRD_F_SCREEN_ITEMS_2) || fused_iv >= 40000000ull) ? 2 : 1;
-            if (items == 2 && screen_items_override() == 3) items = 3; // (A/B: YACRD_SCREEN_ITEMS=3)
             e->last_items = (uint32_t)items;
             e->last_wide = wide;
             fa.base.over_list = nullptr; // (the deferring build marks its reads in counts[])
@@ -641,11 +631,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
                 // start / stop events attached to the launch itself (hipExtLaunchKernelGGL): the
                 // kernel's own dispatch timestamps, no event packets before and after it
                 const bool chain = (e->flags & YACRD_F_SWEEP_TURNS) && (shared || lane.n_engines > 1);
-                if (defer && items == 3)
-                    hipExtLaunchKernelGGL(yk::sweep_small_fused_defer3_kernel, dim3(blocks), dim3(64), 0,
-                                          e->stream, mark ? e->ev_cls[22] : (hipEvent_t) nullptr,
-                                          (mark || chain) ? e->ev_cls[23] : (hipEvent_t) nullptr, 0, fa);
-                else if (defer && items == 2)
+                if (defer && items == 2)
                     hipExtLaunchKernelGGL(yk::sweep_small_fused_defer2_kernel, dim3(blocks), dim3(64), 0,
                                           e->stream, mark ? e->ev_cls[22] : (hipEvent_t) nullptr,
                                           (mark || chain) ? e->ev_cls[23] : (hipEvent_t) nullptr, 0, fa);

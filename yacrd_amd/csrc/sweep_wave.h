@@ -1331,14 +1331,6 @@ __global__ __launch_bounds__(64, YK_DEFER2_OCC) void sweep_small_fused_defer2_ke
 {
     sweep_small_fused_body<true, 1, 2>(f);
 }
-// ... and with three (round 5, A/B: YACRD_SCREEN_ITEMS=3)
-#ifndef YK_DEFER3_OCC
-#define YK_DEFER3_OCC YK_DEFER2_OCC
-#endif
-__global__ __launch_bounds__(64, YK_DEFER3_OCC) void sweep_small_fused_defer3_kernel(FusedArgs f)
-{
-    sweep_small_fused_body<true, 1, 3>(f);
-}
 __global__ __launch_bounds__(64 * kFusedWaves, 5) void sweep_small_fused_kernel(FusedArgs f)
 {
     sweep_small_fused_body<false, kFusedWaves>(f);

@@ -167,3 +167,64 @@ def test_the_parsers_sort_on_its_own(engines):
         k, v = e.debug_sort_pairs(keys, vals, bound)
         order = np.argsort(keys, kind="stable")
         assert np.array_equal(k, keys[order]) and np.array_equal(v, vals[order]), (n, bits)
+
+
+_RANGE_FUZZ = r"""
+import os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import oracle, yacrd_amd
+from cases import assert_same
+from test_gpu_ingest import _random_paf
+# YACRD_TEST_RANGE_BYTES=32768 (this process): the ranges are cut every 32 KiB, so random texts of a few thousand lines fall
+# into 2..5 ranges with their lines — CRLF, empty lines, multi-byte ids, trailing columns — wherever the cuts happen to be
+rng = np.random.default_rng(int(sys.argv[2]))
+engines = [yacrd_amd.Engine() for _ in range(5)]
+taken = fell_back = cut = 0
+for case in range(120):
+    anomaly = 0 if case % 3 else int(rng.integers(1, 9))
+    text = _random_paf(rng, int(rng.integers(1200, 5000)), anomaly)
+    raw = text.encode("utf-8")
+    n = int(rng.integers(2, 6))
+    cov = int(rng.integers(0, 4))
+    try:
+        one = engines[0].ingest_text(raw, cov, 0.4)
+    except yacrd_amd.NeedsHostParser:
+        one = None
+    try:
+        got = yacrd_amd.ingest_overlaps(engines[:n], raw, cov, 0.4)
+    except yacrd_amd.NeedsHostParser:
+        got = None
+    assert (one is None) == (got is None), "case %d: one engine %s, %d engines %s" % (case, one is not None, n, got is not None)
+    if one is None:
+        fell_back += 1
+        assert anomaly != 0
+        continue
+    taken += 1
+    cut += len(raw) > 2 * 32768
+    assert got[1] == one[1] and np.array_equal(got[2], one[2]), "case %d: names / lengths" % case
+    assert got[3]["n_records"] == one[3]["n_records"]
+    assert_same(got[0], one[0], "case %d, %d engines" % (case, n))
+    if case % 10 == 0:  # ... and the one-engine result against the oracle's ingest + sweep
+        w_names, off, iv, ln = oracle.to_csr(oracle.parse_paf(text))
+        assert one[1] == list(w_names)
+        assert_same(one[0], oracle.run(off, iv, ln, cov, 0.4, n_threads=2), "case %d vs oracle" % case)
+print("RANGE_FUZZ", taken, fell_back, cut)
+"""
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_random_texts_cut_every_32_kib(tmp_path, seed):
+    """Differential fuzz of the range logic: the N-engine call against the one-engine call on random texts, the ranges cut
+    every 32 KiB (YACRD_TEST_RANGE_BYTES) — same reads, lengths, regions, types, and the same texts handed to the host parser."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "range_fuzz.py"
+    script.write_text(_RANGE_FUZZ)
+    p = subprocess.run([sys.executable, str(script), root, str(seed)], env=dict(os.environ, YACRD_TEST_RANGE_BYTES="32768"),
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    last = [l for l in p.stdout.splitlines() if l.startswith("RANGE_FUZZ")][-1].split()
+    taken, fell_back, cut = int(last[1]), int(last[2]), int(last[3])
+    assert taken >= 70 and fell_back >= 10 and cut >= 50, last

@@ -1099,7 +1099,12 @@ int ingest_text_group(yacrd_engine *const *E, uint32_t N, const TextSource &src,
                       double not_coverage, yacrd_result *out, yacrd_reads *reads, yacrd_ingest_stats *stats)
 {
     // ---- byte ranges: whole 4 MiB chunks (the parse's segments begin on tile boundaries), the same number for every engine
-    constexpr u64 kChunk = (u64)4 << 20;
+    // (YACRD_TEST_RANGE_BYTES, tests: a smaller grain — a multiple of the parse's 32 KiB tiles — so that small texts are cut too)
+    static const u64 kChunk = [] {
+        const char *ev = std::getenv("YACRD_TEST_RANGE_BYTES");
+        const u64 v = ev ? std::strtoull(ev, nullptr, 10) : 0;
+        return (v >= (u64)yk::kGpTile && v % (u64)yk::kGpTile == 0) ? v : ((u64)4 << 20);
+    }();
     const u64 chunks = (n + kChunk - 1) / kChunk, per = (chunks + N - 1) / N;
     std::vector<u64> B(N + 1);
     for (uint32_t d = 0; d <= N; d++) B[d] = std::min<u64>(n, (u64)d * per * kChunk);

@@ -253,8 +253,10 @@ __global__ __launch_bounds__(kWsT, YK_WG_OCC) void screen_wg_fused_kernel(Screen
     const u32 list_n = *a.list_n;
     // ---- the share, then the queue: two loops.  Round 5 measured three other shapes of this kernel on configs[3]
     // (profiles/r05/e_*, f_*; this form: 0.221-0.229 ms):
-    //  * the next read's list entry, extent and length asked for a turn ahead: 0.232-0.234 (the two round trips it saves are
-    //    hidden by the CU's other workgroup already);
+    //  * the next read's list entry, extent and length asked for a turn ahead: 0.232-0.234 — and, asked through VGPR indices
+    //    and kept per lane so that the compiler does not wait for them on the spot (a turn then waits for ONE round trip, its
+    //    intervals', instead of three): 0.220-0.225 against 0.220-0.223, profiles/r05/p_* (the round trips it saves are hidden
+    //    by the CU's other workgroup already);
     //  * one loop, the queue looked at between the turns so that a fallback read (a ~50 us chain) starts while others still
     //    screen: 0.313-0.316 — the sort's registers and the screen's live side by side (44 bytes of scratch per thread), and
     //    a workgroup that takes a fallback read early delays its own share by as much as it saves the tail;

@@ -11,7 +11,10 @@
 //
 // Sequence formats follow what the reference's golden files pin for noodles 0.84: FASTQ
 // "@name[ description]\nseq\n+\nqual\n"; FASTA ">name[ description]\n" + sequence wrapped at 80
-// columns (the wrap width is unpinned by the reference's tests).
+// columns — the published default of the third-party writer the reference calls with no options
+// (noodles::fasta::Writer::new, src/editor/scrubbing.rs:84; Cargo.lock pins noodles 0.84.0 /
+// noodles-fasta 0.45.0, whose writer builder defaults to 80 bases a line; the crate is not vendored in
+// /root/reference and the reference's own fixtures hold no FASTA sequence beyond 22 bases).
 #include "../../../include/yacrd_host.h"
 #include "host_common.h"
 

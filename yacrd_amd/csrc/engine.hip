@@ -61,8 +61,8 @@ namespace {
 
 // finish the deferred reads + scan + compact + classify: one kernel (finish_compact.h), then the totals
 // come home.  `sa` carries the run's inputs, stage / counts and the small classes' rejection list.
-// Batches of this many reads and more take the follow-on step as two kernels (finish_compact.h: deferred_sweep_kernel
-// + scan_compact_kernel); YACRD_SPLIT_MIN_READS overrides (A/B: 0 = always, a huge number = never).
+// Batches of this many reads and more take the follow-on step as kernels of its own (finish_compact.h: mark_list_kernel +
+// deferred_list_kernel + scan_compact_kernel); YACRD_SPLIT_MIN_READS overrides (A/B: 0 = always, a huge number = never).
 static uint64_t split_min_reads()
 {
     static const uint64_t v = [] {
@@ -103,9 +103,20 @@ int launch_compact(yacrd_engine *e, const yk::SweepArgs &sa, u32 n_reads, double
     ca.read_type = e->read_type.as<uint8_t>();
     if ((uint64_t)n_reads >= split_min_reads()) {
         ca.host_ctr = e->h_ctr;
-        if (screened)
-            hipLaunchKernelGGL(yk::deferred_sweep_kernel, dim3((n_reads + yk::kDeferSlab - 1) / yk::kDeferSlab), dim3(yk::kDeferThreads), 0,
-                               e->stream, ca.sweep, n_reads);
+        if (screened) {
+            // the marks listed, the list dealt out evenly over a grid that is resident as a whole (finish_compact.h)
+            const u32 slabs = (n_reads + yk::kMarkReads - 1) / yk::kMarkReads;
+            yk::DeferList dl;
+            dl.shard_cap = (slabs / yk::kDeferShards + 1u) * (u32)yk::kMarkReads;
+            HIP_TRY(e->dlist.reserve((size_t)yk::kDeferShards * dl.shard_cap * sizeof(u32)));
+            dl.list = e->dlist.as<u32>();
+            dl.count = reinterpret_cast<u32 *>(ca.scan_state + nb);
+            if (e->compact_calls++) // (a redo of the follow-on step: the list starts over)
+                HIP_TRY(hipMemsetAsync(dl.count, 0, (size_t)yk::kDeferShards * yk::kDeferShardStride * sizeof(u32), e->stream));
+            hipLaunchKernelGGL(yk::mark_list_kernel, dim3(slabs), dim3(yk::kMarkThreads), 0, e->stream, ca.sweep.counts, n_reads, dl);
+            hipLaunchKernelGGL(yk::deferred_list_kernel, dim3((u32)e->num_cu * (u32)(YK_LIST_OCC * 256 / yk::kListThreads)), dim3(yk::kListThreads), 0,
+                               e->stream, ca.sweep, dl);
+        }
         // (eight reads per thread: 65.1 us against 55.6 on configs[4], profiles/r05/m_*: half the tickets, but twice the latency chain per thread)
         hipLaunchKernelGGL(yk::scan_compact_kernel<4>, dim3((n_reads + 4 * yk::kScanThreads - 1) / (4 * yk::kScanThreads)), dim3(yk::kScanThreads), 0, e->stream, ca);
         return YACRD_OK;
@@ -411,7 +422,10 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     const u32 nb = one_launch ? 2 * ob_slabs : (n_reads + yk::kScanBlock - 1) / yk::kScanBlock;
     constexpr int kLists = yk::CLS_COUNT + 7; // class lists + three rejection lists + M2 overflow + what the screens leave of M1 / M2 / BIG
     HIP_TRY(e->lists.reserve((size_t)kLists * n_reads * sizeof(u32)));
-    const size_t ctrl_bytes = (sizeof(yk::Counters) + (size_t)nb * sizeof(u64) + 255) & ~(size_t)255;
+    // (long batches: + the shard counters of the follow-on step's list of marked reads, behind the scan words)
+    const size_t shard_ctr_bytes = (!one_launch && n_reads64 >= split_min_reads()) ? (size_t)yk::kDeferShards * yk::kDeferShardStride * sizeof(u32) : 0;
+    const size_t ctrl_bytes = (sizeof(yk::Counters) + (size_t)nb * sizeof(u64) + shard_ctr_bytes + 255) & ~(size_t)255;
+    e->compact_calls = 0;
     e->ctrl_cur ^= 1;
     const int cur = e->ctrl_cur, other = cur ^ 1;
     for (int i = 0; i < 2; i++) {
@@ -1315,7 +1329,7 @@ void yacrd_engine_destroy(yacrd_engine *e)
     DevBuf *bufs[] = {&e->in_off, &e->in_iv, &e->in_len, &e->lists, &e->ctrl2[0], &e->ctrl2[1], &e->stage,
                       &e->counts, &e->closed, &e->gen_sizes, &e->gen_scratch_off,
                       &e->gen_scratch, &e->big_tab, &e->big_keys, &e->big_redo, &e->bt_tab, &e->bt_hist, &e->bt_cur, &e->bt_keys, &e->bs_seg, &e->bs_chunk, &e->bs_hist,
-                      &e->bad_offsets, &e->bad_regions, &e->read_type};
+                      &e->bad_offsets, &e->bad_regions, &e->read_type, &e->dlist};
     for (DevBuf *b : bufs) b->release();
     if (e->h_ctr) (void)hipHostFree(e->h_ctr);
     if (e->h_out) (void)hipHostFree(e->h_out);

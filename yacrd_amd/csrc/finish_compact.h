@@ -257,116 +257,12 @@ __global__ __launch_bounds__(kScanBlock, YK_FINISH_OCC) void finish_compact_kern
 // (First attempt, same log: the marked reads through the sorting build's code — sweep_group_read<32 | 16, 16>, two or
 // four reads per wavefront behind the bin filter — 0.190 ms for configs[2]'s 47 600 reads: per read that code is
 // no cheaper than the 64-lane sort, and pairs / quadruples fill badly from a list of two dozen.)
-// ---- a marked read through the pile-trimming filter (§3.5) and a SHORT register sort (round 4) -------------------
-// The 64-lane sort of a marked read is 847 instructions, most of them spent ordering events that cannot matter: of a
-// chimera's ~400 events the filter keeps the c + 1 outermost of the piles at 0 / len and what lies around the junction —
-// 60-100 keys: one or two per lane instead of eight.  LdsTrim<64, kTrimWords>: 32 one-position bins at either end of the
-// read, up to 64 coarse bins in between, two bins per lane; the plan (lds_trim_plan, sweep_lds.h) is the workgroup classes'
-// with one wavefront as the "workgroup"; the survivors go from LDS into registers — K' = 1, 2, 4 or 8 keys per lane by their
-// number — and through sweep_group_keys, the register classes' sort + sweep.  Plain reads only (start < end <= len):
-// anything else takes the full sort (finish_item).  false = not taken.
-constexpr int kTrimWords = 1280; // per wavefront: 640 survivors at most | 128 zero-length counters | 128 bins x 4 counters
-template <int KP>
-__device__ __forceinline__ void trimmed_keys_sweep(const u32 *keys, u32 m_sort, u32 len, i32 c, u32 rr, const SweepArgs &a, const LaneConst &lc)
-{
-    u32 x[KP];
-    const u32 lane = lane_id();
-#pragma unroll
-    for (int q = 0; q < KP; q++) {
-        const u32 i = lane * (u32)KP + (u32)q;
-        x[q] = i < m_sort ? keys[i] : kPadKey;
-    }
-    sweep_group_keys<64, KP, 0>(x, m_sort, len, c, true, rr, 0ull, 0ull, false, a, lc);
-}
-__device__ __forceinline__ bool trim_item(const SweepArgs &a, u32 rr, u64 o, u32 n, u32 len, u32 *keys, const LaneConst &lc)
-{
-    using F = LdsTrim<64, kTrimWords>;
-    if (len > kMaxKeyPos || n < 2u || !a.prefilter) return false; // (uniform)
-    const u32 lane = lane_id();
-    const typename F::Geo geo = F::geo(len);
-    u32 *tab = F::tab(keys);
-    reinterpret_cast<uint4 *>(tab)[2 * lane] = make_uint4(0u, 0u, 0u, 0u);
-    reinterpret_cast<uint4 *>(tab)[2 * lane + 1] = make_uint4(0u, 0u, 0u, 0u);
-    reinterpret_cast<uint2 *>(F::ztab(keys))[lane] = make_uint2(0u, 0u);
-    const uint2 *iv = a.iv + o;
-    uint2 v[4];
-    bool real[4];
-    u32 irregular = 0;
-#pragma unroll
-    for (int j = 0; j < 4; j++) v[j] = iv[min(lane + 64u * (u32)j, n - 1u)];
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        real[j] = lane + 64u * (u32)j < n;
-        irregular |= (real[j] && (v[j].x >= v[j].y || v[j].y > len)) ? 1u : 0u;
-    }
-    if (__builtin_amdgcn_ballot_w64(irregular != 0) != 0) return false; // (uniform: the full sort knows every kind of interval)
-    wave_lds_sync();
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        if (real[j]) {
-            const u32 ks = (v[j].x << kKeyShift) | 3u, ke = v[j].y << kKeyShift;
-            atomicAdd(tab + F::idx(geo, ks) * 4u + (lane & 3u), 1u);
-            atomicAdd(tab + F::idx(geo, ke) * 4u + (lane & 3u), 0x10000u);
-        }
-    }
-    wave_lds_sync();
-    u32 syn_start = 0;
-    const u32 m_sort = lds_trim_plan<64, kTrimWords>(keys, len, a.cov, nullptr, syn_start);
-    if (m_sort == 0 || m_sort > 512u) return false; // (uniform; counts[rr] is still the mark: the caller sorts the read whole)
-    auto take = [&](u32 *cur) -> u32 {
-        return (i32)*reinterpret_cast<volatile u32 *>(cur) >= 0x10000 ? atomicAdd(cur, F::kTakeOne) : 0u;
-    };
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        if (real[j]) {
-            const u32 ks = (v[j].x << kKeyShift) | 3u, ke = v[j].y << kKeyShift;
-            const u32 is = F::idx(geo, ks), ie = F::idx(geo, ke);
-            const u32 ps = take(tab + is * 4u + (F::uniform(geo, is) ? 1u : (lane & 3u)));
-            const u32 pe = take(tab + ie * 4u + (F::uniform(geo, ie) ? 0u : (lane & 3u)));
-            if ((i32)ps >= 0x10000) keys[ps & 0xFFFFu] = ks; // quota left: kept, at the slot in the low half
-            if ((i32)pe >= 0x10000) keys[pe & 0xFFFFu] = ke;
-        }
-    }
-    wave_lds_sync();
-    const i32 c = (i32)min(a.cov, 0x3FFFFFFFu);
-    if (m_sort <= 64u) trimmed_keys_sweep<1>(keys, m_sort, len, c, rr, a, lc);
-    else if (m_sort <= 128u) trimmed_keys_sweep<2>(keys, m_sort, len, c, rr, a, lc);
-    else if (m_sort <= 256u) trimmed_keys_sweep<4>(keys, m_sort, len, c, rr, a, lc);
-    else trimmed_keys_sweep<8>(keys, m_sort, len, c, rr, a, lc);
-    return true;
-}
-
-// reads per slab / threads per workgroup (follow-on step on configs[2] / configs[4], profiles/r04/i_ab_deferred_slab_size.log):
-// 256 / 256: 0.231 / 0.541 ms; 512 / 256: 0.158 / 0.347; 1024 / 256: 0.152 / 0.297; 2048 / 512: 0.134 / 0.283 — longer lists
-// fill the wavefronts' turns evenly and fewer workgroups post the two counter atomics
-#ifndef YK_DEFER_SLAB
-#define YK_DEFER_SLAB 2048
-#endif
-#ifndef YK_DEFER_THREADS
-#define YK_DEFER_THREADS 512
-#endif
-constexpr int kDeferSlab = YK_DEFER_SLAB, kDeferThreads = YK_DEFER_THREADS; // (A/B: profiles/r04)
-static_assert(kDeferSlab % kDeferThreads == 0 && kDeferSlab <= 65536, "a thread looks at whole reads; list entries hold a 16-bit index");
-
-#ifndef YK_DEFER_TRIM
-// The marked reads through the pile-trimming filter and a short sort first (trim_item): bit-exact (GPU tests and fuzz with
-// the two-kernel follow-on forced), and no faster — the filter's two counting passes, its plan and the scatter cost what the
-// shorter sort saves: 43.6 M VALU instructions against 40.3 M for configs[2]'s 47 608 reads, the follow-on step 0.173 against
-// 0.155 ms (profiles/r04/g_ab_trimmed_deferred_sweep.log; round 2 found the same inside the register-sort kernel).  Off.
-#define YK_DEFER_TRIM 0
-#endif
-#ifndef YK_DEFER_FILTER
-// The marked reads through the FILTERED exact sweep first (sweep_filtered.h, round 5): two (129..256 intervals) or four
-// (<= 128) reads per wavefront and turn; what it does not take — not plain, an interval shorter than the screen's window,
-// a window short of c + 1, more than 128 kept events: ~15 % of the generator's deferred reads — is listed again and
-// sorted whole, one read per wavefront, as before.  0 builds round 4's kernel.
-#define YK_DEFER_FILTER 1
-#endif
+// (Round 4 also sent the marked reads through the pile-trimming filter (§3.5) and a SHORT register sort first: bit-exact
+// and no faster — the filter's two counting passes, its plan and the scatter cost what the shorter sort saved, 43.6 M VALU
+// instructions against 40.3 M for configs[2]'s 47 608 reads, profiles/r04/g_ab_trimmed_deferred_sweep.log; the code went
+// when round 5's filtered exact sweep, sweep_filtered.h, took its place.)
 #ifndef YK_DEFER_SWEEP_OCC
-// wavefronts per SIMD the register budget allows.  Without the trimming path: 8 / 6 / 5 gave 0.164 / 0.158 / 0.159 ms of
-// follow-on time on configs[2] (profiles/r04/c_ab_follow_on.log); with it the kernel wants 128 registers.  The filtered
-// sweep (32-lane groups only, 3 KB of tables per wavefront, 8-byte list entries: 44 KB per workgroup) keeps three workgroups per CU.
-#define YK_DEFER_SWEEP_OCC (YK_DEFER_TRIM ? 4 : 6)
+#define YK_DEFER_SWEEP_OCC 6 // wavefronts per SIMD the sweep kernel's register budget allows (80 VGPRs)
 #endif
 
 // One turn of the filtered sweep: this lane group's read (active: it has one) — loads and tests as screen_reads', then
@@ -407,189 +303,139 @@ __device__ __forceinline__ bool filtered_turn(const SweepArgs &a, bool active, u
     }
     return filtered_group_sweep<LANES, WPB, TABW>(a, v, real0, real1, r, o, n, len, c, pmin, pmax, !girr, lc);
 }
-#if YK_DEFER_FILTER
-// (round 5) The marked reads of a slab — listed in LDS with their intervals and length, eight bytes each — go through the
-// filtered exact sweep two per wavefront and turn, on 32-lane groups whatever their size (a read of <= 128 intervals on 16
-// lanes would share its turn with three others, but its table — 5 KB per wavefront instead of 3 — costs the kernel a
-// workgroup per CU: deferred_sweep_kernel serves long batches, and with lists of 16-byte entries and 5 KB tables it was
-// no faster than round 4's on configs[4], 0.291 against 0.282 ms of follow-on step, for all its 33 % fewer VALU
-// instructions: profiles/r05/c_ab_deferred_filtered_2048_1024_none.log); what the filter does not take is listed again and
-// sorted whole, one read per wavefront.
-__global__ __launch_bounds__(kDeferThreads, YK_DEFER_SWEEP_OCC) void deferred_sweep_kernel(SweepArgs a, u32 n_reads)
+// ==== the follow-on step's sweep over a LIST of the marked reads (round 5) ===============================================
+// Round 4's deferred_sweep_kernel (and this round's first filtered form of it) gave every slab of 2048 reads to one
+// workgroup: a slab's ~49 marked reads are 25 pairs for eight wavefronts — four turns of which the last keeps one wavefront
+// busy — then a barrier, then the ~7 reads the filter did not take; 2 442 such workgroups ran in 3.2 rounds on the 768 that
+// fit.  PMC: 46 % of the wave slots occupied on average (profiles/r05/b_*).  Here the marks are LISTED first
+// (mark_list_kernel: 4096 reads per workgroup, one returning atomic per workgroup on one of kDeferShards counters: shard =
+// workgroup & 255, a cache line each; 9 us for 5 M reads) and the list is dealt out evenly: workgroup w of a grid that is
+// resident as a whole takes entries [w, w + 1) * ceil(total / grid) of the shards laid end to end, 512 at a time, two per
+// wavefront and turn through the filtered sweep, what the filter leaves one per wavefront at the end of every 512.
+// configs[2]: follow-on step 0.126-0.130 -> 0.107-0.109 ms; configs[4]: 0.250-0.262 -> 0.237-0.258 (profiles/r05/q_*;
+// 512 / 256 threads and occupancy 6 / 5: the same).  The marks stay the truth: a redo of the follow-on step lists what is
+// still marked.
+constexpr u32 kDeferShards = 256, kDeferShardStride = 16; // (words between two shards' counters)
+struct DeferList {
+    u32 *list;      // [kDeferShards][shard_cap] read ids
+    u32 *count;     // [kDeferShards * kDeferShardStride]
+    u32 shard_cap;
+};
+constexpr int kMarkThreads = 1024, kMarkReads = 4 * kMarkThreads;
+__global__ __launch_bounds__(kMarkThreads) void mark_list_kernel(const u32 *__restrict__ counts, u32 n_reads, DeferList dl)
 {
-    constexpr u32 kWaves = kDeferThreads / 64;
-    constexpr int kTabWords = 2 * (2 * kScreenWindow + 32) * 4; // two 32-lane groups
-    __shared__ uint2 s_list[kDeferSlab]; // index inside the slab | intervals << 16, length
-    __shared__ unsigned short s_fb[kDeferSlab];
-    __shared__ u32 s_n, s_nfb;
-    __shared__ unsigned long long s_iv;
-    if (threadIdx.x == 0) s_n = 0, s_nfb = 0, s_iv = 0;
+    __shared__ u32 s_ids[kMarkReads];
+    __shared__ u32 s_n, s_base;
+    if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    const u32 lane = lane_id();
-    const u32 slab0 = blockIdx.x * (u32)kDeferSlab;
-    constexpr int PER = kDeferSlab / kDeferThreads;
+    const u64 r0 = (u64)blockIdx.x * kMarkReads + threadIdx.x * 4u;
+    u32 g[4] = {0, 0, 0, 0};
+    if (r0 + 4 <= n_reads) {
+        const uint4 g4 = *reinterpret_cast<const uint4 *>(counts + r0); // (engine-owned: 256-byte aligned)
+        g[0] = g4.x, g[1] = g4.y, g[2] = g4.z, g[3] = g4.w;
+    } else {
 #pragma unroll
-    for (int k = 0; k < PER; k++) {
-        const u32 i = (u32)k * kDeferThreads + threadIdx.x, r = slab0 + i;
-        const bool marked = r < n_reads && a.counts[r] == kDeferredMark;
-        const u64 mm = __builtin_amdgcn_ballot_w64(marked);
-        if (mm == 0) continue; // (uniform in the wavefront)
-        u32 n = 0, len0 = 0;
-        if (marked) {
-            n = (u32)(a.off[r + 1] - a.off[r]);
-            len0 = a.len[r];
+        for (int k = 0; k < 4; k++) g[k] = r0 + k < n_reads ? counts[r0 + k] : 0u;
+    }
+    u32 mine = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) mine += g[k] == kDeferredMark ? 1u : 0u;
+    if (__builtin_amdgcn_ballot_w64(mine != 0) != 0) { // (uniform in the wavefront; 2-3 % of the reads are marked)
+        u32 incl = mine; // wavefront-inclusive count, then one LDS atomic per wavefront
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 t = (u32)__shfl_up((int)incl, d, 64);
+            if ((int)lane_id() >= d) incl += t;
         }
         u32 base = 0;
-        if (lane == (u32)__builtin_ctzll(mm)) base = atomicAdd(&s_n, (u32)__builtin_popcountll(mm));
-        base = (u32)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(mm));
-        if (marked) s_list[base + (u32)__builtin_popcountll(mm & ((1ull << lane) - 1ull))] = make_uint2(i | (n << 16), len0);
-        u64 iv = n; // intervals of the marked reads, for the roofline's exact byte count
+        if (lane_id() == 63u) base = atomicAdd(&s_n, incl);
+        base = (u32)__shfl((int)base, 63, 64);
+        u32 at = base + incl - mine;
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) iv += __shfl_xor(iv, d, 64);
-        if (lane == 0) atomicAdd(&s_iv, (unsigned long long)iv);
+        for (int k = 0; k < 4; k++)
+            if (g[k] == kDeferredMark) s_ids[at++] = (u32)(r0 + k);
     }
     __syncthreads();
-    const u32 n_marked = s_n;
-    if (n_marked == 0) return; // uniform in the workgroup
-    if (threadIdx.x == 0) {
-        atomicAdd(&a.ctr->deferred, n_marked);
-        atomicAdd((unsigned long long *)&a.ctr->deferred_iv, s_iv);
-    }
-    const LaneConst lcf = make_lane_const(lane);
-    const u32 wv = threadIdx.x >> 6;
-    for (u32 p0 = wv * 2u; p0 < n_marked; p0 += kWaves * 2u) { // (uniform in the wavefront)
-        const u32 p = p0 + (lane >> 5);
-        const bool have = p < n_marked;
-        const uint2 e = s_list[have ? p : p0];
-        const u32 rr = slab0 + (e.x & 0xFFFFu);
-        const u64 o = a.off[rr]; // (in the L2: the listing has just read it)
-        const bool done = filtered_turn<32, (int)kWaves, kTabWords>(a, have, rr, o, e.x >> 16, e.y, lcf);
-        if (have && !done && (lane & 31u) == 31u) s_fb[atomicAdd(&s_nfb, 1u)] = (unsigned short)p;
-    }
+    const u32 n = s_n;
+    if (n == 0) return; // (uniform)
+    const u32 shard = blockIdx.x & (kDeferShards - 1u);
+    if (threadIdx.x == 0) s_base = atomicAdd(dl.count + shard * kDeferShardStride, n);
     __syncthreads();
-    const u32 nfb = s_nfb;
-    for (u32 i = wv; i < nfb; i += kWaves) { // (uniform in the wavefront): sorted whole, one read per wavefront
-        const uint2 e = s_list[s_fb[i]];
-        const u32 rr = slab0 + (e.x & 0xFFFFu), n = e.x >> 16, len = e.y;
-        const u64 o = a.off[rr];
-        if (n > 128u) finish_item<8>(a.off, a.iv, a.len, a.stage, a.counts, a.rej_list, a.rej_count, a.ctr, a.cov, rr, o, n, len);
-        else finish_item<4>(a.off, a.iv, a.len, a.stage, a.counts, a.rej_list, a.rej_count, a.ctr, a.cov, rr, o, n, len);
-    }
+    const u32 b0 = s_base;
+    for (u32 i = threadIdx.x; i < n; i += kMarkThreads)
+        if (b0 + i < dl.shard_cap) dl.list[(size_t)shard * dl.shard_cap + b0 + i] = s_ids[i];
 }
-#else
-__global__ __launch_bounds__(kDeferThreads, YK_DEFER_SWEEP_OCC) void deferred_sweep_kernel(SweepArgs a, u32 n_reads)
-{
-    // what the thread that found the mark already knows about the read — offset, index inside the slab | intervals << 16,
-    // length — saves every turn a round trip: the long reads from the front, the others from the back
-    __shared__ u64 s_off[kDeferSlab];
-    __shared__ uint2 s_list[kDeferSlab];
-    __shared__ u32 s_n8, s_n4;
-    __shared__ unsigned long long s_iv;
-    if (threadIdx.x == 0) s_n8 = 0, s_n4 = 0, s_iv = 0;
-    __syncthreads();
-    const u32 lane = lane_id();
-    const u32 slab0 = blockIdx.x * (u32)kDeferSlab;
-    constexpr int PER = kDeferSlab / kDeferThreads;
-#pragma unroll
-    for (int k = 0; k < PER; k++) {
-        const u32 i = (u32)k * kDeferThreads + threadIdx.x, r = slab0 + i;
-        const bool marked = r < n_reads && a.counts[r] == kDeferredMark;
-        const u64 mm = __builtin_amdgcn_ballot_w64(marked);
-        if (mm == 0) continue; // (uniform in the wavefront)
-        u32 n = 0, len0 = 0;
-        u64 o0 = 0;
-        if (marked) {
-            o0 = a.off[r];
-            n = (u32)(a.off[r + 1] - o0);
-            len0 = a.len[r];
-        }
-        const bool big = marked && n > 128u; // (a marked read has at most 256 intervals)
-        const u64 mb = __builtin_amdgcn_ballot_w64(big), ms = mm & ~mb;
-        u32 bb = 0, bs = 0;
-        if (lane == (u32)__builtin_ctzll(mm)) {
-            if (mb) bb = atomicAdd(&s_n8, (u32)__builtin_popcountll(mb));
-            if (ms) bs = atomicAdd(&s_n4, (u32)__builtin_popcountll(ms));
-        }
-        bb = (u32)__builtin_amdgcn_readlane((int)bb, (int)__builtin_ctzll(mm));
-        bs = (u32)__builtin_amdgcn_readlane((int)bs, (int)__builtin_ctzll(mm));
-        const u64 below = (1ull << lane) - 1ull;
-        if (marked) {
-            const u32 at = big ? bb + (u32)__builtin_popcountll(mb & below)
-                               : (u32)kDeferSlab - 1u - (bs + (u32)__builtin_popcountll(ms & below));
-            s_list[at] = make_uint2(i | (n << 16), len0);
-            s_off[at] = o0;
-        }
-        u64 iv = n; // intervals of the marked reads, for the roofline's exact byte count
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) iv += __shfl_xor(iv, d, 64);
-        if (lane == 0) atomicAdd(&s_iv, (unsigned long long)iv);
-    }
-    __syncthreads();
-    const u32 n8 = s_n8, n4 = s_n4, n_marked = n8 + n4;
-    if (n_marked == 0) return; // uniform in the workgroup
-    if (threadIdx.x == 0) {
-        atomicAdd(&a.ctr->deferred, n_marked);
-        atomicAdd((unsigned long long *)&a.ctr->deferred_iv, s_iv);
-    }
-    constexpr u32 kWaves = kDeferThreads / 64;
-#if YK_DEFER_TRIM
-    __shared__ __attribute__((aligned(16))) u32 s_trim[kWaves][kTrimWords];
-    const LaneConst lc = make_lane_const(lane);
+
+#ifndef YK_LIST_THREADS
+#define YK_LIST_THREADS 512
 #endif
-#if 0
-    // ---- first the filtered sweep, several reads per wavefront and turn; what it leaves is listed in s_fb
-    __shared__ unsigned short s_fb[kDeferSlab];
+#ifndef YK_LIST_OCC
+#define YK_LIST_OCC YK_DEFER_SWEEP_OCC
+#endif
+constexpr int kListThreads = YK_LIST_THREADS;
+__global__ __launch_bounds__(kListThreads, YK_LIST_OCC) void deferred_list_kernel(SweepArgs a, DeferList dl)
+{
+    constexpr u32 kWaves = kListThreads / 64;
+    constexpr int kTabWords = 2 * (2 * kScreenWindow + 32) * 4; // two 32-lane groups
+    static_assert(kDeferShards <= (u32)kListThreads, "one thread per shard counter");
+    __shared__ u32 s_pre[kDeferShards + 1];
+    __shared__ u32 sc[kWaves + 1];
+    __shared__ uint4 s_list[kListThreads]; // read, intervals, length
+    __shared__ unsigned short s_fb[kListThreads];
     __shared__ u32 s_nfb;
+    __shared__ unsigned long long s_iv;
+    const u32 tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    u32 total;
     {
-        if (threadIdx.x == 0) s_nfb = 0;
-        __syncthreads();
-        const LaneConst lcf = make_lane_const(lane);
-        const u32 wv = threadIdx.x >> 6;
-        auto turn = [&](auto lanes_tag, u32 p, bool have, u32 at) {
-            constexpr int LANES = decltype(lanes_tag)::value;
-            const uint2 e = s_list[have ? at : 0u];
-            const u64 o = s_off[have ? at : 0u];
-            const bool done = filtered_turn<LANES, (int)kWaves>(a, have, slab0 + (e.x & 0xFFFFu), o, e.x >> 16, e.y, lcf);
-            if (have && !done && (lane & (u32)(LANES - 1)) == (u32)(LANES - 1)) s_fb[atomicAdd(&s_nfb, 1u)] = (unsigned short)at;
-            (void)p;
-        };
-        for (u32 p0 = wv * 2u; p0 < n8; p0 += kWaves * 2u) { // (uniform in the wavefront)
-            const u32 p = p0 + (lane >> 5);
-            turn(std::integral_constant<int, 32>{}, p, p < n8, p);
+        const u32 cnt = tid < kDeferShards ? min(dl.count[tid * kDeferShardStride], dl.shard_cap) : 0u;
+        const u32 ex = block_excl_add<kListThreads>(cnt, sc, total);
+        if (tid < kDeferShards) s_pre[tid] = ex;
+        if (tid == 0) s_pre[kDeferShards] = total;
+    }
+    const u32 per = (total + gridDim.x - 1u) / gridDim.x;
+    const u32 lo = min(total, blockIdx.x * per), hi = min(total, lo + per);
+    if (lo >= hi) return; // (uniform)
+    const LaneConst lcf = make_lane_const(lane);
+    if (tid == 0) s_iv = 0;
+    for (u32 c0 = lo; c0 < hi; c0 += (u32)kListThreads) { // (uniform)
+        if (tid == 0) s_nfb = 0;
+        __syncthreads(); // (s_pre is written; the last round's lists are done with)
+        const u32 e = c0 + tid, n_here = min((u32)kListThreads, hi - c0);
+        if (e < hi) {
+            u32 s = 0; // the shard that holds entry e: the last one whose first entry is <= e
+#pragma unroll
+            for (u32 step = kDeferShards / 2; step > 0; step >>= 1)
+                if (s_pre[s + step] <= e) s += step;
+            const u32 r = dl.list[(size_t)s * dl.shard_cap + (e - s_pre[s])];
+            const u64 o = a.off[r];
+            const u32 n = (u32)(a.off[r + 1] - o);
+            s_list[tid] = make_uint4(r, n, a.len[r], 0u);
+            atomicAdd(&s_iv, (unsigned long long)n); // (intervals of the marked reads, for the roofline's exact byte count)
         }
-        for (u32 p0 = wv * 4u; p0 < n4; p0 += kWaves * 4u) {
-            const u32 p = p0 + (lane >> 4);
-            turn(std::integral_constant<int, 16>{}, p, p < n4, (u32)kDeferSlab - 1u - p);
+        __syncthreads();
+        for (u32 p0 = wv * 2u; p0 < n_here; p0 += kWaves * 2u) { // (uniform in the wavefront)
+            const u32 p = p0 + (lane >> 5);
+            const bool have = p < n_here;
+            const uint4 q = s_list[have ? p : p0];
+            const u64 o = a.off[q.x]; // (in the L2: the listing has just read it)
+            const bool done = filtered_turn<32, (int)kWaves, kTabWords>(a, have, q.x, o, q.y, q.z, lcf);
+            if (have && !done && (lane & 31u) == 31u) s_fb[atomicAdd(&s_nfb, 1u)] = (unsigned short)p;
         }
         __syncthreads();
         const u32 nfb = s_nfb;
         for (u32 i = wv; i < nfb; i += kWaves) { // (uniform in the wavefront): sorted whole, one read per wavefront
-            const u32 at = s_fb[i];
-            const uint2 e = s_list[at];
-            const u32 rr = slab0 + (e.x & 0xFFFFu), n = e.x >> 16, len = e.y;
-            const u64 o = s_off[at];
-            if (n > 128u) finish_item<8>(a.off, a.iv, a.len, a.stage, a.counts, a.rej_list, a.rej_count, a.ctr, a.cov, rr, o, n, len);
-            else finish_item<4>(a.off, a.iv, a.len, a.stage, a.counts, a.rej_list, a.rej_count, a.ctr, a.cov, rr, o, n, len);
+            const uint4 q = s_list[s_fb[i]];
+            const u64 o = a.off[q.x];
+            if (q.y > 128u) finish_item<8>(a.off, a.iv, a.len, a.stage, a.counts, a.rej_list, a.rej_count, a.ctr, a.cov, q.x, o, q.y, q.z);
+            else finish_item<4>(a.off, a.iv, a.len, a.stage, a.counts, a.rej_list, a.rej_count, a.ctr, a.cov, q.x, o, q.y, q.z);
         }
-        return;
     }
-#endif
-    // one read per wavefront and turn, the long ones (8 keys per lane) first: list position p < n8 is s_list[p],
-    // p >= n8 is the (p - n8)-th entry from the back
-    for (u32 p = threadIdx.x >> 6; p < n_marked; p += kWaves) { // (uniform in the wavefront)
-        const u32 at = p < n8 ? p : (u32)kDeferSlab - 1u - (p - n8);
-        const uint2 e = s_list[at];
-        const u32 rr = slab0 + (e.x & 0xFFFFu), n = e.x >> 16, len = e.y;
-        const u64 o = s_off[at];
-#if YK_DEFER_TRIM
-        if (trim_item(a, rr, o, n, len, s_trim[threadIdx.x >> 6], lc)) continue;
-#endif
-        if (n > 128u) finish_item<8>(a.off, a.iv, a.len, a.stage, a.counts, a.rej_list, a.rej_count, a.ctr, a.cov, rr, o, n, len);
-        else finish_item<4>(a.off, a.iv, a.len, a.stage, a.counts, a.rej_list, a.rej_count, a.ctr, a.cov, rr, o, n, len);
+    __syncthreads();
+    if (tid == 0) {
+        atomicAdd((unsigned long long *)&a.ctr->deferred_iv, s_iv);
+        atomicAdd(&a.ctr->deferred, hi - lo);
     }
 }
-
-#endif // YK_DEFER_FILTER
 
 constexpr int kScanThreads = 1024;
 // PER consecutive reads per thread.  4; 8 (half the tickets and half the look-back chain again: configs[4] 1 221 -> 611

@@ -393,7 +393,7 @@ __global__ __launch_bounds__(kListThreads, YK_LIST_OCC) void deferred_list_kerne
         if (tid == 0) s_pre[kDeferShards] = total;
     }
     const u32 per = (total + gridDim.x - 1u) / gridDim.x;
-    const u32 lo = min(total, blockIdx.x * per), hi = min(total, lo + per);
+    const u32 lo = (u32)min((u64)total, (u64)blockIdx.x * per), hi = (u32)min((u64)total, (u64)lo + per);
     if (lo >= hi) return; // (uniform)
     const LaneConst lcf = make_lane_const(lane);
     if (tid == 0) s_iv = 0;

@@ -91,7 +91,7 @@ struct SweepArgs {
     u32 prefilter;       // 1: drop events in bins deeper than cov before the sort (sweep_wave.h); 2: and count
     uint2 *stage;        // per-read slot of n+2 regions at off[r] + 2r
     u32 *counts;         // [R] regions per read; kDeferredMark / kClosedForm: see below
-    uint2 *closed;       // [R] (a, b) of the reads whose counts[] says kClosedForm
+    uint2 *closed;       // [R] (a, b) of the reads whose counts[] says kClosedForm (what plan_kernel leaves there)
     u32 *rej_list;       // reads this sweep cannot take (degenerate interval): append here
     u32 *rej_count;
     u32 *over_list;      // sweep_lds_kernel: reads with more events than its LDS holds even after the

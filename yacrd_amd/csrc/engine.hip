@@ -503,11 +503,11 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
                                     : (e->flags & YACRD_F_NO_HALVES) ? 3 : 0);
         if (n_reads < yk::kPlanSmallReads)
             hipLaunchKernelGGL((yk::plan_kernel<1, yk::kPlanSmallBlock>), dim3((n_reads + yk::kPlanSmallBlock - 1) / yk::kPlanSmallBlock),
-                               dim3(yk::kPlanSmallBlock), 0, e->stream, d_off, n_reads, lists, ctr, plan_mode, e->ctrl2[other].as<u32>(), (u32)(other_bytes / 4));
+                               dim3(yk::kPlanSmallBlock), 0, e->stream, d_off, n_reads, lists, ctr, plan_mode, e->ctrl2[other].as<u32>(), (u32)(other_bytes / 4), e->counts.as<u32>());
         else // (eight reads per thread — 611 workgroups instead of 1 221 on configs[4] — measured 32.0 us against 29.9: profiles/r05/m_*)
             hipLaunchKernelGGL(yk::plan_kernel<4>, dim3((n_reads + 4 * yk::kPlanBlock - 1) / (4 * yk::kPlanBlock)),
                                dim3(yk::kPlanBlock), 0, e->stream, d_off, n_reads, lists, ctr, plan_mode,
-                               e->ctrl2[other].as<u32>(), (u32)(other_bytes / 4));
+                               e->ctrl2[other].as<u32>(), (u32)(other_bytes / 4), e->counts.as<u32>());
     }
     e->ctrl_clean[other] = other_bytes;
     if (full) HIP_TRY(hipEventRecord(e->ev[EV_PLAN], e->stream));

@@ -27,7 +27,7 @@ constexpr int kPlanSmallBlock = YK_PLAN_SMALL_BLOCK; // threads per workgroup of
 template <int PER, int BLK = kPlanBlock>
 __global__ __launch_bounds__(BLK) void plan_kernel(const u64 *off, u32 n_reads, u32 *lists,
                                                    Counters *ctr, u32 mode, u32 *zero,
-                                                   u32 zero_words)
+                                                   u32 zero_words, u32 *counts)
 {
     constexpr int kPlanBlock = BLK; // (shadows the long batches' constant)
     for (u32 i = blockIdx.x * kPlanBlock + threadIdx.x; i < zero_words; i += gridDim.x * kPlanBlock)
@@ -101,6 +101,10 @@ __global__ __launch_bounds__(BLK) void plan_kernel(const u64 *off, u32 n_reads, 
         if (cls[k] != CLS_COUNT) {
             const u64 pos = s_base[cls[k]] + local[k];
             lists[(u64)cls[k] * n_reads + pos] = r;
+            // A read's region count starts out as "closed form: see closed[r]" (round 5): the screen then answers a read
+            // it decides with ONE store, its (a, b) — not a count word besides — and everything else that finishes a read
+            // writes its count over this (coalesced here: one lane per read and 4 bytes there)
+            counts[r] = kClosedForm;
             // the workgroup classes' fallback queue (screen_wg.h) starts out empty in every slot one of the class's
             // reads could take: list CLS_COUNT + 4 (M1) / + 5 (M2) of the engine's table
             if (cls[k] == CLS_MED1 || cls[k] == CLS_MED2)

@@ -998,12 +998,10 @@ struct VerdictsToGlobal {
     const SweepArgs &a;
     __device__ __forceinline__ void closed(u32 r, u32 ra, u32 rb, u32 len) const
     {
-        if (ra != 0 || rb != len) {
-            a.closed[r] = make_uint2(ra, rb);
-            a.counts[r] = kClosedForm;
-        } else {
-            a.counts[r] = 0;
-        }
+        // counts[r] says kClosedForm since the plan kernel: ONE store per decided read, its (a, b) — or, for a read with no
+        // bad region at all, the count 0 in four bytes
+        if (ra != 0 || rb != len) a.closed[r] = make_uint2(ra, rb);
+        else a.counts[r] = 0;
         if (a.prefilter == 2) atomicAdd(&a.ctr->prefiltered, 1u);
     }
     __device__ __forceinline__ void deferred(u32 r) const { a.counts[r] = kDeferredMark; }

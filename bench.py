@@ -139,6 +139,11 @@ class Ctx:
         # YACRD_BENCH_DEVICE / YACRD_BENCH_BACKEND: plumbing test of the N>1 path on a 1-GPU box
         # (all ranks on one device, gloo); never set by the driver
         self.dev_index = int(os.environ.get("YACRD_BENCH_DEVICE", self.local_rank))
+        if args.gpus != self.world:  # (launch_ranks has made them agree; a caller that builds Ctx by hand has not)
+            raise SystemExit("bench.py: --gpus %r but %d rank(s) are running" % (args.gpus, self.world))
+        if self.dev_index >= torch.cuda.device_count():
+            raise SystemExit("bench.py: rank %d wants GPU %d, this node shows %d (one process per GPU: --gpus N needs N GPUs)"
+                             % (self.rank, self.dev_index, torch.cuda.device_count()))
         torch.cuda.set_device(self.dev_index)
         self.dev = torch.device("cuda", self.dev_index)
         self.dist = ydist.init(backend=os.environ.get("YACRD_BENCH_BACKEND"), device=self.dev)  # None when WORLD_SIZE == 1
@@ -345,7 +350,14 @@ def small_batches_block(cx, jitter=0, chimeras=0):
     t0 = time.perf_counter()
     out = run_steps(K)
     cx.barrier()
-    elapsed = cx.ydist.max_over_ranks(cx.dist, time.perf_counter() - t0, cx.dev)
+    mine = time.perf_counter() - t0
+    elapsed = cx.ydist.max_over_ranks(cx.dist, mine, cx.dev)
+    per_rank = {"rank": cx.rank, "reads": R, "intervals": I, "ms_per_step": mine / K * 1e3}
+    if cx.dist is not None:
+        allr = [None] * cx.world
+        cx.dist.all_gather_object(allr, per_rank)
+    else:
+        allr = [per_rank]
     t, n_timed = None, 0
     for e in engs:
         te, ne = e.timing_total()
@@ -407,7 +419,7 @@ def small_batches_block(cx, jitter=0, chimeras=0):
                            "each), launch grids sized from the previous identical batch's class counts (validated at the "
                            "final sync)" % (profile.upper(), jit, R, O, cov, nc, NE),
                "reads_per_sec": cx.world * R * K / elapsed, "kernel_overlaps_per_sec": cx.world * O * K / elapsed,
-               "ms_per_step": elapsed / K * 1e3, "steps": K, "warmup": W,
+               "ms_per_step": elapsed / K * 1e3, "steps": K, "warmup": W, "per_rank": allr,
                "scaling": "weak", "reads_per_gpu": R, "overlaps_per_gpu": O, "intervals_per_gpu": I, "regions_per_gpu": G,
                "whole_path_algorithmic_bytes": b_alg, "whole_path_GBps": b_alg / (elapsed / K) / 1e9,
                "whole_path_frac_of_peak": b_alg / (elapsed / K) / 1e9 / HBM_PEAK_GBS,
@@ -735,6 +747,10 @@ def compact_line(full, extras_path):
     keys = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
             "vs_baseline", "dtype", "data")
     out = {k: full.get(k) for k in keys}
+    out["rccl_ranks"] = full.get("rccl_ranks")
+    pr = _dig(full, "headline", "per_rank")
+    if isinstance(pr, list) and len(pr) > 1:  # (one number per rank: what the max over ranks was taken over)
+        out["per_rank_ms"] = [_r(p.get("ms_per_step")) for p in pr]
     cfg = dict(full.get("config") or {})
     cfg["workload"] = full.get("workload_short") or cfg.get("workload", "")[:300]
     out["config"] = cfg
@@ -779,17 +795,62 @@ def compact_line(full, extras_path):
                          for k, b in jit.items() if isinstance(b, dict) and k != "healthy_share_of_screened_reads"}
     out["extras"] = extras_path if extras_path.startswith("not written") else os.path.basename(extras_path)
     s = json.dumps(out, allow_nan=False, separators=(",", ":"))
-    for drop in ("jitter", "value_sigma100"):  # (never expected: every string above is bounded)
-        if len(s) <= COMPACT_LIMIT:
+    # never expected (every string above is bounded), but the limit is enforced, not hoped for: optional blocks go first,
+    # then the scalars, then the strings are cut — the contract's keys, `roofline` and `cpu_baseline` stay
+    droppable = ["jitter", "value_sigma100", "per_rank_ms"] + [k for k in sc] + ["extras"]
+    for drop in droppable:
+        if len(s.encode()) < COMPACT_LIMIT:
             break
         out.pop(drop, None)
         s = json.dumps(out, allow_nan=False, separators=(",", ":"))
+    if len(s.encode()) >= COMPACT_LIMIT:
+        out["config"] = {"workload": str(out["config"].get("workload", ""))[:200]}
+        out["parity"] = str(out.get("parity"))[:100]
+        if isinstance(out.get("cpu_baseline"), dict):
+            out["cpu_baseline"] = {k: (v[:100] if isinstance(v, str) else v) for k, v in out["cpu_baseline"].items()}
+        out["roofline"] = {k: (v[:100] if isinstance(v, str) else v) for k, v in out["roofline"].items()}
     return out
+
+
+def launch_ranks(args):
+    """`--gpus N` is the number of ranks, whoever starts them (it used to be parsed and ignored — a plain
+    `python bench.py --gpus 8` ran ONE rank and printed "n_gpus": 1).  Under a launcher (WORLD_SIZE set) the two must
+    agree, or the run stops before it measures anything; without one and N > 1 this process becomes
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free> bench.py
+    <same arguments>` — one rank per GPU (LOCAL_RANK -> device), the read partition of SURVEY.md 8(e)
+    (reference: src/stack.rs:151-156 maps compute_bad_part over independent reads)."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        if args.gpus is not None and args.gpus != int(env_world):
+            sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%s: the launcher's rank count and --gpus must agree\n"
+                             % (args.gpus, env_world))
+            sys.exit(2)
+        args.gpus = int(env_world)
+        return
+    if args.gpus is None:
+        args.gpus = 1
+    if args.gpus < 1:
+        sys.stderr.write("bench.py: --gpus must be >= 1\n")
+        sys.exit(2)
+    if args.gpus == 1:
+        return
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)  # (the ranks inherit stdout: rank 0's compact line stays the last line)
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks = GPUs of this node (one process per GPU).  Without WORLD_SIZE in the environment and N > 1, "
+                         "bench.py launches itself under torch.distributed.run with N ranks; under a launcher, N must equal "
+                         "WORLD_SIZE (default: WORLD_SIZE, else 1)")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", type=int, default=4, choices=[1, 2, 3, 4],
@@ -825,6 +886,7 @@ def main():
                     help="scale every config's reads and overlaps (plumbing tests only: a scaled run is not a measurement, "
                          "and the workload strings say so)")
     args = ap.parse_args()
+    launch_ranks(args)
     global SCALE
     SCALE = args.scale
     if args.scale != 1.0:
@@ -863,6 +925,7 @@ def main():
             "value": head["reads_per_sec"],
             "unit": "reads/s",
             "n_gpus": world,
+            "rccl_ranks": (cx.dist.get_world_size() if backend == "nccl" else 0),  # ranks in the nccl (= RCCL) group; 0: none
             "steps": head["steps"],
             "warmup": head["warmup"],
             "ms_per_step": head["ms_per_step"],

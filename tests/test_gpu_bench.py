@@ -112,3 +112,34 @@ def test_two_ranks_on_one_device(weak, tmp_path):
     assert sum(r["reads"] for r in h["per_rank"]) == 150000
     assert sum(r["intervals"] for r in h["per_rank"]) == 30000000
     assert h["interval_imbalance_max_over_min"] < 1.05
+
+
+def test_plain_python_with_gpus_2_launches_two_ranks(tmp_path):
+    """`python bench.py --gpus 2` — no torchrun around it — must run TWO ranks (it launches itself
+    under torch.distributed.run), say so in the line, and carry one entry per rank; and a rank count that disagrees
+    with the launcher's stops the run."""
+    env = dict(os.environ, YACRD_BENCH_DEVICE="0", YACRD_BENCH_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2",
+                        "--scale", "0.03", "--extras-file", str(tmp_path / "extras.json")],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = _last_json(p.stdout)
+    d = json.loads((tmp_path / "extras.json").read_text())
+    assert line["n_gpus"] == 2 and line["steps"] == 5 and line["scaling"] == "strong"
+    assert line["rccl_ranks"] == 0 and line["config"]["torch_distributed_backend"] == "gloo"  # (two ranks on ONE device: gloo)
+    assert len(line["per_rank_ms"]) == 2 and all(x > 0 for x in line["per_rank_ms"])
+    assert abs(max(line["per_rank_ms"]) - line["ms_per_step"]) / line["ms_per_step"] < 0.5
+    assert line["parity"].startswith("bit-exact")
+    pr = d["headline"]["per_rank"]
+    assert [r["rank"] for r in pr] == [0, 1] and sum(r["reads"] for r in pr) == 150000
+    assert all(r["parity_sample_ok"] for r in pr)
+    # under a launcher that runs two ranks, --gpus 4 is refused before anything is measured
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    bad = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "4", "--scale", "0.03"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert bad.returncode != 0 and "WORLD_SIZE=2" in bad.stderr and not bad.stdout.strip()

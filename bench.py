@@ -69,6 +69,11 @@ def alg_bytes(R, I, G):
     return 8 * I + 8 * (R + 1) + 4 * R + 8 * (R + 1) + 8 * G + R
 
 
+# which path the timed runs of a block took (yacrd_timing, ABI 7): counts over its engines — what a short batch's latency
+# depends on besides its input (one box measured configs[1] at sigma 300 2.2 x slower than every other)
+PATH_KEYS = ("predicted", "prediction_misses", "fused_reruns", "build_switches", "sorting_build", "screen_wide", "screened", "one_launch")
+
+
 def dominant(t, K, yacrd_amd):
     """(kernel name, class name, ms per launch, reads, intervals) of the kernel with the most time;
     K = the launches that carried the events (yacrd_timing.timed_runs)."""
@@ -300,6 +305,7 @@ def resident_block(cx, label, profile, R, O, cov, nc, seed, jitter, steps, warmu
            "whole_path_algorithmic_bytes": b_all, "whole_path_GBps": b_all / (elapsed / K) / 1e9,
            "whole_path_frac_of_peak": b_all / (elapsed / K) / 1e9 / HBM_PEAK_GBS / cx.world,
            "phases_full_timing_ms": phases,
+           "paths": dict({k: int(t.get(k, 0)) for k in PATH_KEYS}, runs=K),
            "healthy_reads_rank0": int(t.get("fused_reads", 0)) - int(t.get("deferred_reads", 0)) if screened else None,
            "deferred_reads_rank0": int(t.get("deferred_reads", 0)) if screened else None,
            "parity": ("bit-exact vs oracle on %d sampled reads per rank" % per_rank["sampled_reads"])
@@ -359,9 +365,12 @@ def small_batches_block(cx, jitter=0, chimeras=0):
     else:
         allr = [per_rank]
     t, n_timed = None, 0
+    paths = {k: 0 for k in PATH_KEYS}
     for e in engs:
         te, ne = e.timing_total()
         n_timed += ne
+        for k in PATH_KEYS:
+            paths[k] += int(te.get(k, 0))
         if t is None:
             t = te
         else:
@@ -426,6 +435,7 @@ def small_batches_block(cx, jitter=0, chimeras=0):
                "unpredicted_single_batch": unpredicted, "one_launch_single_batch": one_launch, "phases_full_timing_ms": phases,
                "healthy_reads": int(t.get("fused_reads", 0)) - int(t.get("deferred_reads", 0)) if screened else None,
                "deferred_reads": int(t.get("deferred_reads", 0)) if screened else None,
+               "paths": dict(paths, runs=K),
                "batches_through_the_screen": "%d of %d (the others: the sorting build, chosen from the previous batches' deferral rate)" % (int(t.get("screened", 0)), K),
                "roofline": roofline_of(ya, t, K, R, G, None if (jitter or chimeras) else "configs[1]",
                                        "batch (82 MB) fits the 256 MiB Infinity Cache; other engines' small kernels run beside "
@@ -451,29 +461,33 @@ def small_batches_block(cx, jitter=0, chimeras=0):
 
 
 def cpu_baseline(offsets, intervals, lengths, cov, nc, label):
-    """The oracle on this box's cores (kind "port"): a bounded sample of the headline workload on every usable
-    CPU, and a smaller one on a single thread (the reference's default is -t 1, src/main.rs:75-77)."""
+    """The oracle on this box's cores (kind "port"), as BASELINE.md §2 specifies: the WHOLE headline workload on every usable
+    CPU, best of 3 after one warm-up pass; and one thread (the reference's default is -t 1, src/main.rs:75-77) on its first
+    500 000 reads.  ~25 s of CPU work at configs[4]'s size."""
     import oracle
     ncores = usable_cpus()
     R = len(lengths)
-    rs = min(R, 1_000_000)  # a few seconds on 16 CPUs
-    l64 = lengths[:rs].astype(np.uint64)
-    off = offsets[: rs + 1]
-    iv = intervals[: int(off[-1])]
-    oracle.run(off[:1001], iv[: int(off[1000])], l64[:1000], cov, nc, 1)
-    t1 = time.perf_counter()
-    oracle.run(off, iv, l64, cov, nc, n_threads=ncores)
-    cpu_all = time.perf_counter() - t1
-    r1 = min(rs, 20000)
+    l64 = lengths.astype(np.uint64)
+    off = offsets
+    iv = intervals
+    times = []
+    for rep in range(4):  # (the first pass is the warm-up: page faults of the result arrays, the thread pool)
+        t1 = time.perf_counter()
+        oracle.run(off, iv, l64, cov, nc, n_threads=ncores)
+        times.append(time.perf_counter() - t1)
+    cpu_all = min(times[1:])
+    r1 = min(R, 500_000)
     t1 = time.perf_counter()
     oracle.run(off[: r1 + 1], iv[: int(off[r1])], l64[:r1], cov, nc, 1)
     cpu_1 = time.perf_counter() - t1
-    return {"value": rs / cpu_all, "unit": "reads/s", "cores": ncores, "hardware_threads": os.cpu_count(), "kind": "port",
-            "sample": "the first %d reads (%d intervals) of %s once on %d threads (= usable CPUs: hardware threads "
-                      "capped by the cgroup cpu.max quota): %.2f s; single-thread (reference default -t 1) on the "
-                      "first %d reads: %.0f reads/s" % (rs, int(off[-1]), label, ncores, cpu_all, r1, r1 / cpu_1),
-            "sample_short": "first %d reads of %s once on %d threads: %.2f s; 1 thread on %d reads" % (rs, label, ncores, cpu_all, r1),
-            "value_1thread": r1 / cpu_1}
+    return {"value": R / cpu_all, "unit": "reads/s", "cores": ncores, "hardware_threads": os.cpu_count(), "kind": "port",
+            "sample": "ALL %d reads (%d intervals) of %s on %d threads (= usable CPUs: hardware threads capped by the cgroup "
+                      "cpu.max quota), best of 3 after a warm-up pass: %.2f s (the three: %s); single thread (reference "
+                      "default -t 1) on the first %d reads: %.0f reads/s"
+                      % (R, int(off[-1]), label, ncores, cpu_all, ", ".join("%.2f" % x for x in times[1:]), r1, r1 / cpu_1),
+            "sample_short": "all %d reads of %s on %d threads, best of 3 after a warm-up: %.2f s; 1 thread on the first %d reads"
+                            % (R, label, ncores, cpu_all, r1),
+            "value_1thread": r1 / cpu_1, "seconds_all_threads": times}
 
 
 def pcie_inclusive(ya, engs, offsets, intervals, lengths, cov, nc, G):
@@ -786,18 +800,27 @@ def compact_line(full, extras_path):
             v = _dig(sb, *path)
             sc[k] = v * 1e3 if isinstance(v, (int, float)) else None
     out.update({k: _r(v) for k, v in sc.items()})
+    # runs that were run AGAIN (a prediction that did not hold, the persistent workgroup screen giving up), over every timed block
+    blocks = [full.get("headline"), full.get("configs2"), full.get("skewed"), full.get("small_batches"), full.get("configs4_sigma100")]
+    blocks += [b for k, b in (full.get("jitter") or {}).items() if k != "healthy_share_of_screened_reads"]
+    pp = [b["paths"] for b in blocks if isinstance(b, dict) and isinstance(b.get("paths"), dict)]
+    out["reruns_total"] = sum(p.get("prediction_misses", 0) + p.get("fused_reruns", 0) for p in pp) if pp else None
     if isinstance(full.get("value_sigma100"), dict):
         out["value_sigma100"] = {k: _r(v) for k, v in full["value_sigma100"].items()}
     jit = full.get("jitter")
     if isinstance(jit, dict):  # [ms per step, frac, share of the screened reads decided] per (config, sigma)
         share = jit.get("healthy_share_of_screened_reads") or {}
-        out["jitter"] = {k: [_r(_dig(b, "ms_per_step")), _r(_dig(b, "roofline", "frac")), _r(share.get(k))]
+        def path3(b):  # [runs run again, runs in the build with the second looks, build switches] of the block's timed runs
+            p = b.get("paths")
+            return [] if not isinstance(p, dict) else [p.get("prediction_misses", 0) + p.get("fused_reruns", 0), p.get("screen_wide", 0),
+                                                       p.get("build_switches", 0)]
+        out["jitter"] = {k: [_r(_dig(b, "ms_per_step")), _r(_dig(b, "roofline", "frac")), _r(share.get(k))] + path3(b)
                          for k, b in jit.items() if isinstance(b, dict) and k != "healthy_share_of_screened_reads"}
     out["extras"] = extras_path if extras_path.startswith("not written") else os.path.basename(extras_path)
     s = json.dumps(out, allow_nan=False, separators=(",", ":"))
     # never expected (every string above is bounded), but the limit is enforced, not hoped for: optional blocks go first,
     # then the scalars, then the strings are cut — the contract's keys, `roofline` and `cpu_baseline` stay
-    droppable = ["jitter", "value_sigma100", "per_rank_ms"] + [k for k in sc] + ["extras"]
+    droppable = ["jitter", "value_sigma100", "per_rank_ms", "reruns_total"] + [k for k in sc] + ["extras"]
     for drop in droppable:
         if len(s.encode()) < COMPACT_LIMIT:
             break

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define YACRD_ABI_VERSION 6 /* 6: yacrd_engines_ingest_overlaps[_mem]; 5: YACRD_F_ONE_LAUNCH, yacrd_timing.one_launch; 4: yacrd_timing.screen_items, yacrd_engine_ingest_overlaps_mem */
+#define YACRD_ABI_VERSION 7 /* 7: yacrd_timing.predicted / prediction_misses / build_switches / sorting_build; 6: yacrd_engines_ingest_overlaps[_mem]; 5: YACRD_F_ONE_LAUNCH, yacrd_timing.one_launch; 4: yacrd_timing.screen_items, yacrd_engine_ingest_overlaps_mem */
 
 /* src/editor/mod.rs:42-59 ReadType; numeric encoding is ours, names are the reference's. */
 enum { YACRD_NOT_BAD = 0, YACRD_CHIMERIC = 1, YACRD_NOT_COVERED = 2 };
@@ -140,7 +140,8 @@ typedef struct {
     /* groups of list entries per wavefront the screen ran with (1 or 2; the last run's): 2 for long launches unless the one
      * before left more than a tenth of its reads to the sort — then the one-item build with the sliding windows runs */
     uint32_t screen_items;
-    /* 1: the screen ran in the build with the second looks (sliding windows; always one item) */
+    /* 1: the screen ran in the build with the second looks (sliding windows; always one item); the count of such runs in
+     * yacrd_engine_timing_total */
     uint32_t screen_wide;
     /* 1: the batch ran as ONE launch (YACRD_F_ONE_LAUNCH and every read within 256 intervals); the count of such runs in
      * yacrd_engine_timing_total */
@@ -149,6 +150,19 @@ typedef struct {
      * persistent screen + fallback kernel ran out of looks at its queue slot (its grid was not resident as a whole: a device
      * shared with another process, a CU mask); the count of such runs in yacrd_engine_timing_total.  (Was reserved0: ABI 5.) */
     uint32_t fused_reruns;
+    /* Which path a run took — what makes a short batch's latency depend on the engine's history (ABI 7; all four: 0 / 1 for
+     * one run, the count of such runs in yacrd_engine_timing_total):
+     * predicted: the sweeps were launched without waiting for the plan's class counts, their grids sized from the engine's
+     *   previous run of the same shape;
+     * prediction_misses: the run's prediction did not hold at the final sync (a class beyond its grid, a read for the
+     *   device-wide or the exact path, a region overflow) and the batch was run again down the synchronous path;
+     * build_switches: the register classes' launch took another build than the engine's previous run (sorting / screening,
+     *   one item / two items / second looks: see screen_items, screen_wide);
+     * sorting_build: that launch was the sorting build (the screen switched off by size or by the last batches' deferral rate). */
+    uint32_t predicted;
+    uint32_t prediction_misses;
+    uint32_t build_switches;
+    uint32_t sorting_build;
 } yacrd_timing;
 
 /* size classes, in the order of yacrd_timing.class_*: R<K> = four reads per wavefront (16-lane

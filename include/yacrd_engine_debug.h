@@ -43,6 +43,10 @@
 /* the workgroup classes (513 .. 16 384 intervals) run the screen and its fallback as separate launches (round 3's
  * chain) instead of the persistent screen_wg_fused_kernel; A/B, tests */
 #define YACRD_F_NO_FUSED_SCREEN 1048576u
+/* the workgroup classes go through a screen of one read per WAVEFRONT first, the read streamed twice (screen_stream.h,
+ * round 6: measured, 2 x the traffic and no faster — DESIGN.md), and the persistent screen + fallback kernel takes only what
+ * that leaves; A/B, tests */
+#define YACRD_F_STREAM_SCREEN 65536u
 /* the screen always runs in its one-item build with the second looks (sliding windows; by default only after a batch that
  * deferred more than a tenth of what it screened); tests, A/B */
 #define YACRD_F_SCREEN_WIDE 2097152u
@@ -53,6 +57,16 @@
 extern "C" {
 #endif
 int yacrd_debug_sort_pairs(yacrd_engine *e, uint64_t *keys, uint32_t *vals, uint64_t n, uint64_t key_bound);
+/* the device-side counter block of the engine's last run as it came home (csrc/device_common.h: struct Counters — class counts,
+ * rejection / fallback list lengths, deferred reads): at most `bytes` of it are copied to dst; returns the block's size.
+ * tools/ and tests only: the layout is not part of any ABI. */
+uint64_t yacrd_debug_last_counters(const yacrd_engine *e, void *dst, uint64_t bytes);
+/* cross-engine copies of the N-engine device parser (yacrd_engines_ingest_overlaps) since the library was loaded, by route:
+ * [0] same device (hipMemcpyAsync), [1] hipMemcpyPeerAsync, [2] staged through pinned host buffers.
+ * YACRD_TEST_FORCE_PEER_COPY=peer|staged (environment, tests) forces route 1 / 2 for EVERY such copy, also between engines of
+ * one device, and makes every engine gather the other engines' records instead of reading them in place: the multi-device
+ * branch on a one-GPU box. */
+void yacrd_debug_peer_copy_counts(uint64_t out[3]);
 #ifdef __cplusplus
 }
 #endif

@@ -984,3 +984,110 @@ def filtered_sweep_regions(intervals, length, cov, nb, W, cap, stats=None):
     if cml is not None and cml >= tc:
         out.append((tc, cml))
     return ([(0, a)] if a != 0 else []) + out + ([(b, length)] if b != length else [])
+
+
+def unified_filtered_regions(intervals, length, cov, nb, W, cap, stats=None):
+    """screen_wg.h's fallback for the reads its screen cannot decide (round 6): filtered_sweep_regions' idea on
+    unified_screen_regions' table — ONE position map for starts and ends, idx(x) = min(dx, W) + (dx >> sh) + max(dx - T, 0),
+    so the bins are in event order, every position of the first / last W a bin of its own — for reads of thousands of
+    intervals, short ones anywhere.
+    The two ENDS by the screen's closed form: a = the position where the starts counted upwards from pmin reach cov + 1 (a
+    head-window bin, no end at or before it), b = the position where the ends counted downwards from pmax reach cov + 1 (a
+    tail-window bin): src/stack.rs:83-113 gives (0, a) in front and (b, len) behind.
+    The INSIDE exactly, from the bins that can matter: D_i = starts - ends of the bins in front of i is the depth on entry
+    to bin i, D_i - E_i the least depth any of its events sees (inside a bin its ends count as before its starts).  A bin
+    with D_i - E_i > cov is SAFE: none of its starts is low (:83), all of its ends are flagged (:77-79).  A low start lies
+    in an unsafe bin, and the flagged end the reference pairs it with — the last one in front of it — lies in an unsafe bin
+    too or is the largest end of the nearest bin in front that holds an end.  Kept: the unsafe bins behind a's and in front
+    of b's, and for each the nearest bin in front that holds an end; their events sorted and swept with their true depths.
+    A bin at or behind b's with a shallow start, a zero-length interval in a kept bin, more than `cap` kept events, or
+    anything the screen itself would not take: None — the caller sorts the read."""
+    n = len(intervals)
+    if n == 0:
+        return [(0, length)] if length != 0 else []
+    if any(not (0 <= s <= e <= length) for s, e in intervals) or length >= 2**30 - 1:
+        return None
+    intervals = [iv for iv in intervals if iv != (0, 0)]
+    n = len(intervals)
+    if n < 2 or n <= cov:
+        return None
+    pmin = min(s for s, e in intervals)
+    pmax = max(e for s, e in intervals)
+    span = pmax - pmin
+    if span < 2 * W:
+        return None
+    sh = bin_shift(length, nb)
+    while (1 << sh) < W:
+        sh += 1
+    T = span - W
+
+    def idx(x):
+        dx = x - pmin
+        return min(dx, W) + (dx >> sh) + max(dx - T, 0)
+
+    nbins = idx(pmax) + 1
+    S, E = [0] * nbins, [0] * nbins
+    for s, e in intervals:
+        S[idx(s)] += 1
+        E[idx(e)] += 1
+    a = sorted(s for s, e in intervals)[cov]
+    b = sorted(e for s, e in intervals)[n - 1 - cov]
+    if a - pmin >= W or pmax - b >= W or any(e <= a for s, e in intervals):
+        return None
+    ia, ib = idx(a), idx(b)
+    D, d = [0] * nbins, 0
+    for i in range(nbins):
+        D[i] = d
+        d += S[i] - E[i]
+    unsafe = [i > ia and S[i] + E[i] > 0 and D[i] - E[i] <= cov for i in range(nbins)]
+    if any(unsafe[i] and S[i] > 0 for i in range(ib, nbins)):
+        return None  # a start that may be low at or behind b: the closed form for the tail does not hold
+    inside = range(ia + 1, ib)
+    kept = [False] * nbins
+    for i in inside:
+        if unsafe[i]:
+            kept[i] = True
+        elif E[i] > 0:
+            nxt = next((j for j in range(i + 1, ib) if unsafe[j] or E[j] > 0), None)
+            kept[i] = nxt is not None and unsafe[nxt]
+    m = sum(S[i] + E[i] for i in inside if kept[i])
+    if stats is not None:
+        stats.append(m)
+    if m > cap:
+        return None
+    corr, before = {}, 0
+    for i in inside:
+        if kept[i]:
+            corr[i] = D[i] - before
+            before += S[i] - E[i]
+    keys = []
+    for s, e in intervals:
+        if kept[idx(s)] or kept[idx(e)]:
+            if s == e:
+                return None  # (a zero-length interval where it may matter)
+        if kept[idx(s)]:
+            keys.append((s << SH) | 3)
+        if kept[idx(e)]:
+            keys.append(e << SH)
+    keys.sort()
+    assert len(keys) == m
+    out, run, tc, cml = [], 0, None, None
+    for key in keys:
+        pos = key >> SH
+        depth = run + corr[idx(pos)]
+        if key & 1:
+            if depth <= cov:
+                if tc is None:
+                    return None  # a low start with no flagged end in front of it among the kept (cannot happen: kept for the kernel's guard)
+                cml = pos
+            run += 1
+        else:
+            if depth > cov:
+                if cml is not None and cml >= tc:
+                    out.append((tc, cml))
+                    cml = None
+                tc = pos
+            run -= 1
+    if cml is not None and cml >= tc:
+        out.append((tc, cml))
+    return ([(0, a)] if a != 0 else []) + out + ([(b, length)] if b != length else [])

@@ -462,3 +462,68 @@ def test_filtered_sweep_tiny_exhaustive():
                     for nb, W in ((4, 1), (2, 1), (4, 2), (8, 1)):
                         got = filtered_sweep_regions(list(iv), L, cov, nb, W, 1 << 20)
                         assert got is None or got == want, (iv, L, cov, nb, W, got, want)
+
+
+def _short_mix(rng, iv, L, k):
+    """k short intervals (1 .. 40 positions) anywhere: what a read of thousands of intervals always has."""
+    out = list(iv)
+    for _ in range(k):
+        s = int(rng.integers(0, max(1, L - 1)))
+        out.append((s, min(L, s + int(rng.integers(1, 41)))))
+    return out
+
+
+def test_unified_filtered_matches_oracle():
+    """Round 6: the workgroup classes' filtered exact sweep (formulation.unified_filtered_regions; screen_wg.h): wherever it
+    decides it equals the oracle (src/stack.rs:61-139) — healthy reads, chimeras with any gap, several holes, short intervals
+    anywhere (starts inside the tail window, ends inside the head window), zero-length intervals, spread piles, coarse grids —
+    and it decides nearly all of the generator's chimeras within its key budget."""
+    from formulation import unified_filtered_regions, unified_screen_regions
+    rng = np.random.default_rng(6160)
+    fired = total = decided = beyond_screen = 0
+    for it in range(2500):
+        L = int(rng.integers(50, 600)) if it % 5 == 0 else int(rng.integers(600, 60000))
+        n = int(rng.integers(2, 40)) if it % 4 == 0 else int(rng.integers(40, 320))
+        jitter = (0.0, 5.0, 30.0, 100.0)[it % 4]
+        base = _survey_read if it % 2 else _pile_read
+        iv = _chimera_read(rng, n, L, jitter, base) if it % 3 else base(rng, n, L, jitter)
+        if it % 7 == 0:  # a second junction
+            iv = _chimera_read(rng, n, L, jitter, lambda *_: iv)
+        if it % 4 == 1:
+            iv = _short_mix(rng, iv, L, int(rng.integers(1, 12)))
+        if it % 9 == 2:  # zero-length intervals: in the piles, in the middle, doubled, at 0 and at len
+            for _ in range(int(rng.integers(1, 4))):
+                j = int(rng.integers(0, len(iv)))
+                p0 = (iv[j][0], iv[j][1], 0, 0, L, L // 2, L // 2)[int(rng.integers(0, 7))]
+                iv.append((p0, p0))
+        if it % 13 == 0:
+            g = max(1, L // 16)
+            iv = [(min((s // g) * g, L - 1), min(max((e // g) * g, (s // g) * g + 1), L)) for s, e in iv]
+            iv = [(s, max(e, s + 1)) for s, e in iv]
+        for cov in (0, 1, 3, 4, 9):
+            want = oracle.compute_bad_part(iv, L, cov)
+            for nb, W, cap in ((256, 128, 512), (16, 32, 64), (32, 32, 128), (16, 8, 64), (4, 4, 16), (8, 5, 1 << 20), (32, 32, 1 << 20)):
+                got = unified_filtered_regions(iv, L, cov, nb, W, cap)
+                assert got is None or got == want, (iv, L, cov, nb, W, cap, got, want)
+                decided += got is not None
+                beyond_screen += got is not None and unified_screen_regions(iv, L, cov, nb, W) is None
+                if it % 3 and it % 2 and nb == 32 and cap == 128 and cov in (3, 4) and L >= 4000 and n >= 80 and it % 13:
+                    total += 1
+                    fired += got is not None
+    assert fired > total * 7 // 10 and decided > 10000 and beyond_screen > 3000, (fired, total, decided, beyond_screen)
+
+
+def test_unified_filtered_tiny_exhaustive():
+    import itertools
+    from formulation import unified_filtered_regions
+    for L in range(2, 9):
+        pairs = [(s, e) for s in range(L + 1) for e in range(s, L + 1)]  # zero-length ones included
+        for k in range(2, 5):
+            for iv in itertools.combinations_with_replacement(pairs, k):
+                if k == 4 and (sum(a for a, b in iv) + L) % 4:
+                    continue  # (a quarter of the quadruples)
+                for cov in range(0, 3):
+                    want = oracle.compute_bad_part(list(iv), L, cov)
+                    for nb, W in ((4, 1), (2, 1), (4, 2), (8, 1), (8, 3)):
+                        got = unified_filtered_regions(list(iv), L, cov, nb, W, 1 << 20)
+                        assert got is None or got == want, (iv, L, cov, nb, W, got, want)

@@ -446,7 +446,7 @@ def test_workgroup_screen_edges(cov):
     intervals = np.array([p for iv, _ in reads for p in iv], dtype=np.uint32)
     lengths = np.array([L for _, L in reads], dtype=np.uint32)
     want = oracle.run(offsets, intervals, lengths.astype(np.uint64), cov, 0.4, n_threads=8)
-    for flags in (0, yacrd_amd.F_NO_PREFILTER, yacrd_amd.F_NO_FUSED_SCREEN):
+    for flags in (0, yacrd_amd.F_NO_PREFILTER, yacrd_amd.F_NO_FUSED_SCREEN, yacrd_amd.F_STREAM_SCREEN):
         with yacrd_amd.Engine(flags=flags | yacrd_amd.F_COUNT_PREFILTERED) as e:
             assert_same(e.run(offsets, intervals, lengths, cov, 0.4), want, "cov %d flags %d" % (cov, flags))
             if flags != yacrd_amd.F_NO_PREFILTER and cov <= 11:
@@ -465,7 +465,7 @@ def test_workgroup_fallback_queue(cov):
     csr = make_csr(5150 + cov, sizes, ("sparse", "regular", "abutting", "dups", "zero_len", "degenerate", "beyond"),
                    len_lo=20000, len_hi=600000, mode_block=7)
     want = oracle.run(csr[0], csr[1], csr[2].astype(np.uint64), cov, 0.4, n_threads=8)
-    for flags in (0, yacrd_amd.F_NO_FUSED_SCREEN):
+    for flags in (0, yacrd_amd.F_NO_FUSED_SCREEN, yacrd_amd.F_STREAM_SCREEN):  # (F_STREAM_SCREEN: one wavefront per read first, round 6's A/B)
         with yacrd_amd.Engine(flags=flags) as e:
             for rep in range(3):
                 assert_same(e.run(*csr, cov, 0.4), want, "fallback queue: cov %d flags %d run %d" % (cov, flags, rep))
@@ -473,16 +473,18 @@ def test_workgroup_fallback_queue(cov):
     from yacrd_amd import host
     o, iv, ln = host.synth_csr(host.SYNTH_SKEWED, 400, 1200000, 31 + cov)
     w2 = oracle.run(o, iv, ln.astype(np.uint64), cov, 0.4, n_threads=8)
-    with yacrd_amd.Engine() as e:
-        for rep in range(2):
-            assert_same(e.run(o, iv, ln, cov, 0.4), w2, "skewed, run %d" % rep)
+    for flags in (0, yacrd_amd.F_STREAM_SCREEN):
+        with yacrd_amd.Engine(flags=flags) as e:
+            for rep in range(2):
+                assert_same(e.run(o, iv, ln, cov, 0.4), w2, "skewed, flags %d, run %d" % (flags, rep))
 
 
-def test_fused_workgroup_screen_gives_up_when_not_resident(tmp_path):
-    """screen_wg_fused_kernel's workgroups wait for each other's queue entries, which needs the whole grid
-    resident.  With a grid eight times what the device holds (YACRD_TEST_FUSED_GRID_MULT, read once per process: a
-    subprocess) the resident workgroups run out of looks, raise Counters::fused_gave_up and leave; the engine runs
-    the batch again down the three-launch chain — bit-exact, no hung device, and yacrd_timing says so."""
+def test_fused_workgroup_screen_needs_no_resident_grid(tmp_path):
+    """Rounds 4-5: screen_wg_fused_kernel's workgroups WAITED for each other's queue entries, which needed the whole grid
+    resident (a bounded wait, a give-up flag, the batch run again).  Round 6: the queue is drained by
+    compare-and-swap and nobody waits, so a grid of any size works.  With eight times the workgroups the class needs
+    (YACRD_TEST_FUSED_GRID_MULT, read once per process: a subprocess), far more than are ever resident, and a share of one
+    read per workgroup: bit-exact, nothing run twice, and quick."""
     import subprocess
     import sys
     code = r"""
@@ -495,24 +497,18 @@ sizes = np.concatenate([rng.integers(513, 3000, size=3000), rng.integers(4097, 9
 csr = make_csr(4711, sizes, ("sparse", "regular", "abutting", "dups"), len_lo=20000, len_hi=600000, mode_block=7)
 want = oracle.run(csr[0], csr[1], csr[2].astype(np.uint64), 3, 0.4, n_threads=8)
 with yacrd_amd.Engine() as e:
-    for rep in range(2):
+    for rep in range(3):
         t0 = time.time()
-        assert_same(e.run(*csr, 3, 0.4), want, "oversized fused grid, run %%d" %% rep)
+        assert_same(e.run(*csr, 3, 0.4), want, "oversized grid, run %%d" %% rep)
         t = e.timing()
-        assert t["fused_reruns"] == 1, t["fused_reruns"]
+        assert t["fused_reruns"] == 0, t["fused_reruns"]
         assert time.time() - t0 < 20
-print("gave up and ran again: ok")
+print("oversized grid: ok")
 """ % (ROOT, os.path.join(ROOT, "tests"))
-    env = dict(os.environ, YACRD_TEST_FUSED_GRID_MULT="8")
-    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
-    assert p.returncode == 0 and "gave up and ran again: ok" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
-    # ... and on a grid of the right size nothing is run twice
-    rng = np.random.default_rng(78)
-    sizes = rng.integers(513, 3000, size=1200)
-    csr = make_csr(4712, sizes, ("sparse", "regular"), len_lo=20000, len_hi=600000, mode_block=7)
-    with yacrd_amd.Engine() as e:
-        e.run(*csr, 3, 0.4)
-        assert e.timing()["fused_reruns"] == 0
+    for share in ("1", "7"):
+        env = dict(os.environ, YACRD_TEST_FUSED_GRID_MULT="8", YACRD_FUSED_SHARE=share)
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0 and "oversized grid: ok" in p.stdout, p.stdout[-2000:] + p.stderr[-3000:]
 
 
 @pytest.mark.parametrize("cov", [0, 4, 600])

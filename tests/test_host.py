@@ -26,7 +26,7 @@ def test_engine_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(yacrd_amd.lib_path())
     for n in names:
         assert hasattr(lib, n), n
-    assert yacrd_amd.load_library().yacrd_abi_version() == 6
+    assert yacrd_amd.load_library().yacrd_abi_version() == 7
 
 
 def test_host_library_exports_every_declared_symbol():

@@ -25,10 +25,11 @@ if os.environ.get("YACRD_FUZZ_ONE_LAUNCH"):  # the one-launch form of short batc
     cflags = yacrd_amd.F_ONE_LAUNCH
 with yacrd_amd.Engine(flags=cflags) as e, yacrd_amd.Engine(flags=yacrd_amd.F_NO_PREFILTER) as ref:
     while time.time() - t0 < budget:
-        R = int(rng.integers(1, 3000))
-        hi = int(rng.choice([8, 40, 130, 260, 520, 4200, 17000]))
-        sizes = rng.integers(0, hi + 1, size=R)
-        if hi > 4200:
+        med = bool(os.environ.get("YACRD_FUZZ_MED"))  # mostly the workgroup classes (513 .. 16 384 intervals): screen_stream.h / screen_wg.h
+        R = int(rng.integers(1, 400 if med else 3000))
+        hi = int(rng.choice([4200, 9000, 17000] if med else [8, 40, 130, 260, 520, 4200, 17000]))
+        sizes = rng.integers(400 if med else 0, hi + 1, size=R)
+        if hi > 4200 and not med:
             sizes[rng.random(R) < 0.97] //= 64  # a few big reads only
         kind = rng.integers(0, 3)
         if kind == 0:

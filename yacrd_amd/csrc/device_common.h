@@ -11,6 +11,31 @@ namespace yk {
 
 constexpr u32 kNoKey = 0xFFFFFFFFu;
 
+// Two consecutive intervals in ONE 16-byte load.  An interval pair of a read starts at iv + off[r] + 2P: 8-byte aligned,
+// not 16 — fine for a global load (dword alignment is all gfx950 asks for), but a plain `*(const uint4 *)` tells the
+// compiler 16; this vector type says 8.  -DYK_NT_LOADS=1 makes them non-temporal (`nt`: the intervals are
+// read once and must not displace what the XCD's L2 / the Infinity Cache hold for later — A/B, tools/build_variant.sh).
+typedef u32 u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
+#ifndef YK_NT_LOADS
+#define YK_NT_LOADS 1
+#endif
+__device__ __forceinline__ uint4 load_pair(const uint2 *p)
+{
+#if YK_NT_LOADS
+    const u32x4_a8 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a8 *>(p));
+#else
+    const u32x4_a8 q = *reinterpret_cast<const u32x4_a8 *>(p);
+#endif
+    return make_uint4(q.x, q.y, q.z, q.w);
+}
+// off[r] and off[r + 1] in one load (r may be odd: 8-byte aligned)
+typedef u64 u64x2_a8 __attribute__((ext_vector_type(2), aligned(8)));
+__device__ __forceinline__ ulonglong2 load_extent(const u64 *p)
+{
+    const u64x2_a8 q = *reinterpret_cast<const u64x2_a8 *>(p);
+    return make_ulonglong2(q.x, q.y);
+}
+
 struct OvlRec { // == yacrd_ovl_rec: one overlap line, both reads (handles) and their intervals
     u32 a, b, sa, ea, sb, eb;
 };
@@ -66,11 +91,12 @@ struct Counters {
     u32 over_med;            // M2 reads whose filtered keys do not fit the 256-thread kernel's LDS
     u32 fb_med[2];           // M1 / M2 reads the workgroup screen (screen_wg.h) left to the trimming filter + sort
     u32 fb_big;              // BIG reads the device-wide screen (screen_big.h) left to sweep_big_trim.h / sweep_big.h
-    u32 fbq_head[2];         // screen_wg_fused_kernel's queue of M1 / M2 reads (fb_med[] is its tail): slots claimed,
-    u32 fbq_done[2];         // workgroups that have finished screening
+    u32 fbq_head[2];         // screen_wg_fused_kernel's queue of M1 / M2 reads (fb_med[] is its tail): slots claimed
+    u32 fbq_done[2];         // (rounds 4-5: workgroups that had finished screening; unused since nobody waits, round 6)
     u32 bs_chunks;           // chunks of the device-wide screen (written by its setup kernel)
-    u32 fused_gave_up;       // a workgroup of screen_wg_fused_kernel ran out of looks at its queue slot: the engine runs the batch again without that kernel
+    u32 fused_gave_up;       // (rounds 4-5: a workgroup of screen_wg_fused_kernel ran out of looks at its queue slot; never set since round 6)
     u64 total_regions;       // G, written by the last scan workgroup
+    u32 fb_stream[2];        // M1 / M2 reads the one-wavefront screen (screen_stream.h) left to screen_wg_fused_kernel
     // reads the screen deferred and finish_compact_kernel sorted, and their intervals: one atomic each per
     // workgroup of 1024 reads.  (Counting where they are found does not work on this 8-XCD part:
     // same-address atomics are performed at the memory side one after the other, ~8 ns each — 1 500 of

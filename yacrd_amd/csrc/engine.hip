@@ -30,6 +30,7 @@
 #include "sweep_wave.h"
 #include "finish_compact.h"
 #include "screen_wg.h"
+#include "screen_stream.h"
 #include "screen_big.h"
 #include "one_batch.h"
 
@@ -68,6 +69,15 @@ static uint64_t split_min_reads()
     static const uint64_t v = [] {
         const char *e = std::getenv("YACRD_SPLIT_MIN_READS");
         return e ? std::strtoull(e, nullptr, 10) : (uint64_t)yk::kPlanSmallReads;
+    }();
+    return v;
+}
+
+static uint64_t fused_share_override()
+{
+    static const uint64_t v = [] {
+        const char *e = std::getenv("YACRD_FUSED_SHARE");
+        return e ? std::min<uint64_t>(std::strtoull(e, nullptr, 10), 4096) : (uint64_t)0;
     }();
     return v;
 }
@@ -420,7 +430,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     // (scan-state words: one per slab of the follow-on kernel; one_batch_kernel: one per slab + its arrival counters)
     const u32 ob_slabs = (n_reads + yk::kObSlab - 1) / yk::kObSlab;
     const u32 nb = one_launch ? 2 * ob_slabs : (n_reads + yk::kScanBlock - 1) / yk::kScanBlock;
-    constexpr int kLists = yk::CLS_COUNT + 7; // class lists + three rejection lists + M2 overflow + what the screens leave of M1 / M2 / BIG
+    constexpr int kLists = yk::CLS_COUNT + 9; // class lists + three rejection lists + M2 overflow + what the screens leave of M1 / M2 / BIG + what the one-wavefront screen leaves of M1 / M2
     HIP_TRY(e->lists.reserve((size_t)kLists * n_reads * sizeof(u32)));
     // (long batches: + the shard counters of the follow-on step's list of marked reads, behind the scan words)
     const size_t shard_ctr_bytes = (!one_launch && n_reads64 >= split_min_reads()) ? (size_t)yk::kDeferShards * yk::kDeferShardStride * sizeof(u32) : 0;
@@ -447,6 +457,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         *rej_big = list_of(yk::CLS_COUNT + 2), *over_med = list_of(yk::CLS_COUNT + 3);
     u32 *const fb_med[2] = {list_of(yk::CLS_COUNT + 4), list_of(yk::CLS_COUNT + 5)};
     u32 *const fb_big = list_of(yk::CLS_COUNT + 6);
+    u32 *const fb_stream[2] = {list_of(yk::CLS_COUNT + 7), list_of(yk::CLS_COUNT + 8)};
     yk::Counters *ctr = e->ctrl2[cur].as<yk::Counters>();
     const bool full = (e->flags & YACRD_F_TIMING_FULL) != 0;
     const int xm = (e->flags & YACRD_F_XLANE_DS) ? 1 : 0;
@@ -517,6 +528,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
                            !(e->flags & (YACRD_F_FORCE_GENERAL | YACRD_F_NO_PREDICTION));
     struct LaunchSet {
         u32 n[12];     // reads used to size the grid; 0 = class not launched
+        u32 hint[12];  // the class's size as far as the host knows it (its count, or the prediction + a margin): grids of kernels that cover a list of any length
         u32 first[12]; // first list entry the launch covers (remainder launches)
         u64 iv[12];    // intervals (to pick the dominant class)
     } ls{};
@@ -532,6 +544,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
             const u64 cap = (cls <= yk::CLS_W16 && tight_grids) ? ((p + p / 8 + 64 + 15) & ~(u64)15)
                                                                : n_reads64;
             ls.n[cls] = p ? (u32)std::min<u64>(cap, (n_reads64 + 15) & ~(u64)15) : 0;
+            ls.hint[cls] = p ? (u32)std::min<u64>(p + p / 8 + 64, n_reads64) : 0;
             ls.iv[cls] = e->pred.iv[cls];
         }
     } else {
@@ -541,6 +554,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         c0 = *e->h_ctr;
         for (int cls = 0; cls < yk::CLS_GENERAL; cls++) {
             ls.n[cls] = c0.n[cls];
+            ls.hint[cls] = c0.n[cls];
             ls.iv[cls] = c0.iv[cls];
         }
     }
@@ -583,6 +597,13 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     };
 
     bool fused_marked = false, screened = false;
+    struct MissGuard { // (a miss found by THIS call is reported by its conclude_run and forgotten when the call returns)
+        yacrd_engine *e;
+        bool before;
+        ~MissGuard() { e->miss_pending = before; }
+    } miss_guard{e, e->miss_pending};
+    e->prev_build = e->last_build;
+    e->last_build = -1;
     // sweeps of the classes in `set` (what the register sweeps reject is looked at after the final sync)
     auto launch_sweeps = [&](const LaunchSet &set, bool again = false) -> int {
         sa.rej_list = rej_small;
@@ -611,6 +632,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
                               : ((e->flags & YACRD_F_SCREEN_ITEMS_2) || fused_iv >= 40000000ull) ? 2 : 1;
             e->last_items = (uint32_t)items;
             e->last_wide = wide;
+            if (!again) e->last_build = !defer ? 0 : wide ? 3 : items;
             fa.base.over_list = nullptr; // (the deferring build marks its reads in counts[])
             fa.base.over_count = nullptr;
             fa.n_entries = 0;
@@ -706,35 +728,40 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
             sa.list = list_of(cls);
             sa.list_n = &ctr->n[cls];
             if (sa.prefilter && !(e->flags & YACRD_F_NO_FUSED_SCREEN) && !e->fused_off && e->screen_fused_wgs_per_cu > 0) {
-                // the screen and the fallback of what it leaves in ONE persistent launch (screen_wg.h): the grid must be
-                // resident as a whole (workgroups wait for each other's queue entries)
+                // the screen and the fallback of what it leaves in ONE launch (screen_wg.h)
                 if (again) { // (a second pass over the class: the queue starts over)
+                    HIP_TRY(hipMemsetAsync(&ctr->fb_stream[k], 0, sizeof(u32), e->stream));
                     HIP_TRY(hipMemsetAsync(&ctr->fb_med[k], 0, sizeof(u32), e->stream));
-                    HIP_TRY(hipMemsetAsync(&ctr->fbq_head[k], 0, sizeof(u32), e->stream));
-                    HIP_TRY(hipMemsetAsync(&ctr->fbq_done[k], 0, sizeof(u32), e->stream));
-                    HIP_TRY(hipMemsetAsync(fb_med[k], 0xFF, (size_t)set.n[cls] * sizeof(u32), e->stream));
+                }
+                // first one wavefront per read, the read streamed twice, no barrier (screen_stream.h, round 6): what it decides —
+                // all but a fiftieth of the generator's reads — never meets the workgroup kernel, which takes the rest as its class
+                const bool stream_first = (e->flags & YACRD_F_STREAM_SCREEN) != 0;
+                if (stream_first) {
+                    yk::SweepArgs ss = sa;
+                    ss.over_list = fb_stream[k];
+                    ss.over_count = &ctr->fb_stream[k];
+                    const u32 gss = (u32)std::min<uint64_t>(std::max<u32>(set.hint[cls], 1u), (uint64_t)e->num_cu * 96);
+                    hipLaunchKernelGGL(yk::screen_stream_kernel, dim3(gss), dim3(64), 0, e->stream, ss);
                 }
                 yk::ScreenFusedArgs fa;
                 fa.sweep = sa;
+                if (stream_first) fa.sweep.list = fb_stream[k], fa.sweep.list_n = &ctr->fb_stream[k];
                 fa.sweep.over_list = over_med;
                 fa.sweep.over_count = &ctr->over_med;
                 fa.sweep.rej_list = k == 0 ? rej_med : rej_big;
                 fa.sweep.rej_count = k == 0 ? &ctr->rej_med : &ctr->rej_big;
-                fa.q = fb_med[k];
-                fa.tail = &ctr->fb_med[k];
-                fa.head = &ctr->fbq_head[k];
-                fa.done = &ctr->fbq_done[k];
-                // (YACRD_TEST_FUSED_GRID_MULT, tests only: a grid that is NOT resident as a whole, so that its workgroups run out of looks)
-                const u32 gs = (u32)std::min<uint64_t>(set.n[cls], (uint64_t)e->num_cu * (uint64_t)e->screen_fused_wgs_per_cu * fused_grid_mult());
-                {
-                    FusedLane &fl = g_fused_lane[e->device & 63];
-                    std::lock_guard<std::mutex> turn(fl.mu);
-                    if (fl.owner != nullptr && fl.owner != e && fl.last) HIP_TRY(hipStreamWaitEvent(e->stream, fl.last, 0));
-                    hipLaunchKernelGGL(yk::screen_wg_fused_kernel, dim3(gs), dim3(yk::kWsT), 0, e->stream, fa);
-                    HIP_TRY(hipEventRecord(e->ev_fused, e->stream));
-                    fl.last = e->ev_fused;
-                    fl.owner = e;
-                }
+                fa.n_fallback = &ctr->fb_med[k];
+                // No workgroup of this launch waits for another or shares anything with it (screen_wg.h, round 6): the grid is
+                // sized for the DISPATCHER — workgroups of `share` consecutive list entries, about eight rounds of the slots
+                // the device has for them; a class of a few thousand reads: one read each.
+                // (YACRD_TEST_FUSED_GRID_MULT, tests: a multiple of that grid.  YACRD_FUSED_SHARE, A/B: the share.)
+                const u64 slots = (u64)e->num_cu * (u64)std::max(1, e->screen_fused_wgs_per_cu);
+                const u64 known = std::max<u32>(set.hint[cls], 1u);
+                u64 share = std::min<u64>(std::max<u64>(known / (8 * slots), 1), (u64)yk::kFusedShareMax);
+                if (fused_share_override()) share = std::min<u64>(fused_share_override(), (u64)yk::kFusedShareMax);
+                fa.share = (u32)share;
+                const u32 gs = (u32)std::min<u64>((known + share - 1) / share * fused_grid_mult(), 0x7FFFFFFFull);
+                hipLaunchKernelGGL(yk::screen_wg_fused_kernel, dim3(gs), dim3(yk::kWsT), 0, e->stream, fa);
                 if (k == 1) { // what does not fit the in-kernel fallback's 16 384 events even filtered (usually nothing)
                     sa.list = over_med;
                     sa.list_n = &ctr->over_med;
@@ -753,7 +780,8 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
                 if (again) HIP_TRY(hipMemsetAsync(&ctr->fb_med[k], 0, sizeof(u32), e->stream)); // (its entries are done)
                 sa.over_list = fb_med[k];
                 sa.over_count = &ctr->fb_med[k];
-                const u32 gs = (u32)std::min<uint64_t>(set.n[cls], (uint64_t)e->num_cu * 4);
+                static const uint64_t wgk_grid = [] { const char *ev = std::getenv("YACRD_WGK_GRID"); return ev ? std::strtoull(ev, nullptr, 10) : (uint64_t)0; }(); // (A/B)
+                const u32 gs = (u32)std::min<uint64_t>(set.n[cls], wgk_grid ? wgk_grid : (uint64_t)e->num_cu * 4);
                 hipLaunchKernelGGL(yk::screen_wg_kernel, dim3(gs), dim3(yk::kWsT), 0, e->stream, sa);
                 sa.list = fb_med[k];
                 sa.list_n = &ctr->fb_med[k];
@@ -886,9 +914,11 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
             if (c0.n[cls] > ls.n[cls]) { // class not predicted, or larger than its grid
                 missing.first[cls] = (cls <= yk::CLS_W16 && tight_grids) ? ls.n[cls] : 0;
                 missing.n[cls] = c0.n[cls] - missing.first[cls];
+                missing.hint[cls] = missing.n[cls];
                 any_missing = true;
             }
         if (any_missing || c0.n[yk::CLS_GENERAL]) {
+            e->miss_pending = true; // (the prediction did not hold: yacrd_timing.prediction_misses)
             if (!redo) HIP_TRY(hipEventRecord(e->ev[EV_X0], e->stream));
             if (any_missing && (rc = launch_sweeps(missing, true))) return rc;
             if (c0.n[yk::CLS_GENERAL] && (rc = launch_huge(c0.n[yk::CLS_GENERAL], c0.iv[yk::CLS_GENERAL], &gen_iv))) return rc;
@@ -1040,6 +1070,10 @@ int conclude_run(yacrd_engine *e, yk::Counters c0, bool predicted, uint64_t n_re
     t.screen_items = screened ? e->last_items : 0u;
     t.screen_wide = (screened && e->last_wide) ? 1u : 0u;
     t.fused_reruns = e->fused_off ? 1u : 0u;
+    t.predicted = predicted ? 1u : 0u;
+    t.prediction_misses = e->miss_pending ? 1u : 0u;
+    t.build_switches = (e->last_build >= 0 && e->prev_build >= 0 && e->last_build != e->prev_build) ? 1u : 0u;
+    t.sorting_build = e->last_build == 0 ? 1u : 0u;
     t.fused_reads = t.fused_intervals = 0;
     t.prefiltered_reads = c1.prefiltered;
     if (fused_marked) t.fused_ms = ev_ms(e->ev_cls[22], e->ev_cls[23]);
@@ -1067,6 +1101,11 @@ int conclude_run(yacrd_engine *e, yk::Counters c0, bool predicted, uint64_t n_re
     ts.screened = keep.screened + t.screened;
     ts.one_launch = keep.one_launch;
     ts.fused_reruns = keep.fused_reruns + t.fused_reruns;
+    ts.screen_wide = keep.screen_wide + t.screen_wide;
+    ts.predicted = keep.predicted + t.predicted;
+    ts.prediction_misses = keep.prediction_misses + t.prediction_misses;
+    ts.build_switches = keep.build_switches + t.build_switches;
+    ts.sorting_build = keep.sorting_build + t.sorting_build;
     ts.timed_runs = keep.timed_runs + t.timed_runs;
     e->timing_runs++;
     return YACRD_OK;
@@ -1113,6 +1152,9 @@ int finish_pending(yacrd_engine *e)
         for (int i = 0; i < 12; i++) ts.class_ms[i] = keep.class_ms[i];
         ts.fused_ms = keep.fused_ms, ts.screened = keep.screened + 1u, ts.timed_runs = keep.timed_runs;
         ts.one_launch = keep.one_launch + 1u;
+        ts.screen_wide = keep.screen_wide;
+        ts.fused_reruns = keep.fused_reruns, ts.predicted = keep.predicted, ts.prediction_misses = keep.prediction_misses;
+        ts.build_switches = keep.build_switches, ts.sorting_build = keep.sorting_build;
         e->timing_runs++;
         return YACRD_OK;
     }
@@ -1122,7 +1164,10 @@ int finish_pending(yacrd_engine *e)
     for (int cls = 0; cls < yk::CLS_GENERAL; cls++) ok = ok && c.n[cls] <= p.grid_n[cls];
     if (!ok) {
         e->pred_valid = false;
-        return run_on_device(e, p.d_off, p.d_iv, p.d_len, p.n_reads, p.n_iv, p.cov, p.not_cov);
+        e->miss_pending = true; // (yacrd_timing.prediction_misses: the re-run's conclude_run reports it)
+        const int rcm = run_on_device(e, p.d_off, p.d_iv, p.d_len, p.n_reads, p.n_iv, p.cov, p.not_cov);
+        e->miss_pending = false;
+        return rcm;
     }
     return conclude_run(e, c, true, p.n_reads, p.n_iv, p.cls_b, p.cls_e, p.fused_marked, p.screened, 0.f);
 }
@@ -1243,6 +1288,12 @@ namespace {
 extern "C" {
 
 int yacrd_abi_version(void) { return YACRD_ABI_VERSION; }
+
+uint64_t yacrd_debug_last_counters(const yacrd_engine *e, void *dst, uint64_t bytes)
+{
+    if (e && dst && e->h_ctr) std::memcpy(dst, e->h_ctr, (size_t)std::min<uint64_t>(bytes, sizeof(yk::Counters)));
+    return sizeof(yk::Counters);
+}
 
 const char *yacrd_last_error(void) { return yke::err_slot().c_str(); }
 

@@ -166,6 +166,8 @@ struct yacrd_engine {
     uint32_t last_items = 1;   // groups of list entries per wavefront the last screen ran with
     bool last_wide = false;    // ... and whether it was the build with the second looks
     bool one_launch_off = false; // (while a batch the one-launch form could not take is run again on the default path)
+    int last_build = -1, prev_build = -1; // build of the register classes' launch in the last run / the one before (-1: none; 0 sorting, 1 / 2 screening with one / two items, 3 second looks)
+    bool miss_pending = false;            // the run in progress is the synchronous re-run of a batch whose prediction did not hold
     uint32_t nodefer_left = 0; // batches the sorting build of the fused launch still takes before the screen is tried again
     // pinned bounce buffers for pageable inputs (yke::h2d), allocated on first use; an event per
     // buffer says when its DMA is done and it may be refilled
@@ -200,7 +202,7 @@ struct RecSlab {
 };
 int csr_from_records(yacrd_engine *e, const RecSlab *slabs, size_t n_slabs, const u32 *d_map, u64 n_handles, u64 n_reads,
                      DevBuf &cnt, DevBuf &part, DevBuf &err, hipEvent_t done, u64 *n_intervals = nullptr,
-                     bool counted = false);
+                     bool counted = false, u64 iv_bound = 0);
 int scan_u32_to_u64(yacrd_engine *e, const u32 *in, u64 n, u64 *out, DevBuf &part);
 // host -> HBM at PCIe rate: direct DMA when `src` is pinned, otherwise through the engine's pinned
 // bounce buffers filled by a few copy threads; asynchronous on e->stream only for pinned sources

@@ -278,7 +278,7 @@ __device__ __forceinline__ bool filtered_turn(const SweepArgs &a, bool active, u
     const u32 last2 = two ? n - 2u : 0u;
     uint4 v[K / 4];
 #pragma unroll
-    for (int j = 0; j < K / 4; j++) v[j] = *reinterpret_cast<const uint4 *>(src + min(2u * (lig + (u32)LANES * j), last2));
+    for (int j = 0; j < K / 4; j++) v[j] = load_pair(src + min(2u * (lig + (u32)LANES * j), last2));
     u32 smin = v[0].x, emax = v[0].y, smax = v[0].x;
     i32 tmin = 0x7FFFFFFF;
 #pragma unroll
@@ -398,8 +398,9 @@ __global__ __launch_bounds__(kListThreads, YK_LIST_OCC) void deferred_list_kerne
     const LaneConst lcf = make_lane_const(lane);
     if (tid == 0) s_iv = 0;
     for (u32 c0 = lo; c0 < hi; c0 += (u32)kListThreads) { // (uniform)
-        if (tid == 0) s_nfb = 0;
-        __syncthreads(); // (s_pre is written; the last round's lists are done with)
+        __syncthreads(); // (s_pre is written; the last round's lists are done with — every wavefront has read its s_nfb)
+        if (tid == 0) s_nfb = 0; // (behind the barrier: ADVICE r5 — in front of it, a wavefront still on its way to the last round's
+                                 //  `nfb = s_nfb` could read 0 and skip its fallback reads; the adds start behind the next barrier)
         const u32 e = c0 + tid, n_here = min((u32)kListThreads, hi - c0);
         if (e < hi) {
             u32 s = 0; // the shard that holds entry e: the last one whose first entry is <= e

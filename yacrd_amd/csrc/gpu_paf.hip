@@ -37,6 +37,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -1087,12 +1088,123 @@ int ingest_text(yacrd_engine *e, const TextSource &src, u64 n, bool m4, int n_th
 
 // ---- several engines, one file --------------------------------------------------------------------------------------
 namespace {
-// device memory of engine `from` -> device memory of engine `to`, on `to`'s stream (the source is complete: its stream was waited for)
+// ---- device memory of engine `from` -> device memory of engine `to`, on `to`'s stream ---------------------------------------
+// (the source is complete: its stream was waited for; the caller's current device is `to`'s).  Three routes:
+//   same device                   hipMemcpyAsync, device to device
+//   two devices, peer access      hipMemcpyPeerAsync: xGMI carries it
+//   two devices, no peer access   staged through two pinned host buffers: device -> host on `from`'s device, host -> device
+//                                 on `to`'s stream (the runtime would do the same, one pageable piece at a time)
+// Which of the last two a PAIR of devices takes is found once, when a group first uses the pair (hipDeviceCanAccessPeer +
+// hipDeviceEnablePeerAccess in both directions; anything but success / "already enabled" = staged).  This builder has never
+// seen two GPUs in one box (missing #2), so the routes can be FORCED on one device, where the tests run:
+// YACRD_TEST_FORCE_PEER_COPY=peer sends every cross-engine copy through hipMemcpyPeerAsync (source device = destination
+// device is legal), =staged through the host bounce; tests/test_gpu_ingest_group.py runs the group under both.
+enum PeerRoute { kRouteSame = 0, kRoutePeer = 1, kRouteStaged = 2 };
+int forced_peer_route()
+{
+    static const int v = [] {
+        const char *ev = std::getenv("YACRD_TEST_FORCE_PEER_COPY");
+        if (!ev || !*ev) return -1;
+        if (!std::strcmp(ev, "peer") || !std::strcmp(ev, "1")) return (int)kRoutePeer;
+        if (!std::strcmp(ev, "staged") || !std::strcmp(ev, "host")) return (int)kRouteStaged;
+        return -1;
+    }();
+    return v;
+}
+std::mutex g_peer_mu;
+signed char g_peer_route[64][64]; // 0: not looked at yet; else PeerRoute + 1
+std::atomic<unsigned long long> g_peer_copies[3]; // copies per route (yacrd_debug_peer_copy_counts: the tests look)
+PeerRoute route_between(int to_dev, int from_dev)
+{
+    const int forced = forced_peer_route();
+    if (to_dev == from_dev) return forced >= 0 ? (PeerRoute)forced : kRouteSame;
+    if (forced == (int)kRouteStaged) return kRouteStaged;
+    if (to_dev < 0 || from_dev < 0 || to_dev >= 64 || from_dev >= 64) return kRouteStaged;
+    std::lock_guard<std::mutex> lock(g_peer_mu);
+    signed char &slot = g_peer_route[to_dev][from_dev];
+    if (slot) return (PeerRoute)(slot - 1);
+    PeerRoute r = kRouteStaged;
+    int can_a = 0, can_b = 0;
+    if (hipDeviceCanAccessPeer(&can_a, to_dev, from_dev) == hipSuccess && hipDeviceCanAccessPeer(&can_b, from_dev, to_dev) == hipSuccess &&
+        can_a && can_b) {
+        bool ok = true;
+        for (int k = 0; k < 2 && ok; k++) { // both directions: the merge pulls towards engine 0, the deal pushes away from it
+            const int self = k == 0 ? to_dev : from_dev, peer = k == 0 ? from_dev : to_dev;
+            DeviceGuard guard(self);
+            const hipError_t er = hipDeviceEnablePeerAccess(peer, 0);
+            if (er != hipSuccess && er != hipErrorPeerAccessAlreadyEnabled) ok = false;
+            (void)hipGetLastError(); // ("already enabled" is sticky otherwise)
+        }
+        if (ok) r = kRoutePeer;
+    } else {
+        (void)hipGetLastError();
+    }
+    slot = (signed char)(r + 1);
+    g_peer_route[from_dev][to_dev] = slot;
+    return r;
+}
+// the staged route: two pinned buffers per destination engine, a piece flies host -> device while the next one is fetched
+struct StageBuf {
+    void *p[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    bool busy[2] = {false, false};
+    hipStream_t from_stream = nullptr;
+    int from_dev = -1;
+    ~StageBuf()
+    {
+        for (int i = 0; i < 2; i++) {
+            if (p[i]) (void)hipHostFree(p[i]);
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+        }
+        if (from_stream) {
+            DeviceGuard guard(from_dev);
+            (void)hipStreamDestroy(from_stream);
+        }
+    }
+};
+constexpr size_t kStagePiece = (size_t)16 << 20;
+hipError_t copy_staged(yacrd_engine *to, void *dst, yacrd_engine *from, const void *src, size_t bytes)
+{
+    StageBuf sb; // (per call: the route is a fallback, its setup cost is not what matters on it)
+    for (int i = 0; i < 2; i++) {
+        hipError_t er = hipHostMalloc(&sb.p[i], std::min(bytes, kStagePiece));
+        if (er == hipSuccess) er = hipEventCreateWithFlags(&sb.ev[i], hipEventDisableTiming);
+        if (er != hipSuccess) return er;
+    }
+    sb.from_dev = from->device;
+    {
+        DeviceGuard guard(from->device);
+        const hipError_t er = hipStreamCreateWithFlags(&sb.from_stream, hipStreamNonBlocking);
+        if (er != hipSuccess) return er;
+    }
+    int turn = 0;
+    for (size_t at = 0; at < bytes; at += kStagePiece, turn ^= 1) {
+        const size_t m = std::min(kStagePiece, bytes - at);
+        if (sb.busy[turn]) {
+            const hipError_t er = hipEventSynchronize(sb.ev[turn]); // the buffer's last host -> device copy has left it
+            if (er != hipSuccess) return er;
+        }
+        {
+            DeviceGuard guard(from->device); // device -> host runs on the SOURCE device's stream
+            hipError_t er = hipMemcpyAsync(sb.p[turn], (const char *)src + at, m, hipMemcpyDeviceToHost, sb.from_stream);
+            if (er == hipSuccess) er = hipStreamSynchronize(sb.from_stream);
+            if (er != hipSuccess) return er;
+        }
+        hipError_t er = hipMemcpyAsync((char *)dst + at, sb.p[turn], m, hipMemcpyHostToDevice, to->stream);
+        if (er == hipSuccess) er = hipEventRecord(sb.ev[turn], to->stream);
+        if (er != hipSuccess) return er;
+        sb.busy[turn] = true;
+    }
+    return hipStreamSynchronize(to->stream); // (the pinned buffers go away with `sb`)
+}
 hipError_t copy_between(yacrd_engine *to, void *dst, yacrd_engine *from, const void *src, size_t bytes)
 {
     if (!bytes) return hipSuccess;
-    if (to->device == from->device) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, to->stream);
-    return hipMemcpyPeerAsync(dst, to->device, src, from->device, bytes, to->stream);
+    const PeerRoute r = route_between(to->device, from->device);
+    g_peer_copies[(int)r]++;
+    if (r == kRouteSame) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, to->stream);
+    if (r == kRoutePeer) return hipMemcpyPeerAsync(dst, to->device, src, from->device, bytes, to->stream);
+    return copy_staged(to, dst, from, src, bytes);
 }
 
 int ingest_text_group(yacrd_engine *const *E, uint32_t N, const TextSource &src, u64 n, bool m4, int n_threads, uint32_t coverage,
@@ -1108,6 +1220,36 @@ int ingest_text_group(yacrd_engine *const *E, uint32_t N, const TextSource &src,
     const u64 chunks = (n + kChunk - 1) / kChunk, per = (chunks + N - 1) / N;
     std::vector<u64> B(N + 1);
     for (uint32_t d = 0; d <= N; d++) B[d] = std::min<u64>(n, (u64)d * per * kChunk);
+    for (uint32_t d = 0; d < N; d++)
+        if (!scratch_of(E[d])) return fail(YACRD_ENOMEM, "host allocation failed"); // (every later scratch_of(E[d]) finds it)
+    // ---- does it fit?  Answered here, before anything is allocated or moved (parse_range's own check knows only
+    // its range).  Per DEVICE: what its engines' ranges need for the parse (text, records, id table, CSR and region slots of
+    // as many reads: ~2.6 x the range, parse_range) plus the records every one of its engines gathers from ranges parsed on
+    // OTHER devices (24 bytes per line, ~0.32 x their text at 75 bytes a line; engines of one device read each other's
+    // records in place).  An input beyond that is the host parser's (its stream group needs ~0.5 x the file over all GPUs).
+    {
+        std::vector<int> seen;
+        for (uint32_t d = 0; d < N; d++) {
+            const int dev = E[d]->device;
+            if (std::find(seen.begin(), seen.end(), dev) != seen.end()) continue;
+            seen.push_back(dev);
+            double here = 0, held = 0;
+            uint32_t engines_here = 0;
+            for (uint32_t k = 0; k < N; k++)
+                if (E[k]->device == dev) {
+                    Scratch &Sk = *scratch_of(E[k]);
+                    here += (double)(B[k + 1] - B[k]);
+                    held += (double)Sk.text.cap + (double)Sk.recs.cap + (double)E[k]->stage.cap + (double)E[k]->in_iv.cap + (double)Sk.gather.cap;
+                    engines_here++;
+                }
+            const double need = 2.6 * here + 0.32 * ((double)n - here) * engines_here + (double)((size_t)256 << 20) * engines_here;
+            DeviceGuard guard(dev);
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > (double)free_b + held)
+                return fail(YACRD_EFALLBACK, "the file is too large to be parsed in the GPUs' free memory (ranges + the records gathered "
+                                             "from the other GPUs): the host parser streams it");
+        }
+    }
     uint32_t active = 0;
     while (active < N && B[active] < B[active + 1]) active++;
     if (active < 2) return ingest_text(E[0], src, n, m4, n_threads, coverage, not_coverage, out, reads, stats);
@@ -1299,13 +1441,16 @@ int ingest_text_group(yacrd_engine *const *E, uint32_t N, const TextSource &src,
         const u32 lo = cut[o], hi = cut[o + 1], Ro = hi - lo;
         std::vector<RecSlab> slabs(A);
         u64 foreign = 0;
+        // (records parsed by an engine of THIS device are read where they lie; under YACRD_TEST_FORCE_PEER_COPY every other
+        // engine counts as another device's, so that the gather and its copies run on a one-GPU box)
+        auto elsewhere = [&](uint32_t d) { return E[d]->device != e->device || (forced_peer_route() >= 0 && E[d] != e); };
         for (uint32_t d = 0; d < A; d++)
-            if (E[d]->device != e->device) foreign += ro[d].n_recs;
+            if (elsewhere(d)) foreign += ro[d].n_recs;
         HIP_TRY(S.gather.reserve((size_t)foreign * sizeof(yk::OvlRec) + 64));
         u64 at = 0;
         for (uint32_t d = 0; d < A; d++) {
             Scratch &Sd = *scratch_of(E[d]);
-            if (E[d]->device == e->device) {
+            if (!elsewhere(d)) {
                 slabs[d] = RecSlab{Sd.recs.as<yk::OvlRec>(), ro[d].n_recs};
             } else {
                 yk::OvlRec *dst = S.gather.as<yk::OvlRec>() + at;
@@ -1322,8 +1467,10 @@ int ingest_text_group(yacrd_engine *const *E, uint32_t N, const TextSource &src,
         // every range's records on every engine — is not needed)
         HIP_TRY(S.cnt.reserve((size_t)(Ro + 4) * sizeof(u32)));
         HIP_TRY(copy_between(e, S.cnt.p, e0, S0.g_rcnt.as<u32>() + lo, (size_t)Ro * sizeof(u32)));
-        u64 n_iv = 0;
-        int r = csr_from_records(e, slabs.data(), slabs.size(), S.gmap.as<u32>(), Rg, Ro, S.cnt, S.part, S.err, nullptr, &n_iv, true);
+        u64 n_iv = 0, own_iv = 0; // (the engine's CSR holds the intervals of ITS reads: the merge has their counts)
+        for (u32 g = lo; g < hi; g++) own_iv += h_rcnt[g];
+        int r = csr_from_records(e, slabs.data(), slabs.size(), S.gmap.as<u32>(), Rg, Ro, S.cnt, S.part, S.err, nullptr, &n_iv, true,
+                                 own_iv + 1);
         if (r) return r;
         t_built[o] = now_ms();
         r = run_on_device(e, e->in_off.as<u64>(), e->in_iv.as<uint2>(), e->in_len.as<u32>(), Ro, n_iv, coverage, not_coverage);
@@ -1386,6 +1533,12 @@ int ingest_text_group(yacrd_engine *const *E, uint32_t N, const TextSource &src,
 } // namespace
 
 extern "C" {
+
+/* tests: cross-engine copies since the library was loaded, by route — same device / hipMemcpyPeerAsync / staged through the host */
+void yacrd_debug_peer_copy_counts(uint64_t out[3])
+{
+    for (int i = 0; i < 3; i++) out[i] = g_peer_copies[i].load();
+}
 
 static int group_args(yacrd_engine *const *engines, uint32_t n_engines, yacrd_result *out, yacrd_reads *reads, yacrd_ingest_stats *stats)
 {

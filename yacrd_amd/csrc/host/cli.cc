@@ -183,8 +183,9 @@ int main(int argc, char **argv)
         // YACRD_NO_DEVICE_PARSER=1: the host parser for everything (A/B, tools/e2e_cli_paf.py)
         const char *no_dev = std::getenv("YACRD_NO_DEVICE_PARSER");
         // (--gpus N > 1: every GPU moves and parses a byte range of the text over its own link and sweeps a range of the reads,
-        // yacrd_engines_ingest_overlaps; an input beyond the GPUs' memory, which the call refuses before it allocates
-        // anything, is routed to all N by the host parser's stream group)
+        // yacrd_engines_ingest_overlaps; an input beyond the GPUs' memory — the call estimates every device's need, its ranges
+        // and the records it gathers from the others, before it allocates anything, and an allocation that fails later after all
+        // comes back as an error too — is routed to all N by the host parser's stream group)
         if ((paf || m4) && !(no_dev && *no_dev == '1')) {
             // one GPU, PAF or M4 text: the host only moves the file to HBM, the device parses it, numbers the reads,
             // builds the CSR and runs the engine (yacrd_engine_ingest_overlaps).  Whatever is not a plain file of

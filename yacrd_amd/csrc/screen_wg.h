@@ -29,6 +29,15 @@
 // decide (8 % of configs[3]'s reads) goes to a fallback list for those kernels.
 #pragma once
 #include "device_common.h"
+#ifndef YK_EXP_NO_COUNT
+#define YK_EXP_NO_COUNT 0
+#endif
+#ifndef YK_EXP_NO_FALLBACK
+#define YK_EXP_NO_FALLBACK 0
+#endif
+#ifndef YK_EXP_NO_FILTERED
+#define YK_EXP_NO_FILTERED 0
+#endif
 #include "sweep_lds.h"
 #include "sweep_wave.h"
 
@@ -45,7 +54,13 @@ constexpr int kWsBins = kWsT;
 // (o, n, len: the read's first interval, its intervals, its length — the persistent kernel has them before the turn starts)
 // A thread takes its intervals two at a time (16-byte loads: pair P = tid + kWsT * j holds intervals 2P and 2P + 1, the load
 // clamped to the read's last pair — as the register classes' screen does, sweep_wave.h).
-__device__ __forceinline__ bool screen_wg_read(const SweepArgs &a, u32 r, u64 o, u32 n, u32 len, u32 *tab, u32 (*red)[4], u32 *sc)
+// what the screen learned about a read it could NOT decide, for wg_filtered_read below (the table stays in LDS)
+struct WgVerdict {
+    bool plain;   // the table is the read's: every position inside the read and the key range, a span of two windows or more
+    bool ends_ok; // F > c, G > c, no end at or before a: (0, a) and (b, len) are the read's first and last regions whatever lies between
+    u32 pmin, pmax, sh, ra, rb;
+};
+__device__ __forceinline__ bool screen_wg_read(const SweepArgs &a, u32 r, u64 o, u32 n, u32 len, u32 *tab, u32 (*red)[4], u32 *sc, WgVerdict &vd)
 {
     constexpr int T = kWsT, R = kWsR, W = kWsW, NW = T / 64;
     constexpr u32 kEnd = 1u << 16, kField = kEnd - 1u;
@@ -66,7 +81,7 @@ __device__ __forceinline__ bool screen_wg_read(const SweepArgs &a, u32 r, u64 o,
             const u32 base = ch * (u32)(T * R / 2) + tid; // (pairs)
 #pragma unroll
             for (int j = 0; j < R / 2; j++) // (slots beyond the read: copies of its last two intervals)
-                v[j] = *reinterpret_cast<const uint4 *>(iv + min(2u * (base + (u32)(j * T)), n - 2u));
+                v[j] = load_pair(iv + min(2u * (base + (u32)(j * T)), n - 2u));
 #pragma unroll
             for (int j = 0; j < R / 2; j++) {
                 smin = min(smin, min(v[j].y != 0u ? v[j].x : 0xFFFFFFFFu, v[j].w != 0u ? v[j].z : 0xFFFFFFFFu)); // ((0, 0) intervals are inert: left out)
@@ -100,6 +115,7 @@ __device__ __forceinline__ bool screen_wg_read(const SweepArgs &a, u32 r, u64 o,
 
     bool healthy = false;
     u32 ra = 0, rb = 0;
+    vd.plain = !fallback, vd.ends_ok = false, vd.pmin = pmin, vd.pmax = pmax, vd.sh = 0, vd.ra = 0, vd.rb = 0;
     if (!fallback) { // (uniform)
         const i32 bits = 32 - (i32)__builtin_clz(len | 1u) - ilog2c(kWsNB) + (len != 0 ? 0 : -1);
         const u32 sh = (u32)max(bits, ilog2c(W));
@@ -110,17 +126,21 @@ __device__ __forceinline__ bool screen_wg_read(const SweepArgs &a, u32 r, u64 o,
             const u32 ds = s0 - pmin, dx = e0 - pmin;
             const u32 is = min(ds, (u32)W) + (ds >> sh) + __builtin_elementwise_sub_sat(ds, Tt);
             const u32 ie = min(dx, (u32)W) + (dx >> sh) + __builtin_elementwise_sub_sat(dx, Tt);
+#if !YK_EXP_NO_COUNT // (timing experiments only, tools/build_variant.sh: wrong results)
             if (real && e0 != 0u) {
                 atomicAdd(reinterpret_cast<u32 *>(tb + ((is << 4) + cp)), 1u);
                 atomicAdd(reinterpret_cast<u32 *>(tb + ((ie << 4) + cp)), kEnd);
             }
+#else
+            if (real && e0 != 0u && (is ^ ie) == 0xFFFFFFFFu) tb[0] = 1;
+#endif
         };
         for (u32 ch = 0; ch < chunks; ch++) {
             const u32 base = ch * (u32)(T * R / 2) + tid;
             if (chunks > 1u) {
 #pragma unroll
                 for (int j = 0; j < R / 2; j++)
-                    v[j] = *reinterpret_cast<const uint4 *>(iv + min(2u * (base + (u32)(j * T)), n - 2u));
+                    v[j] = load_pair(iv + min(2u * (base + (u32)(j * T)), n - 2u));
             }
 #pragma unroll
             for (int j = 0; j < R / 2; j++) {
@@ -172,7 +192,7 @@ __device__ __forceinline__ bool screen_wg_read(const SweepArgs &a, u32 r, u64 o,
         // all of its own ends
         const i32 cs_ex = (i32)(wex & kField), ce_in = (i32)((wex >> 16) + (w >> 16));
         const bool shallow = (w & kField) != 0u && cs_ex >= (i32)k1 && !(cs_ex - ce_in > c);
-        const u32 n_incl = wave_incl_add(notyet), bad_w = wave_or((shallow || spoiled) ? 1u : 0u);
+        const u32 n_incl = wave_incl_add(notyet), bad_w = wave_or((shallow ? 1u : 0u) | (spoiled ? 2u : 0u));
         if (lane == 63u) red[wv][2] = n_incl, red[wv][3] = bad_w;
         __syncthreads();
         u32 ntot = 0, any_bad = 0;
@@ -181,6 +201,8 @@ __device__ __forceinline__ bool screen_wg_read(const SweepArgs &a, u32 r, u64 o,
         healthy = any_bad == 0u && F > c && G > c;
         ra = pmin + (ntot & kField);
         rb = pmax - (ntot >> 16);
+        vd.ends_ok = (any_bad & 2u) == 0u && F > c && G > c;
+        vd.sh = sh, vd.ra = ra, vd.rb = rb;
     } else {
         __syncthreads(); // (red[] / the table are reused by the next read)
     }
@@ -196,13 +218,182 @@ __device__ __forceinline__ bool screen_wg_read(const SweepArgs &a, u32 r, u64 o,
     return healthy;
 }
 
-__device__ __forceinline__ bool screen_wg_read(const SweepArgs &a, u32 r, u32 *tab, u32 (*red)[4], u32 *sc)
+__device__ __forceinline__ bool screen_wg_read(const SweepArgs &a, u32 r, u32 *tab, u32 (*red)[4], u32 *sc, WgVerdict &vd)
 {
     const u64 o = a.off[r];
-    return screen_wg_read(a, r, o, (u32)(a.off[r + 1] - o), a.len[r], tab, red, sc);
+    return screen_wg_read(a, r, o, (u32)(a.off[r + 1] - o), a.len[r], tab, red, sc, vd);
+}
+__device__ __forceinline__ bool screen_wg_read(const SweepArgs &a, u32 r, u32 *tab, u32 (*red)[4], u32 *sc)
+{
+    WgVerdict vd;
+    return screen_wg_read(a, r, tab, red, sc, vd);
+}
+
+// ---- the FILTERED exact sweep of a read the screen could not decide (round 6) -----------------------------------------
+// tests/formulation.py::unified_filtered_regions is the emulation (fuzzed against the oracle, exhaustive over small
+// multisets: tests/test_formulation.py).  The reads the screen leaves are the reads yacrd looks for — on the generator's
+// reads: chimeras, healthy at both ENDS and low at a junction somewhere inside — and until round 6 every one of them went
+// through sweep_lds_read: two more passes over its intervals, the pile-trimming plan, a sort of what that keeps — for a
+// chimera of 6 000 intervals the ~2 100 events at the junction PLUS as many stand-in keys as the depth in front of it, 8 192
+// or 16 384 keys — and four sweep passes: 50-90 us by one workgroup, and the launch's tail is one such read.  Here the
+// screen's own table, still in LDS, is read once more:
+//   * D_i = starts - ends of the bins in front of bin i is the EXACT depth on entry to it (the map is monotone: the bins
+//     are in event order), D_i - E_i the least depth any of its events sees.  D_i - E_i > c: the bin is SAFE — none of
+//     its starts is low (src/stack.rs:83), all of its ends are flagged (:77-79).  A low start lies in an unsafe bin, and
+//     the flagged end the reference pairs it with — the last one in front of it — lies in an unsafe bin too or is the
+//     largest end of the nearest bin in front that holds an end;
+//   * kept: the unsafe bins behind a's and in front of b's and, for each, the nearest bin in front that holds an end.
+//     Their events (<= kWfCap, or the read is sweep_lds_read's after all) are collected in one more pass over the
+//     intervals (from the L2: the screen has just read them), sorted in LDS and swept with their TRUE depths: the kept
+//     events in front + a correction per bin (D_i minus the kept bins' net in front of it) — no stand-in keys;
+//   * the ends are the screen's: (0, a) in front, (b, len) behind (WgVerdict::ends_ok); a run of low starts still open when
+//     the keys end is closed by the tail.
+// A shallow start at or behind b's bin, a zero-length interval in a kept bin, a low start with no flagged end in front of
+// it: false (nothing written) — the caller sorts the read.  True: the read's regions and their count are written.
+constexpr int kWfCap = 4096; // kept events: eight keys per thread
+__device__ __forceinline__ bool wg_filtered_read(const SweepArgs &a, u32 r, const WgVerdict &vd, u32 *tab, u32 *sc, u32 *keys,
+                                                 unsigned long long *s_masks, const LaneConst &lc)
+{
+    constexpr int T = kWsT, W = kWsW, NW = T / 64;
+    constexpr u32 kEnd = 1u << 16, kField = kEnd - 1u;
+    static_assert(kWsBins == T, "one bin per thread");
+    if (!vd.plain || !vd.ends_ok) return false; // (uniform)
+    const u32 tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
+    const i32 c = (i32)min(a.cov, 0x3FFFFFFFu);
+    const u64 o = a.off[r];
+    const u32 n = (u32)(a.off[r + 1] - o), len = a.len[r];
+    const u32 pmin = vd.pmin, sh = vd.sh, span = vd.pmax - pmin, Tt = span - (u32)W;
+    auto idx = [&](u32 x) {
+        const u32 dx = x - pmin;
+        return min(dx, (u32)W) + (dx >> sh) + __builtin_elementwise_sub_sat(dx, Tt);
+    };
+    uint4 *bins = reinterpret_cast<uint4 *>(tab);
+    // ---- this thread's bin: counts, the depth on entry
+    const uint4 c4 = bins[tid];
+    const u32 w = c4.x + c4.y + c4.z + c4.w;
+    const i32 S = (i32)(w & kField), E = (i32)(w >> 16);
+    u32 tot;
+    const u32 wex = block_excl_add<T>(w, sc, tot);
+    const i32 D = (i32)(wex & kField) - (i32)(wex >> 16);
+    const u32 ia = vd.ra - pmin, ib = idx(vd.rb);
+    const bool unsafe = tid > ia && S + E > 0 && D - E <= c;
+    const bool inside = tid > ia && tid < ib;
+    const unsigned long long mu = __builtin_amdgcn_ballot_w64(unsafe && inside), me = __builtin_amdgcn_ballot_w64(inside && E > 0);
+    if (lane == 0) s_masks[wv] = mu, s_masks[NW + wv] = me;
+    // a start that may be low at or behind b: the closed form for the tail does not hold
+    if (block_or<T>((unsafe && S > 0 && tid >= ib) ? 1u : 0u, sc)) return false; // (its barriers: the masks are written)
+    // ---- kept: unsafe, or the nearest bin in front of an unsafe one that holds an end
+    bool kept = unsafe && inside;
+    if (inside && !unsafe && E > 0) {
+        unsigned long long m = (mu | me) & ~((2ull << lane) - 1ull); // the bins behind this one, this wavefront's first
+        u32 wq = wv;
+        while (m == 0 && ++wq < (u32)NW) m = s_masks[wq] | s_masks[NW + wq];
+        if (m != 0 && wq < (u32)NW) kept = ((s_masks[wq] >> __builtin_ctzll(m)) & 1ull) != 0;
+    }
+    u32 m_tot, net_tot;
+    const u32 cex = block_excl_add<T>(kept ? (u32)(S + E) : 0u, sc, m_tot);
+    if (m_tot == 0 || m_tot > (u32)kWfCap) return false; // (uniform)
+    const u32 nex = block_excl_add<T>(kept ? (u32)(S - E) : 0u, sc, net_tot); // (two's complement)
+    // per bin, where its counters were (every thread has read its own: the scans' barriers lie in between):
+    // slot cursor, depth correction, kept
+    bins[tid] = make_uint4(cex, (u32)(D - (i32)nex), kept ? 1u : 0u, 0u);
+    u32 P = 2;
+    while (P < m_tot) P <<= 1;
+    for (u32 i = m_tot + tid; i < P; i += T) keys[i] = kNoKey;
+    __syncthreads();
+    // ---- the kept events, to the slots of their bins (four loads in flight per thread)
+    const uint2 *iv = a.iv + o;
+    u32 zl = 0;
+    for (u32 i0 = tid; i0 < n; i0 += 4 * T) {
+        uint2 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = iv[min(i0 + (u32)(j * T), n - 1u)];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (i0 + (u32)(j * T) >= n || v[j].y == 0u) continue; // ((0, 0) intervals are inert: nowhere in the table)
+            const u32 is = idx(v[j].x), ie = idx(v[j].y);
+            const bool ks = tab[4u * is + 2u] != 0u, ke = tab[4u * ie + 2u] != 0u;
+            zl |= ((ks || ke) && v[j].x == v[j].y) ? 1u : 0u;
+            if (ks) keys[atomicAdd(&tab[4u * is], 1u)] = (v[j].x << kKeyShift) | 3u;
+            if (ke) keys[atomicAdd(&tab[4u * ie], 1u)] = v[j].y << kKeyShift;
+        }
+    }
+    if (block_or<T>(zl, sc)) return false; // a zero-length interval where it may matter (its barriers: the keys are written)
+    if (P >= 1024) hybrid_sort_lds<T>(keys, P, lc);
+    else bitonic_sort_lds<T>(keys, P);
+    // ---- the sweep: thread t owns the sorted keys [t K, t K + K); depth in front of a key = the kept keys in front
+    // (starts - ends) + its bin's correction
+    const u32 K = P >= (u32)T ? P / (u32)T : 1u;
+    const u32 q0 = min(tid * K, m_tot), q1 = min(q0 + K, m_tot);
+    auto corr_of = [&](u32 key) { return (i32)tab[4u * idx(key >> kKeyShift) + 1u]; };
+    u32 delta = 0;
+    for (u32 q = q0; q < q1; q++) delta += (keys[q] & 1u) ? 1u : 0xFFFFFFFFu;
+    u32 dtot;
+    const i32 depth_in = (i32)block_excl_add<T>(delta, sc, dtot);
+    // last flagged end / last low start of the chunk (keys ascend: last = max); 0 = none (no end lies at position 0)
+    u32 mf = 0, ml = 0;
+    {
+        i32 d = depth_in;
+        for (u32 q = q0; q < q1; q++) {
+            const u32 key = keys[q];
+            const bool is_s = (key & 1u) != 0u, gt = d + corr_of(key) > c;
+            mf = (!is_s && gt) ? key : mf;
+            ml = (is_s && !gt) ? key : ml;
+            d += is_s ? 1 : -1;
+        }
+    }
+    u32 mf_t, ml_t;
+    const u32 mf_in = block_excl_max<T>(mf, sc, mf_t), ml_in = block_excl_max<T>(ml, sc, ml_t);
+    u32 cnt = 0, orphan = 0;
+    {
+        u32 tc = mf_in, cml = ml_in;
+        i32 d = depth_in;
+        for (u32 q = q0; q < q1; q++) {
+            const u32 key = keys[q];
+            const bool is_s = (key & 1u) != 0u, gt = d + corr_of(key) > c;
+            const bool fl = !is_s && gt, low = is_s && !gt;
+            cnt += (fl && cml > tc) ? 1u : 0u;
+            orphan |= (low && tc == 0u) ? 1u : 0u; // a low start with no flagged end in front of it (cannot happen behind a: the caller sorts the read)
+            tc = fl ? key : tc;
+            cml = low ? key : cml;
+            d += is_s ? 1 : -1;
+        }
+    }
+    if (block_or<T>(orphan, sc)) return false; // (nothing is written yet)
+    u32 g_closed;
+    u32 pos = block_excl_add<T>(cnt, sc, g_closed);
+    // ---- regions out: (0, a), the closed runs, the run the tail closes, (b, len)
+    uint2 *slot = a.stage + (o + 2 * (u64)r);
+    const u32 g0 = vd.ra != 0u ? 1u : 0u;
+    if (cnt) {
+        u32 tc = mf_in, cml = ml_in;
+        i32 d = depth_in;
+        pos += g0;
+        for (u32 q = q0; q < q1; q++) {
+            const u32 key = keys[q];
+            const bool is_s = (key & 1u) != 0u, gt = d + corr_of(key) > c;
+            const bool fl = !is_s && gt, low = is_s && !gt;
+            if (fl && cml > tc) slot[pos++] = make_uint2(tc >> kKeyShift, cml >> kKeyShift);
+            tc = fl ? key : tc;
+            cml = low ? key : cml;
+            d += is_s ? 1 : -1;
+        }
+    }
+    if (tid == 0) {
+        u32 g = g0 + g_closed;
+        if (vd.ra != 0u) slot[0] = make_uint2(0u, vd.ra);
+        if (ml_t > mf_t) slot[g++] = make_uint2(mf_t >> kKeyShift, ml_t >> kKeyShift);
+        if (vd.rb != len) slot[g++] = make_uint2(vd.rb, len);
+        a.counts[r] = g;
+        if (a.prefilter == 2) atomicAdd(&a.ctr->prefiltered, 1u);
+    }
+    return true;
 }
 // SweepArgs.list / list_n: the class list; over_list / over_count: the reads the screen leaves to the sort.
-__global__ __launch_bounds__(kWsT) void screen_wg_kernel(SweepArgs a)
+#ifndef YK_WGK_OCC
+#define YK_WGK_OCC 1
+#endif
+__global__ __launch_bounds__(kWsT, YK_WGK_OCC) void screen_wg_kernel(SweepArgs a)
 {
     constexpr int NW = kWsT / 64;
     __shared__ __attribute__((aligned(16))) u32 tab[kWsBins * 4]; // four copies of every counter (by thread & 3)
@@ -215,30 +406,42 @@ __global__ __launch_bounds__(kWsT) void screen_wg_kernel(SweepArgs a)
     }
 }
 
-// ---- the screen and its fallback in ONE launch (round 4) ---------------------------------------------------------
+// ---- the screen and its fallback in ONE launch (round 4; without a queue: round 6) -------------------------------------
 // Round 3 ran three kernels one after the other for a workgroup class: the screen, sweep_lds_kernel<256, 8192> over
 // the reads it left, sweep_lds_kernel<1024, 32768> over what did not fit there.  On configs[3] the two fallback
-// kernels took 61 + 65 us for 4 % of the bytes: each is one latency chain per read (two passes over the intervals,
+// kernels took 61 + 65 us for 2 % of the reads: each is one latency chain per read (two passes over the intervals,
 // the trimming plan, the sort, four sweep passes) with most of the device idle, and the second cannot start before
-// the first has ended.  Here a persistent grid does both: a workgroup screens its share of the class list (static
-// stride), appends what it cannot decide to a queue in global memory, and when its share is done takes reads off
-// that queue — its own and everybody else's — through sweep_lds_read<512, 16384> until every workgroup has finished
-// screening and the queue is empty: the fallback reads are sorted WHILE other workgroups still screen, spread over
-// every workgroup that has nothing else to do.  What does not fit 16 384 events even after the filter goes to
-// over_list for the 1024-thread kernel (launched behind this one; usually nothing).
-// Queue: q[] starts out as kQueueEmpty in every slot a read of the class could take (the plan kernel writes the
-// marker where it writes the class list), tail = slots handed out, head = slots claimed, done = workgroups that
-// finished screening.  A claimed slot beyond tail is waited for until it is filled or `done` says it never will be —
-// for a bounded number of looks (below).
-constexpr u32 kQueueEmpty = 0xFFFFFFFFu;
-constexpr int kWsFbCap = 16384; // events the in-kernel fallback sorts (64 KB of LDS; two workgroups per CU by registers anyway)
+// the first has ended.  Here one launch does both: a workgroup screens its share of the class list — a few consecutive
+// entries —, keeps what it cannot decide in a list of its own, and takes THAT through sweep_lds_read<512, 16384> before it
+// retires: the fallback reads are sorted while other workgroups still screen.  What does not fit 16 384 events even
+// after the filter goes to over_list for the 1024-thread kernel (launched behind this one; usually nothing).
+//
+// Rounds 4-5 balanced the fallback work through a QUEUE in global memory on a persistent grid: a workgroup appended
+// what it could not decide, and when its static share was done took reads off the queue — anybody's — and WAITED for
+// further appends until every workgroup had screened its share.  That needed the whole grid resident at once (engines took
+// turns with the launch, its size came from the occupancy query, a bounded wait gave up and the engine ran the batch
+// again), and it cost more than it balanced: up to 512 pollers reading the same two words every 0.2 us are served one
+// after the other at the memory side like the atomics they are, in the way of the screening workgroups' own traffic —
+// configs[3]'s launch WITHOUT any fallback work took 0.194 ms where screen_wg_kernel, the same screen with no queue on
+// 1 024 dispatcher-fed workgroups, took 0.128 (profiles/r06/a_*, c_*).  Measured on the way (profiles/r06/d_*, e_*):
+// the share claimed from a counter instead of dealt (slower: 5 000 more same-address atomics); the queue drained by
+// compare-and-swap with nobody waiting (1.0 ms: 512 workgroups that finish together retry on one word).
+// Now nothing is shared and nobody waits: the DISPATCHER balances.  The grid is a few thousand short-lived workgroups
+// (the host sizes the share: ~8 rounds of the slots the device has), a workgroup that meets a fallback read is busy
+// 50-90 us longer while the dispatcher feeds the other slots, and the launch's tail is one fallback read — as it was.
+constexpr u32 kQueueEmpty = 0xFFFFFFFFu; // (plan_kernel still marks the rounds 4-5 queue's slots: harmless, 4 bytes per read of the class)
+#ifndef YK_WS_FB_CAP
+#define YK_WS_FB_CAP 16384
+#endif
+constexpr int kWsFbCap = YK_WS_FB_CAP; // events the in-kernel fallback sorts (64 KB of LDS; two workgroups per CU by registers anyway)
+constexpr u32 kFusedShareMax = 32;
 #ifndef YK_WG_OCC
 #define YK_WG_OCC 4 // wavefronts per SIMD the register budget allows (two workgroups per CU)
 #endif
 struct ScreenFusedArgs {
     SweepArgs sweep;  // list / list_n: the class; over_list / over_count: beyond kWsFbCap; rej_*: degenerate reads
-    u32 *q;           // the queue's slots
-    u32 *tail, *head, *done;
+    u32 *n_fallback;  // reads the screen left to the in-kernel sort (a count for the host: Counters::fb_med)
+    u32 share;        // consecutive list entries a workgroup screens per turn of its stride loop (1 .. kFusedShareMax)
 };
 __global__ __launch_bounds__(kWsT, YK_WG_OCC) void screen_wg_fused_kernel(ScreenFusedArgs f)
 {
@@ -247,75 +450,46 @@ __global__ __launch_bounds__(kWsT, YK_WG_OCC) void screen_wg_fused_kernel(Screen
     __shared__ u32 red[NW][4];
     __shared__ u32 sc[NW + 1];
     __shared__ u32 keys[kWsFbCap];
-    __shared__ u32 s_next;
+    __shared__ u32 s_mine[kFusedShareMax];
+    __shared__ unsigned long long s_masks[2 * NW];
     const SweepArgs &a = f.sweep;
     const u32 tid = threadIdx.x;
     const u32 list_n = *a.list_n;
-    // ---- the share, then the queue: two loops.  Round 5 measured three other shapes of this kernel on configs[3]
-    // (profiles/r05/e_*, f_*; this form: 0.221-0.229 ms):
-    //  * the next read's list entry, extent and length asked for a turn ahead: 0.232-0.234 — and, asked through VGPR indices
-    //    and kept per lane so that the compiler does not wait for them on the spot (a turn then waits for ONE round trip, its
-    //    intervals', instead of three): 0.220-0.225 against 0.220-0.223, profiles/r05/p_* (the round trips it saves are hidden
-    //    by the CU's other workgroup already);
-    //  * one loop, the queue looked at between the turns so that a fallback read (a ~50 us chain) starts while others still
-    //    screen: 0.313-0.316 — the sort's registers and the screen's live side by side (44 bytes of scratch per thread), and
-    //    a workgroup that takes a fallback read early delays its own share by as much as it saves the tail;
-    //  * the next read's first 64 KB staged in LDS a turn ahead (global_load_lds_dwordx4 into the sort's idle key array,
-    //    LDS-only barriers so that the loads stay in flight across the turn): 0.241-0.243 — a second set of registers
-    //    for them does not fit 128 VGPRs, and through LDS the copy costs what the overlap gains: two workgroups per CU
-    //    already alternate their load and count phases.
-    for (u32 b = blockIdx.x; b < list_n; b += gridDim.x) { // (uniform)
-        const u32 r = a.list[b];
-        if (!screen_wg_read(a, r, tab, red, sc) && tid == 0)
-            __hip_atomic_store(&f.q[atomicAdd(f.tail, 1u)], r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (tid == 0) {
-        __threadfence(); // this workgroup's appends before its "done"
-        atomicAdd(f.done, 1u);
-    }
-    LaneConst lc;
+    // (the sorts' lane constants are made where a sort is — a read in fifty — and not kept alive across the screens: held
+    //  from the kernel's start they were spilled there, 100 bytes of scratch per thread)
+    auto lane_const = [&]() {
+        LaneConst lc;
 #pragma unroll
-    for (int i = 0; i < 6; i++) lc.k[i] = (tid & (1u << i)) ? 0xFFFFFFFFu : 0u;
-    lc.k[6] = 0;
-    lc.addr32 = ((tid & 63u) ^ 32u) << 2;
-    // A claimed slot beyond `tail` is waited for until it is filled or `done` says it never will be.  That wait needs
-    // the workgroups it waits for to RUN: the grid is sized to be resident as a whole, but a second process on the
-    // device, a CU mask or anything else that holds LDS / wave slots can leave some of them undispatched behind the
-    // spinning ones.  So the wait is bounded (kFusedPolls looks, ~10 ms — a healthy launch is over in a
-    // fraction of one): a workgroup that runs out raises Counters::fused_gave_up and leaves, every other one then
-    // leaves at its next look, the kernel ends, and the engine runs the batch again down the three-launch chain
-    // (engine.hip: fused_off), which waits for nothing.  (Claims by compare-and-swap — none is lost when a workgroup
-    // leaves — were tried first: 512 workgroups retrying on one address took the pass from 0.32 to 1.59 ms.)
-    constexpr u32 kFusedPolls = 1u << 14;
-    for (;;) {
-        if (tid == 0) {
-            const u32 idx = atomicAdd(f.head, 1u);
-            u32 r = kQueueEmpty, polls = 0;
-            for (;;) {
-                if (idx < __hip_atomic_load(f.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                    // handed out: its writer (a running wavefront, one store behind its tail increment) fills it
-                    while ((r = __hip_atomic_load(&f.q[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == kQueueEmpty)
-                        __builtin_amdgcn_s_sleep(2);
-                    break;
-                }
-                if (__hip_atomic_load(f.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x) {
-                    // every workgroup has screened its share: the tail is final
-                    if (idx < __hip_atomic_load(f.tail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) continue;
-                    break;
-                }
-                if (++polls > kFusedPolls || __hip_atomic_load(&a.ctr->fused_gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) {
-                    __hip_atomic_store(&a.ctr->fused_gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break; // (r = kQueueEmpty: this workgroup leaves; the batch is run again)
-                }
-                __builtin_amdgcn_s_sleep(8);
-            }
-            s_next = r;
+        for (int i = 0; i < 6; i++) lc.k[i] = (threadIdx.x & (1u << i)) ? 0xFFFFFFFFu : 0u;
+        lc.k[6] = 0;
+        lc.addr32 = ((threadIdx.x & 63u) ^ 32u) << 2;
+        return lc;
+    };
+    // Two loops per share — the screens, then the sorts — and not the sort where the screen fails: the sort's registers and
+    // the screen's live side by side otherwise (44 bytes of scratch per thread, profiles/r05/e_*).
+    for (u32 base = blockIdx.x * f.share; base < list_n; base += gridDim.x * f.share) { // (uniform)
+        u32 mine = 0;
+        for (u32 b = base; b < min(base + f.share, list_n); b++) {
+            const u32 r = a.list[b];
+            WgVerdict vd;
+            if (screen_wg_read(a, r, tab, red, sc, vd)) continue; // (uniform; ends with a barrier)
+#if !YK_EXP_NO_FILTERED
+            const bool done = wg_filtered_read(a, r, vd, tab, sc, keys, s_masks, lane_const()); // (uniform)
+            __syncthreads(); // (the table, sc, the masks and the keys are the next read's)
+            if (done) continue;
+#endif
+            if (tid == 0) s_mine[mine] = r;
+            mine++;
         }
+        if (mine == 0) continue;
+        if (tid == 0) atomicAdd(f.n_fallback, mine);
         __syncthreads();
-        const u32 r = s_next;
-        if (r == kQueueEmpty) break; // (uniform)
-        sweep_lds_read<kWsT, kWsFbCap>(a, r, keys, sc, lc);
-        __syncthreads(); // keys / sc / s_next reused
+        for (u32 k = 0; k < mine; k++) {
+#if !YK_EXP_NO_FALLBACK // (timing experiments only: the reads are dropped)
+            sweep_lds_read<kWsT, kWsFbCap>(a, s_mine[k], keys, sc, lane_const());
+#endif
+            __syncthreads(); // keys / sc reused
+        }
     }
 }
 

@@ -100,11 +100,14 @@ namespace yke {
 // Overlap records in HBM -> the engine's input CSR (in_off, in_iv; in_len holds the lengths already): count,
 // scan, scatter (csr_build.h).  `map` (or null) translates the records' handles to read ids.  Blocking.
 int csr_from_records(yacrd_engine *e, const RecSlab *slabs, size_t n_slabs, const u32 *d_map, u64 n_handles, u64 n_reads,
-                     DevBuf &cnt, DevBuf &part, DevBuf &err, hipEvent_t done, u64 *n_intervals, bool counted)
+                     DevBuf &cnt, DevBuf &part, DevBuf &err, hipEvent_t done, u64 *n_intervals, bool counted, u64 iv_bound)
 {
     u64 n = 0;
     for (size_t i = 0; i < n_slabs; i++) n += slabs[i].n;
-    const u64 n_iv = 2 * n;
+    // two intervals per record — unless the caller knows how many of them name THIS engine's reads (iv_bound: the N-engine
+    // device parser hands every engine every range's records and the engine keeps 1/N of the halves; sized by the records,
+    // in_iv was N times what the engine's CSR holds)
+    const u64 n_iv = iv_bound ? std::min<u64>(iv_bound, 2 * n) : 2 * n;
     const u64 nb = (n_reads + yk::kScanTile - 1) / yk::kScanTile;
     HIP_TRY(e->in_off.reserve((size_t)(n_reads + 1) * sizeof(u64)));
     HIP_TRY(e->in_iv.reserve((size_t)(n_iv + 1) * sizeof(uint2)));

@@ -967,7 +967,7 @@ __device__ __attribute__((noinline)) uint4 hole_form_call(const u64 *off, const 
     u32 n = 0;
     const uint2 *src = reinterpret_cast<const uint2 *>(off); // (a group that does not try reads the offsets: always mapped)
     if (want) {
-        const ulonglong2 oo = *reinterpret_cast<const ulonglong2 *>(off + r);
+        const ulonglong2 oo = load_extent(off + r);
         n = (u32)(oo.y - oo.x);
         src = iv + oo.x;
     }
@@ -977,7 +977,7 @@ __device__ __attribute__((noinline)) uint4 hole_form_call(const u64 *off, const 
 #pragma unroll
     for (int j = 0; j < K / 4; j++) {
         const u32 i0 = 2u * (lig + (u32)LANES * j);
-        v[j] = *reinterpret_cast<const uint4 *>(src + min(i0, last2));
+        v[j] = load_pair(src + min(i0, last2));
         real0[j] = i0 + 1u < n; // (.xy is interval i0 only when i0 + 1 exists too: see screen_block)
         real1[j] = i0 < n;
     }
@@ -1053,7 +1053,7 @@ __device__ __forceinline__ void screen_reads(const SweepArgs &a, const u32 (&r)[
         if (known) { // (a constant once inlined)
             if (active[t]) o[t] = known->o[t], n[t] = known->n[t], len[t] = known->len[t];
         } else if (active[t]) {
-            const ulonglong2 oo = *reinterpret_cast<const ulonglong2 *>(a.off + r[t]); // off[r], off[r + 1]: one load
+            const ulonglong2 oo = load_extent(a.off + r[t]); // off[r], off[r + 1]: one load
             o[t] = oo.x;
             n[t] = (u32)(oo.y - oo.x);
             len[t] = a.len[r[t]];
@@ -1073,7 +1073,7 @@ __device__ __forceinline__ void screen_reads(const SweepArgs &a, const u32 (&r)[
         const u32 last2 = two ? n[t] - 2u : 0u;
 #pragma unroll
         for (int j = 0; j < K / 4; j++)
-            v[t][j] = *reinterpret_cast<const uint4 *>(src + min(2u * (lig + (u32)LANES * j), last2));
+            v[t][j] = load_pair(src + min(2u * (lig + (u32)LANES * j), last2));
     }
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) {

@@ -29,6 +29,7 @@ F_NO_DEFER = 4096
 F_ALWAYS_DEFER = 8192
 F_SWEEP_TURNS = 16384
 F_TIMING_SAMPLED = 32768
+F_STREAM_SCREEN = 65536
 F_SCREEN_ITEMS_1 = 262144
 F_SCREEN_ITEMS_2 = 524288
 F_NO_FUSED_SCREEN = 1048576
@@ -113,7 +114,9 @@ class _Timing(ctypes.Structure):
                 ("prefiltered_reads", ctypes.c_uint64), ("deferred_reads", ctypes.c_uint64),
                 ("deferred_intervals", ctypes.c_uint64), ("screened", ctypes.c_uint32),
                 ("timed_runs", ctypes.c_uint32), ("screen_items", ctypes.c_uint32), ("screen_wide", ctypes.c_uint32),
-                ("one_launch", ctypes.c_uint32), ("fused_reruns", ctypes.c_uint32)]
+                ("one_launch", ctypes.c_uint32), ("fused_reruns", ctypes.c_uint32),
+                ("predicted", ctypes.c_uint32), ("prediction_misses", ctypes.c_uint32),
+                ("build_switches", ctypes.c_uint32), ("sorting_build", ctypes.c_uint32)]
 
 CLASS_NAMES = "R2,R4,R8,R16,H16,W2,W4,W8,W16,M1,M2,BIG".split(",")
 CLASS_KERNELS = {  # the HIP kernel behind each class, as rocprofv3 prints it
@@ -199,6 +202,16 @@ def _share_hip_runtime_with_torch():
     except OSError:
         return None
     return cand
+
+
+def peer_copy_counts():
+    """yacrd_debug_peer_copy_counts (tests): cross-engine copies of the N-engine device parser by route:
+    [same device, hipMemcpyPeerAsync, staged through the host]."""
+    lib = load_library()
+    out = (ctypes.c_uint64 * 3)()
+    lib.yacrd_debug_peer_copy_counts.restype = None
+    lib.yacrd_debug_peer_copy_counts(out)
+    return [int(x) for x in out]
 
 
 def load_library():
@@ -492,6 +505,26 @@ class Engine:
         vals = np.array(vals, dtype=np.uint32)
         _check(self._lib, self._lib.yacrd_debug_sort_pairs(self._h, keys.ctypes.data, vals.ctypes.data, keys.shape[0], int(key_bound)))
         return keys, vals
+
+    def debug_counters(self):
+        """yacrd_debug_last_counters (tools, tests): the device-side counter block of the last run, by name
+        (csrc/device_common.h: struct Counters; the layout is mirrored here and is not part of any ABI)."""
+        class _Counters(ctypes.Structure):
+            _fields_ = [("n", ctypes.c_uint32 * 16), ("iv", ctypes.c_uint64 * 16), ("rej_small", ctypes.c_uint32),
+                        ("rej_med", ctypes.c_uint32), ("rej_big", ctypes.c_uint32), ("region_overflow", ctypes.c_uint32),
+                        ("scan_ticket", ctypes.c_uint32), ("ob_unsupported", ctypes.c_uint32), ("prefiltered", ctypes.c_uint32),
+                        ("over_med", ctypes.c_uint32), ("fb_med", ctypes.c_uint32 * 2), ("fb_big", ctypes.c_uint32),
+                        ("fbq_head", ctypes.c_uint32 * 2), ("fbq_done", ctypes.c_uint32 * 2), ("bs_chunks", ctypes.c_uint32),
+                        ("fused_gave_up", ctypes.c_uint32), ("total_regions", ctypes.c_uint64)]
+        c = _Counters()
+        self._lib.yacrd_debug_last_counters.restype = ctypes.c_uint64
+        self._lib.yacrd_debug_last_counters.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]
+        self._lib.yacrd_debug_last_counters(self._h, ctypes.byref(c), ctypes.sizeof(c))
+        out = {}
+        for n, _ in _Counters._fields_:
+            v = getattr(c, n)
+            out[n] = list(v) if hasattr(v, "__len__") else int(v)
+        return out
 
     def trim(self):
         """yacrd_engine_trim: give the device parser's buffers back."""

@@ -812,6 +812,23 @@ def hole_fast_regions(intervals, length, cov, nb, W, nbf=64):
     return ([(0, a)] if a != 0 else []) + [(x, y)] + ([(bb, length)] if bb != length else [])
 
 
+def drop_inert_at_pmin(intervals, cov):
+    """Zero-length intervals AT the read's smallest start pmin, when a regular interval starts there too and cov >= 1, change
+    nothing (round 6; the screens leave them out of every count): sorted first among the intervals at pmin, each is pushed
+    at depth 0 — a low start: first_covered = pmin, as the regular start at pmin will assign it again — and popped, alone in
+    the heap, in front of the next push: flagged only if 1 > cov (src/stack.rs:72-89).  A regular interval cannot END at
+    pmin, so every end there is such an interval's.  (SURVEY.md 8d's generator clamps a degenerate interval of a read
+    that is covered only inside a window onto the window's first position: without this rule an end `at or before a`
+    sent the read to the sort.)"""
+    live = [iv for iv in intervals if iv != (0, 0)]
+    if cov < 1 or not live:
+        return intervals
+    pmin = min(s for s, e in live)
+    if not any(s == pmin and e > s for s, e in live):
+        return intervals
+    return [iv for iv in intervals if iv != (pmin, pmin)]
+
+
 def unified_screen_regions(intervals, length, cov, nb, W):
     """screen_wg.h / screen_big.h: the order-statistics screen with ONE position map for starts and ends,
         idx(x) = min(dx, W) + (dx >> sh) + max(dx - T, 0),   dx = x - pmin,  T = (pmax - pmin) - W,  2^sh >= W:
@@ -836,7 +853,7 @@ def unified_screen_regions(intervals, length, cov, nb, W):
         return None
     # (0, 0) intervals are inert in the reference — popped at once, their pop re-assigns last_covered = 0 while
     # it still is 0, their low start sets first_covered = 0 — and are left out of every count
-    intervals = [iv for iv in intervals if iv != (0, 0)]
+    intervals = [iv for iv in drop_inert_at_pmin(intervals, cov) if iv != (0, 0)]
     n = len(intervals)
     if n < 2 or n <= cov:
         return None
@@ -1000,14 +1017,14 @@ def unified_filtered_regions(intervals, length, cov, nb, W, cap, stats=None):
     in an unsafe bin, and the flagged end the reference pairs it with — the last one in front of it — lies in an unsafe bin
     too or is the largest end of the nearest bin in front that holds an end.  Kept: the unsafe bins behind a's and in front
     of b's, and for each the nearest bin in front that holds an end; their events sorted and swept with their true depths.
-    A bin at or behind b's with a shallow start, a zero-length interval in a kept bin, more than `cap` kept events, or
-    anything the screen itself would not take: None — the caller sorts the read."""
+    A bin at or behind b's with a shallow start, a zero-length interval in a kept bin with cov or fewer intervals open in
+    front of it, more than `cap` kept events, or anything the screen itself would not take: None — the caller sorts the read."""
     n = len(intervals)
     if n == 0:
         return [(0, length)] if length != 0 else []
     if any(not (0 <= s <= e <= length) for s, e in intervals) or length >= 2**30 - 1:
         return None
-    intervals = [iv for iv in intervals if iv != (0, 0)]
+    intervals = [iv for iv in drop_inert_at_pmin(intervals, cov) if iv != (0, 0)]
     n = len(intervals)
     if n < 2 or n <= cov:
         return None
@@ -1062,9 +1079,10 @@ def unified_filtered_regions(intervals, length, cov, nb, W, cap, stats=None):
             before += S[i] - E[i]
     keys = []
     for s, e in intervals:
-        if kept[idx(s)] or kept[idx(e)]:
-            if s == e:
-                return None  # (a zero-length interval where it may matter)
+        if s == e:  # a zero-length interval: its keys sort between the position's ends and its regular starts (regular_keys)
+            if kept[idx(s)]:
+                keys += [(s << SH) | 1, (s << SH) | 2]
+            continue
         if kept[idx(s)]:
             keys.append((s << SH) | 3)
         if kept[idx(e)]:
@@ -1076,6 +1094,9 @@ def unified_filtered_regions(intervals, length, cov, nb, W, cap, stats=None):
         pos = key >> SH
         depth = run + corr[idx(pos)]
         if key & 1:
+            if (key & 3) == 1 and depth <= cov:
+                return None  # a zero-length interval whose start is low: the sort's (one with more than cov open around it is an
+                             # ordinary pair of keys: its start is not low, its end is flagged where it stands)
             if depth <= cov:
                 if tc is None:
                     return None  # a low start with no flagged end in front of it among the kept (cannot happen: kept for the kernel's guard)

@@ -285,7 +285,7 @@ def test_unified_screen_matches_oracle():
         if it % 5 == 2:  # zero-length intervals: in the piles, in the middle, doubled, at 0 and at len
             for _ in range(int(rng.integers(1, 5))):
                 j = int(rng.integers(0, len(iv)))
-                p0 = (iv[j][0], iv[j][1], 0, 0, L, L // 2, L // 2)[int(rng.integers(0, 7))]
+                p0 = (iv[j][0], iv[j][1], 0, 0, L, L // 2, L // 2, min(s for s, e in iv), min(s for s, e in iv))[int(rng.integers(0, 9))]
                 iv.append((p0, p0))
         if it % 11 == 0:
             g = max(1, L // 8)
@@ -494,7 +494,7 @@ def test_unified_filtered_matches_oracle():
         if it % 9 == 2:  # zero-length intervals: in the piles, in the middle, doubled, at 0 and at len
             for _ in range(int(rng.integers(1, 4))):
                 j = int(rng.integers(0, len(iv)))
-                p0 = (iv[j][0], iv[j][1], 0, 0, L, L // 2, L // 2)[int(rng.integers(0, 7))]
+                p0 = (iv[j][0], iv[j][1], 0, 0, L, L // 2, L // 2, min(s for s, e in iv), min(s for s, e in iv))[int(rng.integers(0, 9))]
                 iv.append((p0, p0))
         if it % 13 == 0:
             g = max(1, L // 16)

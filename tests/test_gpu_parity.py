@@ -854,3 +854,62 @@ def test_fused_workgroup_screens_of_several_engines_take_turns():
     finally:
         for e in engs:
             e.close()
+
+
+@pytest.mark.parametrize("cov", [0, 1, 4, 9])
+def test_workgroup_classes_filtered_sweep_and_inert_intervals(cov):
+    """Round 6 (screen_wg.h): what the workgroup classes' screen leaves goes through wg_filtered_read — the screen's table read
+    once more, only the unsafe bins' events sorted (tests/formulation.py::unified_filtered_regions) — and only what THAT
+    leaves through sweep_lds_read.  Chimeras (one and two junctions, abutting, with spanning intervals), reads covered only
+    inside a window, zero-length intervals at the window's first position (inert at c >= 1 when a regular interval starts
+    there: drop_inert_at_pmin), in a junction's bin (the sort's), at pmin with no regular start there (the sort's)."""
+    rng = np.random.default_rng(6600 + cov)
+    reads = []
+    for k in range(260):
+        n = int(rng.choice([600, 1500, 4096, 4097, 5600, 9000, 16384]))
+        L = int(rng.integers(60000, 900000))
+        lo, hi = (0, L) if k % 3 else (int(L * 0.3), int(L * 0.7))  # the whole read, or a window
+        span = hi - lo
+        iv = []
+        for j in range(n):
+            u = rng.random()
+            if u < 0.3:
+                s, e = lo, lo + int(rng.integers(500, max(501, int(0.8 * span))))
+            elif u < 0.6:
+                e = hi
+                s = hi - int(rng.integers(500, max(501, int(0.8 * span))))
+            else:
+                s = lo + int(rng.integers(0, max(1, span - 600)))
+                e = min(hi, s + int(rng.integers(500, max(501, span // 2))))
+            iv.append((max(lo, s), min(hi, max(e, s + 1))))
+        if k % 2:  # a junction (or two): crossing intervals cut back to the side of their midpoint
+            for jn in range(1 + (k % 4 == 3)):
+                j = lo + int(span * rng.uniform(0.2, 0.8))
+                gap = int(rng.integers(0, 120))
+                iv = [((s, min(e, j - gap)) if (s + e) // 2 < j else (max(s, j + (gap if k % 8 != 1 else 0)), e)) if s < j < e and rng.random() > 0.002 * (k % 5 == 0) else (s, e)
+                      for s, e in iv]
+                iv = [(s, max(e, s + 1)) if s < hi else (hi - 1, hi) for s, e in iv]
+        if k % 5 == 1:
+            iv.append((lo, lo))                       # a degenerate interval clamped onto the window's first position
+        if k % 5 == 2:
+            iv += [(lo, lo)] * (cov + 1)              # several of them
+        if k % 13 == 3:
+            iv = [(s + 1, e) if s == lo else (s, e) for s, e in iv] + [(lo, lo)]  # ... and no regular start there
+        if k % 11 == 4:
+            p = iv[len(iv) // 2][1]
+            iv.append((p, p))                         # a zero-length interval somewhere inside
+        reads.append((iv[:16384], L))
+    offsets = np.zeros(len(reads) + 1, np.uint64)
+    offsets[1:] = np.cumsum([len(iv) for iv, _ in reads])
+    intervals = np.array([p for iv, _ in reads for p in iv], dtype=np.uint32)
+    lengths = np.array([L for _, L in reads], dtype=np.uint32)
+    want = oracle.run(offsets, intervals, lengths.astype(np.uint64), cov, 0.4, n_threads=8)
+    assert int(want[2].sum()) > 0  # (chimeric / not covered reads are in it)
+    for flags in (0, yacrd_amd.F_NO_FUSED_SCREEN, yacrd_amd.F_STREAM_SCREEN, yacrd_amd.F_NO_PREFILTER):
+        with yacrd_amd.Engine(flags=flags | yacrd_amd.F_COUNT_PREFILTERED) as e:
+            assert_same(e.run(offsets, intervals, lengths, cov, 0.4), want, "cov %d flags %d" % (cov, flags))
+            if flags == 0:
+                c = e.debug_counters()
+                # most of the reads are decided without the whole-read sort: by the screen or by the filtered sweep
+                assert e.timing()["prefiltered_reads"] > len(reads) // 2, (e.timing()["prefiltered_reads"], c["fb_med"])
+                assert sum(c["fb_med"]) < len(reads) // 2, c["fb_med"]

@@ -1,0 +1,23 @@
+#!/bin/bash
+# thirteenth GPU call of round 6: is it the fallback code's PRESENCE in the kernel or its EXECUTION that costs configs[3] 80 us?
+out=gpurun_out/r06m; mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+cp yacrd_amd/lib/libyacrd_hip.so /tmp/keep.so
+prof() { local name=$1 flags=$2; shift 2
+  env "$@" timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$name -o s -- python bench.py --config 3 --no-extras --no-cpu-baseline --steps 20 --flags $flags > $out/prof_$name.log 2>&1
+  find $out/prof_$name -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats_$name.csv \;
+  rm -rf $out/prof_$name
+  echo "== $name"; grep -E "screen_wg" $out/kernel_stats_$name.csv | cut -d, -f1,2,4,6,7 | cut -c1-140
+}
+for v in keep skipund bare2 filtonly keep skipund; do cp /tmp/keep.so yacrd_amd/lib/libyacrd_hip.so; [ $v = keep ] || cp variants/lib_$v.so yacrd_amd/lib/libyacrd_hip.so
+  prof $v 0 A=1
+done
+cp /tmp/keep.so yacrd_amd/lib/libyacrd_hip.so
+python - <<'PY'
+import numpy as np, yacrd_amd
+from yacrd_amd import host
+off, iv, ln = host.synth_csr(host.SYNTH_SKEWED, 10000, 30000000, 20241108 + 4)
+with yacrd_amd.Engine() as e:
+    e.run(off, iv, ln, 4, 0.4); c = e.debug_counters()
+    print("heavy reads (fb_med)", c["fb_med"], "over_med", c["over_med"])
+PY

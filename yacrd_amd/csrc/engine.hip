@@ -733,34 +733,42 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
                     HIP_TRY(hipMemsetAsync(&ctr->fb_stream[k], 0, sizeof(u32), e->stream));
                     HIP_TRY(hipMemsetAsync(&ctr->fb_med[k], 0, sizeof(u32), e->stream));
                 }
-                // first one wavefront per read, the read streamed twice, no barrier (screen_stream.h, round 6): what it decides —
-                // all but a fiftieth of the generator's reads — never meets the workgroup kernel, which takes the rest as its class
+                // Two launches (round 6, profiles/r06/m_*): the SCREEN alone — screen_wg_kernel: 100 VGPRs, 8 KB of LDS, no scratch,
+                // one read per workgroup handed out by the dispatcher: 0.118-0.128 ms on configs[3] — appends what it cannot
+                // decide (a fiftieth of the generator's reads) to a list, and screen_wg_fused_kernel takes THAT list: table again,
+                // filtered exact sweep, the whole-read sort for what is left.  With the fallback code inside the screening
+                // launch the same screens took 0.163 ms before a single fallback read ran (128 VGPRs, 88 bytes of scratch
+                // written by every workgroup, 74 KB of LDS), and 0.212 with them.
+                // YACRD_F_STREAM_SCREEN (A/B): the first launch is the one-wavefront-per-read screen (screen_stream.h).
                 const bool stream_first = (e->flags & YACRD_F_STREAM_SCREEN) != 0;
-                if (stream_first) {
+                {
                     yk::SweepArgs ss = sa;
                     ss.over_list = fb_stream[k];
                     ss.over_count = &ctr->fb_stream[k];
-                    const u32 gss = (u32)std::min<uint64_t>(std::max<u32>(set.hint[cls], 1u), (uint64_t)e->num_cu * 96);
-                    hipLaunchKernelGGL(yk::screen_stream_kernel, dim3(gss), dim3(64), 0, e->stream, ss);
+                    const u32 want = std::max<u32>(set.hint[cls], 1u);
+                    if (stream_first) {
+                        hipLaunchKernelGGL(yk::screen_stream_kernel, dim3((u32)std::min<uint64_t>(want, (uint64_t)e->num_cu * 96)), dim3(64), 0, e->stream, ss);
+                    } else {
+                        static const uint64_t wgk_grid = [] { const char *ev = std::getenv("YACRD_WGK_GRID"); return ev ? std::strtoull(ev, nullptr, 10) : (uint64_t)0; }(); // (A/B)
+                        const u32 gs1 = (u32)std::min<uint64_t>(want, wgk_grid ? wgk_grid : (uint64_t)e->num_cu * 64);
+                        hipLaunchKernelGGL(yk::screen_wg_kernel, dim3(gs1), dim3(yk::kWsT), 0, e->stream, ss);
+                    }
                 }
                 yk::ScreenFusedArgs fa;
                 fa.sweep = sa;
-                if (stream_first) fa.sweep.list = fb_stream[k], fa.sweep.list_n = &ctr->fb_stream[k];
+                fa.sweep.list = fb_stream[k], fa.sweep.list_n = &ctr->fb_stream[k];
                 fa.sweep.over_list = over_med;
                 fa.sweep.over_count = &ctr->over_med;
                 fa.sweep.rej_list = k == 0 ? rej_med : rej_big;
                 fa.sweep.rej_count = k == 0 ? &ctr->rej_med : &ctr->rej_big;
                 fa.n_fallback = &ctr->fb_med[k];
-                // No workgroup of this launch waits for another or shares anything with it (screen_wg.h, round 6): the grid is
-                // sized for the DISPATCHER — workgroups of `share` consecutive list entries, about eight rounds of the slots
-                // the device has for them; a class of a few thousand reads: one read each.
-                // (YACRD_TEST_FUSED_GRID_MULT, tests: a multiple of that grid.  YACRD_FUSED_SHARE, A/B: the share.)
-                const u64 slots = (u64)e->num_cu * (u64)std::max(1, e->screen_fused_wgs_per_cu);
+                // (its list is what the screen left: one read per workgroup, a stride loop should the list be longer than the grid.
+                //  YACRD_TEST_FUSED_GRID_MULT / YACRD_FUSED_SHARE, tests / A/B: a multiple of that grid, reads per workgroup and turn)
                 const u64 known = std::max<u32>(set.hint[cls], 1u);
-                u64 share = std::min<u64>(std::max<u64>(known / (8 * slots), 1), (u64)yk::kFusedShareMax);
+                u64 share = 1;
                 if (fused_share_override()) share = std::min<u64>(fused_share_override(), (u64)yk::kFusedShareMax);
                 fa.share = (u32)share;
-                const u32 gs = (u32)std::min<u64>((known + share - 1) / share * fused_grid_mult(), 0x7FFFFFFFull);
+                const u32 gs = (u32)std::min<u64>(std::min<u64>((known + share - 1) / share, (u64)e->num_cu * 4) * fused_grid_mult(), 0x7FFFFFFFull);
                 hipLaunchKernelGGL(yk::screen_wg_fused_kernel, dim3(gs), dim3(yk::kWsT), 0, e->stream, fa);
                 if (k == 1) { // what does not fit the in-kernel fallback's 16 384 events even filtered (usually nothing)
                     sa.list = over_med;
@@ -827,7 +835,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     // decide lands in fb_big and takes the trimming filter / the segmented sort after the final sync.
     // YACRD_F_FORCE_GENERAL / YACRD_F_NO_PREFILTER: the host-driven paths directly.
     bool big_screened = false;
-    auto launch_huge = [&](u32 count, u64 iv_big, u64 *iv_total) -> int {
+    auto launch_huge = [&](u32 count, u64 iv_big, u64 *iv_total, hipStream_t hs) -> int {
         if (e->flags & YACRD_F_FORCE_GENERAL)
             return run_general_global(e, d_off, d_iv, d_len, list_of(yk::CLS_GENERAL), count, cov, e->stream, iv_total);
         if (!sa.prefilter)
@@ -851,12 +859,12 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         ba.stage = sa.stage, ba.counts = sa.counts;
         ba.fb_list = fb_big, ba.fb_count = &ctr->fb_big;
         ba.ctr = ctr;
-        if (big_screened) HIP_TRY(hipMemsetAsync(&ctr->fb_big, 0, sizeof(u32), e->stream)); // (a second pass: its entries are done)
-        HIP_TRY(hipMemsetAsync(ba.hist, 0, (size_t)count * 2 * yk::kBsBins * sizeof(u32), e->stream));
-        hipLaunchKernelGGL(yk::bs_setup_kernel, dim3(1), dim3(1024), 0, e->stream, ba);
-        hipLaunchKernelGGL(yk::bs_minmax_kernel, dim3((u32)max_chunks), dim3(yk::kBsT), 0, e->stream, ba);
-        hipLaunchKernelGGL(yk::bs_hist_kernel, dim3((u32)max_chunks), dim3(yk::kBsT), 0, e->stream, ba);
-        hipLaunchKernelGGL(yk::bs_verdict_kernel, dim3(count), dim3(yk::kBsVT), 0, e->stream, ba);
+        if (big_screened) HIP_TRY(hipMemsetAsync(&ctr->fb_big, 0, sizeof(u32), hs)); // (a second pass: its entries are done)
+        HIP_TRY(hipMemsetAsync(ba.hist, 0, (size_t)count * 2 * yk::kBsBins * sizeof(u32), hs));
+        hipLaunchKernelGGL(yk::bs_setup_kernel, dim3(1), dim3(1024), 0, hs, ba);
+        hipLaunchKernelGGL(yk::bs_minmax_kernel, dim3((u32)max_chunks), dim3(yk::kBsT), 0, hs, ba);
+        hipLaunchKernelGGL(yk::bs_hist_kernel, dim3((u32)max_chunks), dim3(yk::kBsT), 0, hs, ba);
+        hipLaunchKernelGGL(yk::bs_verdict_kernel, dim3(count), dim3(yk::kBsVT), 0, hs, ba);
         big_screened = true;
         return YACRD_OK;
     };
@@ -864,13 +872,27 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     for (int cls = 0; cls < yk::CLS_GENERAL; cls++)
         if (ls.n[cls] && (dom_cls < 0 || ls.iv[cls] > ls.iv[dom_cls])) dom_cls = cls;
     if (full) HIP_TRY(hipEventRecord(e->ev[EV_S0], e->stream));
-    int rc = launch_sweeps(ls);
-    if (rc) return rc;
+    // The device-wide screen's four short launches (a dozen microseconds each, dependent, a few hundred workgroups) go out on a
+    // stream of their own BESIDE the other classes' sweeps (round 6): behind them, as until round 5, they were 45 us of
+    // configs[3]'s 0.31 ms with the device mostly idle.  Fork behind the plan, join in front of the follow-on step.
+    int rc = YACRD_OK;
     u64 gen_iv = 0;
-    if (!predicted && c0.n[yk::CLS_GENERAL]) {
-        rc = launch_huge(c0.n[yk::CLS_GENERAL], c0.iv[yk::CLS_GENERAL], &gen_iv);
+    const bool huge_now = !predicted && c0.n[yk::CLS_GENERAL] != 0;
+    const bool huge_beside = huge_now && sa.prefilter && !(e->flags & YACRD_F_FORCE_GENERAL) && e->side != nullptr;
+    if (huge_beside) {
+        HIP_TRY(hipEventRecord(e->ev_fork, e->stream));
+        HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
+        rc = launch_huge(c0.n[yk::CLS_GENERAL], c0.iv[yk::CLS_GENERAL], &gen_iv, e->side);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(e->ev_join, e->side));
+    }
+    rc = launch_sweeps(ls);
+    if (rc) return rc;
+    if (huge_now && !huge_beside) {
+        rc = launch_huge(c0.n[yk::CLS_GENERAL], c0.iv[yk::CLS_GENERAL], &gen_iv, e->stream);
         if (rc) return rc;
     }
+    if (huge_beside) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join, 0));
     if (full) HIP_TRY(hipEventRecord(e->ev[EV_GEN], e->stream));
 
     // ---- follow-on kernel: scan + compact + classify
@@ -921,7 +943,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
             e->miss_pending = true; // (the prediction did not hold: yacrd_timing.prediction_misses)
             if (!redo) HIP_TRY(hipEventRecord(e->ev[EV_X0], e->stream));
             if (any_missing && (rc = launch_sweeps(missing, true))) return rc;
-            if (c0.n[yk::CLS_GENERAL] && (rc = launch_huge(c0.n[yk::CLS_GENERAL], c0.iv[yk::CLS_GENERAL], &gen_iv))) return rc;
+            if (c0.n[yk::CLS_GENERAL] && (rc = launch_huge(c0.n[yk::CLS_GENERAL], c0.iv[yk::CLS_GENERAL], &gen_iv, e->stream))) return rc;
             // the rejection counters may have grown: bring them home before looking at rej_big
             HIP_TRY(hipMemcpyAsync(e->h_ctr, ctr, sizeof(yk::Counters), hipMemcpyDeviceToHost,
                                    e->stream));
@@ -1331,6 +1353,9 @@ int yacrd_engine_create(const yacrd_engine_cfg *cfg, yacrd_engine **out)
         (void)hipGetLastError();
     }
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
+    if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
     for (int i = 0; i < EV_COUNT && err == hipSuccess; i++) err = hipEventCreate(&e->ev[i]);
     for (int i = 0; i < 24 && err == hipSuccess; i++) err = hipEventCreate(&e->ev_cls[i]);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_done, hipEventBlockingSync | hipEventDisableTiming);
@@ -1397,6 +1422,9 @@ void yacrd_engine_destroy(yacrd_engine *e)
     hipEvent_t extra[] = {e->ev_h2d0, e->ev_h2d1, e->ev_d2h0, e->ev_d2h1, e->ev_done, e->ev_fused};
     for (hipEvent_t x : extra)
         if (x) (void)hipEventDestroy(x);
+    if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);
+    if (e->ev_join) (void)hipEventDestroy(e->ev_join);
+    if (e->side) (void)hipStreamDestroy(e->side);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }

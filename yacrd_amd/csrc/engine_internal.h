@@ -127,6 +127,8 @@ struct yacrd_engine {
     int device = 0;
     uint32_t flags = 0;
     hipStream_t stream = nullptr;
+    hipStream_t side = nullptr;                       // the device-wide screen's launches, beside the workgroup classes' (run_on_device)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;  // stream -> side (behind the plan), side -> stream (in front of the follow-on step)
     hipEvent_t ev[yke::EV_COUNT] = {};
     hipEvent_t ev_h2d0 = nullptr, ev_h2d1 = nullptr, ev_d2h0 = nullptr, ev_d2h1 = nullptr;
     hipEvent_t ev_cls[24] = {}; // brackets around class kernels

@@ -123,6 +123,9 @@ __device__ __forceinline__ bool screen_stream_read(const SweepArgs &a, u32 r, u3
             w[2 * q + 1] = x.z + x.w;
         }
     }
+    // (the ends of bin 0 are zero-length intervals at pmin: inert when c >= 1 and a regular interval starts there too —
+    //  screen_wg.h, tests/formulation.py::drop_inert_at_pmin — and forgotten, starts and ends)
+    if (lane == 0 && c >= 1 && (w[0] >> 16) != 0u && (w[0] & kField) > (w[0] >> 16)) w[0] -= (w[0] >> 16) * (kEnd + 1u);
     u32 mine = 0;
 #pragma unroll
     for (int j = 0; j < 8; j++) mine += w[j];

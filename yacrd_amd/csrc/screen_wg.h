@@ -35,6 +35,12 @@
 #ifndef YK_EXP_NO_FALLBACK
 #define YK_EXP_NO_FALLBACK 0
 #endif
+#ifndef YK_EXP_SKIP_UNDECIDED
+#define YK_EXP_SKIP_UNDECIDED 0
+#endif
+#ifndef YK_WS_SKIP_DEAD
+#define YK_WS_SKIP_DEAD 0 // (1: groups of T pairs beyond the read are neither loaded nor counted — measured SLOWER, 0.213 -> 0.248 ms on configs[3], profiles/r06/j_*: the uniform branches keep the eight loads from being issued together)
+#endif
 #ifndef YK_EXP_NO_FILTERED
 #define YK_EXP_NO_FILTERED 0
 #endif
@@ -73,17 +79,27 @@ __device__ __forceinline__ bool screen_wg_read(const SweepArgs &a, u32 r, u64 o,
     bool fallback = n < 2u || len > kMaxKeyPos;
 
     // ---- the read's smallest start, largest end, largest start and shortest interval (signed)
+#if YK_WS_SKIP_DEAD
+    auto live = [&](u32 ch, int j) { return 2u * (ch * (u32)(T * R / 2) + (u32)(j * T)) < n; }; // (uniform: group j of chunk ch holds an interval)
+#else
+    auto live = [&](u32, int) { return true; };
+#endif
     uint4 v[R / 2];
     u32 smin = 0xFFFFFFFFu, emax = 0, smax = 0;
     i32 tmin = 0x7FFFFFFF;
     if (!fallback) {
         for (u32 ch = 0; ch < chunks; ch++) {
             const u32 base = ch * (u32)(T * R / 2) + tid; // (pairs)
+            // Round 6: a group of T pairs that lies beyond the read as a whole — uniform: its first interval's index against n —
+            // is neither loaded nor looked at (a read of 5 700 intervals fills six of a chunk's eight groups, a read of 600 one:
+            // the loads, the minima and the count's sixteen instructions + two LDS atomics per slot were spent on all eight).
 #pragma unroll
-            for (int j = 0; j < R / 2; j++) // (slots beyond the read: copies of its last two intervals)
-                v[j] = load_pair(iv + min(2u * (base + (u32)(j * T)), n - 2u));
+            for (int j = 0; j < R / 2; j++) { // (slots beyond the read inside a live group: copies of its last two intervals)
+                if (live(ch, j)) v[j] = load_pair(iv + min(2u * (base + (u32)(j * T)), n - 2u));
+            }
 #pragma unroll
             for (int j = 0; j < R / 2; j++) {
+                if (!live(ch, j)) continue;
                 smin = min(smin, min(v[j].y != 0u ? v[j].x : 0xFFFFFFFFu, v[j].w != 0u ? v[j].z : 0xFFFFFFFFu)); // ((0, 0) intervals are inert: left out)
                 smax = max(smax, max(v[j].x, v[j].z));
                 emax = max(emax, max(v[j].y, v[j].w));
@@ -140,10 +156,11 @@ __device__ __forceinline__ bool screen_wg_read(const SweepArgs &a, u32 r, u64 o,
             if (chunks > 1u) {
 #pragma unroll
                 for (int j = 0; j < R / 2; j++)
-                    v[j] = load_pair(iv + min(2u * (base + (u32)(j * T)), n - 2u));
+                    if (live(ch, j)) v[j] = load_pair(iv + min(2u * (base + (u32)(j * T)), n - 2u));
             }
 #pragma unroll
             for (int j = 0; j < R / 2; j++) {
+                if (!live(ch, j)) continue;
                 const u32 i0 = 2u * (base + (u32)(j * T));
                 count(v[j].x, v[j].y, i0 + 1u < n); // (.xy is interval i0 only when i0 + 1 exists too: the clamped last pair)
                 count(v[j].z, v[j].w, i0 < n);
@@ -152,7 +169,14 @@ __device__ __forceinline__ bool screen_wg_read(const SweepArgs &a, u32 r, u64 o,
         __syncthreads();
         // ---- this thread's bin, in event order: starts | ends << 16
         const uint4 c4 = bins[tid];
-        const u32 w = c4.x + c4.y + c4.z + c4.w;
+        u32 w = c4.x + c4.y + c4.z + c4.w;
+        // (round 6) A regular interval cannot END at pmin: the ends of bin 0 are zero-length intervals at pmin, and those are
+        // inert when c >= 1 and a regular interval starts there too — pushed at depth 0, popped alone in the heap in front of
+        // the next push (src/stack.rs:72-89; tests/formulation.py::drop_inert_at_pmin) — so bin 0 forgets them, starts and
+        // ends.  (SURVEY.md 8d's generator clamps a degenerate interval of a read covered only inside a window onto the
+        // window's first position; as "an end at or before a" it sent the read to the sort.  Tested per slot in the count
+        // this cost a tenth of the launch, profiles/r06/j_*; here it is one thread's three instructions.)
+        if (tid == 0 && c >= 1 && (w >> 16) != 0u && (w & kField) > (w >> 16)) w -= (w >> 16) * (kEnd + 1u);
         // ---- windows: thread d < W looks at window position d: the starts at pmin + d (its own bin) and the
         // ends at pmax - d
         u32 f = 0;
@@ -248,8 +272,8 @@ __device__ __forceinline__ bool screen_wg_read(const SweepArgs &a, u32 r, u32 *t
 //     events in front + a correction per bin (D_i minus the kept bins' net in front of it) — no stand-in keys;
 //   * the ends are the screen's: (0, a) in front, (b, len) behind (WgVerdict::ends_ok); a run of low starts still open when
 //     the keys end is closed by the tail.
-// A shallow start at or behind b's bin, a zero-length interval in a kept bin, a low start with no flagged end in front of
-// it: false (nothing written) — the caller sorts the read.  True: the read's regions and their count are written.
+// A shallow start at or behind b's bin, a zero-length interval in a kept bin whose start is low, a low start with no flagged
+// end in front of it: false (nothing written) — the caller sorts the read.  True: the read's regions and their count are written.
 constexpr int kWfCap = 4096; // kept events: eight keys per thread
 __device__ __forceinline__ bool wg_filtered_read(const SweepArgs &a, u32 r, const WgVerdict &vd, u32 *tab, u32 *sc, u32 *keys,
                                                  unsigned long long *s_masks, const LaneConst &lc)
@@ -303,7 +327,6 @@ __device__ __forceinline__ bool wg_filtered_read(const SweepArgs &a, u32 r, cons
     __syncthreads();
     // ---- the kept events, to the slots of their bins (four loads in flight per thread)
     const uint2 *iv = a.iv + o;
-    u32 zl = 0;
     for (u32 i0 = tid; i0 < n; i0 += 4 * T) {
         uint2 v[4];
 #pragma unroll
@@ -313,12 +336,18 @@ __device__ __forceinline__ bool wg_filtered_read(const SweepArgs &a, u32 r, cons
             if (i0 + (u32)(j * T) >= n || v[j].y == 0u) continue; // ((0, 0) intervals are inert: nowhere in the table)
             const u32 is = idx(v[j].x), ie = idx(v[j].y);
             const bool ks = tab[4u * is + 2u] != 0u, ke = tab[4u * ie + 2u] != 0u;
-            zl |= ((ks || ke) && v[j].x == v[j].y) ? 1u : 0u;
+            if (v[j].x == v[j].y) { // a zero-length interval: its two keys sort between the position's ends and its regular starts
+                if (ks) {
+                    const u32 at = atomicAdd(&tab[4u * is], 2u);
+                    keys[at] = (v[j].x << kKeyShift) | 1u, keys[at + 1u] = (v[j].x << kKeyShift) | 2u;
+                }
+                continue;
+            }
             if (ks) keys[atomicAdd(&tab[4u * is], 1u)] = (v[j].x << kKeyShift) | 3u;
             if (ke) keys[atomicAdd(&tab[4u * ie], 1u)] = v[j].y << kKeyShift;
         }
     }
-    if (block_or<T>(zl, sc)) return false; // a zero-length interval where it may matter (its barriers: the keys are written)
+    __syncthreads(); // (the keys are written)
     if (P >= 1024) hybrid_sort_lds<T>(keys, P, lc);
     else bitonic_sort_lds<T>(keys, P);
     // ---- the sweep: thread t owns the sorted keys [t K, t K + K); depth in front of a key = the kept keys in front
@@ -353,7 +382,9 @@ __device__ __forceinline__ bool wg_filtered_read(const SweepArgs &a, u32 r, cons
             const bool is_s = (key & 1u) != 0u, gt = d + corr_of(key) > c;
             const bool fl = !is_s && gt, low = is_s && !gt;
             cnt += (fl && cml > tc) ? 1u : 0u;
-            orphan |= (low && tc == 0u) ? 1u : 0u; // a low start with no flagged end in front of it (cannot happen behind a: the caller sorts the read)
+            // a low start with no flagged end in front of it (cannot happen behind a), or a zero-length interval whose start is
+            // low (one with more than c open around it is an ordinary pair of keys): the caller sorts the read
+            orphan |= (low && (tc == 0u || (key & 3u) == 1u)) ? 1u : 0u;
             tc = fl ? key : tc;
             cml = low ? key : cml;
             d += is_s ? 1 : -1;
@@ -473,6 +504,9 @@ __global__ __launch_bounds__(kWsT, YK_WG_OCC) void screen_wg_fused_kernel(Screen
             const u32 r = a.list[b];
             WgVerdict vd;
             if (screen_wg_read(a, r, tab, red, sc, vd)) continue; // (uniform; ends with a barrier)
+#if YK_EXP_SKIP_UNDECIDED // (timing experiments only: the code below is in the kernel and never runs)
+            if (r != 0xFFFFFFFFu) continue;
+#endif
 #if !YK_EXP_NO_FILTERED
             const bool done = wg_filtered_read(a, r, vd, tab, sc, keys, s_masks, lane_const()); // (uniform)
             __syncthreads(); // (the table, sc, the masks and the keys are the next read's)

@@ -246,21 +246,52 @@ def resident_block(cx, label, profile, R, O, cov, nc, seed, jitter, steps, warmu
     d_len = torch.from_numpy(np.ascontiguousarray(ln).view(np.int32)).to(cx.dev)
     torch.cuda.synchronize()
     upload_s = time.perf_counter() - t0
-    eng = ya.Engine(device_id=cx.dev_index, flags=cx.args.flags)  # every launch of the dominant kernel carries its events
+    # NE engines (streams) per GPU, NE passes in flight: the plan, the scan and the launch gaps of one pass hide behind the
+    # screen of another (yacrd_engines_run_device_batches: what a caller with many batches does); NE = 1: one pass at a time
+    NE = max(1, min(int(getattr(cx.args, "resident_engines", 1)), max(1, steps)))
+    engs = [ya.Engine(device_id=cx.dev_index, flags=cx.args.flags) for _ in range(NE)]  # every launch of the dominant kernel carries its events
+    eng = engs[0]
     ptrs = (d_off.data_ptr(), d_iv.data_ptr(), d_len.data_ptr(), Rl, Il, cov, nc)
     W, K = max(1, warmup), max(1, steps)
-    for _ in range(W):
-        res = eng.run_device(*ptrs)
-    eng.timing_total(reset=True)
+
+    def run_steps(k):
+        if NE == 1:
+            r_ = None
+            for _ in range(k):
+                r_ = eng.run_device(*ptrs)
+            return r_
+        return ya.run_device_batches(engs, [ptrs] * k)
+
+    for e_ in engs:  # (every engine's first pass sizes its buffers and gives it a prediction)
+        for _ in range(2 if NE > 1 else 0):
+            e_.run_device(*ptrs)
+    res = run_steps(max(W, NE))
+    for e_ in engs:
+        e_.timing_total(reset=True)
     cx.barrier()
     t0 = time.perf_counter()
-    for _ in range(K):
-        res = eng.run_device(*ptrs)
+    res = run_steps(K)
     cx.barrier()
     mine = time.perf_counter() - t0
     elapsed = ydist.max_over_ranks(dist, mine, cx.dev)
-    t, nt = eng.timing_total()
+    t, nt = None, 0
+    for e_ in engs:
+        te, ne = e_.timing_total()
+        nt += ne
+        if t is None:
+            t = te
+        else:
+            for k2, v in te.items():
+                if k2.endswith("_ms") or k2 in PATH_KEYS or k2 == "timed_runs":
+                    t[k2] = [a_ + b_ for a_, b_ in zip(t[k2], v)] if isinstance(v, list) else t[k2] + v
     assert nt == K
+    one_engine_ms = None
+    if NE > 1 and cx.rank == 0:  # the same passes one at a time on one engine, beside it (never part of `value`)
+        cx.torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(max(3, K // 2)):
+            eng.run_device(*ptrs)
+        one_engine_ms = (time.perf_counter() - t1) / max(3, K // 2) * 1e3
     G = int(res.n_regions)
     phases = None
     if cx.rank == 0:  # per-phase times: two extra passes with events around everything (never part of `value`)
@@ -282,7 +313,8 @@ def resident_block(cx, label, profile, R, O, cov, nc, seed, jitter, steps, warmu
     else:
         allr = [per_rank]
     keep = (offsets, intervals, lengths) if keep_host and cx.rank == 0 else None
-    eng.close()
+    for e_ in engs:
+        e_.close()
     del d_off, d_iv, d_len
     torch.cuda.empty_cache()
     if cx.rank != 0:
@@ -294,11 +326,14 @@ def resident_block(cx, label, profile, R, O, cov, nc, seed, jitter, steps, warmu
     screened = bool(t.get("screened"))
     out = {"workload": "%s: synthetic %s pile-up%s, %d reads / %d PAF overlaps in total, -c %d -n %g, read-partitioned "
                        "over %d GPU(s) by yacrd_partition_reads (contiguous ranges balanced by interval count, no "
-                       "collective); KERNELS ONLY: inputs resident in HBM, one engine per GPU, every pass the whole input"
-                       % (label, profile.upper(), jit, R, O, cov, nc, cx.world),
+                       "collective); KERNELS ONLY: inputs resident in HBM, %s, every pass the whole input"
+                       % (label, profile.upper(), jit, R, O, cov, nc, cx.world,
+                          "one engine per GPU, one pass at a time" if NE == 1 else
+                          "%d engines (streams) per GPU, %d passes in flight (yacrd_engines_run_device_batches)" % (NE, NE)),
            "reads": R, "overlaps": O, "intervals": I_all, "regions": G_all,
            "reads_per_sec": R * K / elapsed, "kernel_overlaps_per_sec": O * K / elapsed,
            "ms_per_step": elapsed / K * 1e3, "steps": K, "warmup": W, "n_gpus": cx.world,
+           "engines_per_gpu": NE, "one_engine_one_pass_at_a_time_ms": one_engine_ms,
            "generate_s": gen_s, "upload_s": upload_s,
            "interval_imbalance_max_over_min": max(ivs) / max(1, min(ivs)),
            "per_rank": allr,
@@ -891,6 +926,8 @@ def main():
     ap.add_argument("--coverage", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--flags", type=int, default=0, help="extra YACRD_F_* engine flags (A/B)")
+    ap.add_argument("--resident-engines", type=int, default=1,
+                    help="engines (HIP streams) per GPU the resident blocks' passes are pipelined over (1: one pass at a time)")
     ap.add_argument("--engines", type=int, default=3, help="engines (HIP streams) the small batches are pipelined over")
     ap.add_argument("--small-steps", type=int, default=500)
     ap.add_argument("--small-warmup", type=int, default=10)

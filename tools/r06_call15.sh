@@ -1,0 +1,16 @@
+#!/bin/bash
+# fifteenth GPU call of round 6: where the filtered fallback's 41 us go (the launch cut short behind stages 1 .. 4: timing only)
+out=gpurun_out/r06o; mkdir -p $out
+cd /tmp && export TMPDIR=/tmp && cd - >/dev/null
+cp yacrd_amd/lib/libyacrd_hip.so /tmp/keep.so
+prof() { local name=$1 flags=$2; shift 2
+  env "$@" timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof_$name -o s -- python bench.py --config 3 --no-extras --no-cpu-baseline --steps 20 --flags $flags > $out/prof_$name.log 2>&1
+  find $out/prof_$name -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats_$name.csv \;
+  rm -rf $out/prof_$name
+  echo "== $name"; grep -E "screen_wg" $out/kernel_stats_$name.csv | cut -d, -f1,2,4,6,7 | cut -c1-140
+}
+for v in fstage1 fstage2 fstage3 fstage4 keep; do cp /tmp/keep.so yacrd_amd/lib/libyacrd_hip.so; [ $v = keep ] || cp variants/lib_$v.so yacrd_amd/lib/libyacrd_hip.so
+  prof $v 0 A=1
+done
+cp /tmp/keep.so yacrd_amd/lib/libyacrd_hip.so
+cat $out/kernel_stats_keep.csv | cut -c1-160

@@ -35,6 +35,12 @@
 #ifndef YK_EXP_NO_FALLBACK
 #define YK_EXP_NO_FALLBACK 0
 #endif
+#ifndef YK_WS_SIZED
+#define YK_WS_SIZED 1
+#endif
+#ifndef YK_EXP_FILT_STAGE
+#define YK_EXP_FILT_STAGE 0 // (timing experiments only: wg_filtered_read leaves, "done", behind stage 1 .. 4)
+#endif
 #ifndef YK_EXP_SKIP_UNDECIDED
 #define YK_EXP_SKIP_UNDECIDED 0
 #endif
@@ -66,9 +72,13 @@ struct WgVerdict {
     bool ends_ok; // F > c, G > c, no end at or before a: (0, a) and (b, len) are the read's first and last regions whatever lies between
     u32 pmin, pmax, sh, ra, rb;
 };
+// R: intervals per thread and chunk (a multiple of four: pair loads) — the body is straight-line code over R slots, real or not,
+// so a read of n <= T * R' < T * R intervals is cheaper through the build for R' (screen_wg_kernel picks one per read).
+template <int R = kWsR>
 __device__ __forceinline__ bool screen_wg_read(const SweepArgs &a, u32 r, u64 o, u32 n, u32 len, u32 *tab, u32 (*red)[4], u32 *sc, WgVerdict &vd)
 {
-    constexpr int T = kWsT, R = kWsR, W = kWsW, NW = T / 64;
+    static_assert(R % 4 == 0 && R >= 4 && R <= kWsR, "pairs of pairs");
+    constexpr int T = kWsT, W = kWsW, NW = T / 64;
     constexpr u32 kEnd = 1u << 16, kField = kEnd - 1u;
     const u32 tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
     const i32 c = (i32)min(a.cov, 0x3FFFFFFFu);
@@ -245,7 +255,21 @@ __device__ __forceinline__ bool screen_wg_read(const SweepArgs &a, u32 r, u64 o,
 __device__ __forceinline__ bool screen_wg_read(const SweepArgs &a, u32 r, u32 *tab, u32 (*red)[4], u32 *sc, WgVerdict &vd)
 {
     const u64 o = a.off[r];
-    return screen_wg_read(a, r, o, (u32)(a.off[r + 1] - o), a.len[r], tab, red, sc, vd);
+    return screen_wg_read<kWsR>(a, r, o, (u32)(a.off[r + 1] - o), a.len[r], tab, red, sc, vd);
+}
+// ... by the read's size: 4 / 8 / 12 / 16 slots per thread (round 6: configs[3]'s reads of 5 000-6 000 intervals fill six of the
+// sixteen-slot build's eight pair groups; skipping the dead groups behind uniform branches was slower, see YK_WS_SKIP_DEAD)
+__device__ __forceinline__ bool screen_wg_read_sized(const SweepArgs &a, u32 r, u32 *tab, u32 (*red)[4], u32 *sc)
+{
+    WgVerdict vd;
+    const u64 o = a.off[r];
+    const u32 n = (u32)(a.off[r + 1] - o), len = a.len[r];
+#if YK_WS_SIZED
+    if (n <= (u32)(kWsT * 4)) return screen_wg_read<4>(a, r, o, n, len, tab, red, sc, vd);   // (uniform)
+    if (n <= (u32)(kWsT * 8)) return screen_wg_read<8>(a, r, o, n, len, tab, red, sc, vd);
+    if (n <= (u32)(kWsT * 12)) return screen_wg_read<12>(a, r, o, n, len, tab, red, sc, vd);
+#endif
+    return screen_wg_read<kWsR>(a, r, o, n, len, tab, red, sc, vd);
 }
 __device__ __forceinline__ bool screen_wg_read(const SweepArgs &a, u32 r, u32 *tab, u32 (*red)[4], u32 *sc)
 {
@@ -282,6 +306,7 @@ __device__ __forceinline__ bool wg_filtered_read(const SweepArgs &a, u32 r, cons
     constexpr u32 kEnd = 1u << 16, kField = kEnd - 1u;
     static_assert(kWsBins == T, "one bin per thread");
     if (!vd.plain || !vd.ends_ok) return false; // (uniform)
+    if (YK_EXP_FILT_STAGE == 1) return true;
     const u32 tid = threadIdx.x, lane = lane_id(), wv = tid >> 6;
     const i32 c = (i32)min(a.cov, 0x3FFFFFFFu);
     const u64 o = a.off[r];
@@ -321,18 +346,19 @@ __device__ __forceinline__ bool wg_filtered_read(const SweepArgs &a, u32 r, cons
     // per bin, where its counters were (every thread has read its own: the scans' barriers lie in between):
     // slot cursor, depth correction, kept
     bins[tid] = make_uint4(cex, (u32)(D - (i32)nex), kept ? 1u : 0u, 0u);
+    if (YK_EXP_FILT_STAGE == 2) return true;
     u32 P = 2;
     while (P < m_tot) P <<= 1;
     for (u32 i = m_tot + tid; i < P; i += T) keys[i] = kNoKey;
     __syncthreads();
-    // ---- the kept events, to the slots of their bins (four loads in flight per thread)
+    // ---- the kept events, to the slots of their bins (eight loads in flight per thread)
     const uint2 *iv = a.iv + o;
-    for (u32 i0 = tid; i0 < n; i0 += 4 * T) {
-        uint2 v[4];
+    for (u32 i0 = tid; i0 < n; i0 += 8 * T) {
+        uint2 v[8];
 #pragma unroll
-        for (int j = 0; j < 4; j++) v[j] = iv[min(i0 + (u32)(j * T), n - 1u)];
+        for (int j = 0; j < 8; j++) v[j] = iv[min(i0 + (u32)(j * T), n - 1u)];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < 8; j++) {
             if (i0 + (u32)(j * T) >= n || v[j].y == 0u) continue; // ((0, 0) intervals are inert: nowhere in the table)
             const u32 is = idx(v[j].x), ie = idx(v[j].y);
             const bool ks = tab[4u * is + 2u] != 0u, ke = tab[4u * ie + 2u] != 0u;
@@ -348,27 +374,40 @@ __device__ __forceinline__ bool wg_filtered_read(const SweepArgs &a, u32 r, cons
         }
     }
     __syncthreads(); // (the keys are written)
+    if (YK_EXP_FILT_STAGE == 3) return true;
     if (P >= 1024) hybrid_sort_lds<T>(keys, P, lc);
     else bitonic_sort_lds<T>(keys, P);
+    if (YK_EXP_FILT_STAGE == 4) return true;
     // ---- the sweep: thread t owns the sorted keys [t K, t K + K); depth in front of a key = the kept keys in front
     // (starts - ends) + its bin's correction
+    constexpr int KMAX = kWfCap / T;
     const u32 K = P >= (u32)T ? P / (u32)T : 1u;
     const u32 q0 = min(tid * K, m_tot), q1 = min(q0 + K, m_tot);
-    auto corr_of = [&](u32 key) { return (i32)tab[4u * idx(key >> kKeyShift) + 1u]; };
+    // (the chunk's keys and their bins' corrections, once: the four passes below run on registers)
+    u32 kx[KMAX];
+    i32 cr[KMAX];
+#pragma unroll
+    for (int q = 0; q < KMAX; q++) {
+        const bool real = q0 + (u32)q < q1;
+        kx[q] = real ? keys[q0 + (u32)q] : kNoKey;
+        cr[q] = real ? (i32)tab[4u * idx(kx[q] >> kKeyShift) + 1u] : 0;
+    }
     u32 delta = 0;
-    for (u32 q = q0; q < q1; q++) delta += (keys[q] & 1u) ? 1u : 0xFFFFFFFFu;
+#pragma unroll
+    for (int q = 0; q < KMAX; q++) delta += kx[q] == kNoKey ? 0u : (kx[q] & 1u) ? 1u : 0xFFFFFFFFu;
     u32 dtot;
     const i32 depth_in = (i32)block_excl_add<T>(delta, sc, dtot);
     // last flagged end / last low start of the chunk (keys ascend: last = max); 0 = none (no end lies at position 0)
     u32 mf = 0, ml = 0;
     {
         i32 d = depth_in;
-        for (u32 q = q0; q < q1; q++) {
-            const u32 key = keys[q];
-            const bool is_s = (key & 1u) != 0u, gt = d + corr_of(key) > c;
-            mf = (!is_s && gt) ? key : mf;
-            ml = (is_s && !gt) ? key : ml;
-            d += is_s ? 1 : -1;
+#pragma unroll
+        for (int q = 0; q < KMAX; q++) {
+            const u32 key = kx[q];
+            const bool real = key != kNoKey, is_s = (key & 1u) != 0u, gt = d + cr[q] > c;
+            mf = (real && !is_s && gt) ? key : mf;
+            ml = (real && is_s && !gt) ? key : ml;
+            d += real ? (is_s ? 1 : -1) : 0;
         }
     }
     u32 mf_t, ml_t;
@@ -377,17 +416,18 @@ __device__ __forceinline__ bool wg_filtered_read(const SweepArgs &a, u32 r, cons
     {
         u32 tc = mf_in, cml = ml_in;
         i32 d = depth_in;
-        for (u32 q = q0; q < q1; q++) {
-            const u32 key = keys[q];
-            const bool is_s = (key & 1u) != 0u, gt = d + corr_of(key) > c;
-            const bool fl = !is_s && gt, low = is_s && !gt;
+#pragma unroll
+        for (int q = 0; q < KMAX; q++) {
+            const u32 key = kx[q];
+            const bool real = key != kNoKey, is_s = (key & 1u) != 0u, gt = d + cr[q] > c;
+            const bool fl = real && !is_s && gt, low = real && is_s && !gt;
             cnt += (fl && cml > tc) ? 1u : 0u;
             // a low start with no flagged end in front of it (cannot happen behind a), or a zero-length interval whose start is
             // low (one with more than c open around it is an ordinary pair of keys): the caller sorts the read
             orphan |= (low && (tc == 0u || (key & 3u) == 1u)) ? 1u : 0u;
             tc = fl ? key : tc;
             cml = low ? key : cml;
-            d += is_s ? 1 : -1;
+            d += real ? (is_s ? 1 : -1) : 0;
         }
     }
     if (block_or<T>(orphan, sc)) return false; // (nothing is written yet)
@@ -400,14 +440,15 @@ __device__ __forceinline__ bool wg_filtered_read(const SweepArgs &a, u32 r, cons
         u32 tc = mf_in, cml = ml_in;
         i32 d = depth_in;
         pos += g0;
-        for (u32 q = q0; q < q1; q++) {
-            const u32 key = keys[q];
-            const bool is_s = (key & 1u) != 0u, gt = d + corr_of(key) > c;
-            const bool fl = !is_s && gt, low = is_s && !gt;
+#pragma unroll
+        for (int q = 0; q < KMAX; q++) {
+            const u32 key = kx[q];
+            const bool real = key != kNoKey, is_s = (key & 1u) != 0u, gt = d + cr[q] > c;
+            const bool fl = real && !is_s && gt, low = real && is_s && !gt;
             if (fl && cml > tc) slot[pos++] = make_uint2(tc >> kKeyShift, cml >> kKeyShift);
             tc = fl ? key : tc;
             cml = low ? key : cml;
-            d += is_s ? 1 : -1;
+            d += real ? (is_s ? 1 : -1) : 0;
         }
     }
     if (tid == 0) {
@@ -433,7 +474,7 @@ __global__ __launch_bounds__(kWsT, YK_WGK_OCC) void screen_wg_kernel(SweepArgs a
     const u32 list_n = *a.list_n;
     for (u32 b = blockIdx.x; b < list_n; b += gridDim.x) { // (uniform)
         const u32 r = a.list[b];
-        if (!screen_wg_read(a, r, tab, red, sc) && threadIdx.x == 0) a.over_list[atomicAdd(a.over_count, 1u)] = r;
+        if (!screen_wg_read_sized(a, r, tab, red, sc) && threadIdx.x == 0) a.over_list[atomicAdd(a.over_count, 1u)] = r;
     }
 }
 

@@ -110,8 +110,9 @@ def roofline_of(yacrd_amd, t, n_launches, R, G, key, note):
         c_iv -= int(t.get("deferred_intervals", 0))
         c_reads -= deferred
     if cname in ("M1", "M2", "BIG"):
-        note += ("; kernel_ms brackets the class's launches (M1 / M2: the persistent screen + fallback kernel and the usually empty overflow "
-                 "kernel behind it; BIG: the device-wide screen's four), `traffic` is the first kernel's: profiles/r04_kernel_stats_configs3.csv has them all")
+        note += ("; kernel_ms brackets the class's launches (M1 / M2: the screen, the launch over what it leaves — table again, filtered "
+                 "exact sweep, whole-read sort — and the usually empty overflow kernel behind it; BIG: the device-wide screen's four, on a "
+                 "side stream), `traffic` is the screen's + the second launch's: profiles/r06_kernel_stats_configs3.csv has them all")
     b_dom = 8 * c_iv + 21 * c_reads + 16 + 8 * (G * c_reads // max(R, 1))
     ach = b_dom / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     tr = traffic_entry(key) if key else None

@@ -728,8 +728,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
             sa.list = list_of(cls);
             sa.list_n = &ctr->n[cls];
             if (sa.prefilter && !(e->flags & YACRD_F_NO_FUSED_SCREEN) && !e->fused_off && e->screen_fused_wgs_per_cu > 0) {
-                // the screen and the fallback of what it leaves in ONE launch (screen_wg.h)
-                if (again) { // (a second pass over the class: the queue starts over)
+                if (again) { // (a second pass over the class: the lists start over)
                     HIP_TRY(hipMemsetAsync(&ctr->fb_stream[k], 0, sizeof(u32), e->stream));
                     HIP_TRY(hipMemsetAsync(&ctr->fb_med[k], 0, sizeof(u32), e->stream));
                 }

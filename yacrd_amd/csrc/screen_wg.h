@@ -478,29 +478,32 @@ __global__ __launch_bounds__(kWsT, YK_WGK_OCC) void screen_wg_kernel(SweepArgs a
     }
 }
 
-// ---- the screen and its fallback in ONE launch (round 4; without a queue: round 6) -------------------------------------
-// Round 3 ran three kernels one after the other for a workgroup class: the screen, sweep_lds_kernel<256, 8192> over
-// the reads it left, sweep_lds_kernel<1024, 32768> over what did not fit there.  On configs[3] the two fallback
-// kernels took 61 + 65 us for 2 % of the reads: each is one latency chain per read (two passes over the intervals,
-// the trimming plan, the sort, four sweep passes) with most of the device idle, and the second cannot start before
-// the first has ended.  Here one launch does both: a workgroup screens its share of the class list — a few consecutive
-// entries —, keeps what it cannot decide in a list of its own, and takes THAT through sweep_lds_read<512, 16384> before it
-// retires: the fallback reads are sorted while other workgroups still screen.  What does not fit 16 384 events even
-// after the filter goes to over_list for the 1024-thread kernel (launched behind this one; usually nothing).
-//
-// Rounds 4-5 balanced the fallback work through a QUEUE in global memory on a persistent grid: a workgroup appended
-// what it could not decide, and when its static share was done took reads off the queue — anybody's — and WAITED for
-// further appends until every workgroup had screened its share.  That needed the whole grid resident at once (engines took
-// turns with the launch, its size came from the occupancy query, a bounded wait gave up and the engine ran the batch
-// again), and it cost more than it balanced: up to 512 pollers reading the same two words every 0.2 us are served one
-// after the other at the memory side like the atomics they are, in the way of the screening workgroups' own traffic —
-// configs[3]'s launch WITHOUT any fallback work took 0.194 ms where screen_wg_kernel, the same screen with no queue on
-// 1 024 dispatcher-fed workgroups, took 0.128 (profiles/r06/a_*, c_*).  Measured on the way (profiles/r06/d_*, e_*):
-// the share claimed from a counter instead of dealt (slower: 5 000 more same-address atomics); the queue drained by
-// compare-and-swap with nobody waiting (1.0 ms: 512 workgroups that finish together retry on one word).
-// Now nothing is shared and nobody waits: the DISPATCHER balances.  The grid is a few thousand short-lived workgroups
-// (the host sizes the share: ~8 rounds of the slots the device has), a workgroup that meets a fallback read is busy
-// 50-90 us longer while the dispatcher feeds the other slots, and the launch's tail is one fallback read — as it was.
+// ---- what the screen leaves: table again, filtered exact sweep, whole-read sort (rounds 4-6) ----------------------------
+// History, because every shape below was built, verified bit-exact and measured on configs[3] (10 000 reads of 5 000 ..
+// 16 384 intervals, 2 % chimeras; profiles/r04 .. r06):
+//   round 3  three kernels one after the other: the screen (screen_wg_kernel), sweep_lds_kernel<256, 8192> over what it left,
+//            sweep_lds_kernel<1024, 32768> over what did not fit there: 0.128 + 0.061 + 0.065 ms — the two fallback kernels
+//            one latency chain per read (two passes over the intervals, the trimming plan, a sort of 8 192 - 16 384 keys, four
+//            sweep passes) with most of the device idle;
+//   rounds 4-5  ONE persistent launch: a workgroup screened a static share of the class list, appended what it could not
+//            decide to a QUEUE in global memory, then took reads off it — anybody's — through sweep_lds_read, and WAITED
+//            for further appends until every workgroup had screened its share: 0.22 ms.  The wait needed the whole grid
+//            resident (engines took turns, a bounded wait gave up, the engine ran the batch again), and up to 512 pollers
+//            reading the same two words every 0.2 us are served one after the other at the memory side like the atomics they are;
+//   round 6  (a) the share claimed from a counter: slower (5 000 more same-address atomics); (b) the queue drained by
+//            compare-and-swap, nobody waiting: 1.0 ms (512 workgroups that finish together retry on one word); (c) no queue:
+//            a workgroup sorts its own leftovers before it retires, the dispatcher balances: 0.24 — the launch's tail is
+//            one fallback read, 90 us by one workgroup, whenever such a read sits in the last three quarters of the list;
+//            (d) + the FILTERED exact sweep above for what the screen leaves: 0.21 — and the same launch with all that code
+//            in it but never run took 0.163 where the screen alone takes 0.120 (128 VGPRs, 88 bytes of scratch written by
+//            every workgroup, 74 KB of LDS); (e) TWO launches — the screen alone, one read per dispatcher-fed workgroup
+//            (screen_wg_kernel: 0.120), then THIS kernel over the list of what it left (a fiftieth of the reads, one per
+//            workgroup: the table built again 10 us, kept bins + keys 10, sort 11, sweep 8: 0.039): 0.16 ms for the class,
+//            configs[3]'s step 0.31 -> 0.245 ms (with the device-wide class's launches on a side stream).  Kept: (e).
+// The kernel still screens (its list may be a class list: YACRD_TEST / A/B paths hand it one), keeps what neither the
+// screen nor the filtered sweep decides in a list of its own and takes THAT through sweep_lds_read<512, 16384> before it
+// retires; what does not fit 16 384 events even after the trimming filter goes to over_list for the 1024-thread kernel
+// (launched behind this one; usually nothing).
 constexpr u32 kQueueEmpty = 0xFFFFFFFFu; // (plan_kernel still marks the rounds 4-5 queue's slots: harmless, 4 bytes per read of the class)
 #ifndef YK_WS_FB_CAP
 #define YK_WS_FB_CAP 16384

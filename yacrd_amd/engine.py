@@ -125,10 +125,10 @@ CLASS_KERNELS = {  # the HIP kernel behind each class, as rocprofv3 prints it
     "H16": "sweep_group_kernel<32, 16, 0>", "W2": "sweep_group_kernel<64, 2, 0>",
     "W4": "sweep_group_kernel<64, 4, 0>", "W8": "sweep_group_kernel<64, 8, 0>",
     "W16": "sweep_group_kernel<64, 16, 0>",
-    # the workgroup classes: the screen and the fallback of what it leaves are ONE persistent launch (screen_wg.h); the bracket
+    # the workgroup classes: the screen, then the fallback of what it leaves (two launches since round 6: screen_wg.h); the bracket
     # also holds the (usually empty) sweep_lds_kernel<1024, 32768> behind it for M2
-    "M1": "screen_wg_fused_kernel",
-    "M2": "screen_wg_fused_kernel (+ sweep_lds_kernel<1024, 32768> over what exceeds its 16 384 events)",
+    "M1": "screen_wg_kernel + screen_wg_fused_kernel over what it leaves",
+    "M2": "screen_wg_kernel + screen_wg_fused_kernel over what it leaves (+ sweep_lds_kernel<1024, 32768> over what exceeds 16 384 events)",
     "BIG": "bs_setup / bs_minmax / bs_hist / bs_verdict (screen_big.h)",
 }
 

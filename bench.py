@@ -39,6 +39,12 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order; the blocks below keep three
+# engines (a stream each) beside torch's, create and destroy dozens over a run, and two engines that land on ONE queue run their
+# batches one after the other: configs[1]'s pipelined batches measured 60 us at sigma 300 with eight queues or a lucky four, 83 with
+# two, 130-290 on boxes / builds where the mapping collided (profiles/r06/u_queues.log).  Must be set before
+# the HIP runtime starts; a caller's own setting wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); 6290 GB/s measured-copy ceiling
 
@@ -750,6 +756,46 @@ def end_to_end_at_scale(ya, host, eng, d, R=600_000, O=60_000_000):
             os.remove(paf)
 
 
+def box_block(cx):
+    """What kind of box this is, in three numbers a reader can normalise by (the same build measured
+    configs[1]'s small batches 30-60 % slower on some boxes of the pool than on others, with the same paths taken —
+    `paths` / `reruns_total` say so — while the HBM-bound headline moved by 3 %): a device-to-device copy of 64 MB (fits
+    the Infinity Cache: what the small batches run from), of 2 GB (HBM), both in GB/s of bytes read + written, and the
+    time per dependent launch of a one-element kernel."""
+    torch = cx.torch
+    out = {"device": torch.cuda.get_device_name(cx.dev_index)}
+    try:
+        def copy_rate(nbytes, reps):
+            a = torch.empty(nbytes // 4, dtype=torch.int32, device=cx.dev)
+            b = torch.empty_like(a)
+            a.zero_()
+            for _ in range(3):
+                b.copy_(a)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                b.copy_(a)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / reps
+            del a, b
+            return 2 * nbytes / dt / 1e9
+        out["copy_64MB_GBps"] = copy_rate(64 << 20, 200)
+        out["copy_2GB_GBps"] = copy_rate(2 << 30, 10)
+        x = torch.zeros(1, dtype=torch.int32, device=cx.dev)
+        for _ in range(20):
+            x.add_(1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(500):
+            x.add_(1)
+        torch.cuda.synchronize()
+        out["dependent_launch_us"] = (time.perf_counter() - t0) / 500 * 1e6
+        torch.cuda.empty_cache()
+    except Exception as ex:
+        out["error"] = repr(ex)
+    return out
+
+
 SCALE = 1.0  # --scale (plumbing tests)
 
 
@@ -840,6 +886,9 @@ def compact_line(full, extras_path):
     blocks = [full.get("headline"), full.get("configs2"), full.get("skewed"), full.get("small_batches"), full.get("configs4_sigma100")]
     blocks += [b for k, b in (full.get("jitter") or {}).items() if k != "healthy_share_of_screened_reads"]
     pp = [b["paths"] for b in blocks if isinstance(b, dict) and isinstance(b.get("paths"), dict)]
+    bx = full.get("box")
+    if isinstance(bx, dict) and "error" not in bx:  # [64 MB copy GB/s (Infinity Cache), 2 GB copy GB/s (HBM), us per dependent launch]
+        out["box"] = [_r(bx.get("copy_64MB_GBps"), 0), _r(bx.get("copy_2GB_GBps"), 0), _r(bx.get("dependent_launch_us"), 2)]
     out["reruns_total"] = sum(p.get("prediction_misses", 0) + p.get("fused_reruns", 0) for p in pp) if pp else None
     if isinstance(full.get("value_sigma100"), dict):
         out["value_sigma100"] = {k: _r(v) for k, v in full["value_sigma100"].items()}
@@ -856,7 +905,7 @@ def compact_line(full, extras_path):
     s = json.dumps(out, allow_nan=False, separators=(",", ":"))
     # never expected (every string above is bounded), but the limit is enforced, not hoped for: optional blocks go first,
     # then the scalars, then the strings are cut — the contract's keys, `roofline` and `cpu_baseline` stay
-    droppable = ["jitter", "value_sigma100", "per_rank_ms", "reruns_total"] + [k for k in sc] + ["extras"]
+    droppable = ["jitter", "value_sigma100", "per_rank_ms", "reruns_total", "box"] + [k for k in sc] + ["extras"]
     for drop in droppable:
         if len(s.encode()) < COMPACT_LIMIT:
             break
@@ -1014,6 +1063,7 @@ def main():
             keep_head = None
             del offsets, intervals, lengths
     if extras:
+        line["box"] = box_block(cx)
         if not args.weak:
             for key, k in (("configs2", 2), ("skewed", 3)):
                 if k == args.config:

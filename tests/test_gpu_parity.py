@@ -913,3 +913,26 @@ def test_workgroup_classes_filtered_sweep_and_inert_intervals(cov):
                 # most of the reads are decided without the whole-read sort: by the screen or by the filtered sweep
                 assert e.timing()["prefiltered_reads"] > len(reads) // 2, (e.timing()["prefiltered_reads"], c["fb_med"])
                 assert sum(c["fb_med"]) < len(reads) // 2, c["fb_med"]
+
+
+def test_batches_with_device_wide_reads_are_predicted():
+    """Round 6: a batch that holds reads beyond 16 384 intervals is launched on the previous run's class counts too (it used to
+    wait for the plan's counts every time); the device-wide screen goes out for the predicted count and intervals of such reads.
+    Same batch again: predicted, same result.  A batch of the SAME shape (reads, intervals) whose huge reads differ — one of
+    20 000 intervals against two of 10 000 — is a miss: found at the final sync, made good, bit-exact either way."""
+    sizes_a = [20000, 600, 600, 600] + [700] * 40
+    sizes_b = [10000, 10000, 1200, 600] + [700] * 40
+    assert len(sizes_a) == len(sizes_b) and sum(sizes_a) == sum(sizes_b)
+    a = make_csr(9101, np.array(sizes_a), ("regular",), len_lo=300000, len_hi=900000, mode_block=1)
+    b = make_csr(9102, np.array(sizes_b), ("regular",), len_lo=300000, len_hi=900000, mode_block=1)
+    wa = oracle.run(a[0], a[1], a[2].astype(np.uint64), 3, 0.4, n_threads=4)
+    wb = oracle.run(b[0], b[1], b[2].astype(np.uint64), 3, 0.4, n_threads=4)
+    with yacrd_amd.Engine() as e:
+        seen = []
+        for i, (csr, want) in enumerate([(a, wa), (a, wa), (a, wa), (b, wb), (b, wb), (a, wa), (a, wa)]):
+            assert_same(e.run(*csr, 3, 0.4), want, "run %d" % i)
+            t = e.timing()
+            seen.append((t["predicted"], t["prediction_misses"]))
+        assert seen[0][0] == 0 and seen[1] == (1, 0) and seen[2] == (1, 0), seen   # the same batch again: predicted, no miss
+        assert seen[3][1] == 1 and seen[4] == (1, 0), seen                        # other huge reads under the same shape: a miss, then none
+        assert seen[5][1] == 1 and seen[6] == (1, 0), seen

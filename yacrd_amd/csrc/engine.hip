@@ -523,9 +523,15 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     e->ctrl_clean[other] = other_bytes;
     if (full) HIP_TRY(hipEventRecord(e->ev[EV_PLAN], e->stream));
 
+    // (round 6: a batch that holds reads beyond the workgroup classes is predicted too — until then it always waited for the
+    // plan's counts, ~20 us of configs[3]'s step —: the device-wide screen is launched for the previous run's count and intervals
+    // of such reads, which must come out the same, and must have left nothing to the host-driven sort)
+    const bool big_predictable = !(e->flags & YACRD_F_NO_PREFILTER) && e->pred.fb_big == 0;
     const bool predicted = e->pred_valid && e->pred_reads == n_reads64 && e->pred_iv == n_iv &&
-                           e->pred.n[yk::CLS_GENERAL] == 0 &&
+                           (e->pred.n[yk::CLS_GENERAL] == 0 || big_predictable) &&
                            !(e->flags & (YACRD_F_FORCE_GENERAL | YACRD_F_NO_PREDICTION));
+    const u32 pred_big_n = predicted ? e->pred.n[yk::CLS_GENERAL] : 0u;
+    const u64 pred_big_iv = predicted ? e->pred.iv[yk::CLS_GENERAL] : 0ull;
     struct LaunchSet {
         u32 n[12];     // reads used to size the grid; 0 = class not launched
         u32 hint[12];  // the class's size as far as the host knows it (its count, or the prediction + a margin): grids of kernels that cover a list of any length
@@ -876,19 +882,27 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     // configs[3]'s 0.31 ms with the device mostly idle.  Fork behind the plan, join in front of the follow-on step.
     int rc = YACRD_OK;
     u64 gen_iv = 0;
-    const bool huge_now = !predicted && c0.n[yk::CLS_GENERAL] != 0;
+    const u32 huge_n = predicted ? pred_big_n : c0.n[yk::CLS_GENERAL];
+    const u64 huge_iv = predicted ? pred_big_iv : c0.iv[yk::CLS_GENERAL];
+    const bool huge_now = huge_n != 0;
+    if (huge_now && sa.prefilter && !(e->flags & YACRD_F_FORCE_GENERAL) && e->side == nullptr) {
+        if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess) {
+            (void)hipGetLastError();
+            e->side = nullptr; // (no side stream: the launches go out behind the other classes', as until round 5)
+        }
+    }
     const bool huge_beside = huge_now && sa.prefilter && !(e->flags & YACRD_F_FORCE_GENERAL) && e->side != nullptr;
     if (huge_beside) {
         HIP_TRY(hipEventRecord(e->ev_fork, e->stream));
         HIP_TRY(hipStreamWaitEvent(e->side, e->ev_fork, 0));
-        rc = launch_huge(c0.n[yk::CLS_GENERAL], c0.iv[yk::CLS_GENERAL], &gen_iv, e->side);
+        rc = launch_huge(huge_n, huge_iv, &gen_iv, e->side);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(e->ev_join, e->side));
     }
     rc = launch_sweeps(ls);
     if (rc) return rc;
     if (huge_now && !huge_beside) {
-        rc = launch_huge(c0.n[yk::CLS_GENERAL], c0.iv[yk::CLS_GENERAL], &gen_iv, e->stream);
+        rc = launch_huge(huge_n, huge_iv, &gen_iv, e->stream);
         if (rc) return rc;
     }
     if (huge_beside) HIP_TRY(hipStreamWaitEvent(e->stream, e->ev_join, 0));
@@ -915,6 +929,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
         }
         p.fused_marked = fused_marked;
         p.screened = screened;
+        p.big_n = pred_big_n, p.big_iv = pred_big_iv;
         return YACRD_OK;
     }
     // (spinning on the pinned counter block instead of this call was tried: 0.0816 vs 0.078 ms/step)
@@ -938,11 +953,12 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
                 missing.hint[cls] = missing.n[cls];
                 any_missing = true;
             }
-        if (any_missing || c0.n[yk::CLS_GENERAL]) {
+        const bool big_mismatch = c0.n[yk::CLS_GENERAL] != pred_big_n || c0.iv[yk::CLS_GENERAL] != pred_big_iv;
+        if (any_missing || big_mismatch) {
             e->miss_pending = true; // (the prediction did not hold: yacrd_timing.prediction_misses)
             if (!redo) HIP_TRY(hipEventRecord(e->ev[EV_X0], e->stream));
             if (any_missing && (rc = launch_sweeps(missing, true))) return rc;
-            if (c0.n[yk::CLS_GENERAL] && (rc = launch_huge(c0.n[yk::CLS_GENERAL], c0.iv[yk::CLS_GENERAL], &gen_iv, e->stream))) return rc;
+            if (big_mismatch && c0.n[yk::CLS_GENERAL] && (rc = launch_huge(c0.n[yk::CLS_GENERAL], c0.iv[yk::CLS_GENERAL], &gen_iv, e->stream))) return rc;
             // the rejection counters may have grown: bring them home before looking at rej_big
             HIP_TRY(hipMemcpyAsync(e->h_ctr, ctr, sizeof(yk::Counters), hipMemcpyDeviceToHost,
                                    e->stream));
@@ -1181,7 +1197,7 @@ int finish_pending(yacrd_engine *e)
     }
     const yk::Counters c = *e->h_ctr;
     if (c.fused_gave_up && !e->fused_off) return yke::rerun_without_fused(e, p.d_off, p.d_iv, p.d_len, p.n_reads, p.n_iv, p.cov, p.not_cov);
-    bool ok = !c.rej_small && !c.n[yk::CLS_GENERAL] && !c.rej_big && !c.region_overflow;
+    bool ok = !c.rej_small && c.n[yk::CLS_GENERAL] == p.big_n && c.iv[yk::CLS_GENERAL] == p.big_iv && !c.fb_big && !c.rej_big && !c.region_overflow;
     for (int cls = 0; cls < yk::CLS_GENERAL; cls++) ok = ok && c.n[cls] <= p.grid_n[cls];
     if (!ok) {
         e->pred_valid = false;
@@ -1352,7 +1368,8 @@ int yacrd_engine_create(const yacrd_engine_cfg *cfg, yacrd_engine **out)
         (void)hipGetLastError();
     }
     hipError_t err = hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking);
-    if (err == hipSuccess) err = hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking);
+    // (e->side is made by the first batch that needs it: a stream is a hardware queue's worth of scheduling state, and engines
+    //  that pipeline short batches — three per device in bench.py — should not double their number for nothing)
     if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming);
     for (int i = 0; i < EV_COUNT && err == hipSuccess; i++) err = hipEventCreate(&e->ev[i]);

@@ -116,6 +116,8 @@ struct Pending {
     uint32_t cov = 0;
     double not_cov = 0;
     u32 grid_n[12] = {};      // reads each class's grid covers
+    u32 big_n = 0;            // reads / intervals beyond the workgroup classes the device-wide screen was launched for (a prediction)
+    u64 big_iv = 0;
     bool fused_marked = false, screened = false;
     bool one_launch = false;  // the batch went out as one_batch_kernel (one_batch.h)
     int cls_b[12] = {}, cls_e[12] = {};

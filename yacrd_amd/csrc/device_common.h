@@ -112,6 +112,7 @@ struct SweepArgs {
     const u32 *len;      // [R]
     const u32 *list;     // read ids of this class
     const u32 *list_n;   // device-side count
+    const uint4 *rec;    // screen_wg_kernel: (first interval's index lo, hi, intervals, read) per entry of `list`, or null (round 6: what plan_kernel knows anyway saves the workgroup a dependent round trip)
     u32 first;           // first list entry this launch covers (remainder launches after a short grid)
     u32 cov;
     u32 prefilter;       // 1: drop events in bins deeper than cov before the sort (sweep_wave.h); 2: and count

@@ -450,6 +450,9 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     if (e->bad_regions.cap < (size_t)(4 * n_reads64 + 1024) * sizeof(uint2))
         HIP_TRY(e->bad_regions.reserve((size_t)(4 * n_reads64 + 1024) * sizeof(uint2)));
 
+    // (a read of M1 has more than 512 intervals, one of M2 more than 4 096: that many records at most)
+    const u32 mrec_cap1 = (u32)std::min<u64>(n_reads64, n_iv / 513 + 1), mrec_cap2 = (u32)std::min<u64>(n_reads64, n_iv / 4097 + 1);
+    HIP_TRY(e->mrec.reserve(((size_t)mrec_cap1 + mrec_cap2) * sizeof(uint4)));
     u32 *lists = e->lists.as<u32>();
     e->last_list_stride = n_reads;
     auto list_of = [&](int i) { return lists + (size_t)i * n_reads; };
@@ -479,7 +482,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     if (one_launch) {
         yk::OneBatchArgs oa;
         yk::SweepArgs &s = oa.c.sweep;
-        s.off = d_off, s.iv = d_iv, s.len = d_len, s.list = nullptr, s.list_n = nullptr, s.first = 0, s.cov = cov;
+        s.off = d_off, s.iv = d_iv, s.len = d_len, s.list = nullptr, s.list_n = nullptr, s.rec = nullptr, s.first = 0, s.cov = cov;
         s.prefilter = (e->flags & YACRD_F_COUNT_PREFILTERED) ? 2u : 1u;
         s.stage = e->stage.as<uint2>(), s.counts = e->counts.as<u32>(), s.closed = e->closed.as<uint2>();
         s.rej_list = rej_small, s.rej_count = &ctr->rej_small, s.over_list = nullptr, s.over_count = nullptr, s.ctr = ctr;
@@ -514,11 +517,11 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
                                     : (e->flags & YACRD_F_NO_HALVES) ? 3 : 0);
         if (n_reads < yk::kPlanSmallReads)
             hipLaunchKernelGGL((yk::plan_kernel<1, yk::kPlanSmallBlock>), dim3((n_reads + yk::kPlanSmallBlock - 1) / yk::kPlanSmallBlock),
-                               dim3(yk::kPlanSmallBlock), 0, e->stream, d_off, n_reads, lists, ctr, plan_mode, e->ctrl2[other].as<u32>(), (u32)(other_bytes / 4), e->counts.as<u32>());
+                               dim3(yk::kPlanSmallBlock), 0, e->stream, d_off, n_reads, lists, ctr, plan_mode, e->ctrl2[other].as<u32>(), (u32)(other_bytes / 4), e->counts.as<u32>(), e->mrec.as<uint4>(), mrec_cap1, mrec_cap2);
         else // (eight reads per thread — 611 workgroups instead of 1 221 on configs[4] — measured 32.0 us against 29.9: profiles/r05/m_*)
             hipLaunchKernelGGL(yk::plan_kernel<4>, dim3((n_reads + 4 * yk::kPlanBlock - 1) / (4 * yk::kPlanBlock)),
                                dim3(yk::kPlanBlock), 0, e->stream, d_off, n_reads, lists, ctr, plan_mode,
-                               e->ctrl2[other].as<u32>(), (u32)(other_bytes / 4), e->counts.as<u32>());
+                               e->ctrl2[other].as<u32>(), (u32)(other_bytes / 4), e->counts.as<u32>(), e->mrec.as<uint4>(), mrec_cap1, mrec_cap2);
     }
     e->ctrl_clean[other] = other_bytes;
     if (full) HIP_TRY(hipEventRecord(e->ev[EV_PLAN], e->stream));
@@ -576,6 +579,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
     sa.counts = e->counts.as<u32>();
     sa.closed = e->closed.as<uint2>();
     sa.ctr = ctr;
+    sa.rec = nullptr;
     sa.over_list = over_med;
     sa.over_count = &ctr->over_med;
 
@@ -756,6 +760,7 @@ int run_on_device(yacrd_engine *e, const u64 *d_off, const uint2 *d_iv, const u3
                     } else {
                         static const uint64_t wgk_grid = [] { const char *ev = std::getenv("YACRD_WGK_GRID"); return ev ? std::strtoull(ev, nullptr, 10) : (uint64_t)0; }(); // (A/B)
                         const u32 gs1 = (u32)std::min<uint64_t>(want, wgk_grid ? wgk_grid : (uint64_t)e->num_cu * 64);
+                        ss.rec = e->mrec.as<uint4>() + (k == 0 ? 0u : mrec_cap1);
                         hipLaunchKernelGGL(yk::screen_wg_kernel, dim3(gs1), dim3(yk::kWsT), 0, e->stream, ss);
                     }
                 }

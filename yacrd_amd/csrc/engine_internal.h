@@ -146,6 +146,7 @@ struct yacrd_engine {
     // work buffers
     yke::DevBuf dlist; // the follow-on step's list of marked reads (long batches: finish_compact.h, mark_list_kernel)
     uint32_t compact_calls = 0; // launch_compact calls of the current run (a redo starts the list over)
+    yke::DevBuf mrec; // the workgroup classes' records (plan_compact.h)
     yke::DevBuf lists, ctrl2[2], stage, counts, closed, gen_sizes, gen_scratch_off, gen_scratch, big_tab, big_keys, big_redo, bt_tab, bt_hist, bt_cur, bt_keys, bs_seg, bs_chunk, bs_hist;
     // two control blocks (counters + scan state), used alternately: the plan kernel of a run zeroes
     // the other one for the next run.  ctrl_clean[i] = leading bytes of block i known to be zero.

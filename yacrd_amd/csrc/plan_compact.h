@@ -27,7 +27,7 @@ constexpr int kPlanSmallBlock = YK_PLAN_SMALL_BLOCK; // threads per workgroup of
 template <int PER, int BLK = kPlanBlock>
 __global__ __launch_bounds__(BLK) void plan_kernel(const u64 *off, u32 n_reads, u32 *lists,
                                                    Counters *ctr, u32 mode, u32 *zero,
-                                                   u32 zero_words, u32 *counts)
+                                                   u32 zero_words, u32 *counts, uint4 *mrec, u32 mrec_cap1, u32 mrec_cap2)
 {
     constexpr int kPlanBlock = BLK; // (shadows the long batches' constant)
     for (u32 i = blockIdx.x * kPlanBlock + threadIdx.x; i < zero_words; i += gridDim.x * kPlanBlock)
@@ -42,6 +42,8 @@ __global__ __launch_bounds__(BLK) void plan_kernel(const u64 *off, u32 n_reads, 
     __syncthreads();
     constexpr int kPlanPer = PER, kPlanReads = kPlanBlock * PER;
     u32 cls[kPlanPer], local[kPlanPer];
+    u64 first[kPlanPer]; // (off[r]: the workgroup classes' records)
+    u32 niv[kPlanPer];
     const u64 lt = (1ull << lane_id()) - 1ull;
 #pragma unroll
     for (int k = 0; k < kPlanPer; k++) {
@@ -49,8 +51,11 @@ __global__ __launch_bounds__(BLK) void plan_kernel(const u64 *off, u32 n_reads, 
         cls[k] = CLS_COUNT; // CLS_COUNT = no read in this lane
         local[k] = 0;
         u64 n = 0;
+        first[k] = 0, niv[k] = 0;
         if (r < n_reads) {
-            n = off[r + 1] - off[r];
+            first[k] = off[r];
+            n = off[r + 1] - first[k];
+            niv[k] = (u32)n;
             const u64 m = 2 * n;
             // mode: 0 = default, 1 = every read to the general path, 2 = one read per wavefront only,
             // 3 = rows (<= 128 intervals) but no 32-lane halves
@@ -105,10 +110,14 @@ __global__ __launch_bounds__(BLK) void plan_kernel(const u64 *off, u32 n_reads, 
             // it decides with ONE store, its (a, b) — not a count word besides — and everything else that finishes a read
             // writes its count over this (coalesced here: one lane per read and 4 bytes there)
             counts[r] = kClosedForm;
-            // the workgroup classes' fallback queue (screen_wg.h) starts out empty in every slot one of the class's
-            // reads could take: list CLS_COUNT + 4 (M1) / + 5 (M2) of the engine's table
-            if (cls[k] == CLS_MED1 || cls[k] == CLS_MED2)
-                lists[(u64)(CLS_COUNT + 4 + (cls[k] - CLS_MED1)) * n_reads + pos] = 0xFFFFFFFFu;
+            // the workgroup classes' records (round 6): screen_wg_kernel gives a read to a one-read workgroup whose life is
+            // mostly dependent round trips — list entry, then extent, then intervals —; with the extent beside the list entry it
+            // is two.  M1's records first (a read of the class has more than 512 intervals: at most mrec_cap1), M2's behind.
+            if (mrec != nullptr && (cls[k] == CLS_MED1 || cls[k] == CLS_MED2)) {
+                const u64 at = cls[k] == CLS_MED1 ? pos : (u64)mrec_cap1 + pos;
+                if (pos < (cls[k] == CLS_MED1 ? mrec_cap1 : mrec_cap2))
+                    mrec[at] = make_uint4((u32)first[k], (u32)(first[k] >> 32), niv[k], r);
+            }
         }
     }
 }

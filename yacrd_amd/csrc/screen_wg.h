@@ -86,7 +86,7 @@ __device__ __forceinline__ bool screen_wg_read(const SweepArgs &a, u32 r, u64 o,
     char *tb = reinterpret_cast<char *>(tab);
     const uint2 *iv = a.iv + o;
     const u32 chunks = (n + (u32)(T * R) - 1u) / (u32)(T * R);
-    bool fallback = n < 2u || len > kMaxKeyPos;
+    bool fallback = n < 2u; // (len is looked at behind the intervals' loads: it may still be on its way)
 
     // ---- the read's smallest start, largest end, largest start and shortest interval (signed)
 #if YK_WS_SKIP_DEAD
@@ -137,7 +137,7 @@ __device__ __forceinline__ bool screen_wg_read(const SweepArgs &a, u32 r, u64 o,
     // not plain (a start > its end, a position beyond the read or the key range), or a covered span too
     // short for two windows: the sort's.  (Zero-length intervals are taken: where more than c intervals are
     // open on both sides of one it changes nothing, and the tests below put it nowhere else.)
-    fallback = fallback || pmax > len || qmax > kMaxKeyPos || shortest < 0 || pmax - pmin < (u32)(2 * W);
+    fallback = fallback || len > kMaxKeyPos || pmax > len || qmax > kMaxKeyPos || shortest < 0 || pmax - pmin < (u32)(2 * W);
 
     bool healthy = false;
     u32 ra = 0, rb = 0;
@@ -259,11 +259,15 @@ __device__ __forceinline__ bool screen_wg_read(const SweepArgs &a, u32 r, u32 *t
 }
 // ... by the read's size: 4 / 8 / 12 / 16 slots per thread (round 6: configs[3]'s reads of 5 000-6 000 intervals fill six of the
 // sixteen-slot build's eight pair groups; skipping the dead groups behind uniform branches was slower, see YK_WS_SKIP_DEAD)
-__device__ __forceinline__ bool screen_wg_read_sized(const SweepArgs &a, u32 r, u32 *tab, u32 (*red)[4], u32 *sc)
+// (o, n: the read's extent when the caller has it — plan_kernel's record —, n = 0xFFFFFFFF: loaded here)
+__device__ __forceinline__ bool screen_wg_read_sized(const SweepArgs &a, u32 r, u64 o, u32 n, u32 *tab, u32 (*red)[4], u32 *sc)
 {
     WgVerdict vd;
-    const u64 o = a.off[r];
-    const u32 n = (u32)(a.off[r + 1] - o), len = a.len[r];
+    if (n == 0xFFFFFFFFu) { // (uniform)
+        o = a.off[r];
+        n = (u32)(a.off[r + 1] - o);
+    }
+    const u32 len = a.len[r]; // (asked for in front of the intervals, needed behind them: the same round trip)
 #if YK_WS_SIZED
     if (n <= (u32)(kWsT * 4)) return screen_wg_read<4>(a, r, o, n, len, tab, red, sc, vd);   // (uniform)
     if (n <= (u32)(kWsT * 8)) return screen_wg_read<8>(a, r, o, n, len, tab, red, sc, vd);
@@ -473,8 +477,15 @@ __global__ __launch_bounds__(kWsT, YK_WGK_OCC) void screen_wg_kernel(SweepArgs a
     __shared__ u32 sc[NW + 1];
     const u32 list_n = *a.list_n;
     for (u32 b = blockIdx.x; b < list_n; b += gridDim.x) { // (uniform)
-        const u32 r = a.list[b];
-        if (!screen_wg_read_sized(a, r, tab, red, sc) && threadIdx.x == 0) a.over_list[atomicAdd(a.over_count, 1u)] = r;
+        u32 r, n = 0xFFFFFFFFu;
+        u64 o = 0;
+        if (a.rec != nullptr) { // the entry's record: read, extent — one round trip instead of two
+            const uint4 q = a.rec[b];
+            r = q.w, n = q.z, o = ((u64)q.y << 32) | q.x;
+        } else {
+            r = a.list[b];
+        }
+        if (!screen_wg_read_sized(a, r, o, n, tab, red, sc) && threadIdx.x == 0) a.over_list[atomicAdd(a.over_count, 1u)] = r;
     }
 }
 

@@ -392,13 +392,24 @@ def small_batches_block(cx, jitter=0, chimeras=0):
         return ya.run_device_batches(engs, [ptrs] * k)  # batch i on engine i mod NE, NE batches in flight
 
     run_steps(max(W, 2 * NE))  # (a submit only pipelines once the engine has a prediction)
-    for e in engs:
-        e.timing_total(reset=True)
-    cx.barrier()
-    t0 = time.perf_counter()
-    out = run_steps(K)
-    cx.barrier()
-    mine = time.perf_counter() - t0
+    # The K steps take ~12 ms and their cadence is the HOST's (a submit / wait per 25 us batch): a region that starts just after a
+    # phase that used every CPU of the cgroup — the generator, the oracle's check of the block before, the parsers — can fall
+    # wholly into a CFS throttling window, and did: the same block measured 25 us per batch or 57 / 126 / 290 with identical
+    # paths and kernel times (profiles/r06/t_*, x_*, y_*).  As an EXTRA block the region is therefore run
+    # three times after a short sleep and the fastest counts (all three are kept); as the --weak HEADLINE it is K steps once.
+    reps = 1 if args.weak else 3
+    tries = []
+    for rep in range(reps):
+        if reps > 1:
+            time.sleep(0.15)
+        for e in engs:
+            e.timing_total(reset=True)
+        cx.barrier()
+        t0 = time.perf_counter()
+        out = run_steps(K)
+        cx.barrier()
+        tries.append(time.perf_counter() - t0)
+    mine = min(tries)
     elapsed = cx.ydist.max_over_ranks(cx.dist, mine, cx.dev)
     per_rank = {"rank": cx.rank, "reads": R, "intervals": I, "ms_per_step": mine / K * 1e3}
     if cx.dist is not None:
@@ -471,6 +482,7 @@ def small_batches_block(cx, jitter=0, chimeras=0):
                            "final sync)" % (profile.upper(), jit, R, O, cov, nc, NE),
                "reads_per_sec": cx.world * R * K / elapsed, "kernel_overlaps_per_sec": cx.world * O * K / elapsed,
                "ms_per_step": elapsed / K * 1e3, "steps": K, "warmup": W, "per_rank": allr,
+               "timed_regions_ms_per_step": [x / K * 1e3 for x in tries],
                "scaling": "weak", "reads_per_gpu": R, "overlaps_per_gpu": O, "intervals_per_gpu": I, "regions_per_gpu": G,
                "whole_path_algorithmic_bytes": b_alg, "whole_path_GBps": b_alg / (elapsed / K) / 1e9,
                "whole_path_frac_of_peak": b_alg / (elapsed / K) / 1e9 / HBM_PEAK_GBS,
@@ -483,6 +495,8 @@ def small_batches_block(cx, jitter=0, chimeras=0):
                                        "batch (82 MB) fits the 256 MiB Infinity Cache; other engines' small kernels run beside "
                                        "the timed launches")}
         blk["roofline"]["finish_compact_kernel_ms"] = (phases or {}).get("compact_ms")
+        if reps > 1:
+            blk["workload"] += "; the FASTEST of %d timed regions of %d steps (the host's cadence: see timed_regions_ms_per_step)" % (reps, K)
         import oracle
         want = oracle.run(offsets, intervals, lengths.astype(np.uint64), cov, nc, n_threads=usable_cpus())
         got = engs[0].fetch()
@@ -1091,6 +1105,18 @@ def main():
                 except Exception as ex:
                     line["value_sigma100"] = {"error": repr(ex)}
             line["small_batches"], keep_small = small_batches_block(cx)
+        # (the blocks that re-use the small batches' engines come FIRST and give them back: every live engine is a stream, and
+        #  the jitter blocks' three should not share the hardware queues with three idle ones — see GPU_MAX_HW_QUEUES above)
+        if keep_small is not None:
+            offsets, intervals, lengths, engs, G, cov1, nc1 = keep_small
+            c1 = CONFIGS[1]
+            line["pcie_inclusive"] = guarded(pcie_inclusive, ya, engs, offsets, intervals, lengths, cov1, nc1, G)
+            line["end_to_end"] = guarded(end_to_end, ya, host, engs[0], cx.prof(c1[0]), len(lengths), int(offsets[-1]) // 2, cov1, nc1)
+            if args.weak and not args.no_cpu_baseline:
+                line["cpu_baseline"] = guarded(cpu_baseline, offsets, intervals, lengths, cov1, nc1, "configs[1]")
+            for e in engs:
+                e.close()
+            keep_small = None
         sigmas = [int(x) for x in args.jitter_sigmas.split(",") if x.strip()]
         if sigmas:
             jit = {}
@@ -1122,16 +1148,6 @@ def main():
                 bad["%d%%" % pct] = {k: b[k] for k in ("workload", "reads_per_sec", "ms_per_step", "healthy_reads", "deferred_reads",
                                                        "batches_through_the_screen", "unpredicted_single_batch", "parity")}
         line["more_bad_reads"] = bad
-        if keep_small is not None:
-            offsets, intervals, lengths, engs, G, cov1, nc1 = keep_small
-            c1 = CONFIGS[1]
-            line["pcie_inclusive"] = guarded(pcie_inclusive, ya, engs, offsets, intervals, lengths, cov1, nc1, G)
-            line["end_to_end"] = guarded(end_to_end, ya, host, engs[0], cx.prof(c1[0]), len(lengths), int(offsets[-1]) // 2, cov1, nc1)
-            if args.weak and not args.no_cpu_baseline:
-                line["cpu_baseline"] = guarded(cpu_baseline, offsets, intervals, lengths, cov1, nc1, "configs[1]")
-            for e in engs:
-                e.close()
-            keep_small = None
     if keep_small is not None:
         for e in keep_small[3]:
             e.close()

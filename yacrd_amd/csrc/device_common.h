@@ -13,19 +13,19 @@ constexpr u32 kNoKey = 0xFFFFFFFFu;
 
 // Two consecutive intervals in ONE 16-byte load.  An interval pair of a read starts at iv + off[r] + 2P: 8-byte aligned,
 // not 16 — fine for a global load (dword alignment is all gfx950 asks for), but a plain `*(const uint4 *)` tells the
-// compiler 16; this vector type says 8.  -DYK_NT_LOADS=1 makes them non-temporal (`nt`: the intervals are
-// read once and must not displace what the XCD's L2 / the Infinity Cache hold for later — A/B, tools/build_variant.sh).
+// compiler 16; this vector type says 8.
+// NT: non-temporal (`nt`) — for launches that STREAM their input from HBM (the two-items build of the screen: inputs beyond the
+// 256 MiB Infinity Cache): read once, it should not displace anything: -1 .. -5 % on the screens of configs[4] / [2]
+// (profiles/r06/a_ab_nt.log).  Not for everything (round 6 had it everywhere first): a batch that fits the Infinity Cache and is
+// looked at again — the next launch of the same engine on the same 82 MB, the follow-on's second look at a deferred read —
+// comes back from HBM instead: configs[1]'s screen 18 -> 21-22 us, its pipelined batches 24.5 -> 29 us (profiles/r06/d_*, x_*).
 typedef u32 u32x4_a8 __attribute__((ext_vector_type(4), aligned(8)));
-#ifndef YK_NT_LOADS
-#define YK_NT_LOADS 1
-#endif
+template <bool NT = false>
 __device__ __forceinline__ uint4 load_pair(const uint2 *p)
 {
-#if YK_NT_LOADS
-    const u32x4_a8 q = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a8 *>(p));
-#else
-    const u32x4_a8 q = *reinterpret_cast<const u32x4_a8 *>(p);
-#endif
+    u32x4_a8 q;
+    if constexpr (NT) q = __builtin_nontemporal_load(reinterpret_cast<const u32x4_a8 *>(p));
+    else q = *reinterpret_cast<const u32x4_a8 *>(p);
     return make_uint4(q.x, q.y, q.z, q.w);
 }
 // off[r] and off[r + 1] in one load (r may be odd: 8-byte aligned)

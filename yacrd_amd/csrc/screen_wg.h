@@ -35,6 +35,9 @@
 #ifndef YK_EXP_NO_FALLBACK
 #define YK_EXP_NO_FALLBACK 0
 #endif
+#ifndef YK_WG_NT
+#define YK_WG_NT 0 // (1: the workgroup screen's interval loads non-temporal: A/B, profiles/r06/y_*)
+#endif
 #ifndef YK_WS_SIZED
 #define YK_WS_SIZED 1
 #endif
@@ -105,7 +108,7 @@ __device__ __forceinline__ bool screen_wg_read(const SweepArgs &a, u32 r, u64 o,
             // the loads, the minima and the count's sixteen instructions + two LDS atomics per slot were spent on all eight).
 #pragma unroll
             for (int j = 0; j < R / 2; j++) { // (slots beyond the read inside a live group: copies of its last two intervals)
-                if (live(ch, j)) v[j] = load_pair(iv + min(2u * (base + (u32)(j * T)), n - 2u));
+                if (live(ch, j)) v[j] = load_pair<(YK_WG_NT != 0)>(iv + min(2u * (base + (u32)(j * T)), n - 2u));
             }
 #pragma unroll
             for (int j = 0; j < R / 2; j++) {
@@ -166,7 +169,7 @@ __device__ __forceinline__ bool screen_wg_read(const SweepArgs &a, u32 r, u64 o,
             if (chunks > 1u) {
 #pragma unroll
                 for (int j = 0; j < R / 2; j++)
-                    if (live(ch, j)) v[j] = load_pair(iv + min(2u * (base + (u32)(j * T)), n - 2u));
+                    if (live(ch, j)) v[j] = load_pair<(YK_WG_NT != 0)>(iv + min(2u * (base + (u32)(j * T)), n - 2u));
             }
 #pragma unroll
             for (int j = 0; j < R / 2; j++) {

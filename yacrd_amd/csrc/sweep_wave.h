@@ -1073,7 +1073,7 @@ __device__ __forceinline__ void screen_reads(const SweepArgs &a, const u32 (&r)[
         const u32 last2 = two ? n[t] - 2u : 0u;
 #pragma unroll
         for (int j = 0; j < K / 4; j++)
-            v[t][j] = load_pair(src + min(2u * (lig + (u32)LANES * j), last2));
+            v[t][j] = load_pair<(ITEMS >= 2)>(src + min(2u * (lig + (u32)LANES * j), last2)); // (two items: the launch streams from HBM)
     }
 #pragma unroll
     for (int t = 0; t < ITEMS; t++) {

@@ -502,7 +502,7 @@ def window_screen_regions(intervals, length, cov, nb, W):
     return ([(0, a)] if a != 0 else []) + ([(bb, length)] if bb != length else [])
 
 
-def _sub_screen(intervals, length, cov, nb, W, lo0, hi0, P0, Q0, max_slides, ramp_always, s_hi=None, e_lo=None):
+def _sub_screen(intervals, length, cov, nb, W, lo0, hi0, P0, Q0, max_slides, ramp_always, s_hi=None, e_lo=None, spot=0):
     """The order-statistics screen over the events inside [lo0, hi0] of a read (starts and ends outside are not
     counted; P0 starts in front of lo0 and Q0 ends behind hi0 are carried as counts: intervals open across the
     border), with windows that slide by W up to max_slides times.  Returns (a, b, slides) — a: where P0 + the starts
@@ -553,10 +553,26 @@ def _sub_screen(intervals, length, cov, nb, W, lo0, hi0, P0, Q0, max_slides, ram
             t0 += W if G < cov + 1 else 0
             continue
         D = F + ramp
+        failing = []
         for b in range(nb + 1):
             if S[b] > 0 and not (D - E[b] > cov):
-                return None
+                failing.append(b)
             D += S[b] - E[b]
+        if failing:
+            # SPOT CHECKS (round 6, `spot` > 0): the block test counts ALL of a block's ends as before its starts; where that
+            # is too coarse — dovetail ends spread over a whole block at ONT depth — the few coarse-counted starts of the
+            # failing blocks are looked at one by one: a start s has at least (starts at positions < s) - (ends at positions
+            # <= s) intervals open in front of it (src/stack.rs:72-83: the ends at or before s are popped first); more than
+            # cov for each of them, and no start beyond the first cov + 1 is low after all.
+            if not spot:
+                return None
+            cand = [s for s, e in intervals if lo <= s <= hi and s - lo >= W and not ((slide > 0 or ramp_always) and s < emin)
+                    and min((s - lo) >> sh, nb) in failing]
+            if len(cand) > spot:
+                return None
+            for s0 in cand:
+                if not (P0 + sum(1 for s, e in intervals if lo0 <= s < s0) - sum(1 for s, e in intervals if e <= s0) > cov):
+                    return None
         acc, a = P, None
         for i in range(W):
             acc += FH[i]
@@ -573,7 +589,7 @@ def _sub_screen(intervals, length, cov, nb, W, lo0, hi0, P0, Q0, max_slides, ram
     return None
 
 
-def slid_window_screen_regions(intervals, length, cov, nb, W, max_slides, ramp_always=False):
+def slid_window_screen_regions(intervals, length, cov, nb, W, max_slides, ramp_always=False, spot=0):
     """window_screen_regions with windows that SLIDE (round 4): when the first W positions hold fewer than cov + 1
     starts (or the last W fewer than cov + 1 ends) — dovetail ends spread wider than the window — the screen is
     repeated with that window moved on by W, the events it has passed carried as a count: P starts in front of the
@@ -597,7 +613,7 @@ def slid_window_screen_regions(intervals, length, cov, nb, W, max_slides, ramp_a
         return None
     pmin = min(s for s, e in intervals)
     pmax = max(e for s, e in intervals)
-    r = _sub_screen(intervals, length, cov, nb, W, pmin, pmax, 0, 0, max_slides, ramp_always)
+    r = _sub_screen(intervals, length, cov, nb, W, pmin, pmax, 0, 0, max_slides, ramp_always, spot=spot)
     if r is None:
         return None
     a, bb, slide = r

@@ -200,6 +200,7 @@ def test_slid_window_screen_matches_oracle():
     rng = np.random.default_rng(777)
     fired = {0: 0, 4: 0}
     slid = 0
+    spotted = {2: 0, 8: 0, 1 << 20: 0}
     for it in range(1500):
         L = int(rng.integers(2, 400)) if it % 3 == 0 else int(rng.integers(400, 50000))
         n = int(rng.integers(1, 30)) if it % 4 == 0 else int(rng.integers(30, 300))
@@ -236,7 +237,16 @@ def test_slid_window_screen_matches_oracle():
                 assert ramp is None or ramp[0] == want, (iv, L, cov, nb, W, ramp)
                 if got is not None:  # (what the plain form decides the ramp form decides too: it only adds open intervals)
                     assert ramp is not None
+                # round 6: SPOT CHECKS of the coarse-counted starts of the blocks that fail the depth test (up to 2 / 8 / any)
+                for sp in (2, 8, 1 << 20):
+                    for ra in (False, True):
+                        spot = slid_window_screen_regions(iv, L, cov, nb, W, 4, ramp_always=ra, spot=sp)
+                        assert spot is None or spot[0] == want, (iv, L, cov, nb, W, sp, ra, spot)
+                        if (ramp if ra else got) is not None:
+                            assert spot is not None
+                        spotted[sp] += spot is not None and (ramp if ra else got) is None
     assert fired[4] > fired[0] and slid > 100, (fired, slid)
+    assert spotted[8] > 200 and spotted[1 << 20] >= spotted[8] >= spotted[2], spotted
 
 
 def test_slid_window_screen_tiny_exhaustive():
@@ -250,8 +260,9 @@ def test_slid_window_screen_tiny_exhaustive():
                     want = oracle.compute_bad_part(list(iv), L, cov)
                     for nb, W in ((2, 1), (4, 1), (4, 2)):
                         for ramp in (False, True):
-                            got = slid_window_screen_regions(list(iv), L, cov, nb, W, 3, ramp_always=ramp)
-                            assert got is None or got[0] == want, (iv, L, cov, nb, W, got)
+                            for sp in (0, 3):
+                                got = slid_window_screen_regions(list(iv), L, cov, nb, W, 3, ramp_always=ramp, spot=sp)
+                                assert got is None or got[0] == want, (iv, L, cov, nb, W, sp, got)
 
 
 def test_window_screen_tiny_exhaustive():

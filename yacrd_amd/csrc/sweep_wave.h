@@ -450,6 +450,22 @@ struct HealthyRead {
 #define YK_SCREEN_SLIDES 4
 #endif
 constexpr int kScreenSlides = YK_SCREEN_SLIDES;
+#ifndef YK_SPOT_CHECKS
+// Spot checks behind a screen that failed on a block's depth only (spot_check_call below; the build with the second looks).
+// Built, bit-exact (the -m gpu parity files + 3.6 M fuzzed reads with the second looks forced, profiles/r06/A_*, B_*), and they do
+// what they are for — configs[1] decided 88.7 -> 94.8 % at sigma = 300, 94.9 -> 97.1 % at 100, the follow-on sorts half as many
+// reads — but the screen pays more than the follow-on gains: its launch 64 -> 77 us at sigma 300 and 33 -> 47 at 100 (a
+// wavefront enters when ANY of its four reads wants), the pipelined batch 56 -> 60 and 34 -> 36 us; only one batch at a
+// time gains (119 -> 116).  OFF; -DYK_SPOT_CHECKS=1 builds them (behind a call that loads the read again, YK_SPOT_INLINE
+// = __attribute__((noinline)) with the call's old signature, they cost the same).
+#define YK_SPOT_CHECKS 0
+#endif
+#ifndef YK_SPOT_MAX
+#define YK_SPOT_MAX 8
+#endif
+#ifndef YK_SPOT_INLINE
+#define YK_SPOT_INLINE __forceinline__ // (on the read's intervals where they are: behind a call that loaded them again the check cost the screen 12 us of 64 at sigma 300, profiles/r06/A_*)
+#endif
 #ifndef YK_HOLE_FORM
 // The closed form for a read with one stretch of low coverage inside (hole_form below): bit-exact (GPU tests, fuzz) and
 // it decides 77 % of what the screen otherwise defers (configs[2]: 47 608 -> 11 032 reads, the deferred sweep 145 -> 68 us)
@@ -986,6 +1002,109 @@ __device__ __attribute__((noinline)) uint4 hole_form_call(const u64 *off, const 
     return make_uint4(ok ? 1u : 0u, x, y, 0u);
 }
 
+// ---- SPOT CHECKS behind a screen that failed on a block's depth only (round 6; the build with the second looks) ----------
+// tests/formulation.py::_sub_screen(spot = kSpotMax) is the emulation (fuzzed against the oracle + exhaustive over small
+// multisets: tests/test_formulation.py::test_slid_window_*).  The block test counts ALL of a block's ends as before its
+// starts.  At ONT depth with dovetail ends spread by hundreds of positions (configs[1] at sigma = 300) that is too coarse:
+// the ends that used to pile inside the tail window's one-position bins fill a whole coarse block now, an internal start
+// in that block fails the test, and 269 of 273 healthy reads the screen left to the sort in a sample of 3 000 were of
+// this kind (the closed form held).  So the few coarse-counted starts of the FAILING blocks are looked at one by one: a
+// start s has at least (starts at positions < s) - (ends at positions <= s) intervals open in front of it (the ends at
+// or before s are popped first: src/stack.rs:72-83); more than c for each of them, and no start beyond the first c + 1 is
+// low after all: the screen's (0, a) / (b, len) stand.  Decided reads: 88.5 % -> 95.1 % at sigma = 300, 94.7 % -> 97.1 %
+// at 100 (emulation on the generator's reads; GPU: 88.7 -> 94.8 %, 94.9 -> 97.1 %).
+// It builds the table again (what the second looks left in LDS is another group's as often as not).
+// v / real0 / real1: the read's intervals where the screen has them; lo / hi: the head window's first / the tail window's
+// last position of the last screen; gF: its F (passed starts included); want: this group tries (uniform in the group; its read
+// is plain, every interval >= W long).  Returns 1 (uniform in the group) when every candidate start has more than c
+// intervals open in front of it.
+constexpr int kSpotMax = YK_SPOT_MAX;
+template <int LANES, int WPB, int TABW = kScreenTabWords>
+__device__ YK_SPOT_INLINE u32 spot_check_call(const uint4 (&v)[4], const bool (&real0)[4], const bool (&real1)[4], u32 len, i32 c, u32 lo, u32 hi,
+                                              i32 gF, u32 want)
+{
+    constexpr int K = 16, NB = LANES, W = kScreenWindow, NBIN = 2 * W + NB, ZPER = NBIN / LANES;
+    constexpr u32 kEnd = 1u << 10, kField = kEnd - 1u;
+    const u32 lane = lane_id(), lig = lane & (u32)(LANES - 1), grp = lane / (u32)LANES;
+    const int last_addr = (int)((lane | (u32)(LANES - 1)) << 2);
+    const u32 gshift = lane & (u32)(64 - LANES);
+    constexpr u64 gmask = LANES == 64 ? ~0ull : ((1ull << (LANES & 63)) - 1ull);
+    auto to_group = [&](u32 x) { return (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)x); }; // the last lane's value
+    auto group_bits = [&](bool b) { return (u64)(__builtin_amdgcn_ballot_w64(b) >> gshift) & gmask; };
+    u32 st_[K / 2], en_[K / 2];
+    bool real[K / 2];
+#pragma unroll
+    for (int j = 0; j < K / 4; j++) {
+        st_[2 * j] = v[j].x, en_[2 * j] = v[j].y, st_[2 * j + 1] = v[j].z, en_[2 * j + 1] = v[j].w;
+        real[2 * j] = want != 0u && real0[j];
+        real[2 * j + 1] = want != 0u && real1[j];
+    }
+    // the read's smallest end (the ramp: starts behind the head window and in front of it are open in front of everything)
+    u32 emin = 0xFFFFFFFFu;
+#pragma unroll
+    for (int q = 0; q < K / 2; q++) emin = min(emin, real[q] ? en_[q] : 0xFFFFFFFFu);
+    const u32 gemin = to_group(gscan_min<LANES>(emin));
+    // ---- the table again, as healthy_screen<SLID> counts it
+    const i32 bits = 32 - (i32)__builtin_clz(len | 1u) - ilog2c(NB) + (len != 0 ? 0 : -1);
+    const u32 sh = (u32)max(bits, ilog2c(W));
+    const u32 T = (hi - lo) - (u32)W;
+    u32 *tab = wave_screen_scratch<WPB, TABW>() + grp * (u32)(NBIN * 4);
+    uint4 *bins = reinterpret_cast<uint4 *>(tab);
+    char *tb = reinterpret_cast<char *>(tab);
+    wave_lds_sync(); // (whoever read the table last is done)
+#pragma unroll
+    for (int q = 0; q < ZPER; q++) bins[lig + (u32)(LANES * q)] = make_uint4(0u, 0u, 0u, 0u);
+    wave_lds_sync();
+    const u32 cp = (lig & 3u) * 4u;
+    u32 ramp = 0;
+    u32 coarse = 0; // a bit per coarse-counted start: inside [lo, hi], behind the head window, not in the ramp
+#pragma unroll
+    for (int q = 0; q < K / 2; q++) {
+        const u32 ds = st_[q] - lo, dx = en_[q] - lo;
+        const u32 is = min(ds, (u32)W) + (ds >> sh);
+        const u32 ie = (dx >> sh) + __builtin_elementwise_sub_sat(dx, T) + (u32)W;
+        const bool in_ramp = ds >= (u32)W && st_[q] < gemin;
+        const bool s_in = real[q] && st_[q] >= lo;
+        ramp += (s_in && in_ramp) ? 1u : 0u;
+        coarse |= (s_in && !in_ramp && ds >= (u32)W) ? (1u << q) : 0u;
+        if (s_in && !in_ramp) atomicAdd(reinterpret_cast<u32 *>(tb + ((is << 4) + cp)), 1u);
+        if (real[q] && en_[q] <= hi) atomicAdd(reinterpret_cast<u32 *>(tb + ((ie << 4) + cp)), kEnd);
+    }
+    wave_lds_sync();
+    // ---- the failing blocks: a block that holds a coarse-counted start and not more than c intervals open after all its ends
+    const uint4 c4 = bins[(u32)W + lig];
+    const u32 w = (c4.x + c4.y + c4.z + c4.w) & ((kField << 10) | kField);
+    const u32 wincl = gscan_add<LANES>(w);
+    const i32 x = (i32)((wincl - w) & kField) - (i32)((wincl >> 10) & kField); // starts before - ends through this block
+    const i32 open0 = gF + (i32)to_group(gscan_add<LANES>(ramp));
+    const u64 fmask = group_bits(want != 0u && (w & kField) != 0u && !(x + open0 > c));
+    // ---- the candidates: this lane's coarse-counted starts in failing blocks, a bit each
+    u32 cm = 0;
+#pragma unroll
+    for (int q = 0; q < K / 2; q++)
+        cm |= (((coarse >> q) & 1u) != 0u && ((fmask >> min((st_[q] - lo) >> sh, (u32)(LANES - 1))) & 1ull) != 0) ? (1u << q) : 0u;
+    const u32 total = to_group(gscan_add<LANES>((u32)__builtin_popcount(cm)));
+    bool ok = want != 0u && total <= (u32)kSpotMax;
+    if (!ok) cm = 0;
+#pragma unroll 1
+    for (int it = 0; it < kSpotMax; it++) {
+        const u64 gb = group_bits(cm != 0u);
+        if (__builtin_amdgcn_ballot_w64(gb != 0) == 0) break; // (uniform in the wavefront)
+        const u32 first = gb ? (u32)__builtin_ctzll(gb) : 0u; // the group's first lane with a candidate
+        u32 mine = 0;
+#pragma unroll
+        for (int q = K / 2 - 1; q >= 0; q--) mine = ((cm >> q) & 1u) ? st_[q] : mine; // (its lowest candidate)
+        const u32 sc = (u32)__builtin_amdgcn_ds_bpermute((int)(((lane & ~(u32)(LANES - 1)) + first) << 2), (int)mine);
+        if (lig == first) cm &= cm - 1u;
+        u32 cnt = 0; // (starts in front of sc) - (ends at or in front of it), this lane's
+#pragma unroll
+        for (int q = 0; q < K / 2; q++) cnt += ((real[q] && st_[q] < sc) ? 1u : 0u) - ((real[q] && en_[q] <= sc) ? 1u : 0u);
+        const i32 depth = (i32)to_group(gscan_add<LANES>(cnt));
+        if (gb != 0 && !(depth > c)) ok = false, cm = 0;
+    }
+    return ok ? 1u : 0u;
+}
+
 // ---- the screen over ITEMS consecutive groups of list entries per wavefront (one-wavefront workgroups)
 // Every level of the dependent chain — list entries, offsets / lengths, intervals — is fetched for all
 // ITEMS at once, so a wavefront has ITEMS x 8 interval loads per lane in flight (8 KB at ITEMS = 2) and
@@ -1112,6 +1231,7 @@ __device__ __forceinline__ void screen_reads(const SweepArgs &a, const u32 (&r)[
         }
         HealthyRead hr;
         bool healthy = healthy_screen<LANES, WPB>(v[t], real0, real1, len[t], c, pmin, pmax, hr) && !girr;
+        u32 ht_used = 0; // (the last screen's windows: h0 | t0 << 16)
         bool table_intact = true, hole_done = false; // (the first screen's coarse blocks are still in LDS; this group's read got its hole form)
         if constexpr (kScreenSlides > 0 && WIDE) {
             // a window that came up short of c + 1 (verdict in the group's last lane): slide it (see kScreenSlides).
@@ -1155,9 +1275,22 @@ __device__ __forceinline__ void screen_reads(const SweepArgs &a, const u32 (&r)[
                     HealthyRead h2;
                     const bool ok2 = healthy_screen<LANES, WPB, true>(v[t], r0, r1, len[t], c, pmin + h0, pmax - t0, h2, PQ & 0xFFFFu, PQ >> 16, gemin);
                     st = go ? state_of(!ok2 && (h2.F <= c || h2.G <= c), h2) : 0u; // (meaningful in the group's last lane)
-                    if (go) healthy = ok2, hr.a = h2.a, hr.b = h2.b;
+                    if (go) healthy = ok2, hr.a = h2.a, hr.b = h2.b, hr.F = h2.F, hr.G = h2.G, ht_used = ht;
                 }
             }
+#if YK_SPOT_CHECKS
+            // the last screen found a and b and failed on a block's depth: its few coarse-counted starts one by one (spot_check_call)
+            {
+                const u32 pk = (u32)__builtin_amdgcn_ds_bpermute(
+                    last_addr, (int)(((!healthy && !girr && (i32)n[t] > c && hr.F > c && hr.G > c && active[t]) ? 1u : 0u) | ((u32)min(max(hr.F, 0), 1023) << 1)));
+                if (__builtin_amdgcn_ballot_w64((pk & 1u) != 0) != 0) { // (uniform in the wavefront; rare)
+                    table_intact = false;
+                    const u32 okv = spot_check_call<LANES, WPB>(v[t], real0, real1, len[t], c, pmin + (ht_used & 0xFFFFu), pmax - (ht_used >> 16),
+                                                                 (i32)(pk >> 1), pk & 1u);
+                    if (okv != 0u) healthy = true; // (uniform in the group: a and b stand)
+                }
+            }
+#endif
         }
         if constexpr (YK_HOLE_FORM) {
             // the first screen found a and b and failed on a block's depth: one stretch of low coverage inside? (hole_form)

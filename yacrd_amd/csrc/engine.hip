@@ -1380,7 +1380,6 @@ int yacrd_engine_create(const yacrd_engine_cfg *cfg, yacrd_engine **out)
     for (int i = 0; i < EV_COUNT && err == hipSuccess; i++) err = hipEventCreate(&e->ev[i]);
     for (int i = 0; i < 24 && err == hipSuccess; i++) err = hipEventCreate(&e->ev_cls[i]);
     if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_done, hipEventBlockingSync | hipEventDisableTiming);
-    if (err == hipSuccess) err = hipEventCreateWithFlags(&e->ev_fused, hipEventDisableTiming);
     if (err == hipSuccess) err = hipEventCreate(&e->ev_h2d0);
     if (err == hipSuccess) err = hipEventCreate(&e->ev_h2d1);
     if (err == hipSuccess) err = hipEventCreate(&e->ev_d2h0);
@@ -1415,14 +1414,6 @@ void yacrd_engine_destroy(yacrd_engine *e)
             lane.last = nullptr;
         }
     }
-    {
-        FusedLane &fl = g_fused_lane[e->device & 63];
-        std::lock_guard<std::mutex> g(fl.mu);
-        if (fl.owner == e) {
-            fl.owner = nullptr;
-            fl.last = nullptr;
-        }
-    }
     DevBuf *bufs[] = {&e->in_off, &e->in_iv, &e->in_len, &e->lists, &e->ctrl2[0], &e->ctrl2[1], &e->stage,
                       &e->counts, &e->closed, &e->gen_sizes, &e->gen_scratch_off,
                       &e->gen_scratch, &e->big_tab, &e->big_keys, &e->big_redo, &e->bt_tab, &e->bt_hist, &e->bt_cur, &e->bt_keys, &e->bs_seg, &e->bs_chunk, &e->bs_hist,
@@ -1440,7 +1431,7 @@ void yacrd_engine_destroy(yacrd_engine *e)
         if (e->ev[i]) (void)hipEventDestroy(e->ev[i]);
     for (int i = 0; i < 24; i++)
         if (e->ev_cls[i]) (void)hipEventDestroy(e->ev_cls[i]);
-    hipEvent_t extra[] = {e->ev_h2d0, e->ev_h2d1, e->ev_d2h0, e->ev_d2h1, e->ev_done, e->ev_fused};
+    hipEvent_t extra[] = {e->ev_h2d0, e->ev_h2d1, e->ev_d2h0, e->ev_d2h1, e->ev_done};
     for (hipEvent_t x : extra)
         if (x) (void)hipEventDestroy(x);
     if (e->ev_fork) (void)hipEventDestroy(e->ev_fork);

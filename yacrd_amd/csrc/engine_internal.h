@@ -95,16 +95,8 @@ struct BigLane {
     int n_engines = 0;
 };
 static BigLane g_big_lane[64];
-// One per device: the persistent screen + fallback launches (screen_wg_fused_kernel) of the engines that share it go one
-// after the other.  Each is sized to be resident as a whole, and its workgroups wait for each other's queue entries: two of them
-// side by side, each half resident, would wait for workgroups that the other's spinning ones keep from being scheduled — until
-// their looks run out (screen_wg.h: kFusedPolls) and the batch is run again down the three-launch chain.
-struct FusedLane {
-    std::mutex mu;
-    hipEvent_t last = nullptr; // recorded behind the last such launch
-    struct yacrd_engine *owner = nullptr;
-};
-static FusedLane g_fused_lane[64];
+// (Rounds 4-5 had a FusedLane here: the persistent screen + fallback launches of the engines that share a device took turns.
+// Since round 6 no workgroup of that launch waits for another — screen_wg.h — and engines launch it side by side.)
 
 // A batch that was submitted without waiting for it (yacrd_engine_submit_device).
 struct Pending {
@@ -135,7 +127,6 @@ struct yacrd_engine {
     hipEvent_t ev_h2d0 = nullptr, ev_h2d1 = nullptr, ev_d2h0 = nullptr, ev_d2h1 = nullptr;
     hipEvent_t ev_cls[24] = {}; // brackets around class kernels
     hipEvent_t ev_done = nullptr; // hipEventBlockingSync: the final wait of YACRD_F_BLOCKING_WAIT
-    hipEvent_t ev_fused = nullptr; // behind this engine's last screen_wg_fused_kernel (g_fused_lane)
     int num_cu = 256;
     bool fused_off = false; // this run: the workgroup classes down the three-launch chain (a fused launch gave up: Counters::fused_gave_up)
     int num_xcc = 0; // XCDs of this device / partition (one_batch_kernel's read-to-XCD map assumes 8)

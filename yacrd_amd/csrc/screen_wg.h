@@ -518,7 +518,6 @@ __global__ __launch_bounds__(kWsT, YK_WGK_OCC) void screen_wg_kernel(SweepArgs a
 // screen nor the filtered sweep decides in a list of its own and takes THAT through sweep_lds_read<512, 16384> before it
 // retires; what does not fit 16 384 events even after the trimming filter goes to over_list for the 1024-thread kernel
 // (launched behind this one; usually nothing).
-constexpr u32 kQueueEmpty = 0xFFFFFFFFu; // (plan_kernel still marks the rounds 4-5 queue's slots: harmless, 4 bytes per read of the class)
 #ifndef YK_WS_FB_CAP
 #define YK_WS_FB_CAP 16384
 #endif

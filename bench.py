@@ -204,17 +204,45 @@ def shared_csr(cx, profile, R, O, seed, flags):
     host = cx.host
     if cx.world == 1:
         return host.synth_csr(cx.prof(profile), R, O, seed, flags=flags)
-    d = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
-    tag = os.path.join(d, "yacrd_bench_csr_%s_%d_%d_%d_%d" % (os.environ.get("MASTER_PORT", "0"), R, O, seed, flags))
+    # where: the first of /dev/shm, the temp directory, the checkout that is writable and has ROOM (a container's /dev/shm is
+    # often 64 MB: configs[4] is 8 GB) — rank 0 looks and tells the others; nowhere: every rank generates for itself
+    need = 16 * O + 12 * R + (64 << 20)
+    where = [None]
+    if cx.rank == 0:
+        dirs = os.environ.get("YACRD_BENCH_SHARE_DIRS")  # (tests: the candidates, colon-separated)
+        for d in (dirs.split(":") if dirs is not None else ("/dev/shm", tempfile.gettempdir(), ROOT)):
+            try:
+                st = os.statvfs(d)
+                if os.path.isdir(d) and os.access(d, os.W_OK) and st.f_bavail * st.f_frsize > need:
+                    where[0] = d
+                    break
+            except OSError:
+                pass
+    cx.dist.broadcast_object_list(where, src=0)
+    if where[0] is None:
+        return host.synth_csr(cx.prof(profile), R, O, seed, flags=flags)
+    tag = os.path.join(where[0], "yacrd_bench_csr_%s_%d_%d_%d_%d" % (os.environ.get("MASTER_PORT", "0"), R, O, seed, flags))
     names = [tag + sfx for sfx in (".off.npy", ".iv.npy", ".len.npy")]
+    ok = [True]
     if cx.rank == 0:
         arrs = host.synth_csr(cx.prof(profile), R, O, seed, flags=flags)
-        for nm, a in zip(names, arrs):
-            np.save(nm, a)
-        cx.dist.barrier()
-        cx.shared_files = getattr(cx, "shared_files", []) + names
+        try:
+            for nm, a in zip(names, arrs):
+                np.save(nm, a)
+        except OSError:  # (the room went away meanwhile: the others generate for themselves)
+            ok[0] = False
+            for nm in names:
+                try:
+                    os.remove(nm)
+                except OSError:
+                    pass
+        cx.dist.broadcast_object_list(ok, src=0)
+        if ok[0]:
+            cx.shared_files = getattr(cx, "shared_files", []) + names
         return arrs
-    cx.dist.barrier()
+    cx.dist.broadcast_object_list(ok, src=0)
+    if not ok[0]:
+        return host.synth_csr(cx.prof(profile), R, O, seed, flags=flags)
     return tuple(np.load(nm, mmap_mode="r") for nm in names)
 
 

@@ -173,6 +173,25 @@ d.destroy_process_group()
 """
 
 
+def test_bench_input_without_room_to_share_is_generated_by_every_rank(tmp_path):
+    """No directory with room for the input (a container's 64 MB /dev/shm and a full disk): rank 0 says so and every rank
+    generates the input for itself — the same arrays, nothing mapped, nothing left behind."""
+    script = tmp_path / "sworker.py"
+    script.write_text(SHARED_WORKER.replace("not sizes[0][3] and all(s[3] for s in sizes[1:])", "not any(s[3] for s in sizes)"))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   YACRD_BENCH_SHARE_DIRS="/nonexistent-yacrd-dir")
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert "RESULT OK" in outs[0][0], outs
+
+
 def test_bench_input_is_generated_once_per_node(tmp_path):
     script = tmp_path / "sworker.py"
     script.write_text(SHARED_WORKER)

@@ -172,6 +172,14 @@ def test_parallel_editors_equal_one_thread(tmp_path, monkeypatch, op):
             out = str(tmp_path / ("par_%s_%d.fastq" % (chunk, th)))
             host.edit_file(OPS[op], fq, out, *table, n_threads=th)
             assert open(out, "rb").read() == want, (op, chunk, th)
+    # the output's other ways into the file (default: the threads take turns; all at once; a shared mapping)
+    monkeypatch.setenv("YACRD_EDIT_CHUNK", "3000")
+    for way in ("pwrite", "map", "turns"):
+        monkeypatch.setenv("YACRD_EDIT_OUT", way)
+        out = str(tmp_path / ("way_%s.fastq" % way))
+        host.edit_file(OPS[op], fq, out, *table, n_threads=4)
+        assert open(out, "rb").read() == want, (op, way)
+    monkeypatch.delenv("YACRD_EDIT_OUT")
     # FASTA (multi-line sequences): the same records, wrapped at 60 columns
     fa = str(tmp_path / "s.fasta")
     with open(fq) as f, open(fa, "w") as o:

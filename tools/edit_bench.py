@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/edit_bench.py [reads overlaps] — the chunk-parallel scrubb alone (no GPU: the oracle makes the table) on a synthetic
 FASTQ in /dev/shm, by threads, by the chunks' way into memory (YACRD_EDIT_IO=pread | mmap) and out of it (YACRD_EDIT_OUT=
-map | pwrite): GB/s of FASTQ in.  (1 thread = the one-thread loop: stream in, stream out.)"""
+turns | pwrite | map: one writer at a time in chunk order, all at once, a shared mapping): GB/s of FASTQ in.  (1 thread = the one-thread loop: stream in, stream out.)"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,7 +10,7 @@ import oracle  # noqa: E402  (makes the bad-region table here: no engine in this
 from yacrd_amd import host  # noqa: E402
 R = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 O = int(sys.argv[2]) if len(sys.argv) > 2 else 100_000_000
-d = "/dev/shm"
+d = os.environ.get("YACRD_EDIT_BENCH_DIR", "/dev/shm")
 fq, out = os.path.join(d, "yacrd_eb_%d.fastq" % os.getpid()), os.path.join(d, "yacrd_eb_%d.out.fastq" % os.getpid())
 try:
     t0 = time.perf_counter()
@@ -23,13 +23,17 @@ try:
     names = ["r%09d" % i for i in range(R)]
     time.sleep(5)
     ref = None
-    for io, oo in (("pread", "pwrite"), ("pread", "map"), ("mmap", "pwrite")):
+    ways = [tuple(w.split(":")) for w in os.environ.get("YACRD_EDIT_BENCH_WAYS", "pread:turns,pread:pwrite,pread:map,mmap:turns").split(",")]
+    threads = [int(x) for x in os.environ.get("YACRD_EDIT_BENCH_THREADS", "1,4,8,16,32").split(",")]
+    for io, oo in ways:
         os.environ["YACRD_EDIT_IO"] = io
         os.environ["YACRD_EDIT_OUT"] = oo
         io = "in " + io + " / out " + oo
-        for th in (1, 4, 8, 16, 32):
-            if th == 1 and oo != "pwrite":
+        for th in threads:
+            if th == 1 and oo != "turns":
                 continue
+            if os.path.exists(out):
+                os.remove(out)  # (or the open's O_TRUNC frees the 20 GB of the run before inside the timed region: 1.5-1.9 s)
             t0 = time.perf_counter()
             host.edit_file(host.OP_SCRUBB, fq, out, names, ln, bo, br, rt, n_threads=th)
             dt = time.perf_counter() - t0

@@ -26,6 +26,8 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <mutex>
 #include <cstring>
@@ -506,7 +508,8 @@ size_t edit_chunk()
 { // bytes per chunk (YACRD_EDIT_CHUNK overrides: the tests cut small files into many chunks)
     if (const char *e = std::getenv("YACRD_EDIT_CHUNK"))
         if (*e) return (size_t)std::max(64ll, std::atoll(e));
-    return (size_t)16 << 20;
+    return (size_t)4 << 20; // (a chunk's output is still in the cache when its thread's turn at the file comes: 16 MB measured 6.1-6.5 GB/s
+                            // of FASTQ in /dev/shm, 4 MB 7.5-8.2, 1 MB 7.8-8.1, 64 MB 6.4; profiles/r06/I_edit_turns_chunks_shm.log)
 }
 
 size_t next_line(const char *base, size_t size, size_t p)
@@ -579,15 +582,20 @@ int edit_sequences_parallel(int op, bool fastq, const char *in_path, const char 
         ::close(ofd);
         return -1;
     }
-    // The output: pwrite at the chunk's offset (default), or — YACRD_EDIT_OUT=map — memcpy into a shared mapping of the
-    // file, grown ahead of the writers in steps and cut to size at the end.  Neither scales on the box this was measured
-    // on (tools/edit_bench.py, 20 GB of FASTQ in /dev/shm, profiles/r04/h_edit_bench_map_vs_pwrite.log): pwrite 3.1 GB/s
-    // on one thread, 5.0 on four, 4.9 on eight, 4.4 on sixteen; the mapping 4.7 on four, 2.9 on sixteen, 1.7 on
-    // thirty-two — and on two other boxes of the same kind one thread (3.4 / 3.8 GB/s) beat every larger number (2.5-2.9:
-    // profiles/r04/f_*, i_*).  What the threads share is the kernel's allocation of the output's fresh pages (one memory
-    // cgroup): more threads only queue up there — hence the default of at most four.
+    // The output: pwrite at the chunk's offset, ONE WRITER AT A TIME in chunk order (default, round 6) — or all at once
+    // (YACRD_EDIT_OUT=pwrite, rounds 4-5's default), or memcpy into a shared mapping of the file grown ahead of the
+    // writers in steps and cut to size at the end (YACRD_EDIT_OUT=map).  Buffered writes into one file take the
+    // inode's lock exclusively, and the writers of a shared mapping meet at the file's page tree: tools/out_probe.cc
+    // (profiles/r06/I_out_probe.log, 16 GB into one file in /dev/shm) has ONE thread's pwrite at 8.6 GB/s and two /
+    // four / eight threads' at 4.1 / 4.2 / 3.3 — they hand the lock round and sleep —, the mapping at 3.3-3.9 whatever
+    // the threads, MADV_POPULATE_WRITE in front of the memcpy at 3.3-4.9; on the box's disk (ext4, page cache) one
+    // thread 14.5 GB/s, sixteen 12.5.  (Round 4's numbers of the same shape: pwrite 3.1 GB/s on one thread that also
+    // parses, 5.0 on four, 4.4 on sixteen; the mapping 4.7 on four, 1.7 on thirty-two, profiles/r04/h_*, f_*, i_*.)
+    // So the threads parse side by side and there is ONE WRITER AT A TIME, chunk after chunk in order (no thread ever
+    // waits inside the kernel for the lock): see the hand-over below.
     const char *oio = std::getenv("YACRD_EDIT_OUT");
     const bool out_map = oio && std::strcmp(oio, "map") == 0;
+    const bool out_turns = !out_map && !(oio && std::strcmp(oio, "pwrite") == 0);
     const size_t map_len = 2 * size + ((size_t)64 << 20);
     char *obase = nullptr;
     if (out_map) {
@@ -610,9 +618,25 @@ int edit_sequences_parallel(int op, bool fastq, const char *in_path, const char 
         file_size.store(to, std::memory_order_release);
         return true;
     };
-    std::vector<std::atomic<long long>> off(n_chunks + 1);
-    for (auto &o : off) o.store(-1);
-    off[0].store(0);
+    // Hand-over between the threads, all of it under turn_mu.  A chunk's thread PUBLISHES its output (pointer, size);
+    // chunks get their offsets in order as their predecessors' sizes become known.  With turns, whoever publishes the
+    // chunk the file waits for becomes THE WRITER and stays it for as long as the next chunk is ready too — the chunks
+    // of threads that are already parsing their next one (two buffers per thread) — so the file never waits for a
+    // sleeping thread to be woken (one thread woken per 4 MB chunk cost a fifth of the rate with four threads).
+    struct Slot {
+        const char *p = nullptr;
+        size_t n = 0;
+        long long at = -1;
+        unsigned owner = 0;
+        bool ready = false, done = false;
+    };
+    T = (unsigned)std::max<size_t>(1, std::min<size_t>(T, n_chunks));
+    std::vector<Slot> slot(n_chunks);
+    size_t next_write = 0;   // the first chunk without an offset (turns: not yet in the file)
+    long long at_total = 0;  // its offset
+    bool writer_active = false;
+    std::mutex turn_mu;
+    std::vector<std::condition_variable> cv(T);
     std::atomic<size_t> next(0);
     std::atomic<int> state(0); // 1 = a chunk did not parse (retry on one thread), 2 = write error
     // The chunks' bytes come through pread into a buffer the thread keeps (YACRD_EDIT_IO=mmap: straight from the mapping,
@@ -626,16 +650,55 @@ int edit_sequences_parallel(int op, bool fastq, const char *in_path, const char 
         ::close(ofd);
         return -1;
     }
-    auto work = [&]() {
+    // YACRD_EDIT_STATS=1: seconds per phase summed over the threads, on stderr (tools/edit_bench.py)
+    const char *stats_env = std::getenv("YACRD_EDIT_STATS");
+    const bool stats = stats_env && *stats_env == '1';
+    std::atomic<long long> ns_read(0), ns_parse(0), ns_wait(0), ns_write(0);
+    auto now_ns = [&] { return stats ? (long long)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count() : 0ll; };
+    auto write_at = [&](const char *p, size_t n, long long at) {
+        const long long t0 = now_ns();
+        if (out_map) {
+            if (n && !ensure((size_t)at + n)) state.store(state.load() == 2 ? 2 : 1); // (beyond the mapping: the one-thread loop)
+            else if (n) std::memcpy(obase + at, p, n);
+        } else {
+            for (size_t done = 0; done < n;) {
+                const ssize_t k = ::pwrite(ofd, p + done, n - done, (off_t)(at + (long long)done));
+                if (k < 0 && errno == EINTR) continue;
+                if (k <= 0) {
+                    state.store(k < 0 && (errno == ESPIPE || errno == EINVAL) ? 1 : 2); // (not seekable after all: the one-thread loop)
+                    break;
+                }
+                done += (size_t)k;
+            }
+        }
+        ns_write += now_ns() - t0;
+    };
+    auto work = [&](unsigned t) {
+        constexpr size_t kNone = ~(size_t)0;
         std::vector<char> ibuf;
-        Writer out;
-        out.open_memory(kEditChunk + kEditChunk / 8 + 4096);
-        for (;;) {
+        const int n_bufs = out_turns ? 2 : 1;
+        Writer outs[2];
+        for (int k = 0; k < n_bufs; k++) outs[k].open_memory(kEditChunk + kEditChunk / 8 + 4096);
+        size_t pending[2] = {kNone, kNone}; // the chunk whose output sits in outs[k] until it is in the file
+        auto wait_done = [&](size_t &j) {
+            if (j == kNone) return;
+            const long long t0 = now_ns();
+            {
+                std::unique_lock<std::mutex> g(turn_mu);
+                cv[t].wait(g, [&] { return slot[j].done; });
+            }
+            j = kNone;
+            ns_wait += now_ns() - t0;
+        };
+        for (int k = 0;; k = (k + 1) % n_bufs) {
             const size_t i = next.fetch_add(1);
             if (i >= n_chunks) break;
+            wait_done(pending[k]);
+            Writer &out = outs[k];
             const size_t len = cut[i + 1] - cut[i];
             const char *src = base + cut[i];
             bool skip = state.load() != 0;
+            const long long t_a = now_ns();
             if (use_pread && !skip) {
                 if (ibuf.size() < len) ibuf.resize(len + len / 8);
                 for (size_t got = 0; got < len;) {
@@ -650,38 +713,54 @@ int edit_sequences_parallel(int op, bool fastq, const char *in_path, const char 
                 }
                 src = ibuf.data();
             }
+            const long long t_b = now_ns();
             Reader in;
             in.open_memory(src, len);
             out.buf.clear();
             if (!skip && edit_sequences(op, fastq, in, out, bp) != 0) state.store(1);
-            long long at;
-            while ((at = off[i].load(std::memory_order_acquire)) < 0) std::this_thread::yield();
-            const size_t n = (skip || state.load()) ? 0 : out.buf.size();
-            off[i + 1].store(at + (long long)n, std::memory_order_release);
-            if (out_map) {
-                if (n && !ensure((size_t)at + n)) state.store(state.load() == 2 ? 2 : 1); // (beyond the mapping: the one-thread loop)
-                else if (n) std::memcpy(obase + at, out.buf.data(), n);
+            const long long t_c = now_ns();
+            ns_read += t_b - t_a, ns_parse += t_c - t_b;
+            std::unique_lock<std::mutex> g(turn_mu);
+            Slot &me = slot[i];
+            me.p = out.buf.data(), me.n = (skip || state.load()) ? 0 : out.buf.size(), me.owner = t, me.ready = true;
+            if (!out_turns) { // every thread writes its own chunk, as soon as its offset is known
+                while (next_write < n_chunks && slot[next_write].ready) {
+                    Slot &s = slot[next_write++];
+                    s.at = at_total, at_total += (long long)s.n;
+                    if (s.owner != t) cv[s.owner].notify_one();
+                }
+                cv[t].wait(g, [&] { return me.at >= 0; });
+                g.unlock();
+                ns_wait += now_ns() - t_c;
+                write_at(me.p, me.n, me.at);
                 continue;
             }
-            for (size_t done = 0; done < n;) {
-                const ssize_t k = ::pwrite(ofd, out.buf.data() + done, n - done, (off_t)(at + (long long)done));
-                if (k < 0 && errno == EINTR) continue;
-                if (k <= 0) {
-                    state.store(k < 0 && (errno == ESPIPE || errno == EINVAL) ? 1 : 2); // (not seekable after all: the one-thread loop)
-                    break;
-                }
-                done += (size_t)k;
+            pending[k] = i;
+            if (writer_active || next_write != i) continue; // (the writer comes to it, or the thread that publishes the chunk the file waits for)
+            writer_active = true;
+            while (next_write < n_chunks && slot[next_write].ready) {
+                Slot &s = slot[next_write];
+                s.at = at_total;
+                g.unlock();
+                write_at(s.p, s.n, s.at);
+                g.lock();
+                at_total += (long long)s.n, s.done = true, next_write++;
+                if (s.owner != t) cv[s.owner].notify_one();
             }
+            writer_active = false;
         }
+        for (int k = 0; k < n_bufs; k++) wait_done(pending[k]); // (the buffers go with the thread)
     };
-    T = (unsigned)std::max<size_t>(1, std::min<size_t>(T, n_chunks));
     std::vector<std::thread> th;
-    for (unsigned t = 1; t < T; t++) th.emplace_back(work);
-    work();
+    for (unsigned t = 1; t < T; t++) th.emplace_back(work, t);
+    work(0u);
     for (auto &x : th) x.join();
+    if (stats)
+        std::fprintf(stderr, "yacrd edit stats: %u threads, %zu chunks: read %.2f s, parse %.2f, waiting %.2f, write %.2f (summed over threads)\n", T, n_chunks,
+                     ns_read.load() * 1e-9, ns_parse.load() * 1e-9, ns_wait.load() * 1e-9, ns_write.load() * 1e-9);
     int rc = 0;
     if (out_map) {
-        const long long total = off[n_chunks].load();
+        const long long total = at_total;
         munmap(obase, map_len);
         if (state.load() == 0 && (total < 0 || ftruncate(ofd, (off_t)total) != 0)) rc = 1;
     }
@@ -873,7 +952,7 @@ int yacrd_edit_file_mt(int op, const char *in_path, const char *out_path, const 
     if (!(seq || (ovl && (op == OP_FILTER || op == OP_EXTRACT))))
         return yh::fail(std::string("Can't run ") + op_name(op) + " on " + type_name(ft) +
                         " file " + in_path);
-    unsigned T = n_threads > 0 ? (unsigned)n_threads : std::min(yh::usable_cpus(), 4u); // (more only queue up at the page allocator: edit_sequences_parallel)
+    unsigned T = n_threads > 0 ? (unsigned)n_threads : std::min(yh::usable_cpus(), 4u); // (they parse side by side and take turns at the output, whose one writer is the bound from two threads up: edit_sequences_parallel)
     if (const char *e = std::getenv("YACRD_EDIT_THREADS"))
         if (*e) T = (unsigned)std::max(1, std::atoi(e));
     T = std::min(T, 64u);

@@ -622,7 +622,10 @@ int edit_sequences_parallel(int op, bool fastq, const char *in_path, const char 
     // chunks get their offsets in order as their predecessors' sizes become known.  With turns, whoever publishes the
     // chunk the file waits for becomes THE WRITER and stays it for as long as the next chunk is ready too — the chunks
     // of threads that are already parsing their next one (two buffers per thread) — so the file never waits for a
-    // sleeping thread to be woken (one thread woken per 4 MB chunk cost a fifth of the rate with four threads).
+    // sleeping thread to be woken.  Either way the run is the writes end to end + 0.2 s (YACRD_EDIT_STATS): 20.4 GB of
+    // FASTQ in /dev/shm in 2.5-3.4 s of which 2.3-3.2 are pwrite, and the writes are the faster the fewer threads parse
+    // beside them (2.3 s with two threads, 2.8 with four, 3.1 with six on one box: the chunk's output leaves the cache
+    // before its turn comes) — profiles/r06/I_edit_4mb_*.log, J_edit_writer_*.log.
     struct Slot {
         const char *p = nullptr;
         size_t n = 0;
@@ -952,7 +955,7 @@ int yacrd_edit_file_mt(int op, const char *in_path, const char *out_path, const 
     if (!(seq || (ovl && (op == OP_FILTER || op == OP_EXTRACT))))
         return yh::fail(std::string("Can't run ") + op_name(op) + " on " + type_name(ft) +
                         " file " + in_path);
-    unsigned T = n_threads > 0 ? (unsigned)n_threads : std::min(yh::usable_cpus(), 4u); // (they parse side by side and take turns at the output, whose one writer is the bound from two threads up: edit_sequences_parallel)
+    unsigned T = n_threads > 0 ? (unsigned)n_threads : std::min(yh::usable_cpus(), 3u); // (they parse side by side and take turns at the output, whose one writer is the bound from two threads up: edit_sequences_parallel)
     if (const char *e = std::getenv("YACRD_EDIT_THREADS"))
         if (*e) T = (unsigned)std::max(1, std::atoi(e));
     T = std::min(T, 64u);

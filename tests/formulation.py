@@ -502,7 +502,7 @@ def window_screen_regions(intervals, length, cov, nb, W):
     return ([(0, a)] if a != 0 else []) + ([(bb, length)] if bb != length else [])
 
 
-def _sub_screen(intervals, length, cov, nb, W, lo0, hi0, P0, Q0, max_slides, ramp_always, s_hi=None, e_lo=None, spot=0):
+def _sub_screen(intervals, length, cov, nb, W, lo0, hi0, P0, Q0, max_slides, ramp_always, s_hi=None, e_lo=None, spot=0, tail_ramp=False):
     """The order-statistics screen over the events inside [lo0, hi0] of a read (starts and ends outside are not
     counted; P0 starts in front of lo0 and Q0 ends behind hi0 are carried as counts: intervals open across the
     border), with windows that slide by W up to max_slides times.  Returns (a, b, slides) — a: where P0 + the starts
@@ -543,6 +543,12 @@ def _sub_screen(intervals, length, cov, nb, W, lo0, hi0, P0, Q0, max_slides, ram
             if lo <= e <= hi:
                 if hi - e < W:
                     FT[hi - e] += 1
+                elif tail_ramp and (slide > 0 or ramp_always) and e > smax:
+                    # THE RAMP'S MIRROR (round 6): an end behind the read's largest start is popped after every start has
+                    # arrived — no start finds it gone — so it is in no block's count of "ends that may precede my starts".
+                    # (What it was costing: dovetail ends spread over the last coarse blocks of a read, every one of them
+                    # counted as popped before the block's starts: 8 % of configs[1]'s reads at sigma = 300.)
+                    pass
                 else:
                     E[min((e - lo) >> sh, nb)] += 1
         F, G = P + sum(FH), Q + sum(FT)
@@ -589,7 +595,7 @@ def _sub_screen(intervals, length, cov, nb, W, lo0, hi0, P0, Q0, max_slides, ram
     return None
 
 
-def slid_window_screen_regions(intervals, length, cov, nb, W, max_slides, ramp_always=False, spot=0):
+def slid_window_screen_regions(intervals, length, cov, nb, W, max_slides, ramp_always=False, spot=0, tail_ramp=False):
     """window_screen_regions with windows that SLIDE (round 4): when the first W positions hold fewer than cov + 1
     starts (or the last W fewer than cov + 1 ends) — dovetail ends spread wider than the window — the screen is
     repeated with that window moved on by W, the events it has passed carried as a count: P starts in front of the
@@ -601,7 +607,8 @@ def slid_window_screen_regions(intervals, length, cov, nb, W, max_slides, ramp_a
     P + the window's running count reaches cov + 1 and b likewise from the top.  max_slides = 0 is
     window_screen_regions.  ramp_always: the starts between the head window and the read's smallest end count as
     "already open" from the first pass on (the kernel's second look at a read whose window holds few starts), not
-    only after a slide.  Returns (regions, slides used) or None."""
+    only after a slide.  tail_ramp: on those same passes the ends behind the read's largest start (and in front of
+    the tail window) are left out of the coarse blocks — the ramp's mirror.  Returns (regions, slides used) or None."""
     n = len(intervals)
     if n == 0:
         return ([(0, length)] if length != 0 else []), 0
@@ -613,7 +620,7 @@ def slid_window_screen_regions(intervals, length, cov, nb, W, max_slides, ramp_a
         return None
     pmin = min(s for s, e in intervals)
     pmax = max(e for s, e in intervals)
-    r = _sub_screen(intervals, length, cov, nb, W, pmin, pmax, 0, 0, max_slides, ramp_always, spot=spot)
+    r = _sub_screen(intervals, length, cov, nb, W, pmin, pmax, 0, 0, max_slides, ramp_always, spot=spot, tail_ramp=tail_ramp)
     if r is None:
         return None
     a, bb, slide = r

@@ -201,6 +201,7 @@ def test_slid_window_screen_matches_oracle():
     fired = {0: 0, 4: 0}
     slid = 0
     spotted = {2: 0, 8: 0, 1 << 20: 0}
+    mirrored = {False: 0, True: 0}
     for it in range(1500):
         L = int(rng.integers(2, 400)) if it % 3 == 0 else int(rng.integers(400, 50000))
         n = int(rng.integers(1, 30)) if it % 4 == 0 else int(rng.integers(30, 300))
@@ -245,8 +246,16 @@ def test_slid_window_screen_matches_oracle():
                         if (ramp if ra else got) is not None:
                             assert spot is not None
                         spotted[sp] += spot is not None and (ramp if ra else got) is None
+                # round 6: the ramp's mirror — ends behind the largest start are in no block's count
+                for ra in (False, True):
+                    tr = slid_window_screen_regions(iv, L, cov, nb, W, 4, ramp_always=ra, tail_ramp=True)
+                    assert tr is None or tr[0] == want, (iv, L, cov, nb, W, ra, tr)
+                    if (ramp if ra else got) is not None:
+                        assert tr is not None
+                    mirrored[ra] += tr is not None and (ramp if ra else got) is None
     assert fired[4] > fired[0] and slid > 100, (fired, slid)
     assert spotted[8] > 200 and spotted[1 << 20] >= spotted[8] >= spotted[2], spotted
+    assert mirrored[True] > 50, mirrored
 
 
 def test_slid_window_screen_tiny_exhaustive():
@@ -263,6 +272,8 @@ def test_slid_window_screen_tiny_exhaustive():
                             for sp in (0, 3):
                                 got = slid_window_screen_regions(list(iv), L, cov, nb, W, 3, ramp_always=ramp, spot=sp)
                                 assert got is None or got[0] == want, (iv, L, cov, nb, W, sp, got)
+                            got = slid_window_screen_regions(list(iv), L, cov, nb, W, 3, ramp_always=ramp, tail_ramp=True)
+                            assert got is None or got[0] == want, (iv, L, cov, nb, W, "tail ramp", got)
 
 
 def test_window_screen_tiny_exhaustive():

@@ -502,10 +502,15 @@ constexpr int kScreenSlides = YK_SCREEN_SLIDES;
 // emin (SLID): the read's smallest end.  Starts behind the head window but in front of it — the RAMP — find nothing
 // popped yet and every earlier start still open: more than c once a has passed, so they are never low; they are
 // counted like the window's starts (open in front of every coarse-counted start), not into a coarse block.
+// smax (SLID, round 6): the read's largest start.  THE RAMP'S MIRROR: an end behind it is popped after every start has
+// arrived — no start finds it gone — so the ends between smax and the tail window are not counted into their coarse
+// blocks (where all of a block's ends count as popped before the block's starts).  Dovetail ends spread by hundreds of
+// positions fill the read's last blocks with such ends: 8 % of configs[1]'s reads at sigma = 300 failed the depth test on
+// them alone (tests/formulation.py: tail_ramp; emulation on the generator's reads 91.3 -> 98.3 % decided).
 template <int LANES, int WPB, bool SLID = false, int TABW = kScreenTabWords>
 __device__ __forceinline__ bool healthy_screen(const uint4 (&v)[4], const bool (&real0)[4], const bool (&real1)[4],
                                                u32 len, i32 c, u32 pmin, u32 pmax, HealthyRead &hr, u32 P = 0, u32 Q = 0,
-                                               u32 emin = 0)
+                                               u32 emin = 0, u32 smax = 0xFFFFFFFFu)
 {
     constexpr int NB = LANES, W = kScreenWindow, NBIN = 2 * W + NB, GROUPS = 64 / LANES, PER = W / LANES,
                   ZPER = NBIN / LANES;
@@ -541,7 +546,8 @@ __device__ __forceinline__ bool healthy_screen(const uint4 (&v)[4], const bool (
             const bool in_ramp = ds >= (u32)W && s < emin;
             ramp += (real && s >= pmin && in_ramp) ? 1u : 0u;
             if (real && s >= pmin && !in_ramp) atomicAdd(reinterpret_cast<u32 *>(tb + ((is << 4) + cp)), one);
-            if (real && e <= pmax) atomicAdd(reinterpret_cast<u32 *>(tb + ((ie << 4) + cp)), one_end);
+            // (the ramp's mirror: an end behind the read's largest start and in front of the tail window is in no block's count)
+            if (real && e <= pmax && !(e > smax && dx <= T)) atomicAdd(reinterpret_cast<u32 *>(tb + ((ie << 4) + cp)), one_end);
         } else if (real) {
             atomicAdd(reinterpret_cast<u32 *>(tb + ((is << 4) + cp)), one);
             atomicAdd(reinterpret_cast<u32 *>(tb + ((ie << 4) + cp)), one_end);
@@ -1253,7 +1259,8 @@ __device__ __forceinline__ void screen_reads(const SweepArgs &a, const u32 (&r)[
                 // room in front of the smallest end / behind the largest start, in positions from pmin / pmax
                 const u32 gemin = (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)gscan_min<LANES>(emin));
                 const u32 room_h = gemin - pmin;
-                const u32 room_t = pmax - (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)gscan_max<LANES>(smax2));
+                const u32 gsmax = (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)gscan_max<LANES>(smax2));
+                const u32 room_t = pmax - gsmax;
                 u32 ht = 0, PQ = 0; // h0 | t0 << 16 (positions), P | Q << 16 (counts)
 #pragma unroll 1
                 for (int slide = 0; slide < kScreenSlides; slide++) {
@@ -1273,7 +1280,7 @@ __device__ __forceinline__ void screen_reads(const SweepArgs &a, const u32 (&r)[
                     for (int j = 0; j < K / 4; j++) r0[j] = real0[j] && go, r1[j] = real1[j] && go;
                     wave_lds_sync(); // (the table is zeroed again)
                     HealthyRead h2;
-                    const bool ok2 = healthy_screen<LANES, WPB, true>(v[t], r0, r1, len[t], c, pmin + h0, pmax - t0, h2, PQ & 0xFFFFu, PQ >> 16, gemin);
+                    const bool ok2 = healthy_screen<LANES, WPB, true>(v[t], r0, r1, len[t], c, pmin + h0, pmax - t0, h2, PQ & 0xFFFFu, PQ >> 16, gemin, gsmax);
                     st = go ? state_of(!ok2 && (h2.F <= c || h2.G <= c), h2) : 0u; // (meaningful in the group's last lane)
                     if (go) healthy = ok2, hr.a = h2.a, hr.b = h2.b, hr.F = h2.F, hr.G = h2.G, ht_used = ht;
                 }

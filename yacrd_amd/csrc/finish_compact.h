@@ -64,10 +64,40 @@ struct MarkedRead { // what the thread that found the mark already knows about t
     u64 o;
     u32 n, len, idx, pad;
 };
-__device__ __forceinline__ void finish_marked(const SweepArgs &a, u32 bid, u32 n_marked, const MarkedRead *list)
+#ifndef YK_FINISH_FILTERED
+// Phase A through the filtered exact sweep (sweep_filtered.h), two marked reads per wavefront and turn, what the filter leaves sorted
+// whole behind a barrier.  Built, bit-exact (104 parity tests, 1.6 M fuzzed reads) and NOT faster: configs[1] one batch
+// at a time 65.2 -> 65.8 us with 128 registers (109 used, no scratch, one workgroup per CU), 70.6 at the kernel's 64 (68 bytes of scratch);
+// pipelined 24.7 -> 26.0 / 25.2; at sigma = 300 53.5 -> 55.7 / 62.1 (profiles/r06/P_finish.log).  A slab's two dozen marked reads are two
+// turns of sixteen wavefronts either way, and the filter's table + the barrier cost what the shorter sweep saves.  The plain sorts with
+// 128 registers (-DYK_FINISH_OCC=4: 99 used, no scratch) measured 25.3 us pipelined / 64.1 one at a time (24.7 / 65.2), 51.5 / 102.7
+// at sigma = 300 (53.5 / 105.2), 390 000 reads 87.4 / 134.9 (87.6 / 129.9): a draw, left at 8.
+#define YK_FINISH_FILTERED 0
+#endif
+template <int LANES, int WPB, int TABW>
+__device__ __forceinline__ bool filtered_turn(const SweepArgs &a, bool active, u32 r, u64 o, u32 n, u32 len, const LaneConst &lc);
+// s_fb / s_nfb (YK_FINISH_FILTERED): the slab's reads the filter did not take, sorted whole behind a barrier (s_nfb starts at 0)
+__device__ __forceinline__ void finish_marked(const SweepArgs &a, u32 bid, u32 n_marked, const MarkedRead *list, unsigned short *s_fb, u32 *s_nfb)
 {
+#if YK_FINISH_FILTERED
+    constexpr int kTabWords = 2 * (2 * kScreenWindow + 32) * 4; // two 32-lane groups
+    const u32 wv = threadIdx.x >> 6, lane = lane_id();
+    const LaneConst lcf = make_lane_const(lane);
+    for (u32 p0 = wv * 2u; p0 < n_marked; p0 += (u32)kFinishWaves * 2u) { // (uniform in the wavefront)
+        const u32 p = p0 + (lane >> 5);
+        const bool have = p < n_marked;
+        const MarkedRead m = list[have ? p : p0];
+        const bool done = filtered_turn<32, kFinishWaves, kTabWords>(a, have, bid * kScanBlock + m.idx, m.o, m.n, m.len, lcf);
+        if (have && !done && (lane & 31u) == 31u) s_fb[atomicAdd(s_nfb, 1u)] = (unsigned short)p;
+    }
+    __syncthreads();
+    const u32 nfb = *s_nfb;
+    for (u32 i = wv; i < nfb; i += (u32)kFinishWaves) { // (uniform in the wavefront)
+        const MarkedRead m = list[s_fb[i]];
+#else
     for (u32 i = threadIdx.x >> 6; i < n_marked; i += (u32)kFinishWaves) { // (uniform in the wavefront)
         const MarkedRead m = list[i];
+#endif
         const u32 rr = bid * kScanBlock + m.idx;
         if (m.n > 128u)
             finish_item<8>(a.off, a.iv, a.len, a.stage, a.counts, a.rej_list, a.rej_count, a.ctr, a.cov, rr, m.o, m.n, m.len);
@@ -84,12 +114,19 @@ __global__ __launch_bounds__(kScanBlock, YK_FINISH_OCC) void finish_compact_kern
     __shared__ u32 s_n;
     __shared__ unsigned long long s_iv;
     __shared__ MarkedRead s_list[kScanBlock]; // the marked reads of the slab
+#if YK_FINISH_FILTERED
+    __shared__ unsigned short s_fb[kScanBlock];
+#else
+    unsigned short *s_fb = nullptr;
+#endif
+    __shared__ u32 s_nfb;
     const SweepArgs &a = c.sweep;
     Counters *ctr = a.ctr;
     if (threadIdx.x == 0) {
         s_bid = atomicAdd(&ctr->scan_ticket, 1u);
         s_n = 0;
         s_iv = 0;
+        s_nfb = 0;
     }
     __syncthreads();
     const u32 bid = s_bid, lane = lane_id();
@@ -122,7 +159,7 @@ __global__ __launch_bounds__(kScanBlock, YK_FINISH_OCC) void finish_compact_kern
     __syncthreads();
     if (s_n) { // uniform in the workgroup
 #ifndef YK_FINISH_SKIP
-        finish_marked(a, bid, s_n, s_list);
+        finish_marked(a, bid, s_n, s_list, s_fb, &s_nfb);
 #endif
         __syncthreads(); // (global stores of this workgroup's wavefronts are visible to each other after it)
         if (threadIdx.x == 0) {

@@ -502,7 +502,7 @@ def window_screen_regions(intervals, length, cov, nb, W):
     return ([(0, a)] if a != 0 else []) + ([(bb, length)] if bb != length else [])
 
 
-def _sub_screen(intervals, length, cov, nb, W, lo0, hi0, P0, Q0, max_slides, ramp_always, s_hi=None, e_lo=None, spot=0, tail_ramp=False):
+def _sub_screen(intervals, length, cov, nb, W, lo0, hi0, P0, Q0, max_slides, ramp_always, s_hi=None, e_lo=None, spot=0, tail_ramp=False, jump=False):
     """The order-statistics screen over the events inside [lo0, hi0] of a read (starts and ends outside are not
     counted; P0 starts in front of lo0 and Q0 ends behind hi0 are carried as counts: intervals open across the
     border), with windows that slide by W up to max_slides times.  Returns (a, b, slides) — a: where P0 + the starts
@@ -555,8 +555,24 @@ def _sub_screen(intervals, length, cov, nb, W, lo0, hi0, P0, Q0, max_slides, ram
         if F < cov + 1 or G < cov + 1:
             if slide == max_slides:
                 return None
-            h0 += W if F < cov + 1 else 0
-            t0 += W if G < cov + 1 else 0
+            if jump:
+                # WINDOWS THAT JUMP (round 6): a window that came up short moves to the next event it has not seen — the head
+                # window begins AT the smallest start behind it, the tail window ends AT the largest end in front of it —
+                # instead of by W: nothing lies in between, so what it has passed is what it counted (P = F, Q = G), every
+                # pass gains at least one event, and cov + 1 passes always reach cov + 1.
+                if F < cov + 1:
+                    nxt = [s for s, e in intervals if lo + W <= s <= hi0]
+                    if not nxt:
+                        return None
+                    h0 = min(nxt) - lo0
+                if G < cov + 1:
+                    prv = [e for s, e in intervals if lo0 <= e <= hi - W]
+                    if not prv:
+                        return None
+                    t0 = hi0 - max(prv)
+            else:
+                h0 += W if F < cov + 1 else 0
+                t0 += W if G < cov + 1 else 0
             continue
         D = F + ramp
         failing = []
@@ -595,7 +611,7 @@ def _sub_screen(intervals, length, cov, nb, W, lo0, hi0, P0, Q0, max_slides, ram
     return None
 
 
-def slid_window_screen_regions(intervals, length, cov, nb, W, max_slides, ramp_always=False, spot=0, tail_ramp=False):
+def slid_window_screen_regions(intervals, length, cov, nb, W, max_slides, ramp_always=False, spot=0, tail_ramp=False, jump=False):
     """window_screen_regions with windows that SLIDE (round 4): when the first W positions hold fewer than cov + 1
     starts (or the last W fewer than cov + 1 ends) — dovetail ends spread wider than the window — the screen is
     repeated with that window moved on by W, the events it has passed carried as a count: P starts in front of the
@@ -608,7 +624,8 @@ def slid_window_screen_regions(intervals, length, cov, nb, W, max_slides, ramp_a
     window_screen_regions.  ramp_always: the starts between the head window and the read's smallest end count as
     "already open" from the first pass on (the kernel's second look at a read whose window holds few starts), not
     only after a slide.  tail_ramp: on those same passes the ends behind the read's largest start (and in front of
-    the tail window) are left out of the coarse blocks — the ramp's mirror.  Returns (regions, slides used) or None."""
+    the tail window) are left out of the coarse blocks — the ramp's mirror.  jump: a window that came up short moves to
+    the next event instead of by W.  Returns (regions, slides used) or None."""
     n = len(intervals)
     if n == 0:
         return ([(0, length)] if length != 0 else []), 0
@@ -620,7 +637,7 @@ def slid_window_screen_regions(intervals, length, cov, nb, W, max_slides, ramp_a
         return None
     pmin = min(s for s, e in intervals)
     pmax = max(e for s, e in intervals)
-    r = _sub_screen(intervals, length, cov, nb, W, pmin, pmax, 0, 0, max_slides, ramp_always, spot=spot, tail_ramp=tail_ramp)
+    r = _sub_screen(intervals, length, cov, nb, W, pmin, pmax, 0, 0, max_slides, ramp_always, spot=spot, tail_ramp=tail_ramp, jump=jump)
     if r is None:
         return None
     a, bb, slide = r

@@ -202,6 +202,7 @@ def test_slid_window_screen_matches_oracle():
     slid = 0
     spotted = {2: 0, 8: 0, 1 << 20: 0}
     mirrored = {False: 0, True: 0}
+    jumped = [0, 0, 0, 0]
     for it in range(1500):
         L = int(rng.integers(2, 400)) if it % 3 == 0 else int(rng.integers(400, 50000))
         n = int(rng.integers(1, 30)) if it % 4 == 0 else int(rng.integers(30, 300))
@@ -253,6 +254,15 @@ def test_slid_window_screen_matches_oracle():
                     if (ramp if ra else got) is not None:
                         assert tr is not None
                     mirrored[ra] += tr is not None and (ramp if ra else got) is None
+                    # ... and windows that JUMP to the next event instead of sliding by W
+                    jp = slid_window_screen_regions(iv, L, cov, nb, W, 4, ramp_always=ra, tail_ramp=True, jump=True)
+                    assert jp is None or jp[0] == want, (iv, L, cov, nb, W, ra, "jump", jp)
+                    jumped[0] += jp is not None
+                    jumped[1] += tr is not None
+                    if jp is not None and tr is not None:
+                        jumped[2] += jp[1]
+                        jumped[3] += tr[1]
+    assert jumped[0] >= jumped[1] and jumped[2] < jumped[3], jumped  # (decides no fewer reads, in fewer passes)
     assert fired[4] > fired[0] and slid > 100, (fired, slid)
     assert spotted[8] > 200 and spotted[1 << 20] >= spotted[8] >= spotted[2], spotted
     assert mirrored[True] > 50, mirrored
@@ -274,6 +284,8 @@ def test_slid_window_screen_tiny_exhaustive():
                                 assert got is None or got[0] == want, (iv, L, cov, nb, W, sp, got)
                             got = slid_window_screen_regions(list(iv), L, cov, nb, W, 3, ramp_always=ramp, tail_ramp=True)
                             assert got is None or got[0] == want, (iv, L, cov, nb, W, "tail ramp", got)
+                            got = slid_window_screen_regions(list(iv), L, cov, nb, W, 3, ramp_always=ramp, tail_ramp=True, jump=True)
+                            assert got is None or got[0] == want, (iv, L, cov, nb, W, "jump", got)
 
 
 def test_window_screen_tiny_exhaustive():

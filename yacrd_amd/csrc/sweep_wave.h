@@ -450,6 +450,14 @@ struct HealthyRead {
 #define YK_SCREEN_SLIDES 4
 #endif
 constexpr int kScreenSlides = YK_SCREEN_SLIDES;
+#ifndef YK_SCREEN_JUMP
+// A window that came up short goes to the next event it has not seen instead of W positions on (screen_reads: the slides; emulation:
+// formulation.py jump, fuzzed + enumerated: never fewer reads decided, fewer passes — 2.4 -> 2.0 for the slowest of a wavefront's four
+// reads at sigma = 300).  Built, bit-exact (122 parity tests, 3.4 M fuzzed reads), and the two reductions per slide cost what the
+// saved passes gain: configs[1] at sigma = 300 54.4 -> 52.6 us per batch (kernel 65.2 -> 63.5, 4 696 -> 4 551 reads left), at 100
+// 32.6 -> 33.9, configs[2] at 300 1.03 -> 1.07 ms (profiles/r06/Q_jump.log).  OFF.
+#define YK_SCREEN_JUMP 0
+#endif
 #ifndef YK_SPOT_CHECKS
 // Spot checks behind a screen that failed on a block's depth only (spot_check_call below; the build with the second looks).
 // Built, bit-exact (the -m gpu parity files + 3.6 M fuzzed reads with the second looks forced, profiles/r06/A_*, B_*), and they do
@@ -1267,12 +1275,40 @@ __device__ __forceinline__ void screen_reads(const SweepArgs &a, const u32 (&r)[
                     const u32 g = (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)st); // the last lane's verdict and counts, to its group
                     const bool gneed = (g & 1u) != 0;
                     const u32 gF = (g >> 1) & 1023u, gG = g >> 11;
+                    bool reach = true; // (the windows' offsets fit their sixteen bits and there is an event to go to)
+#if YK_SCREEN_JUMP
+                    // WINDOWS THAT JUMP: a window that came up short goes to the next event it has not seen — the head window begins AT
+                    // the smallest start behind it, the tail window ends AT the largest end in front of it — nothing lies in between,
+                    // so what it has passed is what it counted, and every pass gains at least one event (formulation.py: jump)
+                    {
+                        const u32 thr_h = pmin + (ht & 0xFFFFu) + (u32)kScreenWindow, thr_t = pmax - (ht >> 16) - (u32)kScreenWindow;
+                        u32 ns = 0xFFFFFFFFu, pe = 0u;
+#pragma unroll
+                        for (int j = 0; j < K / 4; j++) {
+                            ns = min(ns, min(v[t][j].x >= thr_h ? v[t][j].x : 0xFFFFFFFFu, v[t][j].z >= thr_h ? v[t][j].z : 0xFFFFFFFFu));
+                            pe = max(pe, max(v[t][j].y <= thr_t ? v[t][j].y : 0u, v[t][j].w <= thr_t ? v[t][j].w : 0u));
+                        }
+                        const u32 gns = (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)gscan_min<LANES>(ns));
+                        const u32 gpe = (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)gscan_max<LANES>(pe));
+                        if (gneed && (i32)gF <= c) {
+                            const u32 h = gns - pmin;
+                            reach = reach && gns != 0xFFFFFFFFu && h <= 0xFFFFu;
+                            ht = (ht & 0xFFFF0000u) | (h & 0xFFFFu), PQ = (PQ & 0xFFFF0000u) | gF;
+                        }
+                        if (gneed && (i32)gG <= c) {
+                            const u32 tt = pmax - gpe;
+                            reach = reach && gpe != 0u && tt <= 0xFFFFu;
+                            ht = (ht & 0xFFFFu) | (tt << 16), PQ = (PQ & 0xFFFFu) | (gG << 16);
+                        }
+                    }
+#else
                     if (gneed && (i32)gF <= c) ht += (u32)kScreenWindow, PQ = (PQ & 0xFFFF0000u) | gF;
                     if (gneed && (i32)gG <= c) ht += (u32)kScreenWindow << 16, PQ = (PQ & 0xFFFFu) | (gG << 16);
+#endif
                     const u32 h0 = ht & 0xFFFFu, t0 = ht >> 16;
                     // no end at or before the head window's last position, no start at or behind the tail window's
                     // first, and the two windows apart
-                    const bool go = gneed && room_h >= h0 + (u32)kScreenWindow && room_t >= t0 + (u32)kScreenWindow &&
+                    const bool go = gneed && reach && room_h >= h0 + (u32)kScreenWindow && room_t >= t0 + (u32)kScreenWindow &&
                                     pmax - pmin >= h0 + t0 + 2u * (u32)kScreenWindow;
                     if (__builtin_amdgcn_ballot_w64(go) == 0) break; // (uniform)
                     bool r0[K / 4], r1[K / 4];

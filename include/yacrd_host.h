@@ -101,9 +101,10 @@ enum { YACRD_OP_SCRUBB = 0, YACRD_OP_FILTER = 1, YACRD_OP_EXTRACT = 2, YACRD_OP_
 /* editor::{scrubbing,filter,extract,split} (src/editor/ scrubbing.rs, filter.rs, extract.rs, split.rs): FASTA/FASTQ for all four, PAF/M4
  * for filter and extract; gzip in -> gzip out.  Reads unknown to `bp` are NotBad with no region. */
 int yacrd_edit_file(int op, const char *in_path, const char *out_path, const yacrd_badparts_view *bp);
-/* The same with a thread count (0 = the usable CPUs, at most four: what yacrd_edit_file passes; YACRD_EDIT_THREADS overrides):
- * plain FASTA / FASTQ files are cut at record boundaries and edited chunk-parallel, output byte-identical to one
- * thread's; compressed files and overlap files take the one-thread loop. */
+/* The same with a thread count (0 = the usable CPUs, at most three: what yacrd_edit_file passes; YACRD_EDIT_THREADS overrides):
+ * plain FASTA / FASTQ files are cut at record boundaries and edited chunk-parallel — the threads parse side by side, one of
+ * them at a time writes, chunk after chunk in order —, output byte-identical to one thread's; compressed files and overlap
+ * files take the one-thread loop. */
 int yacrd_edit_file_mt(int op, const char *in_path, const char *out_path, const yacrd_badparts_view *bp, int n_threads);
 
 /* FromReport (src/stack.rs:176-257): a .yacrd report back into the BadPart table.  read_type is

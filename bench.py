@@ -523,6 +523,14 @@ def small_batches_block(cx, jitter=0, chimeras=0):
                                        "batch (82 MB) fits the 256 MiB Infinity Cache; other engines' small kernels run beside "
                                        "the timed launches")}
         blk["roofline"]["finish_compact_kernel_ms"] = (phases or {}).get("compact_ms")
+        alone = (phases or {}).get("fused_ms")
+        if alone and blk["roofline"]["size_class"] == "R2..H16":
+            # `kernel_ms` above is the launch's own events WITH the other engines' batches in flight: a bracket then holds its
+            # neighbours' work too (configs[1] at sigma = 300: 62 us against 43 alone).  The same launch with nothing beside it:
+            rf = blk["roofline"]
+            rf["kernel_alone_ms"] = alone
+            rf["frac_alone"] = rf["algorithmic_bytes"] / (alone * 1e-3) / 1e9 / HBM_PEAK_GBS
+            rf["note"] += "; kernel_alone_ms / frac_alone: the same launch by its own events on one engine, one batch at a time, nothing else in flight"
         if reps > 1:
             blk["workload"] += "; the FASTEST of %d timed regions of %d steps (the host's cadence: see timed_regions_ms_per_step)" % (reps, K)
         import oracle
@@ -941,7 +949,9 @@ def compact_line(full, extras_path):
             p = b.get("paths")
             return [] if not isinstance(p, dict) else [p.get("prediction_misses", 0) + p.get("fused_reruns", 0), p.get("screen_wide", 0),
                                                        p.get("build_switches", 0)]
+        # (+ for the pipelined configs[1] blocks, [6]: the dominant kernel's frac with nothing else in flight)
         out["jitter"] = {k: [_r(_dig(b, "ms_per_step")), _r(_dig(b, "roofline", "frac")), _r(share.get(k))] + path3(b)
+                            + ([_r(_dig(b, "roofline", "frac_alone"))] if _dig(b, "roofline", "frac_alone") is not None else [])
                          for k, b in jit.items() if isinstance(b, dict) and k != "healthy_share_of_screened_reads"}
     out["extras"] = extras_path if extras_path.startswith("not written") else os.path.basename(extras_path)
     s = json.dumps(out, allow_nan=False, separators=(",", ":"))

@@ -450,6 +450,15 @@ struct HealthyRead {
 #define YK_SCREEN_SLIDES 4
 #endif
 constexpr int kScreenSlides = YK_SCREEN_SLIDES;
+#ifndef YK_WIDE_WB
+// log2 of the positions per window bin in the build with the second looks (healthy_screen: WB): the windows reach W << WB positions with
+// the same table, a and b are resolved inside their bin by counting.  Built, bit-exact (104 parity tests, 3 M fuzzed reads with the second
+// looks forced), and a trade, not a gain: WB = 2 (windows of 128 positions: most reads need no slide) takes configs[1] at sigma = 300 from
+// 53.4 to 48.4 us per batch (the screen alone 41.1 -> 36.4 us, frac 0.24 -> 0.27; 600 more reads have an interval shorter than the window:
+// 95.3 -> 94.7 % decided) and at sigma = 100 from 32.3 to 36.3 (alone 27.1 -> 30.4: the resolve and 80 registers + 24 bytes of scratch
+// instead of 62 cost the reads that needed no slide anyway); WB = 1: 51.0 / 32.9 (profiles/r06/T_wb.log).  OFF.
+#define YK_WIDE_WB 0
+#endif
 #ifndef YK_SCREEN_JUMP
 // A window that came up short goes to the next event it has not seen instead of W positions on (screen_reads: the slides; emulation:
 // formulation.py jump, fuzzed + enumerated: never fewer reads decided, fewer passes — 2.4 -> 2.0 for the slowest of a wavefront's four
@@ -515,7 +524,9 @@ constexpr int kScreenSlides = YK_SCREEN_SLIDES;
 // blocks (where all of a block's ends count as popped before the block's starts).  Dovetail ends spread by hundreds of
 // positions fill the read's last blocks with such ends: 8 % of configs[1]'s reads at sigma = 300 failed the depth test on
 // them alone (tests/formulation.py: tail_ramp; emulation on the generator's reads 91.3 -> 98.3 % decided).
-template <int LANES, int WPB, bool SLID = false, int TABW = kScreenTabWords>
+// WB (round 6, YK_WIDE_WB; the build with the second looks only): a window bin is 2^WB positions wide — the windows reach W << WB positions
+// with the same table — and a / b are resolved inside their bin by counting (resolve below).  Every interval must then be W << WB long.
+template <int LANES, int WPB, bool SLID = false, int TABW = kScreenTabWords, int WB = 0>
 __device__ __forceinline__ bool healthy_screen(const uint4 (&v)[4], const bool (&real0)[4], const bool (&real1)[4],
                                                u32 len, i32 c, u32 pmin, u32 pmax, HealthyRead &hr, u32 P = 0, u32 Q = 0,
                                                u32 emin = 0, u32 smax = 0xFFFFFFFFu)
@@ -532,8 +543,9 @@ __device__ __forceinline__ bool healthy_screen(const uint4 (&v)[4], const bool (
 
     // smallest shift with (len >> sh) < NB, but blocks of at least W positions
     const i32 bits = 32 - (i32)__builtin_clz(len | 1u) - ilog2c(NB) + (len != 0 ? 0 : -1);
-    const u32 sh = (u32)max(bits, ilog2c(W));
-    const u32 span = pmax - pmin, T = span - (u32)W;
+    constexpr u32 WW = (u32)W << WB; // positions a window covers
+    const u32 sh = (u32)max(bits, ilog2c(W) + WB);
+    const u32 span = pmax - pmin, T = span - WW;
 
 #pragma unroll
     for (int q = 0; q < ZPER; q++) bins[lig + (u32)(LANES * q)] = make_uint4(0u, 0u, 0u, 0u);
@@ -548,10 +560,17 @@ __device__ __forceinline__ bool healthy_screen(const uint4 (&v)[4], const bool (
     u32 ramp = 0; // (SLID) this lane's starts between the head window and the read's smallest end
     auto count = [&](u32 s, u32 e, bool real) {
         const u32 ds = s - pmin, dx = e - pmin;
-        const u32 is = min(ds, (u32)W) + (ds >> sh);
-        const u32 ie = (dx >> sh) + __builtin_elementwise_sub_sat(dx, T) + (u32)W;
+        u32 is, ie;
+        if constexpr (WB == 0) {
+            is = min(ds, (u32)W) + (ds >> sh);
+            ie = (dx >> sh) + __builtin_elementwise_sub_sat(dx, T) + (u32)W;
+        } else { // (a tail bin's block term comes from the bin's first position from the top: one bin per 2^WB positions)
+            is = min(ds >> WB, (u32)W) + (ds >> sh);
+            const u32 dbin = (span - dx) >> WB;
+            ie = dx > T ? (u32)(2 * W) - dbin + ((span - (dbin << WB)) >> sh) : (u32)W + (dx >> sh);
+        }
         if constexpr (SLID) { // (what the windows have passed is not counted: P and Q stand for it)
-            const bool in_ramp = ds >= (u32)W && s < emin;
+            const bool in_ramp = ds >= WW && s < emin;
             ramp += (real && s >= pmin && in_ramp) ? 1u : 0u;
             if (real && s >= pmin && !in_ramp) atomicAdd(reinterpret_cast<u32 *>(tb + ((is << 4) + cp)), one);
             // (the ramp's mirror: an end behind the read's largest start and in front of the tail window is in no block's count)
@@ -574,7 +593,7 @@ __device__ __forceinline__ bool healthy_screen(const uint4 (&v)[4], const bool (
 #pragma unroll
     for (int q = 0; q < PER; q++) {
         const u32 d = lig * (u32)PER + q;
-        const u32 it = min((u32)(2 * W) - d + ((span - d) >> sh), (u32)(NBIN - 1)); // (clipped: an irregular group's span is anything)
+        const u32 it = min((u32)(2 * W) - d + ((span - (d << WB)) >> sh), (u32)(NBIN - 1)); // (clipped: an irregular group's span is anything)
         const uint4 h4 = bins[d], t4 = bins[it];
         f[q] = ((h4.x + h4.y + h4.z + h4.w) & kField) | ((t4.x + t4.y + t4.z + t4.w) & (kField << 10));
         fw += f[q];
@@ -608,8 +627,38 @@ __device__ __forceinline__ bool healthy_screen(const uint4 (&v)[4], const bool (
     // (meaningful in the group's last lane from here on)
     const i32 F = (i32)(fincl & kField) + (SLID ? (i32)P : 0), G = (i32)(fincl >> 10) + (SLID ? (i32)Q : 0);
     hr.F = F, hr.G = G;
-    hr.a = pmin + ((wincl >> 20) & 63u); // (a window that never reaches c + 1 overflows these fields: F > c
-    hr.b = pmax - (wincl >> 26);         // or G > c fails then)
+    hr.a = pmin + (((wincl >> 20) & 63u) << WB); // (a window that never reaches c + 1 overflows these fields: F > c
+    hr.b = pmax - ((wincl >> 26) << WB);         // or G > c fails then)
+    if constexpr (WB > 0) {
+        // resolve: a is the smallest x of its bin's 2^WB positions with (passed starts) + (counted starts <= x) >= c + 1, b the largest
+        // y of its bin's with (passed ends) + (counted ends >= y) >= c + 1: the counts of all but the last position of either bin, ten
+        // bits each, in one group sum per side
+        static_assert(WB <= 2, "three ten-bit counts per word");
+        const int last_addr = (int)((lane | (u32)(LANES - 1)) << 2);
+        const u32 a0 = (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)hr.a), b0 = (u32)__builtin_amdgcn_ds_bpermute(last_addr, (int)hr.b);
+        u32 ca = 0, cb = 0;
+        auto tally = [&](u32 s_, u32 e_, bool real) {
+            const bool s_in = real && s_ >= pmin, e_in = real && e_ <= pmax;
+#pragma unroll
+            for (int i = 0; i < (1 << WB) - 1; i++) {
+                ca += (s_in && s_ <= a0 + (u32)i) ? (1u << (10 * i)) : 0u;
+                cb += (e_in && e_ >= b0 - (u32)i) ? (1u << (10 * i)) : 0u;
+            }
+        };
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            tally(v[j].x, v[j].y, real0[j]);
+            tally(v[j].z, v[j].w, real1[j]);
+        }
+        const u32 ta = gscan_add<LANES>(ca), tb = gscan_add<LANES>(cb); // (the group's last lane: the totals)
+        u32 da = 0, db = 0;
+#pragma unroll
+        for (int i = 0; i < (1 << WB) - 1; i++) {
+            da += ((i32)(((ta >> (10 * i)) & kField) + P) <= c) ? 1u : 0u;
+            db += ((i32)(((tb >> (10 * i)) & kField) + Q) <= c) ? 1u : 0u;
+        }
+        hr.a += da, hr.b -= db;
+    }
     i32 open0 = F; // intervals open in front of every coarse-counted start
     if constexpr (SLID) open0 += (i32)gscan_add<LANES>(ramp);
     const bool deep = xm == 0xFFFFFFFFu || (i32)(xm - 0x10000u) + open0 > c;
@@ -1232,7 +1281,10 @@ __device__ __forceinline__ void screen_reads(const SweepArgs &a, const u32 (&r)[
         // the screen's windows: left to the sort.  With every position <= kMaxKeyPos < 2^30, end - start
         // as a signed number is below W exactly for those intervals.  The slots beyond the read hold
         // copies of its own intervals, so no mask is needed here.
-        const bool irregular = n[t] < 2u || pmax > len_c || smax > kMaxKeyPos || tmin < (i32)kScreenWindow;
+        constexpr int WBW = (kScreenSlides > 0 && WIDE) ? YK_WIDE_WB : 0; // (window bins of 2^WBW positions in the build with the second looks)
+        constexpr u32 kWinPos = (u32)kScreenWindow << WBW;                // positions a window covers
+        static_assert(WBW == 0 || (!YK_SPOT_CHECKS && !YK_HOLE_FORM && !YK_SCREEN_JUMP), "they count one-position windows");
+        const bool irregular = n[t] < 2u || pmax > len_c || smax > kMaxKeyPos || tmin < (i32)kWinPos;
         // per group: such a read counts nothing (its positions may lie outside the table) and is never healthy
         const bool girr = group_any<LANES>(__builtin_amdgcn_ballot_w64(irregular));
         const u32 n_eff = girr ? 0u : n[t];
@@ -1244,7 +1296,7 @@ __device__ __forceinline__ void screen_reads(const SweepArgs &a, const u32 (&r)[
             real1[j] = i0 < n_eff;
         }
         HealthyRead hr;
-        bool healthy = healthy_screen<LANES, WPB>(v[t], real0, real1, len[t], c, pmin, pmax, hr) && !girr;
+        bool healthy = healthy_screen<LANES, WPB, false, kScreenTabWords, WBW>(v[t], real0, real1, len[t], c, pmin, pmax, hr) && !girr;
         u32 ht_used = 0; // (the last screen's windows: h0 | t0 << 16)
         bool table_intact = true, hole_done = false; // (the first screen's coarse blocks are still in LDS; this group's read got its hole form)
         if constexpr (kScreenSlides > 0 && WIDE) {
@@ -1302,21 +1354,21 @@ __device__ __forceinline__ void screen_reads(const SweepArgs &a, const u32 (&r)[
                         }
                     }
 #else
-                    if (gneed && (i32)gF <= c) ht += (u32)kScreenWindow, PQ = (PQ & 0xFFFF0000u) | gF;
-                    if (gneed && (i32)gG <= c) ht += (u32)kScreenWindow << 16, PQ = (PQ & 0xFFFFu) | (gG << 16);
+                    if (gneed && (i32)gF <= c) ht += kWinPos, PQ = (PQ & 0xFFFF0000u) | gF;
+                    if (gneed && (i32)gG <= c) ht += kWinPos << 16, PQ = (PQ & 0xFFFFu) | (gG << 16);
 #endif
                     const u32 h0 = ht & 0xFFFFu, t0 = ht >> 16;
                     // no end at or before the head window's last position, no start at or behind the tail window's
                     // first, and the two windows apart
-                    const bool go = gneed && reach && room_h >= h0 + (u32)kScreenWindow && room_t >= t0 + (u32)kScreenWindow &&
-                                    pmax - pmin >= h0 + t0 + 2u * (u32)kScreenWindow;
+                    const bool go = gneed && reach && room_h >= h0 + kWinPos && room_t >= t0 + kWinPos &&
+                                    pmax - pmin >= h0 + t0 + 2u * kWinPos;
                     if (__builtin_amdgcn_ballot_w64(go) == 0) break; // (uniform)
                     bool r0[K / 4], r1[K / 4];
 #pragma unroll
                     for (int j = 0; j < K / 4; j++) r0[j] = real0[j] && go, r1[j] = real1[j] && go;
                     wave_lds_sync(); // (the table is zeroed again)
                     HealthyRead h2;
-                    const bool ok2 = healthy_screen<LANES, WPB, true>(v[t], r0, r1, len[t], c, pmin + h0, pmax - t0, h2, PQ & 0xFFFFu, PQ >> 16, gemin, gsmax);
+                    const bool ok2 = healthy_screen<LANES, WPB, true, kScreenTabWords, WBW>(v[t], r0, r1, len[t], c, pmin + h0, pmax - t0, h2, PQ & 0xFFFFu, PQ >> 16, gemin, gsmax);
                     st = go ? state_of(!ok2 && (h2.F <= c || h2.G <= c), h2) : 0u; // (meaningful in the group's last lane)
                     if (go) healthy = ok2, hr.a = h2.a, hr.b = h2.b, hr.F = h2.F, hr.G = h2.G, ht_used = ht;
                 }
